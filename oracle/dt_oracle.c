@@ -1,0 +1,345 @@
+/*
+ * dt_oracle.c -- CPU restatement of datatable's DT[i, j, by()] hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported baseline.  The
+ * product path is libdthip.so (datatable_amd/csrc) and never calls in here.
+ *
+ * Parity pinning: this restatement is checked against outputs of the
+ * unmodified reference (h2oai/datatable @ /root/reference, built in this
+ * container) stored as fixtures under tests/golden/ (generator:
+ * tests/golden/make_golden.py), including the reference's own golden
+ * vectors from tests/ijby/test-sort.py, tests/test-groups.py and
+ * tests/test-reduce.py.  See tests/test_oracle_golden.py.
+ *
+ * What is restated (all paths relative to /root/reference/src/core):
+ *   key -> unsigned radix key   sort.cc:689-720 (_initB), :728-776 (_initI),
+ *                               :808-845 (_initF)
+ *   ordering + groups           sort.cc:1411-1495 (group), :1128-1162
+ *                               (radix_psort), sort_groups.cc:41-117
+ *   bool mask -> RowIndex       rowindex_array.cc:130-170
+ *   gather through a RowIndex   column/view.cc:140-145, column_impl.cc:78-101
+ *   reducers                    column/sumprod.h:34-59, mean.h:33-52,
+ *                               minmax.h:33-62, count.h:35-88
+ *   reducer output stypes       expr/fexpr_sumprod.cc:47-82, fexpr_mean.cc:45-89,
+ *                               fexpr_minmax.cc:47-83, fexpr_count.cc:36-131
+ *
+ * The reference's ordering is "stable MSD radix sort of the transformed key,
+ * NA first; groups = runs of equal transformed keys" (sort.cc:24-104).  The
+ * permutation produced by any stable sort of those keys is identical, so the
+ * restatement uses a stable LSD byte-radix sort of the same transformed keys
+ * (the MSD recursion/insertion-sort thresholds of sort.cc:917-934,1206-1353
+ * only affect speed, not results).  Reducers follow the reference loops
+ * literally (sequential, left to right, in group order) so float sums are
+ * bit-identical to the reference.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+/* reference SType codes, stype.h:41-62 */
+enum { ST_BOOL = 1, ST_INT8 = 2, ST_INT16 = 3, ST_INT32 = 4, ST_INT64 = 5,
+       ST_FLOAT32 = 6, ST_FLOAT64 = 7 };
+/* reducer codes shared with include/dthip.h */
+enum { OP_SUM = 0, OP_MEAN = 1, OP_MIN = 2, OP_MAX = 3, OP_COUNT = 4, OP_COUNT0 = 5 };
+enum { NA_FIRST = 0, NA_LAST = 1 };           /* sort.h NaPosition (REMOVE not restated) */
+enum { FLAG_DESC = 1 };                       /* SortFlag::DESCENDING, sort.h:38-44 */
+
+typedef struct {
+  const void* data;
+  int32_t stype;
+  int32_t flags;
+} dto_col;
+
+static int stype_size(int st) {
+  switch (st) {
+    case ST_BOOL: case ST_INT8: return 1;
+    case ST_INT16: return 2;
+    case ST_INT32: case ST_FLOAT32: return 4;
+    case ST_INT64: case ST_FLOAT64: return 8;
+    default: return 0;
+  }
+}
+int dto_stype_size(int st) { return stype_size(st); }
+
+/* NA sentinels, stype.h:186-197: INT*_MIN for ints (bool: int8 -128), NaN for floats */
+static int64_t load_int(const void* data, int st, int64_t i, int* isna) {
+  switch (st) {
+    case ST_BOOL: case ST_INT8: { int8_t v = ((const int8_t*)data)[i]; *isna = (v == INT8_MIN); return v; }
+    case ST_INT16: { int16_t v = ((const int16_t*)data)[i]; *isna = (v == INT16_MIN); return v; }
+    case ST_INT32: { int32_t v = ((const int32_t*)data)[i]; *isna = (v == INT32_MIN); return v; }
+    default:       { int64_t v = ((const int64_t*)data)[i]; *isna = (v == INT64_MIN); return v; }
+  }
+}
+
+/* ------------------------------------------------------------------------
+ * Key transform: column value -> unsigned key whose ascending order is the
+ * requested order (NA first/last, asc/desc).  Returns nsigbits.
+ * ---------------------------------------------------------------------- */
+static int nbits_u64(uint64_t v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
+
+static int transform_key(const dto_col* col, int64_t n, const int32_t* order,
+                         int na_pos, uint64_t* x)
+{
+  const int st = col->stype;
+  const int asc = !(col->flags & FLAG_DESC);
+  if (st == ST_BOOL) {
+    /* sort.cc:689-720: NA -> 0 (first) / 3 (last); ASC: x+1; DESC: (128-x)>>6 */
+    const uint8_t* xi = (const uint8_t*)col->data;
+    uint8_t rna = (na_pos == NA_LAST) ? 3 : 0;
+    for (int64_t j = 0; j < n; j++) {
+      uint8_t t = xi[order ? order[j] : j];
+      x[j] = (t == 128) ? rna : asc ? (uint8_t)(t + 1) : (uint8_t)((uint8_t)(128 - t) >> 6);
+    }
+    return 2;
+  }
+  if (st == ST_FLOAT32 || st == ST_FLOAT64) {
+    /* sort.cc:808-845 */
+    const int w = (st == ST_FLOAT64);
+    const uint64_t EXP = w ? 0x7FF0000000000000ULL : 0x7F800000ULL;
+    const uint64_t SIG = w ? 0x000FFFFFFFFFFFFFULL : 0x007FFFFFULL;
+    const uint64_t SBT = w ? 0x8000000000000000ULL : 0x80000000ULL;
+    const uint64_t ALL = w ? 0xFFFFFFFFFFFFFFFFULL : 0xFFFFFFFFULL;
+    const int SHIFT = w ? 63 : 31;
+    const uint64_t rna = (na_pos == NA_LAST) ? ALL : 0;
+    for (int64_t j = 0; j < n; j++) {
+      int64_t i = order ? order[j] : j;
+      uint64_t t = w ? ((const uint64_t*)col->data)[i] : ((const uint32_t*)col->data)[i];
+      if ((t & EXP) == EXP && (t & SIG) != 0) x[j] = rna;
+      else if (asc) x[j] = (t ^ (SBT | (0 - (t >> SHIFT)))) & ALL;
+      else          x[j] = (t ^ (~SBT & ((t >> SHIFT) - 1))) & ALL;
+    }
+    return w ? 64 : 32;
+  }
+  /* integers: sort.cc:728-776 -- min/max over valid values (stats.cc:601-640),
+     x = NA ? 0 : key - min + 1   (ASC, NA first)
+         NA ? 0 : max - key + 1   (DESC, NA first)
+     NA last: NA -> max-min+1 and no +1 increment. */
+  int64_t mn = INT64_MAX, mx = INT64_MIN; int any = 0;
+  for (int64_t j = 0; j < n; j++) {
+    int na; int64_t v = load_int(col->data, st, j, &na);
+    if (na) continue;
+    any = 1; if (v < mn) mn = v; if (v > mx) mx = v;
+  }
+  if (!any) { mn = 0; mx = 0; }
+  const uint64_t range1 = (uint64_t)mx - (uint64_t)mn + 1;    /* max-min+1, may wrap to 0 */
+  const uint64_t rna = (na_pos == NA_LAST) ? range1 : 0;
+  const uint64_t inc = (na_pos == NA_LAST) ? 0 : 1;
+  for (int64_t j = 0; j < n; j++) {
+    int na; int64_t v = load_int(col->data, st, order ? order[j] : j, &na);
+    x[j] = na ? rna : asc ? ((uint64_t)v - (uint64_t)mn + inc)
+                          : ((uint64_t)mx - (uint64_t)v + inc);
+  }
+  int nb = nbits_u64(range1);
+  return nb ? nb : 64;
+}
+
+/* Stable LSD byte-radix sort of (x, o) by x, skipping constant bytes. */
+static void stable_sort_pairs(uint64_t* x, int32_t* o, int64_t n, int nsigbits)
+{
+  if (n < 2) return;
+  uint64_t* x2 = (uint64_t*)malloc((size_t)n * 8);
+  int32_t*  o2 = (int32_t*)malloc((size_t)n * 4);
+  int nbytes = (nsigbits + 7) / 8;
+  for (int b = 0; b < nbytes; b++) {
+    int64_t cnt[256]; memset(cnt, 0, sizeof(cnt));
+    const int sh = b * 8;
+    for (int64_t i = 0; i < n; i++) cnt[(x[i] >> sh) & 255]++;
+    int constant = 0;
+    for (int d = 0; d < 256; d++) if (cnt[d] == n) constant = 1;
+    if (constant) continue;
+    int64_t s = 0;
+    for (int d = 0; d < 256; d++) { int64_t c = cnt[d]; cnt[d] = s; s += c; }
+    for (int64_t i = 0; i < n; i++) {
+      int64_t k = cnt[(x[i] >> sh) & 255]++;
+      x2[k] = x[i]; o2[k] = o[i];
+    }
+    memcpy(x, x2, (size_t)n * 8); memcpy(o, o2, (size_t)n * 4);
+  }
+  free(x2); free(o2);
+}
+
+/*
+ * group(): sort.cc:1411-1495.  keys[0] is the most significant key.
+ * Outputs: rowindex[n] (ARR32 ordering), offsets[ngroups+1] (Groupby,
+ * groupby.h:54-91), *ngroups.  `offsets` must have room for n+1 entries
+ * (same as the reference's scratch, sort.cc:513).
+ * Multi-key (continue_sort, sort.cc:561-595): each existing group is
+ * sub-sorted by the next key; equivalent to a stable sort by the last key
+ * first, then by each earlier key (LSD over columns), which is what we do.
+ */
+int dto_group(const dto_col* keys, int nkeys, int64_t n, int na_pos,
+              int32_t* rowindex, int32_t* offsets, int64_t* ngroups)
+{
+  if (n > INT32_MAX) return -1;
+  if (n == 0) { *ngroups = 0; offsets[0] = 0; return 0; }   /* Groupby::zero_groups */
+  for (int64_t i = 0; i < n; i++) rowindex[i] = (int32_t)i;
+  uint64_t* x = (uint64_t*)malloc((size_t)n * 8);
+  for (int k = nkeys - 1; k >= 0; k--) {
+    int nsig = transform_key(&keys[k], n, rowindex, na_pos, x);
+    stable_sort_pairs(x, rowindex, n, nsig);
+  }
+  /* group boundaries: a new group starts wherever any transformed key differs
+     from the previous row's (GroupGatherer::from_data, sort_groups.cc:41-82) */
+  uint8_t* head = (uint8_t*)calloc((size_t)n, 1);
+  head[0] = 1;
+  for (int k = 0; k < nkeys; k++) {
+    transform_key(&keys[k], n, rowindex, na_pos, x);
+    for (int64_t i = 1; i < n; i++) if (x[i] != x[i - 1]) head[i] = 1;
+  }
+  int64_t ng = 0;
+  for (int64_t i = 0; i < n; i++) if (head[i]) offsets[ng++] = (int32_t)i;
+  offsets[ng] = (int32_t)n;
+  *ngroups = ng;
+  free(head); free(x);
+  return 0;
+}
+
+/* rowindex_array.cc:130-170: ascending ARR32 of rows where mask is 1 and not NA */
+int64_t dto_bool_to_rowindex(const int8_t* mask, int64_t n, int32_t* out)
+{
+  int64_t k = 0;
+  for (int64_t i = 0; i < n; i++) {
+    int8_t v = mask[i];
+    if (v != INT8_MIN && v) out[k++] = (int32_t)i;
+  }
+  return k;
+}
+
+/* x > c style predicate as the reference evaluates it before building the
+ * RowIndex (expr/fbinary/fexpr__compare__.cc): NA compares false.
+ * cmp: 0 '>', 1 '>=', 2 '<', 3 '<=', 4 '==', 5 '!='  ('!=' is true for NA vs value) */
+int64_t dto_filter_cmp(const dto_col* col, int64_t n, int cmp, double cf, int64_t ci,
+                       int32_t* out)
+{
+  int64_t k = 0;
+  const int st = col->stype;
+  for (int64_t i = 0; i < n; i++) {
+    int r;
+    if (st == ST_FLOAT32 || st == ST_FLOAT64) {
+      double v = (st == ST_FLOAT64) ? ((const double*)col->data)[i] : (double)((const float*)col->data)[i];
+      int na = isnan(v);
+      switch (cmp) {
+        case 0: r = !na && v > cf; break;  case 1: r = !na && v >= cf; break;
+        case 2: r = !na && v < cf; break;  case 3: r = !na && v <= cf; break;
+        case 4: r = !na && v == cf; break; default: r = na || v != cf; break;
+      }
+    } else {
+      int na; int64_t v = load_int(col->data, st, i, &na);
+      switch (cmp) {
+        case 0: r = !na && v > ci; break;  case 1: r = !na && v >= ci; break;
+        case 2: r = !na && v < ci; break;  case 3: r = !na && v <= ci; break;
+        case 4: r = !na && v == ci; break; default: r = na || v != ci; break;
+      }
+    }
+    if (r) out[k++] = (int32_t)i;
+  }
+  return k;
+}
+
+/* materialise a column through an ARR32 RowIndex: column/view.cc:140-145
+ * (negative index -> NA) + column_impl.cc:78-101 */
+int dto_gather(const dto_col* col, const int32_t* ri, int64_t nout, void* out)
+{
+  const int st = col->stype; const int sz = stype_size(st);
+  for (int64_t i = 0; i < nout; i++) {
+    int32_t j = ri[i];
+    if (j >= 0) { memcpy((char*)out + i * sz, (const char*)col->data + (int64_t)j * sz, sz); continue; }
+    switch (st) {
+      case ST_BOOL: case ST_INT8: ((int8_t*)out)[i] = INT8_MIN; break;
+      case ST_INT16: ((int16_t*)out)[i] = INT16_MIN; break;
+      case ST_INT32: ((int32_t*)out)[i] = INT32_MIN; break;
+      case ST_INT64: ((int64_t*)out)[i] = INT64_MIN; break;
+      case ST_FLOAT32: ((float*)out)[i] = NAN; break;
+      default: ((double*)out)[i] = NAN; break;
+    }
+  }
+  return 0;
+}
+
+/* output stype of a reducer: fexpr_sumprod.cc:47-66, fexpr_mean.cc:45-74,
+ * fexpr_minmax.cc:47-68, fexpr_count.cc (always int64) */
+int dto_reduce_out_stype(int op, int st)
+{
+  switch (op) {
+    case OP_SUM:  return st == ST_FLOAT32 ? ST_FLOAT32 : st == ST_FLOAT64 ? ST_FLOAT64 : ST_INT64;
+    case OP_MEAN: return st == ST_FLOAT32 ? ST_FLOAT32 : ST_FLOAT64;
+    case OP_MIN: case OP_MAX: return st;
+    default: return ST_INT64;
+  }
+}
+
+/*
+ * Per-group reducers.  value column is read through `ri` (nullable: identity)
+ * at positions [offsets[g], offsets[g+1]).  `out` has the reducer's output
+ * stype and NA results are stored as that stype's sentinel (what
+ * _materialize_fw writes, column_impl.cc:92-99).
+ */
+int dto_reduce(int op, const dto_col* col, const int32_t* ri, const int32_t* offsets,
+               int64_t ng, void* out)
+{
+  const int st = col ? col->stype : 0;
+  const int isf = (st == ST_FLOAT32 || st == ST_FLOAT64);
+  for (int64_t g = 0; g < ng; g++) {
+    const int64_t i0 = offsets[g], i1 = offsets[g + 1];
+    if (op == OP_COUNT0) { ((int64_t*)out)[g] = i1 - i0; continue; }     /* count.h:77-88 */
+    if (isf) {
+      double dsum = 0; float fsum = 0; int64_t cnt = 0;
+      double best = 0; int have = 0;
+      for (int64_t gi = i0; gi < i1; gi++) {
+        int64_t j = ri ? ri[gi] : gi;
+        if (j < 0) continue;                                             /* NA index -> NA value */
+        double v; float vf = 0;
+        if (st == ST_FLOAT64) v = ((const double*)col->data)[j];
+        else { vf = ((const float*)col->data)[j]; v = (double)vf; }
+        if (isnan(v)) continue;
+        cnt++;
+        if (op == OP_SUM) { if (st == ST_FLOAT64) dsum = dsum + v; else fsum = fsum + vf; }  /* sumprod.h:48-55: accumulate in T */
+        else if (op == OP_MEAN) dsum += v;                                /* mean.h:41-47: double */
+        else if (op == OP_MIN) { if (v < best || !have) { best = v; have = 1; } }  /* minmax.h:44-57 */
+        else if (op == OP_MAX) { if (v > best || !have) { best = v; have = 1; } }
+      }
+      switch (op) {
+        case OP_SUM: if (st == ST_FLOAT64) ((double*)out)[g] = dsum; else ((float*)out)[g] = fsum; break;
+        case OP_MEAN:
+          if (st == ST_FLOAT64) ((double*)out)[g] = cnt ? dsum / (double)cnt : NAN;
+          else ((float*)out)[g] = cnt ? (float)(dsum / (double)cnt) : NAN;   /* mean.h:50 static_cast<T>(sum/count) */
+          break;
+        case OP_MIN: case OP_MAX:
+          if (st == ST_FLOAT64) ((double*)out)[g] = have ? best : NAN;
+          else ((float*)out)[g] = have ? (float)best : NAN;
+          break;
+        default: ((int64_t*)out)[g] = cnt; break;                           /* count.h:35-58 */
+      }
+    } else {
+      uint64_t isum = 0; double dsum = 0; int64_t cnt = 0; int64_t best = 0; int have = 0;
+      for (int64_t gi = i0; gi < i1; gi++) {
+        int64_t j = ri ? ri[gi] : gi;
+        if (j < 0) continue;
+        int na; int64_t v = load_int(col->data, st, j, &na);
+        if (na) continue;
+        cnt++;
+        if (op == OP_SUM) isum += (uint64_t)v;             /* int64 accumulate, wraps (fexpr_sumprod.cc:55-60) */
+        else if (op == OP_MEAN) dsum += (double)v;         /* cast to double first (fexpr_mean.cc:60-62) */
+        else if (op == OP_MIN) { if (v < best || !have) { best = v; have = 1; } }
+        else if (op == OP_MAX) { if (v > best || !have) { best = v; have = 1; } }
+      }
+      switch (op) {
+        case OP_SUM: ((int64_t*)out)[g] = (int64_t)isum; break;
+        case OP_MEAN: ((double*)out)[g] = cnt ? dsum / (double)cnt : NAN; break;
+        case OP_MIN: case OP_MAX:
+          switch (st) {
+            case ST_BOOL: case ST_INT8: ((int8_t*)out)[g] = have ? (int8_t)best : INT8_MIN; break;
+            case ST_INT16: ((int16_t*)out)[g] = have ? (int16_t)best : INT16_MIN; break;
+            case ST_INT32: ((int32_t*)out)[g] = have ? (int32_t)best : INT32_MIN; break;
+            default: ((int64_t*)out)[g] = have ? best : INT64_MIN; break;
+          }
+          break;
+        default: ((int64_t*)out)[g] = cnt; break;
+      }
+    }
+  }
+  return 0;
+}

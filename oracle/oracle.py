@@ -1,0 +1,133 @@
+"""ctypes binding of oracle/libdtoracle.so (see dt_oracle.c for the reference
+file:line each function restates).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdtoracle.so")
+
+# reference SType codes (src/core/stype.h:41-62)
+BOOL, INT8, INT16, INT32, INT64, FLOAT32, FLOAT64 = 1, 2, 3, 4, 5, 6, 7
+SUM, MEAN, MIN, MAX, COUNT, COUNT0 = 0, 1, 2, 3, 4, 5
+OPS = {"sum": SUM, "mean": MEAN, "min": MIN, "max": MAX, "count": COUNT, "count0": COUNT0}
+_NP2ST = {np.dtype(np.bool_): BOOL, np.dtype(np.int8): INT8, np.dtype(np.int16): INT16,
+          np.dtype(np.int32): INT32, np.dtype(np.int64): INT64,
+          np.dtype(np.float32): FLOAT32, np.dtype(np.float64): FLOAT64}
+_ST2NP = {BOOL: np.int8, INT8: np.int8, INT16: np.int16, INT32: np.int32, INT64: np.int64,
+          FLOAT32: np.float32, FLOAT64: np.float64}
+
+
+class _Col(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stype", C.c_int32), ("flags", C.c_int32)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libdtoracle.so"])
+
+
+def _lib():
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "dt_oracle.c")):
+        build()
+    lib = C.CDLL(_SO)
+    lib.dto_group.restype = C.c_int
+    lib.dto_bool_to_rowindex.restype = C.c_int64
+    lib.dto_filter_cmp.restype = C.c_int64
+    lib.dto_filter_cmp.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_int64, C.c_void_p]
+    return lib
+
+
+_L = None
+
+
+def lib():
+    global _L
+    if _L is None:
+        _L = _lib()
+    return _L
+
+
+def stype_of(a, stype=None):
+    if stype is not None:
+        return stype
+    return _NP2ST[a.dtype]
+
+
+def _col(a, stype=None, desc=False):
+    a = np.ascontiguousarray(a)
+    st = stype_of(a, stype)
+    if a.dtype == np.bool_:
+        a = a.view(np.int8)
+    return a, _Col(a.ctypes.data, st, 1 if desc else 0)
+
+
+def group(keys, stypes=None, desc=None, na_last=False):
+    """keys: list of numpy arrays (first = most significant).
+    Returns (rowindex int32[n], offsets int32[ng+1])."""
+    n = len(keys[0])
+    keep, cols = [], (_Col * len(keys))()
+    for i, k in enumerate(keys):
+        a, c = _col(k, stypes[i] if stypes else None, bool(desc[i]) if desc else False)
+        keep.append(a)
+        cols[i] = c
+    ri = np.empty(n, np.int32)
+    off = np.empty(n + 1, np.int32)
+    ng = C.c_int64(0)
+    rc = lib().dto_group(cols, C.c_int(len(keys)), C.c_int64(n), C.c_int(1 if na_last else 0),
+                         C.c_void_p(ri.ctypes.data), C.c_void_p(off.ctypes.data), C.byref(ng))
+    if rc != 0:
+        raise ValueError("dto_group failed")
+    return ri, off[:ng.value + 1].copy()
+
+
+def reduce(op, values, ri, offsets, stype=None):
+    """op: name or code. values: numpy array or None (count0). Returns numpy array[ng]
+    in the reducer's output stype with NA stored as the stype sentinel."""
+    opc = OPS[op] if isinstance(op, str) else op
+    ng = len(offsets) - 1
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    rip = None
+    if ri is not None:
+        ri = np.ascontiguousarray(ri, np.int32)
+        rip = C.c_void_p(ri.ctypes.data)
+    if opc == COUNT0:
+        out = np.empty(ng, np.int64)
+        lib().dto_reduce(C.c_int(opc), None, rip, C.c_void_p(offsets.ctypes.data), C.c_int64(ng),
+                         C.c_void_p(out.ctypes.data))
+        return out
+    a, c = _col(values, stype)
+    ost = lib().dto_reduce_out_stype(C.c_int(opc), C.c_int(c.stype))
+    out = np.empty(ng, _ST2NP[ost])
+    lib().dto_reduce(C.c_int(opc), C.byref(c), rip, C.c_void_p(offsets.ctypes.data), C.c_int64(ng),
+                     C.c_void_p(out.ctypes.data))
+    return out
+
+
+def bool_to_rowindex(mask):
+    m = np.ascontiguousarray(mask)
+    if m.dtype == np.bool_:
+        m = m.view(np.int8)
+    out = np.empty(len(m), np.int32)
+    k = lib().dto_bool_to_rowindex(C.c_void_p(m.ctypes.data), C.c_int64(len(m)), C.c_void_p(out.ctypes.data))
+    return out[:k].copy()
+
+
+CMP = {">": 0, ">=": 1, "<": 2, "<=": 3, "==": 4, "!=": 5}
+
+
+def filter_cmp(values, cmp, scalar, stype=None):
+    a, c = _col(values, stype)
+    out = np.empty(len(a), np.int32)
+    isf = c.stype in (FLOAT32, FLOAT64)
+    k = lib().dto_filter_cmp(C.addressof(c), len(a), CMP[cmp], float(scalar), 0 if isf else int(scalar),
+                             out.ctypes.data)
+    return out[:k].copy()
+
+
+def gather(values, ri, stype=None):
+    a, c = _col(values, stype)
+    ri = np.ascontiguousarray(ri, np.int32)
+    out = np.empty(len(ri), a.dtype)
+    lib().dto_gather(C.byref(c), C.c_void_p(ri.ctypes.data), C.c_int64(len(ri)), C.c_void_p(out.ctypes.data))
+    return out
