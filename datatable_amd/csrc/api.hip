@@ -1,0 +1,924 @@
+// api.hip -- the C ABI of libdthip.so (include/dthip.h): context management and
+// the host-side orchestration of the groupby / reduce / RowIndex kernels.
+//
+// Orchestration mirrors what the reference does around its kernels:
+//   dthip_groupby      ~ group()                    src/core/sort.cc:1411-1495
+//   dthip_groupby_agg  ~ EvalContext::evaluate()    src/core/expr/eval_context.cc:144-172,
+//                        compute_groupby_and_sort() :249-288, evaluate_select() :497-508
+//   dthip_reduce       ~ FExpr_ReduceUnary::evaluate_n  src/core/expr/fexpr_reduce_unary.cc:32-69
+#include <cstdarg>
+#include <algorithm>
+#include "common.hpp"
+
+namespace dthip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- caching device allocator ------------------------------------------------
+int dev_alloc(dthip_ctx* ctx, size_t bytes, void** out) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0) bytes = 256;
+  auto it = ctx->cache.lower_bound(bytes);
+  if (it != ctx->cache.end() && it->first <= bytes + bytes / 4 + 4096) {
+    *out = it->second;
+    ctx->live[it->second] = it->first;
+    ctx->cached_bytes -= it->first;
+    ctx->cache.erase(it);
+    return DTHIP_OK;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    dev_trim(ctx);
+    e = hipMalloc(&p, bytes);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    return DTHIP_ENOMEM;
+  }
+  ctx->live[p] = bytes;
+  *out = p;
+  return DTHIP_OK;
+}
+
+void dev_release(dthip_ctx* ctx, void* p) {
+  if (!p) return;
+  auto it = ctx->live.find(p);
+  if (it == ctx->live.end()) return;
+  ctx->cache.emplace(it->second, p);
+  ctx->cached_bytes += it->second;
+  ctx->live.erase(it);
+}
+
+int dev_trim(dthip_ctx* ctx) {
+  if (ctx->cache.empty()) return DTHIP_OK;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->cache) (void)hipFree(kv.second);
+  ctx->cache.clear();
+  ctx->cached_bytes = 0;
+  return DTHIP_OK;
+}
+
+int read_back(dthip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+  if (bytes > ctx->pinned_bytes) {
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr;
+    size_t nb = std::max<size_t>(bytes, 1 << 16);
+    DTHIP_CHECK_HIP(hipHostMalloc(&ctx->pinned, nb, hipHostMallocDefault));
+    ctx->pinned_bytes = nb;
+  }
+  DTHIP_CHECK_HIP(hipMemcpyAsync(ctx->pinned, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  memcpy(host_dst, ctx->pinned, bytes);
+  return DTHIP_OK;
+}
+
+hipEvent_t prof_event(dthip_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    hipEvent_t e = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+int prof_flush(dthip_ctx* ctx) {
+  if (ctx->pending.empty()) return DTHIP_OK;
+  DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      auto& a = ctx->acc[r.name];
+      a.ms += ms;
+      a.n += 1;
+    }
+    ctx->event_pool.push_back(r.a);
+    ctx->event_pool.push_back(r.b);
+  }
+  ctx->pending.clear();
+  return DTHIP_OK;
+}
+
+// ---- staging of host columns ---------------------------------------------------
+static int stage_in(dthip_ctx* ctx, Scratch& sc, const void* src, size_t bytes, int mem, const void** dev) {
+  if (mem == DTHIP_DEVICE || src == nullptr) { *dev = src; return DTHIP_OK; }
+  unsigned char* d = nullptr;
+  DTHIP_TRY(sc.get<unsigned char>(bytes, &d));
+  if (bytes) DTHIP_CHECK_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *dev = d;
+  return DTHIP_OK;
+}
+
+static int copy_out(dthip_ctx* ctx, void* dst, const void* dev_src, size_t bytes, int mem) {
+  if (bytes == 0) return DTHIP_OK;
+  if (!dst || !dev_src) { set_error("copy_out: null pointer"); return DTHIP_EINVAL; }
+  if (mem == DTHIP_DEVICE) {
+    DTHIP_CHECK_HIP(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    DTHIP_CHECK_HIP(hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return DTHIP_OK;
+}
+
+// ---- sort planning ---------------------------------------------------------------
+static int nbits_u64(unsigned long long v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
+
+struct KeyPlan {
+  int nkeys = 0;
+  KeyColDev col[MAX_KEYCOLS];
+  int nsig[MAX_KEYCOLS];
+  // stages of consecutive keys whose packed width is <= 64 bits; stage 0 holds the most significant keys
+  int nstages = 0;
+  int stage_first[MAX_KEYCOLS], stage_last[MAX_KEYCOLS], stage_bits[MAX_KEYCOLS];
+};
+
+// min/max of integer keys -> transform parameters (sort.cc:728-776), packing layout
+static int plan_keys(dthip_ctx* ctx, Scratch& sc, const dthip_col* keys_dev, int nkeys, int64_t n, int na_pos,
+                     KeyPlan* plan) {
+  if (nkeys < 1 || nkeys > MAX_KEYCOLS) { set_error("number of key columns must be 1..%d", MAX_KEYCOLS); return DTHIP_EINVAL; }
+  plan->nkeys = nkeys;
+  MinMax* d_mm = nullptr;
+  DTHIP_TRY(sc.get<MinMax>(nkeys, &d_mm));
+  bool any_int = false;
+  for (int k = 0; k < nkeys; k++) {
+    const int st = keys_dev[k].stype;
+    if (stype_size(st) == 0) { set_error("unsupported key stype %d", st); return DTHIP_ENOTIMPL; }
+    if (st >= DTHIP_INT8 && st <= DTHIP_INT64) {
+      DTHIP_TRY(launch_minmax(ctx, keys_dev[k].data, st, n, d_mm + k));
+      any_int = true;
+    }
+  }
+  MinMax mm[MAX_KEYCOLS];
+  if (any_int) DTHIP_TRY(read_back(ctx, mm, d_mm, sizeof(MinMax) * nkeys));
+  for (int k = 0; k < nkeys; k++) {
+    KeyColDev& c = plan->col[k];
+    const int st = keys_dev[k].stype;
+    c.data = keys_dev[k].data;
+    c.stype = st;
+    c.desc = (keys_dev[k].flags & DTHIP_FLAG_DESCENDING) ? 1 : 0;
+    c.shift = 0;
+    if (st == DTHIP_BOOL) {
+      c.edge = 0; c.inc = 0; c.na_repl = (na_pos == DTHIP_NA_LAST) ? 3 : 0;
+      plan->nsig[k] = 2;
+    } else if (st == DTHIP_FLOAT32) {
+      c.edge = 0; c.inc = 0; c.na_repl = (na_pos == DTHIP_NA_LAST) ? 0xFFFFFFFFULL : 0;
+      plan->nsig[k] = 32;
+    } else if (st == DTHIP_FLOAT64) {
+      c.edge = 0; c.inc = 0; c.na_repl = (na_pos == DTHIP_NA_LAST) ? 0xFFFFFFFFFFFFFFFFULL : 0;
+      plan->nsig[k] = 64;
+    } else {
+      long long mn = mm[k].mn, mx = mm[k].mx;
+      if (mm[k].nvalid == 0) { mn = 0; mx = 0; }
+      const unsigned long long range1 = (unsigned long long)mx - (unsigned long long)mn + 1ULL;
+      c.edge = c.desc ? (unsigned long long)mx : (unsigned long long)mn;
+      c.inc = (na_pos == DTHIP_NA_LAST) ? 0 : 1;
+      c.na_repl = (na_pos == DTHIP_NA_LAST) ? range1 : 0;
+      const int nb = nbits_u64(range1);
+      plan->nsig[k] = nb ? nb : 64;
+    }
+  }
+  // stages, built from the least significant key backwards
+  int stages_rev_first[MAX_KEYCOLS], stages_rev_last[MAX_KEYCOLS], stages_rev_bits[MAX_KEYCOLS];
+  int ns = 0;
+  int k = nkeys - 1;
+  while (k >= 0) {
+    int bits = 0, last = k;
+    while (k >= 0 && bits + plan->nsig[k] <= 64) { bits += plan->nsig[k]; k--; }
+    stages_rev_first[ns] = k + 1; stages_rev_last[ns] = last; stages_rev_bits[ns] = bits;
+    ns++;
+  }
+  plan->nstages = ns;
+  for (int s = 0; s < ns; s++) {
+    plan->stage_first[s] = stages_rev_first[ns - 1 - s];
+    plan->stage_last[s] = stages_rev_last[ns - 1 - s];
+    plan->stage_bits[s] = stages_rev_bits[ns - 1 - s];
+    int sh = 0;
+    for (int j = plan->stage_last[s]; j >= plan->stage_first[s]; j--) { plan->col[j].shift = sh; sh += plan->nsig[j]; }
+  }
+  return DTHIP_OK;
+}
+
+struct PaySpec {
+  int n = 0;
+  const void* in[MAX_PAYCOLS];
+  int width[MAX_PAYCOLS];
+  bool iota = false;            // column 0 is the row number
+};
+
+struct SortOut {
+  void* keys = nullptr;         // sorted packed keys (scratch-owned)
+  int key64 = 0;
+  void* pay[MAX_PAYCOLS];       // sorted payload columns (scratch-owned, or the input itself if nothing moved)
+  int npasses_run = 0;
+};
+
+// Stable sort of rows by one stage of packed keys, moving the payload columns along.
+// `order` (nullable): the key columns are read through this ordering (later stages).
+static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stage, int64_t n,
+                      const int32_t* order, const PaySpec& pay, SortOut* out) {
+  const int bits = plan.stage_bits[stage];
+  const int key64 = bits > 32;
+  const size_t ksz = key64 ? 8 : 4;
+  out->key64 = key64;
+  int npass = (bits + 7) / 8;
+  if (npass > MAX_PASSES) npass = MAX_PASSES;
+  XformArgs xa;
+  memset(&xa, 0, sizeof(xa));
+  xa.ncols = plan.stage_last[stage] - plan.stage_first[stage] + 1;
+  for (int j = 0; j < xa.ncols; j++) xa.cols[j] = plan.col[plan.stage_first[stage] + j];
+  xa.n = (uint32_t)n;
+  xa.order = order;
+  xa.out64 = key64;
+  xa.npass = npass;
+  {
+    const int base = bits / npass, rem = bits % npass;
+    int sh = 0;
+    for (int p = 0; p < npass; p++) { xa.pbits[p] = base + (p < rem ? 1 : 0); xa.pshift[p] = sh; sh += xa.pbits[p]; }
+  }
+  unsigned char* kA = nullptr;
+  DTHIP_TRY(sc.get<unsigned char>((size_t)n * ksz, &kA));
+  uint32_t* hist = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)2 * MAX_PASSES * HIST_STRIDE, &hist));
+  uint32_t* base = hist + MAX_PASSES * HIST_STRIDE;
+  DTHIP_CHECK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * MAX_PASSES * HIST_STRIDE, ctx->stream));
+  xa.out = kA;
+  xa.hist = hist;
+  DTHIP_TRY(launch_xform_hist(ctx, xa));
+  // which passes actually permute anything?
+  std::vector<uint32_t> hh((size_t)npass * HIST_STRIDE);
+  DTHIP_TRY(read_back(ctx, hh.data(), hist, hh.size() * sizeof(uint32_t)));
+  int active[MAX_PASSES], nactive = 0;
+  for (int p = 0; p < npass; p++) {
+    bool constant = false;
+    for (int d = 0; d < (1 << xa.pbits[p]); d++) if (hh[(size_t)p * HIST_STRIDE + d] == (uint32_t)n) constant = true;
+    if (!constant) active[nactive++] = p;
+  }
+  out->npasses_run = nactive;
+  for (int c = 0; c < pay.n; c++) out->pay[c] = const_cast<void*>(pay.in[c]);
+  if (nactive == 0) {
+    out->keys = kA;
+    if (pay.iota) {
+      int32_t* ri = nullptr;
+      DTHIP_TRY(sc.get<int32_t>((size_t)n, &ri));
+      DTHIP_TRY(launch_iota(ctx, ri, n));
+      out->pay[0] = ri;
+    }
+    return DTHIP_OK;
+  }
+  DTHIP_TRY(launch_hist_scan(ctx, hist, base, npass));
+  const uint32_t tile = radix_tile_items(key64, 8);
+  const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
+  size_t state_words = 0;
+  for (int i = 0; i < nactive; i++) state_words += (size_t)ntiles << xa.pbits[active[i]];
+  unsigned long long* state = nullptr;
+  DTHIP_TRY(sc.get<unsigned long long>(state_words + 64, &state));
+  DTHIP_CHECK_HIP(hipMemsetAsync(state, 0, (state_words + 64) * 8, ctx->stream));
+  uint32_t* tickets = reinterpret_cast<uint32_t*>(state + state_words);   // [MAX_PASSES] + err flag
+  int* err = reinterpret_cast<int*>(tickets + 16);
+  unsigned char* kB = nullptr;
+  DTHIP_TRY(sc.get<unsigned char>((size_t)n * ksz, &kB));
+  void* pbuf[2][MAX_PAYCOLS];
+  for (int c = 0; c < pay.n; c++) {
+    unsigned char* b0 = nullptr;
+    DTHIP_TRY(sc.get<unsigned char>((size_t)n * pay.width[c], &b0));
+    pbuf[0][c] = b0;
+    pbuf[1][c] = nullptr;
+    if (nactive > 1) {
+      unsigned char* b1 = nullptr;
+      DTHIP_TRY(sc.get<unsigned char>((size_t)n * pay.width[c], &b1));
+      pbuf[1][c] = b1;
+    }
+  }
+  unsigned char* kin = kA; unsigned char* kout = kB;
+  size_t st_off = 0;
+  for (int i = 0; i < nactive; i++) {
+    const int p = active[i];
+    RadixPass rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.kin = kin; rp.kout = kout; rp.key64 = key64; rp.n = (uint32_t)n;
+    rp.shift = xa.pshift[p]; rp.bits = xa.pbits[p];
+    rp.base = base + (size_t)p * HIST_STRIDE;
+    rp.state = state + st_off;
+    st_off += (size_t)ntiles << xa.pbits[p];
+    rp.ticket = tickets + i;
+    rp.err = err;
+    rp.iota = (i == 0 && pay.iota) ? 1 : 0;
+    rp.pay.n = pay.n;
+    for (int c = 0; c < pay.n; c++) {
+      rp.pay.in[c] = (i == 0) ? pay.in[c] : pbuf[(i - 1) & 1][c];
+      rp.pay.out[c] = pbuf[i & 1][c];
+      rp.pay.width[c] = pay.width[c];
+    }
+    DTHIP_TRY(launch_radix_pass(ctx, rp));
+    std::swap(kin, kout);
+  }
+  out->keys = kin;
+  for (int c = 0; c < pay.n; c++) out->pay[c] = pbuf[(nactive - 1) & 1][c];
+  return DTHIP_OK;
+}
+
+}  // namespace dthip
+
+using namespace dthip;
+
+struct dthip_result {
+  int64_t nrows = 0, ngroups = 0;
+  int32_t* rowindex = nullptr;
+  int32_t* offsets = nullptr;
+  int nkeys = 0;
+  void* key[MAX_KEYCOLS] = {};
+  int key_stype[MAX_KEYCOLS] = {};
+  int naggs = 0;
+  std::vector<void*> agg;
+  std::vector<int> agg_stype;
+  std::vector<void*> owned;
+};
+
+namespace dthip {
+
+static int result_alloc(dthip_ctx* ctx, dthip_result* r, size_t bytes, void** out) {
+  DTHIP_TRY(dev_alloc(ctx, bytes, out));
+  r->owned.push_back(*out);
+  return DTHIP_OK;
+}
+
+static void result_adopt(Scratch& sc, dthip_result* r, void* p) {
+  sc.disown(p);
+  r->owned.push_back(p);
+}
+
+static void result_destroy(dthip_ctx* ctx, dthip_result* r) {
+  for (void* p : r->owned) dev_release(ctx, p);
+  delete r;
+}
+
+// internal grouping state shared by groupby / groupby_agg / generic path
+struct Grouping {
+  int64_t n = 0, ngroups = 0;
+  int32_t* rowindex = nullptr;          // scratch-owned (nullable)
+  int32_t* offsets = nullptr;           // result-owned
+  unsigned long long* bitmap = nullptr; // scratch-owned
+  uint32_t* tile_first = nullptr;       // scratch-owned: index of first head per 2048-tile
+  void* sorted_keys = nullptr; int key64 = 0;
+  void* pay[MAX_PAYCOLS];
+};
+
+static int heads_to_offsets(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const void* keys, int key64,
+                            const uint8_t* heads, int64_t n, Grouping* g) {
+  const uint32_t nt = (uint32_t)((n + SEG_TILE - 1) / SEG_TILE);
+  uint32_t* tile_counts = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 2, &tile_counts));
+  unsigned long long* bitmap = nullptr;
+  DTHIP_TRY(sc.get<unsigned long long>((size_t)((n + 63) / 64) + 1, &bitmap));
+  int64_t ng = 0;
+  DTHIP_TRY(launch_count_heads(ctx, keys, key64, heads, n, tile_counts, bitmap, tile_counts + nt, &ng));
+  void* off = nullptr;
+  DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * (size_t)(ng + 1), &off));
+  DTHIP_TRY(launch_write_offsets(ctx, keys, key64, heads, n, tile_counts, ng, static_cast<int32_t*>(off)));
+  g->n = n; g->ngroups = ng; g->offsets = static_cast<int32_t*>(off);
+  g->bitmap = bitmap; g->tile_first = tile_counts;
+  return DTHIP_OK;
+}
+
+// full group(): ordering + offsets (+ head bitmap) for any number of keys
+static int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthip_col* keys_dev, int nkeys,
+                      int64_t n, int na_pos, KeyPlan* plan, Grouping* g) {
+  DTHIP_TRY(plan_keys(ctx, sc, keys_dev, nkeys, n, na_pos, plan));
+  const int32_t* order = nullptr;
+  SortOut so;
+  for (int s = plan->nstages - 1; s >= 0; s--) {
+    PaySpec ps;
+    ps.n = 1; ps.width[0] = 4;
+    if (order) { ps.in[0] = order; ps.iota = false; } else { ps.in[0] = nullptr; ps.iota = true; }
+    DTHIP_TRY(sort_stage(ctx, sc, *plan, s, n, order, ps, &so));
+    order = static_cast<const int32_t*>(so.pay[0]);
+  }
+  g->rowindex = const_cast<int32_t*>(order);
+  g->sorted_keys = so.keys; g->key64 = so.key64;
+  if (plan->nstages == 1) {
+    DTHIP_TRY(heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, n, g));
+  } else {
+    uint8_t* heads = nullptr;
+    DTHIP_TRY(sc.get<uint8_t>((size_t)n, &heads));
+    DTHIP_CHECK_HIP(hipMemsetAsync(heads, 0, (size_t)n, ctx->stream));
+    for (int s = 0; s < plan->nstages; s++) {
+      const int bits = plan->stage_bits[s];
+      XformArgs xa;
+      memset(&xa, 0, sizeof(xa));
+      xa.ncols = plan->stage_last[s] - plan->stage_first[s] + 1;
+      for (int j = 0; j < xa.ncols; j++) xa.cols[j] = plan->col[plan->stage_first[s] + j];
+      xa.n = (uint32_t)n; xa.order = order; xa.out64 = bits > 32; xa.npass = 0;
+      unsigned char* kk = nullptr;
+      DTHIP_TRY(sc.get<unsigned char>((size_t)n * (xa.out64 ? 8 : 4), &kk));
+      uint32_t* dummy = nullptr;
+      DTHIP_TRY(sc.get<uint32_t>(16, &dummy));
+      xa.out = kk; xa.hist = dummy;
+      DTHIP_TRY(launch_xform_hist(ctx, xa));
+      DTHIP_TRY(launch_mark_heads(ctx, kk, xa.out64, n, heads));
+    }
+    DTHIP_TRY(heads_to_offsets(ctx, sc, res, nullptr, 0, heads, n, g));
+  }
+  return DTHIP_OK;
+}
+
+static int check_common(dthip_ctx* ctx, int64_t nrows, int mem) {
+  if (!ctx) { set_error("null context"); return DTHIP_EINVAL; }
+  if (nrows < 0 || nrows > (int64_t)INT32_MAX) {
+    set_error("nrows=%lld is outside [0, 2^31-1]: RowIndex and group offsets are int32", (long long)nrows);
+    return DTHIP_EINVAL;
+  }
+  if (mem != DTHIP_HOST && mem != DTHIP_DEVICE) { set_error("bad mem space %d", mem); return DTHIP_EINVAL; }
+  DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  return DTHIP_OK;
+}
+
+static int stage_cols(dthip_ctx* ctx, Scratch& sc, const dthip_col* cols, int ncols, int64_t nrows, int mem,
+                      std::vector<dthip_col>* out) {
+  out->resize(ncols);
+  for (int i = 0; i < ncols; i++) {
+    const int sz = stype_size(cols[i].stype);
+    if (sz == 0) { set_error("unsupported stype %d", cols[i].stype); return DTHIP_ENOTIMPL; }
+    if (nrows > 0 && cols[i].data == nullptr) { set_error("null column data"); return DTHIP_EINVAL; }
+    (*out)[i] = cols[i];
+    DTHIP_TRY(stage_in(ctx, sc, cols[i].data, (size_t)nrows * sz, mem, &(*out)[i].data));
+  }
+  return DTHIP_OK;
+}
+
+static int empty_result(dthip_ctx* ctx, dthip_result* res) {
+  void* off = nullptr;
+  DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t), &off));
+  DTHIP_CHECK_HIP(hipMemsetAsync(off, 0, sizeof(int32_t), ctx->stream));
+  res->offsets = static_cast<int32_t*>(off);
+  res->nrows = 0; res->ngroups = 0;
+  return DTHIP_OK;
+}
+
+static int reduce_outs_for(int op, void* dst, ReduceOuts* o) {
+  switch (op) {
+    case DTHIP_SUM: o->sum = dst; break;
+    case DTHIP_MEAN: o->mean = dst; break;
+    case DTHIP_MIN: o->mn = dst; break;
+    case DTHIP_MAX: o->mx = dst; break;
+    case DTHIP_COUNT: o->count = static_cast<int64_t*>(dst); break;
+    default: set_error("bad reducer op %d", op); return DTHIP_EINVAL;
+  }
+  return DTHIP_OK;
+}
+
+}  // namespace dthip
+
+extern "C" {
+
+int dthip_abi_version(void) { return DTHIP_ABI_VERSION; }
+const char* dthip_last_error(void) { return g_err; }
+
+int dthip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int dthip_init(int device, void* stream, dthip_ctx** out) {
+  if (!out) { set_error("null out"); return DTHIP_EINVAL; }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available (%s): libdthip has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    return DTHIP_EDEVICE;
+  }
+  if (device < 0 || device >= n) { set_error("device %d out of range (0..%d)", device, n - 1); return DTHIP_EINVAL; }
+  DTHIP_CHECK_HIP(hipSetDevice(device));
+  dthip_ctx* ctx = new dthip_ctx();
+  ctx->device = device;
+  if (stream) { ctx->stream = static_cast<hipStream_t>(stream); ctx->own_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx; set_error("hipStreamCreate failed"); return DTHIP_EDEVICE;
+    }
+    ctx->own_stream = true;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  (void)hipEventCreate(&ctx->t0);
+  (void)hipEventCreate(&ctx->t1);
+  *out = ctx;
+  return DTHIP_OK;
+}
+
+int dthip_destroy(dthip_ctx* ctx) {
+  if (!ctx) return DTHIP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  prof_flush(ctx);
+  dev_trim(ctx);
+  for (auto& kv : ctx->live) (void)hipFree(kv.first);
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return DTHIP_OK;
+}
+
+int dthip_sync(dthip_ctx* ctx) {
+  if (!ctx) { set_error("null context"); return DTHIP_EINVAL; }
+  DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return DTHIP_OK;
+}
+
+int dthip_trim(dthip_ctx* ctx) { return ctx ? dev_trim(ctx) : DTHIP_EINVAL; }
+
+int dthip_malloc(dthip_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) { set_error("null argument"); return DTHIP_EINVAL; }
+  DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  return dev_alloc(ctx, bytes, dptr);
+}
+int dthip_free(dthip_ctx* ctx, void* dptr) {
+  if (!ctx) return DTHIP_EINVAL;
+  dev_release(ctx, dptr);
+  return DTHIP_OK;
+}
+int dthip_memcpy_h2d(dthip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return DTHIP_EINVAL;
+  if (bytes == 0) return DTHIP_OK;
+  DTHIP_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return DTHIP_OK;
+}
+int dthip_memcpy_d2h(dthip_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return DTHIP_EINVAL;
+  if (bytes == 0) return DTHIP_OK;
+  DTHIP_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return DTHIP_OK;
+}
+
+int dthip_timer_start(dthip_ctx* ctx) {
+  if (!ctx) return DTHIP_EINVAL;
+  DTHIP_CHECK_HIP(hipEventRecord(ctx->t0, ctx->stream));
+  return DTHIP_OK;
+}
+int dthip_timer_stop(dthip_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return DTHIP_EINVAL;
+  DTHIP_CHECK_HIP(hipEventRecord(ctx->t1, ctx->stream));
+  DTHIP_CHECK_HIP(hipEventSynchronize(ctx->t1));
+  DTHIP_CHECK_HIP(hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+  return DTHIP_OK;
+}
+
+int dthip_profile_enable(dthip_ctx* ctx, int on) {
+  if (!ctx) return DTHIP_EINVAL;
+  if (!on) prof_flush(ctx);
+  ctx->prof = on != 0;
+  return DTHIP_OK;
+}
+int dthip_profile_reset(dthip_ctx* ctx) {
+  if (!ctx) return DTHIP_EINVAL;
+  prof_flush(ctx);
+  ctx->acc.clear();
+  return DTHIP_OK;
+}
+int dthip_profile_get(dthip_ctx* ctx, const char* name, double* total_ms, int64_t* launches) {
+  if (!ctx || !name) return DTHIP_EINVAL;
+  DTHIP_TRY(prof_flush(ctx));
+  double ms = 0; int64_t n = 0;
+  for (auto& kv : ctx->acc) if (kv.first.find(name) != std::string::npos) { ms += kv.second.ms; n += kv.second.n; }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  return DTHIP_OK;
+}
+int dthip_profile_names(dthip_ctx* ctx, char* buf, size_t buflen) {
+  if (!ctx || !buf || buflen == 0) return DTHIP_EINVAL;
+  DTHIP_TRY(prof_flush(ctx));
+  std::string s;
+  for (auto& kv : ctx->acc) { s += kv.first; s += "\n"; }
+  snprintf(buf, buflen, "%s", s.c_str());
+  return DTHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------
+int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrows, int na_pos, int mem,
+                  int want_rowindex, dthip_result** out) {
+  DTHIP_TRY(check_common(ctx, nrows, mem));
+  if (!keys || !out) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (na_pos != DTHIP_NA_FIRST && na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", na_pos); return DTHIP_ENOTIMPL; }
+  dthip_result* res = new dthip_result();
+  res->nkeys = nkeys;
+  int rc = DTHIP_OK;
+  {
+    Scratch sc(ctx);
+    std::vector<dthip_col> kd;
+    rc = stage_cols(ctx, sc, keys, nkeys, nrows, mem, &kd);
+    if (rc == DTHIP_OK) {
+      if (nrows == 0) {
+        rc = empty_result(ctx, res);   // Groupby::zero_groups(), sort.cc:1428-1431
+      } else {
+        KeyPlan plan; Grouping g;
+        rc = group_core(ctx, sc, res, kd.data(), nkeys, nrows, na_pos, &plan, &g);
+        if (rc == DTHIP_OK) {
+          res->nrows = nrows; res->ngroups = g.ngroups; res->offsets = g.offsets;
+          if (want_rowindex) {
+            // the ordering may alias nothing user-owned here: it is always a scratch buffer
+            result_adopt(sc, res, g.rowindex);
+            res->rowindex = g.rowindex;
+          }
+        }
+      }
+    }
+  }
+  if (rc != DTHIP_OK) { result_destroy(ctx, res); return rc; }
+  *out = res;
+  return DTHIP_OK;
+}
+
+int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dthip_col* values, int nvalues,
+                      const dthip_agg* aggs, int naggs, int64_t nrows, int na_pos, int mem, dthip_result** out) {
+  DTHIP_TRY(check_common(ctx, nrows, mem));
+  if (!keys || !out || (naggs > 0 && !aggs) || (nvalues > 0 && !values)) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (na_pos != DTHIP_NA_FIRST && na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", na_pos); return DTHIP_ENOTIMPL; }
+  for (int a = 0; a < naggs; a++) {
+    if (aggs[a].op < DTHIP_SUM || aggs[a].op > DTHIP_COUNT0) { set_error("bad reducer op %d", aggs[a].op); return DTHIP_EINVAL; }
+    if (aggs[a].op != DTHIP_COUNT0 && (aggs[a].col < 0 || aggs[a].col >= nvalues)) {
+      set_error("agg %d refers to value column %d of %d", a, aggs[a].col, nvalues); return DTHIP_EINVAL;
+    }
+  }
+  dthip_result* res = new dthip_result();
+  res->nkeys = nkeys; res->naggs = naggs;
+  res->agg.assign(naggs, nullptr); res->agg_stype.assign(naggs, 0);
+  for (int a = 0; a < naggs; a++)
+    res->agg_stype[a] = dthip_reduce_out_stype(aggs[a].op, aggs[a].op == DTHIP_COUNT0 ? DTHIP_INT64 : values[aggs[a].col].stype);
+  for (int k = 0; k < nkeys && k < MAX_KEYCOLS; k++) res->key_stype[k] = keys[k].stype;
+  int rc = DTHIP_OK;
+  do {
+    Scratch sc(ctx);
+    std::vector<dthip_col> kd, vd;
+    if ((rc = stage_cols(ctx, sc, keys, nkeys, nrows, mem, &kd)) != DTHIP_OK) break;
+    if ((rc = stage_cols(ctx, sc, values, nvalues, nrows, mem, &vd)) != DTHIP_OK) break;
+    if (nrows == 0) { rc = empty_result(ctx, res); break; }
+    // value columns actually referenced
+    std::vector<int> used;
+    for (int a = 0; a < naggs; a++)
+      if (aggs[a].op != DTHIP_COUNT0 && std::find(used.begin(), used.end(), aggs[a].col) == used.end()) used.push_back(aggs[a].col);
+    bool fused = (int)used.size() <= MAX_PAYCOLS;
+    for (int c : used) if (stype_size(vd[c].stype) < 4) fused = false;
+    KeyPlan plan; Grouping g;
+    std::vector<const void*> sorted_val(nvalues, nullptr);
+    const int32_t* gather_ri = nullptr;
+    if (fused) {
+      if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan)) != DTHIP_OK) break;
+      if (plan.nstages != 1) fused = false;
+    }
+    if (fused) {
+      // values ride through the sort; the RowIndex is never materialised
+      PaySpec ps;
+      ps.n = (int)used.size();
+      for (int i = 0; i < ps.n; i++) { ps.in[i] = vd[used[i]].data; ps.width[i] = stype_size(vd[used[i]].stype); }
+      SortOut so;
+      if ((rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so)) != DTHIP_OK) break;
+      for (int i = 0; i < ps.n; i++) sorted_val[used[i]] = so.pay[i];
+      g.sorted_keys = so.keys; g.key64 = so.key64;
+      if ((rc = heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, nrows, &g)) != DTHIP_OK) break;
+    } else {
+      if ((rc = group_core(ctx, sc, res, kd.data(), nkeys, nrows, na_pos, &plan, &g)) != DTHIP_OK) break;
+      for (int c : used) sorted_val[c] = vd[c].data;
+      gather_ri = g.rowindex;
+    }
+    res->nrows = nrows; res->ngroups = g.ngroups; res->offsets = g.offsets;
+    const int64_t ng = g.ngroups;
+    // group-key columns: value of each key at the first row of its group
+    for (int k = 0; k < nkeys; k++) {
+      void* kp = nullptr;
+      if ((rc = result_alloc(ctx, res, (size_t)ng * stype_size(kd[k].stype), &kp)) != DTHIP_OK) break;
+      res->key[k] = kp;
+      if (fused) {
+        rc = launch_untransform_keys(ctx, g.sorted_keys, g.key64, g.offsets, ng, plan.col[k], plan.nsig[k], kp);
+      } else {
+        int32_t* firstrow = nullptr;
+        if ((rc = sc.get<int32_t>((size_t)ng, &firstrow)) != DTHIP_OK) break;
+        if ((rc = launch_gather(ctx, g.rowindex, DTHIP_INT32, g.offsets, ng, firstrow)) != DTHIP_OK) break;
+        rc = launch_gather(ctx, kd[k].data, kd[k].stype, firstrow, ng, kp);
+      }
+      if (rc != DTHIP_OK) break;
+    }
+    if (rc != DTHIP_OK) break;
+    // aggregates
+    for (int a = 0; a < naggs && rc == DTHIP_OK; a++) {
+      void* ap = nullptr;
+      rc = result_alloc(ctx, res, (size_t)ng * stype_size(res->agg_stype[a]), &ap);
+      res->agg[a] = ap;
+    }
+    if (rc != DTHIP_OK) break;
+    for (int c : used) {
+      ReduceOuts ro;
+      std::vector<std::pair<int, int>> dups;   // (agg index, first agg index with same op)
+      int first_of_op[6] = {-1, -1, -1, -1, -1, -1};
+      for (int a = 0; a < naggs; a++) {
+        if (aggs[a].op == DTHIP_COUNT0 || aggs[a].col != c) continue;
+        if (first_of_op[aggs[a].op] >= 0) { dups.push_back({a, first_of_op[aggs[a].op]}); continue; }
+        first_of_op[aggs[a].op] = a;
+        if ((rc = reduce_outs_for(aggs[a].op, res->agg[a], &ro)) != DTHIP_OK) break;
+      }
+      if (rc != DTHIP_OK) break;
+      rc = launch_reduce(ctx, sorted_val[c], vd[c].stype, gather_ri, reinterpret_cast<const uint8_t*>(g.bitmap),
+                         g.tile_first, nrows, ro);
+      if (rc != DTHIP_OK) break;
+      for (auto& d : dups) {
+        if (hipMemcpyAsync(res->agg[d.first], res->agg[d.second], (size_t)ng * stype_size(res->agg_stype[d.first]),
+                           hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { set_error("D2D copy failed"); rc = DTHIP_EDEVICE; break; }
+      }
+      if (rc != DTHIP_OK) break;
+    }
+    if (rc != DTHIP_OK) break;
+    for (int a = 0; a < naggs; a++) {
+      if (aggs[a].op != DTHIP_COUNT0) continue;
+      if ((rc = launch_count0(ctx, g.offsets, ng, static_cast<int64_t*>(res->agg[a]))) != DTHIP_OK) break;
+    }
+  } while (0);
+  if (rc != DTHIP_OK) { result_destroy(ctx, res); return rc; }
+  *out = res;
+  return DTHIP_OK;
+}
+
+int64_t dthip_result_ngroups(const dthip_result* r) { return r ? r->ngroups : -1; }
+int64_t dthip_result_nrows(const dthip_result* r) { return r ? r->nrows : -1; }
+const int32_t* dthip_result_rowindex(const dthip_result* r) { return r ? r->rowindex : nullptr; }
+const int32_t* dthip_result_offsets(const dthip_result* r) { return r ? r->offsets : nullptr; }
+const void* dthip_result_key(const dthip_result* r, int k) { return (r && k >= 0 && k < r->nkeys) ? r->key[k] : nullptr; }
+const void* dthip_result_agg(const dthip_result* r, int a) { return (r && a >= 0 && a < r->naggs) ? r->agg[a] : nullptr; }
+int dthip_result_agg_stype(const dthip_result* r, int a) { return (r && a >= 0 && a < r->naggs) ? r->agg_stype[a] : 0; }
+
+int dthip_result_copy_rowindex(dthip_ctx* ctx, const dthip_result* r, int32_t* dst, int mem) {
+  if (!ctx || !r) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (r->nrows == 0) return DTHIP_OK;
+  if (!r->rowindex) { set_error("result holds no RowIndex (want_rowindex=0 or fused aggregation)"); return DTHIP_EINVAL; }
+  return copy_out(ctx, dst, r->rowindex, sizeof(int32_t) * (size_t)r->nrows, mem);
+}
+int dthip_result_copy_offsets(dthip_ctx* ctx, const dthip_result* r, int32_t* dst, int mem) {
+  if (!ctx || !r) { set_error("null argument"); return DTHIP_EINVAL; }
+  return copy_out(ctx, dst, r->offsets, sizeof(int32_t) * (size_t)(r->ngroups + 1), mem);
+}
+int dthip_result_copy_key(dthip_ctx* ctx, const dthip_result* r, int k, void* dst, int mem) {
+  if (!ctx || !r || k < 0 || k >= r->nkeys) { set_error("bad key index"); return DTHIP_EINVAL; }
+  if (r->ngroups == 0) return DTHIP_OK;
+  if (!r->key[k]) { set_error("result holds no group-key columns (use dthip_result_group_keys)"); return DTHIP_EINVAL; }
+  return copy_out(ctx, dst, r->key[k], (size_t)r->ngroups * stype_size(r->key_stype[k]), mem);
+}
+int dthip_result_copy_agg(dthip_ctx* ctx, const dthip_result* r, int a, void* dst, int mem) {
+  if (!ctx || !r || a < 0 || a >= r->naggs) { set_error("bad agg index"); return DTHIP_EINVAL; }
+  if (r->ngroups == 0) return DTHIP_OK;
+  return copy_out(ctx, dst, r->agg[a], (size_t)r->ngroups * stype_size(r->agg_stype[a]), mem);
+}
+
+int dthip_result_group_keys(dthip_ctx* ctx, const dthip_result* r, const dthip_col* key, int mem, void* dst) {
+  if (!ctx || !r || !key) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (r->ngroups == 0) return DTHIP_OK;
+  if (!dst) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (!r->rowindex) { set_error("result holds no RowIndex"); return DTHIP_EINVAL; }
+  DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  const int sz = stype_size(key->stype);
+  if (!sz) { set_error("unsupported stype %d", key->stype); return DTHIP_ENOTIMPL; }
+  Scratch sc(ctx);
+  const void* kd = nullptr;
+  DTHIP_TRY(stage_in(ctx, sc, key->data, (size_t)r->nrows * sz, mem, &kd));
+  int32_t* firstrow = nullptr;
+  DTHIP_TRY(sc.get<int32_t>((size_t)r->ngroups, &firstrow));
+  DTHIP_TRY(launch_gather(ctx, r->rowindex, DTHIP_INT32, r->offsets, r->ngroups, firstrow));
+  if (mem == DTHIP_DEVICE) return launch_gather(ctx, kd, key->stype, firstrow, r->ngroups, dst);
+  unsigned char* tmp = nullptr;
+  DTHIP_TRY(sc.get<unsigned char>((size_t)r->ngroups * sz, &tmp));
+  DTHIP_TRY(launch_gather(ctx, kd, key->stype, firstrow, r->ngroups, tmp));
+  return copy_out(ctx, dst, tmp, (size_t)r->ngroups * sz, mem);
+}
+
+int dthip_result_free(dthip_ctx* ctx, dthip_result* r) {
+  if (!ctx) return DTHIP_EINVAL;
+  if (r) result_destroy(ctx, r);
+  return DTHIP_OK;
+}
+
+int dthip_reduce_out_stype(int op, int st) {
+  switch (op) {
+    case DTHIP_SUM: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : st == DTHIP_FLOAT64 ? DTHIP_FLOAT64 : DTHIP_INT64;
+    case DTHIP_MEAN: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : DTHIP_FLOAT64;
+    case DTHIP_MIN: case DTHIP_MAX: return st;
+    default: return DTHIP_INT64;
+  }
+}
+
+int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* rowindex, const int32_t* offsets,
+                 int64_t ngroups, int64_t nrows, int mem, void* out) {
+  DTHIP_TRY(check_common(ctx, nrows, mem));
+  if (ngroups < 0 || ngroups > nrows) { set_error("ngroups=%lld inconsistent with nrows=%lld", (long long)ngroups, (long long)nrows); return DTHIP_EINVAL; }
+  if (ngroups == 0) return DTHIP_OK;
+  if (!offsets || !out) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (op < DTHIP_SUM || op > DTHIP_COUNT0) { set_error("bad reducer op %d", op); return DTHIP_EINVAL; }
+  if (op != DTHIP_COUNT0 && (!value || !value->data)) { set_error("reducer needs a value column"); return DTHIP_EINVAL; }
+  Scratch sc(ctx);
+  const void* d_off = nullptr;
+  DTHIP_TRY(stage_in(ctx, sc, offsets, sizeof(int32_t) * (size_t)(ngroups + 1), mem, &d_off));
+  const int ost = dthip_reduce_out_stype(op, op == DTHIP_COUNT0 ? DTHIP_INT64 : value->stype);
+  const size_t obytes = (size_t)ngroups * stype_size(ost);
+  void* d_out = out;
+  if (mem == DTHIP_HOST) {
+    unsigned char* t = nullptr;
+    DTHIP_TRY(sc.get<unsigned char>(obytes, &t));
+    d_out = t;
+  }
+  if (op == DTHIP_COUNT0) {
+    DTHIP_TRY(launch_count0(ctx, static_cast<const int32_t*>(d_off), ngroups, static_cast<int64_t*>(d_out)));
+  } else {
+    const int sz = stype_size(value->stype);
+    if (!sz) { set_error("unsupported stype %d", value->stype); return DTHIP_ENOTIMPL; }
+    const void* d_ri = nullptr;
+    DTHIP_TRY(stage_in(ctx, sc, rowindex, sizeof(int32_t) * (size_t)nrows, mem, &d_ri));
+    // the value column may be longer than nrows when read through a RowIndex; the caller
+    // guarantees rowindex values index into it.  Host staging copies max(index)+1 rows.
+    const void* d_val = value->data;
+    if (mem == DTHIP_HOST) {
+      int64_t vrows = nrows;
+      if (rowindex) { vrows = 0; for (int64_t i = 0; i < nrows; i++) if (rowindex[i] >= vrows) vrows = (int64_t)rowindex[i] + 1; }
+      DTHIP_TRY(stage_in(ctx, sc, value->data, (size_t)vrows * sz, mem, &d_val));
+    }
+    unsigned long long* bitmap = nullptr;
+    DTHIP_TRY(sc.get<unsigned long long>((size_t)((nrows + 63) / 64) + 1, &bitmap));
+    const uint32_t nt = (uint32_t)((nrows + SEG_TILE - 1) / SEG_TILE);
+    uint32_t* tile_counts = nullptr;
+    DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 2, &tile_counts));
+    DTHIP_TRY(launch_bitmap_from_offsets(ctx, static_cast<const int32_t*>(d_off), ngroups, nrows, bitmap, tile_counts,
+                                         tile_counts + nt));
+    ReduceOuts ro;
+    DTHIP_TRY(reduce_outs_for(op, d_out, &ro));
+    DTHIP_TRY(launch_reduce(ctx, d_val, value->stype, static_cast<const int32_t*>(d_ri),
+                            reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, ro));
+  }
+  if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, obytes, mem));
+  return DTHIP_OK;
+}
+
+static int compact_common(dthip_ctx* ctx, const PredArgs& p0, size_t elem, int64_t n, int mem, int32_t* out, int64_t* nout) {
+  DTHIP_TRY(check_common(ctx, n, mem));
+  if (!nout || (n > 0 && (!p0.data || !out))) { set_error("null argument"); return DTHIP_EINVAL; }
+  Scratch sc(ctx);
+  PredArgs p = p0;
+  DTHIP_TRY(stage_in(ctx, sc, p0.data, (size_t)n * elem, mem, &p.data));
+  int32_t* d_out = out;
+  if (mem == DTHIP_HOST) DTHIP_TRY(sc.get<int32_t>((size_t)n, &d_out));
+  DTHIP_TRY(launch_compact(ctx, p, n, d_out, nout));
+  if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, sizeof(int32_t) * (size_t)*nout, mem));
+  return DTHIP_OK;
+}
+
+int dthip_bool_to_rowindex(dthip_ctx* ctx, const int8_t* mask, int64_t n, int mem, int32_t* out, int64_t* nout) {
+  PredArgs p;
+  memset(&p, 0, sizeof(p));
+  p.data = mask; p.stype = DTHIP_BOOL; p.is_mask = 1;
+  return compact_common(ctx, p, 1, n, mem, out, nout);
+}
+
+int dthip_filter_cmp(dthip_ctx* ctx, const dthip_col* col, int64_t n, int cmp, double cf, int64_t ci, int mem,
+                     int32_t* out, int64_t* nout) {
+  if (!col) { set_error("null column"); return DTHIP_EINVAL; }
+  if (cmp < DTHIP_GT || cmp > DTHIP_NE) { set_error("bad comparison %d", cmp); return DTHIP_EINVAL; }
+  const int sz = stype_size(col->stype);
+  if (!sz) { set_error("unsupported stype %d", col->stype); return DTHIP_ENOTIMPL; }
+  PredArgs p;
+  memset(&p, 0, sizeof(p));
+  p.data = col->data; p.stype = col->stype; p.cmp = cmp; p.cf = cf; p.ci = ci; p.is_mask = 0;
+  return compact_common(ctx, p, sz, n, mem, out, nout);
+}
+
+int dthip_gather(dthip_ctx* ctx, const dthip_col* col, const int32_t* rowindex, int64_t nout, int mem, void* out) {
+  DTHIP_TRY(check_common(ctx, nout, mem));
+  if (nout == 0) return DTHIP_OK;
+  if (!col || !col->data || !rowindex || !out) { set_error("null argument"); return DTHIP_EINVAL; }
+  const int sz = stype_size(col->stype);
+  if (!sz) { set_error("unsupported stype %d", col->stype); return DTHIP_ENOTIMPL; }
+  if (mem == DTHIP_DEVICE) return launch_gather(ctx, col->data, col->stype, rowindex, nout, out);
+  Scratch sc(ctx);
+  int64_t vrows = 0;
+  for (int64_t i = 0; i < nout; i++) if (rowindex[i] >= vrows) vrows = (int64_t)rowindex[i] + 1;
+  const void* d_val = nullptr; const void* d_ri = nullptr;
+  DTHIP_TRY(stage_in(ctx, sc, col->data, (size_t)vrows * sz, mem, &d_val));
+  DTHIP_TRY(stage_in(ctx, sc, rowindex, sizeof(int32_t) * (size_t)nout, mem, &d_ri));
+  unsigned char* d_out = nullptr;
+  DTHIP_TRY(sc.get<unsigned char>((size_t)nout * sz, &d_out));
+  DTHIP_TRY(launch_gather(ctx, d_val, col->stype, static_cast<const int32_t*>(d_ri), nout, d_out));
+  return copy_out(ctx, out, d_out, (size_t)nout * sz, mem);
+}
+
+}  // extern "C"

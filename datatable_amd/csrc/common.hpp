@@ -1,0 +1,213 @@
+// common.hpp -- context, error handling, caching device allocator and launch
+// accounting shared by the libdthip translation units.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/dthip.h"
+
+namespace dthip {
+
+void set_error(const char* fmt, ...);
+
+#define DTHIP_CHECK_HIP(expr)                                                        \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      ::dthip::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                         __FILE__, __LINE__);                                        \
+      return (_e == hipErrorOutOfMemory) ? DTHIP_ENOMEM : DTHIP_EDEVICE;             \
+    }                                                                                \
+  } while (0)
+
+#define DTHIP_TRY(expr)            \
+  do {                             \
+    int _rc = (expr);              \
+    if (_rc != DTHIP_OK) return _rc; \
+  } while (0)
+
+inline int stype_size(int st) {
+  switch (st) {
+    case DTHIP_BOOL: case DTHIP_INT8: return 1;
+    case DTHIP_INT16: return 2;
+    case DTHIP_INT32: case DTHIP_FLOAT32: return 4;
+    case DTHIP_INT64: case DTHIP_FLOAT64: return 8;
+    default: return 0;
+  }
+}
+inline bool stype_is_float(int st) { return st == DTHIP_FLOAT32 || st == DTHIP_FLOAT64; }
+
+struct ProfRec { const char* name; hipEvent_t a, b; };
+struct ProfAcc { double ms = 0; int64_t n = 0; };
+
+}  // namespace dthip
+
+struct dthip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // caching allocator: blocks are reused on the same stream, so returning a
+  // block to the cache while kernels that use it are still queued is safe.
+  std::multimap<size_t, void*> cache;
+  std::unordered_map<void*, size_t> live;
+  size_t cached_bytes = 0;
+  // pinned host scratch for small synchronous read-backs
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  // timers / per-kernel accounting
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  bool prof = false;
+  std::vector<dthip::ProfRec> pending;
+  std::vector<hipEvent_t> event_pool;
+  std::map<std::string, dthip::ProfAcc> acc;
+  int num_cus = 256;
+};
+
+namespace dthip {
+
+int dev_alloc(dthip_ctx* ctx, size_t bytes, void** out);
+void dev_release(dthip_ctx* ctx, void* p);   // back to the cache
+int dev_trim(dthip_ctx* ctx);                // cache -> hipFree
+int prof_flush(dthip_ctx* ctx);
+hipEvent_t prof_event(dthip_ctx* ctx);
+
+// Scoped set of temporary device buffers returned to the cache on exit.
+struct Scratch {
+  dthip_ctx* ctx;
+  std::vector<void*> bufs;
+  explicit Scratch(dthip_ctx* c) : ctx(c) {}
+  ~Scratch() { for (void* p : bufs) dev_release(ctx, p); }
+  template <typename T>
+  int get(size_t count, T** out) {
+    void* p = nullptr;
+    int rc = dev_alloc(ctx, (count ? count : 1) * sizeof(T), &p);
+    if (rc != DTHIP_OK) return rc;
+    bufs.push_back(p);
+    *out = static_cast<T*>(p);
+    return DTHIP_OK;
+  }
+  // hand a buffer over to a longer-lived owner
+  void disown(void* p) {
+    for (auto& b : bufs) if (b == p) { b = bufs.back(); bufs.pop_back(); return; }
+  }
+};
+
+// Launch with optional per-kernel event accounting.
+#define DTHIP_LAUNCH(ctx, kname, kernel, grid, block, shmem, ...)                           \
+  do {                                                                                      \
+    hipEvent_t _ea = nullptr, _eb = nullptr;                                                \
+    if ((ctx)->prof) { _ea = ::dthip::prof_event(ctx); _eb = ::dthip::prof_event(ctx);      \
+                       (void)hipEventRecord(_ea, (ctx)->stream); }                                \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), (ctx)->stream, __VA_ARGS__); \
+    if ((ctx)->prof) { (void)hipEventRecord(_eb, (ctx)->stream);                                  \
+                       (ctx)->pending.push_back({kname, _ea, _eb});                         \
+                       if ((ctx)->pending.size() > 2048) ::dthip::prof_flush(ctx); }        \
+    hipError_t _le = hipGetLastError();                                                     \
+    if (_le != hipSuccess) {                                                                \
+      ::dthip::set_error("launch of %s failed: %s", kname, hipGetErrorString(_le));         \
+      return DTHIP_EDEVICE;                                                                 \
+    }                                                                                       \
+  } while (0)
+
+// small synchronous device->host read-back through pinned memory
+int read_back(dthip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+
+// ---- kernels' host entry points (one per .hip file) ------------------------
+
+// stats.hip: min / max / valid-count of an integer column (NumericStats::compute_minmax)
+struct MinMax { long long mn, mx, nvalid; };
+int launch_minmax(dthip_ctx* ctx, const void* data, int stype, int64_t n, MinMax* d_out);
+
+// radix.hip
+constexpr int MAX_KEYCOLS = 8;
+constexpr int MAX_PASSES = 10;
+constexpr int HIST_STRIDE = 512;
+struct KeyColDev {
+  const void* data;
+  int stype;
+  int desc;
+  unsigned long long edge;     // min (ascending) or max (descending), as the column's unsigned image
+  unsigned long long na_repl;  // transformed value of NA
+  unsigned long long inc;      // 1 when NA is first, else 0
+  int shift;                   // bit position of this key inside the packed key
+};
+struct XformArgs {
+  KeyColDev cols[MAX_KEYCOLS];
+  int ncols;
+  uint32_t n;
+  const int32_t* order;  // nullable: read column rows through this ordering
+  void* out;             // uint32_t[n] or uint64_t[n]
+  int out64;
+  uint32_t* hist;        // [npass][HIST_STRIDE], zeroed by the caller
+  int npass;
+  int pshift[MAX_PASSES];
+  int pbits[MAX_PASSES];
+};
+int launch_xform_hist(dthip_ctx* ctx, const XformArgs& a);
+int launch_hist_scan(dthip_ctx* ctx, const uint32_t* hist, uint32_t* base, int npass);
+
+constexpr int MAX_PAYCOLS = 8;
+struct PayCols {
+  int n;
+  const void* in[MAX_PAYCOLS];
+  void* out[MAX_PAYCOLS];
+  int width[MAX_PAYCOLS];  // 4 or 8 bytes
+};
+struct RadixPass {
+  const void* kin; void* kout; int key64;
+  uint32_t n; int shift; int bits;
+  const uint32_t* base;          // [1<<bits] exclusive bucket starts for this pass
+  unsigned long long* state;     // [ntiles << bits], zeroed
+  uint32_t* ticket;              // zeroed
+  int* err;
+  int iota;                      // payload column 0 is the row number (not loaded)
+  PayCols pay;
+};
+uint32_t radix_tile_items(int key64, int maxpaywidth);
+int launch_radix_pass(dthip_ctx* ctx, const RadixPass& p);
+
+// group.hip: run heads of a sorted key sequence -> offsets, head bitmap, tile head counts
+// (tiles of 2048 positions, shared with reduce.hip)
+constexpr int SEG_TILE = 2048;
+int launch_scan_tiles(dthip_ctx* ctx, uint32_t* counts, uint32_t m, uint32_t* total);
+// tile_counts[ntiles] <- exclusive scan of heads per tile; bitmap (nullable) <- 1 bit per position;
+// d_total <- ngroups; ngroups_host (nullable) <- synchronous read-back of d_total
+int launch_count_heads(dthip_ctx* ctx, const void* keys, int key64, const uint8_t* heads, int64_t n,
+                       uint32_t* tile_counts, unsigned long long* bitmap, uint32_t* d_total,
+                       int64_t* ngroups_host);
+int launch_write_offsets(dthip_ctx* ctx, const void* keys, int key64, const uint8_t* heads, int64_t n,
+                         const uint32_t* tile_base, int64_t ngroups, int32_t* offsets);
+int launch_mark_heads(dthip_ctx* ctx, const void* keys, int key64, int64_t n, uint8_t* heads);
+int launch_bitmap_from_offsets(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n,
+                               unsigned long long* bitmap, uint32_t* tile_counts, uint32_t* d_total);
+int launch_iota(dthip_ctx* ctx, int32_t* out, int64_t n);
+int launch_untransform_keys(dthip_ctx* ctx, const void* sorted_keys, int key64, const int32_t* offsets,
+                            int64_t ngroups, const KeyColDev& col, int bits, void* out);
+
+// reduce.hip
+struct ReduceOuts {
+  void* sum = nullptr;    // int64 (integer stypes) / float (f32) / double (f64)
+  void* mean = nullptr;   // double, or float for f32 input
+  void* mn = nullptr;     // input stype
+  void* mx = nullptr;     // input stype
+  int64_t* count = nullptr;   // valid (non-NA) rows
+};
+int launch_reduce(dthip_ctx* ctx, const void* values, int stype, const int32_t* rowindex,
+                  const uint8_t* bitmap, const uint32_t* tile_first_head, int64_t nrows,
+                  const ReduceOuts& outs);
+int launch_count0(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t* out);
+
+// rowindex.hip
+struct PredArgs {
+  const void* data; int stype; int cmp; double cf; long long ci; int is_mask;
+};
+int launch_compact(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out, int64_t* nout_host);
+int launch_gather(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, int64_t nout, void* out);
+
+}  // namespace dthip

@@ -1,0 +1,76 @@
+// device_utils.hpp -- wave64 / workgroup primitives for gfx950 (CDNA4).
+// Wavefront width is 64 everywhere in this library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace dthip {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// number of set bits of `m` strictly below the calling lane (v_mbcnt_lo/hi)
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Workgroup exclusive scan of one uint32 per thread.  `scratch` needs
+// BLOCK/64 words of LDS.  Contains two __syncthreads(); all threads must call.
+template <int BLOCK>
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* scratch, uint32_t* total) {
+  constexpr int WAVES = BLOCK / 64;
+  const int lane = lane_id(), wave = wave_id();
+  const uint32_t incl = wave_incl_scan_u32(v);
+  if (lane == 63) scratch[wave] = incl;
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < WAVES; w++) {
+    const uint32_t s = scratch[w];
+    if (w < wave) off += s;
+    tot += s;
+  }
+  __syncthreads();
+  if (total) *total = tot;
+  return off + incl - v;
+}
+
+// 64-bit shuffle helpers
+__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int o) {
+  uint32_t lo = __shfl_up((uint32_t)v, o, 64), hi = __shfl_up((uint32_t)(v >> 32), o, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double shfl_up_f64(double v, int o) {
+  return __longlong_as_double((long long)shfl_up_u64((unsigned long long)__double_as_longlong(v), o));
+}
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+  uint32_t lo = __shfl((uint32_t)v, src, 64), hi = __shfl((uint32_t)(v >> 32), src, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// agent-scope relaxed accesses to a 64-bit {flag,value} word: the word is its
+// own flag, so no fence is needed (decoupled look-back state).
+__device__ __forceinline__ void st_agent_u64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent_u64(unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace dthip

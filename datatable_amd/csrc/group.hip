@@ -1,0 +1,281 @@
+// group.hip -- group boundaries of a sorted key sequence -> Groupby offsets.
+//
+// Reproduces what GroupGatherer builds on the CPU (src/core/sort_groups.cc:30-117,
+// src/core/sort.h:118-147): offsets[0]=0, offsets[g] = first sorted position of
+// group g, offsets[ngroups] = nrows (src/core/groupby.h:54-91).  The reference
+// compacts per-thread group lists serially; here a run head is any position
+// whose transformed key differs from its predecessor's, found with 64-wide
+// ballots, ranked with a workgroup scan, and scanned across tiles.
+//
+// The same sweep also emits the head BITMAP (1 bit per sorted position) and
+// per-tile head counts that the segmented reducers (reduce.hip) consume.
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace dthip {
+
+constexpr int GB_BLOCK = 256;
+constexpr int GB_ITEMS = 8;                         // rounds of 64 per wave
+constexpr int GB_TILE = GB_BLOCK * GB_ITEMS;        // 2048 positions per workgroup (== reduce tile)
+static_assert(GB_TILE == 2048, "reduce.hip assumes 2048-position tiles");
+
+template <typename KeyT>
+__device__ __forceinline__ bool head_at(const KeyT* K, const uint8_t* H, uint32_t i) {
+  if (H) return H[i] != 0;
+  return i == 0 || K[i] != K[i - 1];
+}
+
+// sweep: per-lane bit k = head flag of position  tile_base + wave*512 + k*64 + lane
+template <typename KeyT>
+__device__ __forceinline__ uint32_t sweep_heads(const KeyT* K, const uint8_t* H, uint32_t n,
+                                                uint32_t wave_base, uint32_t* wave_count,
+                                                unsigned long long* bitmap) {
+  const int lane = lane_id();
+  uint32_t bits = 0, cnt = 0;
+#pragma unroll
+  for (int k = 0; k < GB_ITEMS; k++) {
+    const uint32_t idx = wave_base + 64u * k + lane;
+    const bool f = idx < n && head_at<KeyT>(K, H, idx);
+    const unsigned long long bal = __ballot(f);
+    bits |= (uint32_t)f << k;
+    cnt += (uint32_t)__popcll(bal);
+    if (bitmap && lane == 0 && (wave_base + 64u * k) < n) bitmap[(wave_base + 64u * k) >> 6] = bal;
+  }
+  *wave_count = cnt;
+  return bits;
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(GB_BLOCK) count_heads_kernel(const KeyT* K, const uint8_t* H, uint32_t n,
+                                                               uint32_t* tile_counts,
+                                                               unsigned long long* bitmap) {
+  __shared__ uint32_t wc[GB_BLOCK / 64];
+  const uint32_t wave_base = blockIdx.x * GB_TILE + wave_id() * (64 * GB_ITEMS);
+  uint32_t cnt;
+  sweep_heads<KeyT>(K, H, n, wave_base, &cnt, bitmap);
+  if (lane_id() == 0) wc[wave_id()] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t s = 0;
+    for (int w = 0; w < GB_BLOCK / 64; w++) s += wc[w];
+    tile_counts[blockIdx.x] = s;
+  }
+}
+
+// in-place exclusive scan of `counts[0..m)` by one workgroup; total -> *total
+__global__ void __launch_bounds__(1024) scan_tiles_kernel(uint32_t* counts, uint32_t m, uint32_t* total) {
+  __shared__ uint32_t scratch[16];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < m; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < m ? counts[i] : 0;
+    uint32_t tot;
+    const uint32_t e = block_excl_scan_u32<1024>(v, scratch, &tot);
+    if (i < m) counts[i] = carry + e;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+int launch_scan_tiles(dthip_ctx* ctx, uint32_t* counts, uint32_t m, uint32_t* total) {
+  DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_tiles_kernel, 1, 1024, 0, counts, m, total);
+  return DTHIP_OK;
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(GB_BLOCK) write_offsets_kernel(const KeyT* K, const uint8_t* H, uint32_t n,
+                                                                 const uint32_t* tile_base, uint32_t ngroups,
+                                                                 int32_t* offsets) {
+  __shared__ uint32_t wc[GB_BLOCK / 64];
+  const int lane = lane_id(), wave = wave_id();
+  const uint32_t wave_base = blockIdx.x * GB_TILE + wave * (64 * GB_ITEMS);
+  uint32_t cnt;
+  const uint32_t bits = sweep_heads<KeyT>(K, H, n, wave_base, &cnt, nullptr);
+  if (lane == 0) wc[wave] = cnt;
+  __syncthreads();
+  uint32_t running = tile_base[blockIdx.x];
+  for (int w = 0; w < wave; w++) running += wc[w];
+#pragma unroll
+  for (int k = 0; k < GB_ITEMS; k++) {
+    const bool f = (bits >> k) & 1u;
+    const unsigned long long bal = __ballot(f);
+    if (f) offsets[running + mbcnt64(bal)] = (int32_t)(wave_base + 64u * k + lane);
+    running += (uint32_t)__popcll(bal);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[ngroups] = (int32_t)n;
+}
+
+static uint32_t ntiles_of(int64_t n) { return (uint32_t)((n + GB_TILE - 1) / GB_TILE); }
+
+// tile_counts: [ntiles] (becomes the exclusive scan = index of the first head of each tile)
+int launch_count_heads(dthip_ctx* ctx, const void* keys, int key64, const uint8_t* heads, int64_t n,
+                       uint32_t* tile_counts, unsigned long long* bitmap, uint32_t* d_total,
+                       int64_t* ngroups_host) {
+  const uint32_t nt = ntiles_of(n);
+  if (key64) {
+    DTHIP_LAUNCH(ctx, "count_heads_kernel", count_heads_kernel<unsigned long long>, nt, GB_BLOCK, 0,
+                 static_cast<const unsigned long long*>(keys), heads, (uint32_t)n, tile_counts, bitmap);
+  } else {
+    DTHIP_LAUNCH(ctx, "count_heads_kernel", count_heads_kernel<uint32_t>, nt, GB_BLOCK, 0,
+                 static_cast<const uint32_t*>(keys), heads, (uint32_t)n, tile_counts, bitmap);
+  }
+  DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_tiles_kernel, 1, 1024, 0, tile_counts, nt, d_total);
+  if (ngroups_host) {
+    uint32_t t = 0;
+    DTHIP_TRY(read_back(ctx, &t, d_total, sizeof(t)));
+    *ngroups_host = t;
+  }
+  return DTHIP_OK;
+}
+
+int launch_write_offsets(dthip_ctx* ctx, const void* keys, int key64, const uint8_t* heads, int64_t n,
+                         const uint32_t* tile_base, int64_t ngroups, int32_t* offsets) {
+  const uint32_t nt = ntiles_of(n);
+  if (key64) {
+    DTHIP_LAUNCH(ctx, "write_offsets_kernel", write_offsets_kernel<unsigned long long>, nt, GB_BLOCK, 0,
+                 static_cast<const unsigned long long*>(keys), heads, (uint32_t)n, tile_base, (uint32_t)ngroups,
+                 offsets);
+  } else {
+    DTHIP_LAUNCH(ctx, "write_offsets_kernel", write_offsets_kernel<uint32_t>, nt, GB_BLOCK, 0,
+                 static_cast<const uint32_t*>(keys), heads, (uint32_t)n, tile_base, (uint32_t)ngroups, offsets);
+  }
+  return DTHIP_OK;
+}
+
+// OR "key differs from predecessor" into a byte-per-position head array
+// (multi-stage sorts whose packed keys exceed 64 bits)
+template <typename KeyT>
+__global__ void __launch_bounds__(256) mark_heads_kernel(const KeyT* K, uint32_t n, uint8_t* heads) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    if (i == 0 || K[i] != K[i - 1]) heads[i] = 1;
+}
+
+int launch_mark_heads(dthip_ctx* ctx, const void* keys, int key64, int64_t n, uint8_t* heads) {
+  if (n == 0) return DTHIP_OK;
+  long long blocks = (n + 2047) / 2048;
+  if (blocks > ctx->num_cus * 8) blocks = ctx->num_cus * 8;
+  if (key64) {
+    DTHIP_LAUNCH(ctx, "mark_heads_kernel", mark_heads_kernel<unsigned long long>, (unsigned)blocks, 256, 0,
+                 static_cast<const unsigned long long*>(keys), (uint32_t)n, heads);
+  } else {
+    DTHIP_LAUNCH(ctx, "mark_heads_kernel", mark_heads_kernel<uint32_t>, (unsigned)blocks, 256, 0,
+                 static_cast<const uint32_t*>(keys), (uint32_t)n, heads);
+  }
+  return DTHIP_OK;
+}
+
+// head bitmap from an offsets array (dthip_reduce on caller-supplied groupings)
+__global__ void __launch_bounds__(256) offsets_to_bitmap_kernel(const int32_t* offsets, uint32_t ngroups,
+                                                                uint32_t* bitmap32) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g < ngroups) {
+    const uint32_t p = (uint32_t)offsets[g];
+    atomicOr(&bitmap32[p >> 5], 1u << (p & 31));
+  }
+}
+
+__global__ void __launch_bounds__(256) bitmap_tile_counts_kernel(const unsigned long long* bitmap, uint32_t nwords,
+                                                                 uint32_t ntiles, uint32_t* tile_counts) {
+  // one wave per tile: 2048 positions = 32 words of 64 bits
+  const uint32_t tile = blockIdx.x * 4 + wave_id();
+  if (tile >= ntiles) return;
+  const int lane = lane_id();
+  const uint32_t w = tile * 32 + lane;
+  uint32_t c = (lane < 32 && w < nwords) ? (uint32_t)__popcll(bitmap[w]) : 0;
+  c = wave_reduce_sum_u32(c);
+  if (lane == 0) tile_counts[tile] = c;
+}
+
+int launch_bitmap_from_offsets(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n,
+                               unsigned long long* bitmap, uint32_t* tile_counts, uint32_t* d_total) {
+  const uint32_t nwords = (uint32_t)((n + 63) / 64);
+  const uint32_t nt = ntiles_of(n);
+  DTHIP_CHECK_HIP(hipMemsetAsync(bitmap, 0, (size_t)nwords * 8, ctx->stream));
+  if (ngroups > 0) {
+    DTHIP_LAUNCH(ctx, "offsets_to_bitmap_kernel", offsets_to_bitmap_kernel, (unsigned)((ngroups + 255) / 256), 256, 0,
+                 offsets, (uint32_t)ngroups, reinterpret_cast<uint32_t*>(bitmap));
+  }
+  DTHIP_LAUNCH(ctx, "bitmap_tile_counts_kernel", bitmap_tile_counts_kernel, (nt + 3) / 4, 256, 0,
+               bitmap, nwords, nt, tile_counts);
+  DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_tiles_kernel, 1, 1024, 0, tile_counts, nt, d_total);
+  return DTHIP_OK;
+}
+
+__global__ void __launch_bounds__(256) iota_kernel(int32_t* out, uint32_t n) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = (int32_t)i;
+}
+
+int launch_iota(dthip_ctx* ctx, int32_t* out, int64_t n) {
+  if (n == 0) return DTHIP_OK;
+  long long blocks = (n + 2047) / 2048;
+  if (blocks > ctx->num_cus * 8) blocks = ctx->num_cus * 8;
+  DTHIP_LAUNCH(ctx, "iota_kernel", iota_kernel, (unsigned)blocks, 256, 0, out, (uint32_t)n);
+  return DTHIP_OK;
+}
+
+// Group-key column of a fused groupby: invert the key transform on the sorted
+// packed key at the first position of each group (what the reference obtains as
+// key[o[off[g]]], eval_context.cc:473-485).
+struct UntransformArgs {
+  const void* keys; int key64;
+  const int32_t* offsets; uint32_t ngroups;
+  int stype; int desc; unsigned long long edge, na_repl, inc; int shift; int bits;
+  void* out;
+};
+
+__global__ void __launch_bounds__(256) untransform_kernel(UntransformArgs a) {
+  typedef unsigned long long u64;
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= a.ngroups) return;
+  const uint32_t p = (uint32_t)a.offsets[g];
+  u64 k = a.key64 ? static_cast<const u64*>(a.keys)[p] : (u64)static_cast<const uint32_t*>(a.keys)[p];
+  k >>= a.shift;
+  if (a.bits < 64) k &= (1ULL << a.bits) - 1ULL;
+  const bool na = (k == a.na_repl);
+  switch (a.stype) {
+    case DTHIP_BOOL: {
+      int8_t v = a.desc ? (int8_t)(2 - (int)k) : (int8_t)((int)k - 1);
+      static_cast<int8_t*>(a.out)[g] = na ? INT8_MIN : v;
+      break;
+    }
+    case DTHIP_INT8: case DTHIP_INT16: case DTHIP_INT32: case DTHIP_INT64: {
+      const u64 u = a.desc ? a.edge - (k - a.inc) : (k - a.inc) + a.edge;
+      const long long v = (long long)u;
+      if (a.stype == DTHIP_INT8) static_cast<int8_t*>(a.out)[g] = na ? INT8_MIN : (int8_t)v;
+      else if (a.stype == DTHIP_INT16) static_cast<int16_t*>(a.out)[g] = na ? INT16_MIN : (int16_t)v;
+      else if (a.stype == DTHIP_INT32) static_cast<int32_t*>(a.out)[g] = na ? INT32_MIN : (int32_t)v;
+      else static_cast<long long*>(a.out)[g] = na ? INT64_MIN : v;
+      break;
+    }
+    case DTHIP_FLOAT32: {
+      const uint32_t x = (uint32_t)k;
+      uint32_t t;
+      if (a.desc) t = (x & 0x80000000u) ? x : (x ^ 0x7FFFFFFFu);
+      else t = (x & 0x80000000u) ? (x ^ 0x80000000u) : ~x;
+      static_cast<uint32_t*>(a.out)[g] = na ? 0x7FC00000u : t;
+      break;
+    }
+    default: {
+      u64 t;
+      if (a.desc) t = (k & 0x8000000000000000ULL) ? k : (k ^ 0x7FFFFFFFFFFFFFFFULL);
+      else t = (k & 0x8000000000000000ULL) ? (k ^ 0x8000000000000000ULL) : ~k;
+      static_cast<u64*>(a.out)[g] = na ? 0x7FF8000000000000ULL : t;
+      break;
+    }
+  }
+}
+
+int launch_untransform_keys(dthip_ctx* ctx, const void* sorted_keys, int key64, const int32_t* offsets,
+                            int64_t ngroups, const KeyColDev& col, int bits, void* out) {
+  if (ngroups == 0) return DTHIP_OK;
+  UntransformArgs a;
+  a.keys = sorted_keys; a.key64 = key64; a.offsets = offsets; a.ngroups = (uint32_t)ngroups;
+  a.stype = col.stype; a.desc = col.desc; a.edge = col.edge; a.na_repl = col.na_repl; a.inc = col.inc;
+  a.shift = col.shift; a.bits = bits; a.out = out;
+  DTHIP_LAUNCH(ctx, "untransform_kernel", untransform_kernel, (unsigned)((ngroups + 255) / 256), 256, 0, a);
+  return DTHIP_OK;
+}
+
+}  // namespace dthip

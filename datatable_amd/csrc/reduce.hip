@@ -1,0 +1,369 @@
+// reduce.hip -- per-group reducers sum / mean / min / max / count as one
+// segmented reduction over the grouped row order.
+//
+// Reference semantics (src/core/column/sumprod.h:34-59, mean.h:33-52,
+// minmax.h:33-62, count.h:35-58): for each group g the rows
+// [offsets[g], offsets[g+1]) are visited in order, NA values are skipped,
+//   sum   = T-typed sum (int64 for all integer stypes, wraps), 0 for an all-NA group
+//   mean  = double sum / valid count, NA for an all-NA group (float32 in -> float32 out)
+//   min/max = first valid then strict compare (ties keep the earlier row), NA if none
+//   count = number of valid rows
+// The reference runs one sequential loop per group and per reducer, each
+// re-gathering the column through the RowIndex (column/view.cc:140-145).  Here
+// every position is visited exactly once per value column and all five
+// statistics are produced together:
+//   - workgroup = 2048 consecutive grouped positions, 8 per thread, values
+//     optionally gathered through the RowIndex
+//   - group heads come from the head bitmap written by group.hip (1 bit per
+//     position); the index of the first head of each tile from its scan
+//   - thread-serial combine, then a wave64 shuffle segmented scan, then across
+//     the 4 waves through LDS
+//   - groups entirely inside a tile are finalised and stored directly; the two
+//     open ends of a tile go to a side buffer that `seg_fixup_kernel` stitches
+//     (one wave per tile, scanning forward until the next tile with a head)
+// Combine order is position order, so integer results and min/max (including
+// which of equal values wins) are identical to the sequential loops; float
+// sums are re-associated (<= 1e-6 relative, stated in the tests).
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace dthip {
+
+constexpr int SR_BLOCK = 256;
+constexpr int SR_ITEMS = 8;
+constexpr int SR_TILE = SR_BLOCK * SR_ITEMS;   // 2048, must equal group.hip's GB_TILE
+
+// ---- accumulator states ---------------------------------------------------
+struct StF {   // float32 / float64 values
+  double sum, mn, mx;
+  long long cnt;
+};
+struct StI {   // bool / int8 / int16 / int32 / int64 values
+  unsigned long long isum;
+  double dsum;
+  long long mn, mx, cnt;
+};
+
+__device__ __forceinline__ StF ident(StF*) { return StF{0.0, __builtin_huge_val(), -__builtin_huge_val(), 0}; }
+__device__ __forceinline__ StI ident(StI*) { return StI{0ULL, 0.0, INT64_MAX, INT64_MIN, 0}; }
+
+// a = earlier positions, b = later positions
+__device__ __forceinline__ StF comb(const StF& a, const StF& b) {
+  StF r;
+  r.sum = a.sum + b.sum;
+  r.mn = (b.mn < a.mn) ? b.mn : a.mn;
+  r.mx = (b.mx > a.mx) ? b.mx : a.mx;
+  r.cnt = a.cnt + b.cnt;
+  return r;
+}
+__device__ __forceinline__ StI comb(const StI& a, const StI& b) {
+  StI r;
+  r.isum = a.isum + b.isum;
+  r.dsum = a.dsum + b.dsum;
+  r.mn = (b.mn < a.mn) ? b.mn : a.mn;
+  r.mx = (b.mx > a.mx) ? b.mx : a.mx;
+  r.cnt = a.cnt + b.cnt;
+  return r;
+}
+
+__device__ __forceinline__ StF shfl_up_st(const StF& s, int o) {
+  StF r;
+  r.sum = shfl_up_f64(s.sum, o); r.mn = shfl_up_f64(s.mn, o); r.mx = shfl_up_f64(s.mx, o);
+  r.cnt = (long long)shfl_up_u64((unsigned long long)s.cnt, o);
+  return r;
+}
+__device__ __forceinline__ StI shfl_up_st(const StI& s, int o) {
+  StI r;
+  r.isum = shfl_up_u64(s.isum, o); r.dsum = shfl_up_f64(s.dsum, o);
+  r.mn = (long long)shfl_up_u64((unsigned long long)s.mn, o);
+  r.mx = (long long)shfl_up_u64((unsigned long long)s.mx, o);
+  r.cnt = (long long)shfl_up_u64((unsigned long long)s.cnt, o);
+  return r;
+}
+__device__ __forceinline__ StF shfl_st(const StF& s, int src) {
+  StF r;
+  r.sum = __longlong_as_double((long long)shfl_u64((unsigned long long)__double_as_longlong(s.sum), src));
+  r.mn = __longlong_as_double((long long)shfl_u64((unsigned long long)__double_as_longlong(s.mn), src));
+  r.mx = __longlong_as_double((long long)shfl_u64((unsigned long long)__double_as_longlong(s.mx), src));
+  r.cnt = (long long)shfl_u64((unsigned long long)s.cnt, src);
+  return r;
+}
+__device__ __forceinline__ StI shfl_st(const StI& s, int src) {
+  StI r;
+  r.isum = shfl_u64(s.isum, src);
+  r.dsum = __longlong_as_double((long long)shfl_u64((unsigned long long)__double_as_longlong(s.dsum), src));
+  r.mn = (long long)shfl_u64((unsigned long long)s.mn, src);
+  r.mx = (long long)shfl_u64((unsigned long long)s.mx, src);
+  r.cnt = (long long)shfl_u64((unsigned long long)s.cnt, src);
+  return r;
+}
+
+// ---- per-stype value traits -------------------------------------------------
+template <typename T> struct VT;
+template <> struct VT<double> {
+  typedef StF St; typedef double SumT; typedef double MeanT;
+  static __device__ __forceinline__ bool isna(double v) { return v != v; }
+  static __device__ __forceinline__ double na() { return __builtin_nan(""); }
+};
+template <> struct VT<float> {
+  typedef StF St; typedef float SumT; typedef float MeanT;
+  static __device__ __forceinline__ bool isna(float v) { return v != v; }
+  static __device__ __forceinline__ float na() { return __builtin_nanf(""); }
+};
+#define DTHIP_INT_VT(T, NA)                                                     \
+  template <> struct VT<T> {                                                    \
+    typedef StI St; typedef long long SumT; typedef double MeanT;               \
+    static __device__ __forceinline__ bool isna(T v) { return v == (NA); }      \
+    static __device__ __forceinline__ T na() { return (NA); }                   \
+  };
+DTHIP_INT_VT(int8_t, INT8_MIN)
+DTHIP_INT_VT(int16_t, INT16_MIN)
+DTHIP_INT_VT(int32_t, INT32_MIN)
+DTHIP_INT_VT(long long, INT64_MIN)
+
+template <typename T> __device__ __forceinline__ void accum(StF& s, T v) {
+  const double d = (double)v;
+  s.sum += d;
+  if (d < s.mn) s.mn = d;
+  if (d > s.mx) s.mx = d;
+  s.cnt += 1;
+}
+template <typename T> __device__ __forceinline__ void accum(StI& s, T v) {
+  const long long x = (long long)v;
+  s.isum += (unsigned long long)x;
+  s.dsum += (double)x;
+  if (x < s.mn) s.mn = x;
+  if (x > s.mx) s.mx = x;
+  s.cnt += 1;
+}
+
+template <typename T>
+struct OutsT {
+  typename VT<T>::SumT* sum;
+  typename VT<T>::MeanT* mean;
+  T* mn;
+  T* mx;
+  long long* count;
+};
+
+template <typename T> __device__ __forceinline__ void emit(const OutsT<T>& o, uint32_t g, const StF& s) {
+  if (o.sum) o.sum[g] = (typename VT<T>::SumT)s.sum;
+  if (o.mean) o.mean[g] = s.cnt ? (typename VT<T>::MeanT)(s.sum / (double)s.cnt) : (typename VT<T>::MeanT)VT<T>::na();
+  if (o.mn) o.mn[g] = s.cnt ? (T)s.mn : VT<T>::na();
+  if (o.mx) o.mx[g] = s.cnt ? (T)s.mx : VT<T>::na();
+  if (o.count) o.count[g] = s.cnt;
+}
+template <typename T> __device__ __forceinline__ void emit(const OutsT<T>& o, uint32_t g, const StI& s) {
+  if (o.sum) o.sum[g] = (long long)s.isum;
+  if (o.mean) o.mean[g] = s.cnt ? s.dsum / (double)s.cnt : __builtin_nan("");
+  if (o.mn) o.mn[g] = s.cnt ? (T)s.mn : VT<T>::na();
+  if (o.mx) o.mx[g] = s.cnt ? (T)s.mx : VT<T>::na();
+  if (o.count) o.count[g] = s.cnt;
+}
+
+// per-tile open ends
+template <typename St>
+struct TileSide {
+  St first;      // positions before the first head of the tile (whole tile if it has none)
+  St last;       // positions from the last head to the end of the tile
+  uint32_t has_head;
+  uint32_t last_gid;   // group of `last`
+};
+
+template <typename T>
+__global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restrict__ vals, const int32_t* __restrict__ ri,
+                                                              const uint8_t* __restrict__ bitmap,
+                                                              const uint32_t* __restrict__ tile_first_head,
+                                                              uint32_t n, OutsT<T> outs,
+                                                              TileSide<typename VT<T>::St>* side) {
+  typedef typename VT<T>::St St;
+  __shared__ St w_val[SR_BLOCK / 64];
+  __shared__ uint32_t w_flag[SR_BLOCK / 64];
+  __shared__ uint32_t w_nh[SR_BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t p0 = tile * SR_TILE + tid * SR_ITEMS;    // this thread's first grouped position
+  const uint32_t G = tile_first_head[tile];               // group index of the first head in this tile
+
+  // head bits of this thread's 8 positions: exactly one bitmap byte
+  uint32_t hb = 0;
+  if (p0 < n) hb = bitmap[p0 >> 3];
+
+  // values (optionally gathered through the RowIndex), NA -> not accumulated
+  T x[SR_ITEMS];
+  bool ok[SR_ITEMS];
+#pragma unroll
+  for (int j = 0; j < SR_ITEMS; j++) {
+    const uint32_t p = p0 + j;
+    ok[j] = false;
+    x[j] = T(0);
+    if (p < n) {
+      if (ri) {
+        const int32_t r = ri[p];
+        if (r >= 0) { x[j] = vals[r]; ok[j] = true; }
+      } else {
+        x[j] = vals[p]; ok[j] = true;
+      }
+      if (ok[j] && VT<T>::isna(x[j])) ok[j] = false;
+    } else {
+      hb &= ~(1u << j);
+    }
+  }
+
+  // thread summary: value of the open segment at the end of the thread's range
+  St cur = ident((St*)nullptr);
+#pragma unroll
+  for (int j = 0; j < SR_ITEMS; j++) {
+    if ((hb >> j) & 1u) cur = ident((St*)nullptr);
+    if (ok[j]) accum<T>(cur, x[j]);
+  }
+  const uint32_t nh = (uint32_t)__popc(hb);
+  uint32_t flag = nh ? 1u : 0u;
+
+  // inclusive segmented scan over the wave: (flag, value, nheads)
+  St sv = cur; uint32_t sf = flag; uint32_t sn = nh;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const St pv = shfl_up_st(sv, o);
+    const uint32_t pf = __shfl_up(sf, o, 64);
+    const uint32_t pn = __shfl_up(sn, o, 64);
+    if (lane >= o) {
+      if (!sf) sv = comb(pv, sv);
+      sf |= pf;
+      sn += pn;
+    }
+  }
+  if (lane == 63) { w_val[wave] = sv; w_flag[wave] = sf; w_nh[wave] = sn; }
+  __syncthreads();
+  // exclusive carry for this thread = (carry from earlier waves) (+) (exclusive within wave)
+  St carry = ident((St*)nullptr); uint32_t cflag = 0, hc = 0;
+  for (int w = 0; w < wave; w++) {
+    if (w_flag[w]) { carry = w_val[w]; cflag = 1; } else { carry = comb(carry, w_val[w]); }
+    hc += w_nh[w];
+  }
+  {
+    St ev = shfl_up_st(sv, 1);
+    uint32_t ef = __shfl_up(sf, 1, 64), en = __shfl_up(sn, 1, 64);
+    if (lane == 0) { ev = ident((St*)nullptr); ef = 0; en = 0; }
+    if (ef) { carry = ev; cflag = 1; } else { carry = comb(carry, ev); }
+    hc += en;
+  }
+
+  // emit every segment that ends inside this thread's range
+  St acc = carry;
+  uint32_t k = hc;
+#pragma unroll
+  for (int j = 0; j < SR_ITEMS; j++) {
+    if ((hb >> j) & 1u) {
+      if (k == 0) side[tile].first = acc;           // started in an earlier tile
+      else emit<T>(outs, G + k - 1, acc);           // complete group
+      acc = ident((St*)nullptr);
+      k++;
+    }
+    if (ok[j]) accum<T>(acc, x[j]);
+  }
+  if (tid == SR_BLOCK - 1) {
+    const bool any = cflag || flag;
+    if (any) {
+      side[tile].last = acc;
+    } else {
+      side[tile].first = acc;                       // no head in this tile at all
+      side[tile].last = ident((St*)nullptr);
+    }
+    side[tile].has_head = any ? 1u : 0u;
+    side[tile].last_gid = G + k - 1;                // meaningful only if any
+  }
+}
+
+// One wave per tile that contains a head: its trailing open segment is
+// completed with the `first` parts of the following tiles up to and including
+// the next tile that has a head, then finalised.
+template <typename T>
+__global__ void __launch_bounds__(256) seg_fixup_kernel(const TileSide<typename VT<T>::St>* side, uint32_t ntiles,
+                                                        OutsT<T> outs) {
+  typedef typename VT<T>::St St;
+  const uint32_t t = blockIdx.x * 4 + wave_id();
+  if (t >= ntiles) return;
+  if (!side[t].has_head) return;
+  const int lane = lane_id();
+  St acc = side[t].last;
+  uint32_t u = t + 1;
+  bool done = (u >= ntiles);
+  // common case first: the next tile has a head
+  if (!done) {
+    const uint32_t hh = side[u].has_head;
+    acc = comb(acc, side[u].first);
+    u++;
+    done = hh || (u >= ntiles);
+  }
+  while (!done) {
+    const uint32_t v = u + lane;
+    St s = ident((St*)nullptr);
+    uint32_t hh = 0;
+    if (v < ntiles) { s = side[v].first; hh = side[v].has_head; }
+    const unsigned long long bal = __ballot(hh != 0);
+    const int stop = bal ? (__ffsll((long long)bal) - 1) : 63;   // last lane that contributes
+    if (lane > stop) s = ident((St*)nullptr);
+    // ordered inclusive scan, take the value at lane `stop`
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const St pv = shfl_up_st(s, o);
+      if (lane >= o) s = comb(pv, s);
+    }
+    const St tot = shfl_st(s, stop);
+    acc = comb(acc, tot);
+    u += 64;
+    done = (bal != 0) || (u >= ntiles);
+  }
+  if (lane == 0) emit<T>(outs, side[t].last_gid, acc);
+}
+
+template <typename T>
+static int reduce_t(dthip_ctx* ctx, const void* values, const int32_t* ri, const uint8_t* bitmap,
+                    const uint32_t* tile_first_head, int64_t nrows, const ReduceOuts& o) {
+  typedef typename VT<T>::St St;
+  const uint32_t nt = (uint32_t)((nrows + SR_TILE - 1) / SR_TILE);
+  if (nt == 0) return DTHIP_OK;
+  Scratch sc(ctx);
+  TileSide<St>* side = nullptr;
+  DTHIP_TRY(sc.get<TileSide<St>>(nt, &side));
+  OutsT<T> outs;
+  outs.sum = static_cast<typename VT<T>::SumT*>(o.sum);
+  outs.mean = static_cast<typename VT<T>::MeanT*>(o.mean);
+  outs.mn = static_cast<T*>(o.mn);
+  outs.mx = static_cast<T*>(o.mx);
+  outs.count = reinterpret_cast<long long*>(o.count);
+  DTHIP_LAUNCH(ctx, "seg_reduce_kernel", seg_reduce_kernel<T>, nt, SR_BLOCK, 0,
+               static_cast<const T*>(values), ri, bitmap, tile_first_head, (uint32_t)nrows, outs, side);
+  DTHIP_LAUNCH(ctx, "seg_fixup_kernel", seg_fixup_kernel<T>, (nt + 3) / 4, 256, 0, side, nt, outs);
+  return DTHIP_OK;
+}
+
+int launch_reduce(dthip_ctx* ctx, const void* values, int stype, const int32_t* rowindex,
+                  const uint8_t* bitmap, const uint32_t* tile_first_head, int64_t nrows,
+                  const ReduceOuts& outs) {
+  switch (stype) {
+    case DTHIP_BOOL: case DTHIP_INT8: return reduce_t<int8_t>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
+    case DTHIP_INT16: return reduce_t<int16_t>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
+    case DTHIP_INT32: return reduce_t<int32_t>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
+    case DTHIP_INT64: return reduce_t<long long>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
+    case DTHIP_FLOAT32: return reduce_t<float>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
+    case DTHIP_FLOAT64: return reduce_t<double>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
+    default: set_error("reduce: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
+  }
+}
+
+// count(): rows per group = offsets[g+1] - offsets[g]   (count.h:77-88)
+__global__ void __launch_bounds__(256) count0_kernel(const int32_t* offsets, uint32_t ngroups, long long* out) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g < ngroups) out[g] = (long long)offsets[g + 1] - (long long)offsets[g];
+}
+
+int launch_count0(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t* out) {
+  if (ngroups == 0) return DTHIP_OK;
+  DTHIP_LAUNCH(ctx, "count0_kernel", count0_kernel, (unsigned)((ngroups + 255) / 256), 256, 0,
+               offsets, (uint32_t)ngroups, reinterpret_cast<long long*>(out));
+  return DTHIP_OK;
+}
+
+}  // namespace dthip

@@ -1,0 +1,151 @@
+// rowindex.hip -- RowIndex construction and application.
+//
+//   compact:  boolean mask (or  col <cmp> scalar  predicate) -> ascending ARR32
+//             of passing rows.  Reference: ArrayRowIndexImpl::init_from_boolean_column
+//             (src/core/rowindex_array.cc:130-170): parallel count, then a SERIAL
+//             compaction loop; here count + scan + ordered scatter, all parallel.
+//   gather:   out[i] = col[ri[i]] (NA for negative indices) -- the loop behind
+//             ArrayView_ColumnImpl + _materialize_fw (src/core/column/view.cc:140-145,
+//             column_impl.cc:78-101).
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace dthip {
+
+constexpr int CP_BLOCK = 256;
+constexpr int CP_ITEMS = 8;
+constexpr int CP_TILE = CP_BLOCK * CP_ITEMS;
+
+// comparison of a column element with a scalar; NA compares false (NE: true),
+// like the reference's comparison FExprs feed init_from_boolean_column
+__device__ __forceinline__ bool pred_at(const PredArgs& p, uint32_t i) {
+  if (p.is_mask) {
+    const int8_t v = static_cast<const int8_t*>(p.data)[i];
+    return v != INT8_MIN && v != 0;
+  }
+  bool na; double fv = 0; long long iv = 0; bool isf = false;
+  switch (p.stype) {
+    case DTHIP_BOOL: case DTHIP_INT8: { int8_t v = static_cast<const int8_t*>(p.data)[i]; na = v == INT8_MIN; iv = v; break; }
+    case DTHIP_INT16: { int16_t v = static_cast<const int16_t*>(p.data)[i]; na = v == INT16_MIN; iv = v; break; }
+    case DTHIP_INT32: { int32_t v = static_cast<const int32_t*>(p.data)[i]; na = v == INT32_MIN; iv = v; break; }
+    case DTHIP_INT64: { long long v = static_cast<const long long*>(p.data)[i]; na = v == INT64_MIN; iv = v; break; }
+    case DTHIP_FLOAT32: { float v = static_cast<const float*>(p.data)[i]; na = v != v; fv = v; isf = true; break; }
+    default: { double v = static_cast<const double*>(p.data)[i]; na = v != v; fv = v; isf = true; break; }
+  }
+  if (isf) {
+    switch (p.cmp) {
+      case DTHIP_GT: return !na && fv > p.cf;   case DTHIP_GE: return !na && fv >= p.cf;
+      case DTHIP_LT: return !na && fv < p.cf;   case DTHIP_LE: return !na && fv <= p.cf;
+      case DTHIP_EQ: return !na && fv == p.cf;  default: return na || fv != p.cf;
+    }
+  }
+  switch (p.cmp) {
+    case DTHIP_GT: return !na && iv > p.ci;   case DTHIP_GE: return !na && iv >= p.ci;
+    case DTHIP_LT: return !na && iv < p.ci;   case DTHIP_LE: return !na && iv <= p.ci;
+    case DTHIP_EQ: return !na && iv == p.ci;  default: return na || iv != p.ci;
+  }
+}
+
+__device__ __forceinline__ uint32_t sweep_pred(const PredArgs& p, uint32_t n, uint32_t wave_base, uint32_t* cnt) {
+  const int lane = lane_id();
+  uint32_t bits = 0, c = 0;
+#pragma unroll
+  for (int k = 0; k < CP_ITEMS; k++) {
+    const uint32_t idx = wave_base + 64u * k + lane;
+    const bool f = idx < n && pred_at(p, idx);
+    bits |= (uint32_t)f << k;
+    c += (uint32_t)__popcll(__ballot(f));
+  }
+  *cnt = c;
+  return bits;
+}
+
+__global__ void __launch_bounds__(CP_BLOCK) compact_count_kernel(PredArgs p, uint32_t n, uint32_t* tile_counts) {
+  __shared__ uint32_t wc[CP_BLOCK / 64];
+  uint32_t cnt;
+  sweep_pred(p, n, blockIdx.x * CP_TILE + wave_id() * (64 * CP_ITEMS), &cnt);
+  if (lane_id() == 0) wc[wave_id()] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t s = 0;
+    for (int w = 0; w < CP_BLOCK / 64; w++) s += wc[w];
+    tile_counts[blockIdx.x] = s;
+  }
+}
+
+__global__ void __launch_bounds__(CP_BLOCK) compact_write_kernel(PredArgs p, uint32_t n, const uint32_t* tile_base,
+                                                                 int32_t* out) {
+  __shared__ uint32_t wc[CP_BLOCK / 64];
+  const int lane = lane_id(), wave = wave_id();
+  const uint32_t wave_base = blockIdx.x * CP_TILE + wave * (64 * CP_ITEMS);
+  uint32_t cnt;
+  const uint32_t bits = sweep_pred(p, n, wave_base, &cnt);
+  if (lane == 0) wc[wave] = cnt;
+  __syncthreads();
+  uint32_t running = tile_base[blockIdx.x];
+  for (int w = 0; w < wave; w++) running += wc[w];
+#pragma unroll
+  for (int k = 0; k < CP_ITEMS; k++) {
+    const bool f = (bits >> k) & 1u;
+    const unsigned long long bal = __ballot(f);
+    if (f) out[running + mbcnt64(bal)] = (int32_t)(wave_base + 64u * k + lane);
+    running += (uint32_t)__popcll(bal);
+  }
+}
+
+int launch_compact(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out, int64_t* nout_host) {
+  *nout_host = 0;
+  if (n == 0) return DTHIP_OK;
+  const uint32_t nt = (uint32_t)((n + CP_TILE - 1) / CP_TILE);
+  Scratch sc(ctx);
+  uint32_t* tile_counts = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>(nt + 1, &tile_counts));
+  DTHIP_LAUNCH(ctx, "compact_count_kernel", compact_count_kernel, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts);
+  DTHIP_TRY(launch_scan_tiles(ctx, tile_counts, nt, tile_counts + nt));
+  DTHIP_LAUNCH(ctx, "compact_write_kernel", compact_write_kernel, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts, out);
+  uint32_t total = 0;
+  DTHIP_TRY(read_back(ctx, &total, tile_counts + nt, sizeof(total)));
+  *nout_host = total;
+  return DTHIP_OK;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gather_kernel(const T* __restrict__ data, const int32_t* __restrict__ ri,
+                                                     uint32_t n, T* __restrict__ out, T na) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int32_t r = ri[i];
+    out[i] = r >= 0 ? data[r] : na;
+  }
+}
+
+int launch_gather(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, int64_t nout, void* out) {
+  if (nout == 0) return DTHIP_OK;
+  long long blocks = (nout + 1023) / 1024;
+  if (blocks > ctx->num_cus * 16) blocks = ctx->num_cus * 16;
+  const unsigned g = (unsigned)blocks;
+  const uint32_t n = (uint32_t)nout;
+  switch (stype_size(stype)) {
+    case 1:
+      DTHIP_LAUNCH(ctx, "gather_kernel", gather_kernel<uint8_t>, g, 256, 0, static_cast<const uint8_t*>(data), ri, n,
+                   static_cast<uint8_t*>(out), (uint8_t)0x80);
+      break;
+    case 2:
+      DTHIP_LAUNCH(ctx, "gather_kernel", gather_kernel<uint16_t>, g, 256, 0, static_cast<const uint16_t*>(data), ri, n,
+                   static_cast<uint16_t*>(out), (uint16_t)0x8000);
+      break;
+    case 4:
+      DTHIP_LAUNCH(ctx, "gather_kernel", gather_kernel<uint32_t>, g, 256, 0, static_cast<const uint32_t*>(data), ri, n,
+                   static_cast<uint32_t*>(out), stype == DTHIP_FLOAT32 ? 0x7FC00000u : 0x80000000u);
+      break;
+    case 8:
+      DTHIP_LAUNCH(ctx, "gather_kernel", gather_kernel<unsigned long long>, g, 256, 0,
+                   static_cast<const unsigned long long*>(data), ri, n, static_cast<unsigned long long*>(out),
+                   stype == DTHIP_FLOAT64 ? 0x7FF8000000000000ULL : 0x8000000000000000ULL);
+      break;
+    default: set_error("gather: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
+  }
+  return DTHIP_OK;
+}
+
+}  // namespace dthip

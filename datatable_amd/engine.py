@@ -1,0 +1,277 @@
+"""Thin object layer over the C ABI (include/dthip.h): Context, Result.
+
+Host API: numpy arrays in datatable's storage convention (sentinel NAs:
+INT*_MIN, NaN; bool8 as int8 with -128 = NA).  Device API: `DevCol(ptr, stype)`
+wrappers around raw HBM pointers (e.g. torch `tensor.data_ptr()`), nothing copied.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+NP2ST = {np.dtype(np.bool_): L.BOOL, np.dtype(np.int8): L.INT8, np.dtype(np.int16): L.INT16,
+         np.dtype(np.int32): L.INT32, np.dtype(np.int64): L.INT64,
+         np.dtype(np.float32): L.FLOAT32, np.dtype(np.float64): L.FLOAT64}
+ST2NP = {L.BOOL: np.dtype(np.int8), L.INT8: np.dtype(np.int8), L.INT16: np.dtype(np.int16),
+         L.INT32: np.dtype(np.int32), L.INT64: np.dtype(np.int64),
+         L.FLOAT32: np.dtype(np.float32), L.FLOAT64: np.dtype(np.float64)}
+OPS = {"sum": L.SUM, "mean": L.MEAN, "min": L.MIN, "max": L.MAX, "count": L.COUNT, "count0": L.COUNT0}
+CMP = {">": L.GT, ">=": L.GE, "<": L.LT, "<=": L.LE, "==": L.EQ, "!=": L.NE}
+
+
+class DevCol:
+    """A typed column living in HBM: raw device pointer + stype (+ sort flags)."""
+    __slots__ = ("ptr", "stype", "desc", "keepalive")
+
+    def __init__(self, ptr, stype, desc=False, keepalive=None):
+        self.ptr = int(ptr)
+        self.stype = int(stype)
+        self.desc = bool(desc)
+        self.keepalive = keepalive
+
+
+def _host_col(a, stype=None, desc=False):
+    a = np.ascontiguousarray(a)
+    st = stype if stype is not None else NP2ST[a.dtype]
+    if a.dtype == np.bool_:
+        a = a.view(np.int8)
+    if st in ST2NP and a.dtype.itemsize != ST2NP[st].itemsize:
+        raise TypeError("array dtype %s does not match stype %d" % (a.dtype, st))
+    return a, L.Col(a.ctypes.data, st, L.FLAG_DESCENDING if desc else 0)
+
+
+def _cols(cols, stypes=None, desc=None):
+    """-> (ctypes array of Col, mem space, keepalive list)"""
+    n = len(cols)
+    arr = (L.Col * max(n, 1))()
+    keep = []
+    mem = None
+    for i, c in enumerate(cols):
+        if isinstance(c, DevCol):
+            m = L.DEVICE
+            arr[i] = L.Col(c.ptr, c.stype, L.FLAG_DESCENDING if c.desc else 0)
+        else:
+            m = L.HOST
+            a, cc = _host_col(c, stypes[i] if stypes else None, bool(desc[i]) if desc else False)
+            keep.append(a)
+            arr[i] = cc
+        if mem is None:
+            mem = m
+        elif mem != m:
+            raise ValueError("cannot mix host arrays and device columns in one call")
+    return arr, (L.HOST if mem is None else mem), keep
+
+
+class Result:
+    """Device-resident result of a groupby (dthip_result)."""
+
+    def __init__(self, ctx, handle, key_stypes, naggs):
+        self._ctx = ctx
+        self._h = handle
+        self.key_stypes = list(key_stypes)
+        self.naggs = naggs
+        lib = ctx._lib
+        self.ngroups = lib.dthip_result_ngroups(handle)
+        self.nrows = lib.dthip_result_nrows(handle)
+
+    # raw device pointers (valid until free())
+    @property
+    def rowindex_ptr(self):
+        return self._ctx._lib.dthip_result_rowindex(self._h)
+
+    @property
+    def offsets_ptr(self):
+        return self._ctx._lib.dthip_result_offsets(self._h)
+
+    def key_ptr(self, k):
+        return self._ctx._lib.dthip_result_key(self._h, k)
+
+    def agg_ptr(self, a):
+        return self._ctx._lib.dthip_result_agg(self._h, a)
+
+    def agg_stype(self, a):
+        return self._ctx._lib.dthip_result_agg_stype(self._h, a)
+
+    # host copies
+    def rowindex(self):
+        out = np.empty(self.nrows, np.int32)
+        L.check(self._ctx._lib.dthip_result_copy_rowindex(self._ctx._h, self._h, out.ctypes.data, L.HOST))
+        return out
+
+    def offsets(self):
+        out = np.empty(self.ngroups + 1, np.int32)
+        L.check(self._ctx._lib.dthip_result_copy_offsets(self._ctx._h, self._h, out.ctypes.data, L.HOST))
+        return out
+
+    def key(self, k):
+        out = np.empty(self.ngroups, ST2NP[self.key_stypes[k]])
+        L.check(self._ctx._lib.dthip_result_copy_key(self._ctx._h, self._h, k, out.ctypes.data, L.HOST))
+        return out
+
+    def agg(self, a):
+        out = np.empty(self.ngroups, ST2NP[self.agg_stype(a)])
+        L.check(self._ctx._lib.dthip_result_copy_agg(self._ctx._h, self._h, a, out.ctypes.data, L.HOST))
+        return out
+
+    def group_keys(self, key, stype=None):
+        """by-column of a plain groupby result: key[rowindex[offsets[g]]]"""
+        arr, mem, keep = _cols([key], [stype] if stype is not None else None)
+        st = arr[0].stype
+        if mem == L.HOST:
+            out = np.empty(self.ngroups, ST2NP[st])
+            L.check(self._ctx._lib.dthip_result_group_keys(self._ctx._h, self._h, arr, mem, out.ctypes.data))
+            return out
+        raise ValueError("device group_keys: call dthip_result_group_keys with your own output buffer")
+
+    def free(self):
+        if self._h is not None:
+            self._ctx._lib.dthip_result_free(self._ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            if self._ctx._h is not None:
+                self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One device + one HIP stream + cached workspace (dthip_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = L.load()
+        h = C.c_void_p()
+        rc = self._lib.dthip_init(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        L.check(rc)
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h is not None:
+            self._lib.dthip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        L.check(self._lib.dthip_sync(self._h))
+
+    def trim(self):
+        L.check(self._lib.dthip_trim(self._h))
+
+    # ---- timing -----------------------------------------------------------
+    def timer_start(self):
+        L.check(self._lib.dthip_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        L.check(self._lib.dthip_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def profile(self, on=True):
+        L.check(self._lib.dthip_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        L.check(self._lib.dthip_profile_reset(self._h))
+
+    def profile_get(self, name):
+        ms, n = C.c_double(0), C.c_int64(0)
+        L.check(self._lib.dthip_profile_get(self._h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def profile_names(self):
+        buf = C.create_string_buffer(8192)
+        L.check(self._lib.dthip_profile_names(self._h, buf, len(buf)))
+        return [s for s in buf.value.decode().split("\n") if s]
+
+    # ---- S-grp ------------------------------------------------------------
+    def groupby(self, keys, nrows=None, stypes=None, desc=None, na_last=False, want_rowindex=True):
+        arr, mem, keep = _cols(keys, stypes, desc)
+        if nrows is None:
+            nrows = len(keep[0])
+        h = C.c_void_p()
+        L.check(self._lib.dthip_groupby(self._h, arr, len(keys), nrows, L.NA_LAST if na_last else L.NA_FIRST, mem,
+                                        1 if want_rowindex else 0, C.byref(h)))
+        return Result(self, h, [arr[i].stype for i in range(len(keys))], 0)
+
+    def groupby_agg(self, keys, values, aggs, nrows=None, key_stypes=None, value_stypes=None, desc=None,
+                    na_last=False):
+        """aggs: list of (op, value_index); op a name ('sum','mean','min','max','count','count0') or code."""
+        karr, kmem, kkeep = _cols(keys, key_stypes, desc)
+        varr, vmem, vkeep = _cols(values, value_stypes)
+        if values and kmem != vmem:
+            raise ValueError("keys and values must live in the same memory space")
+        if nrows is None:
+            nrows = len(kkeep[0])
+        aarr = (L.Agg * max(len(aggs), 1))()
+        for i, (op, col) in enumerate(aggs):
+            aarr[i] = L.Agg(OPS[op] if isinstance(op, str) else int(op), -1 if col is None else int(col))
+        h = C.c_void_p()
+        L.check(self._lib.dthip_groupby_agg(self._h, karr, len(keys), varr, len(values), aarr, len(aggs), nrows,
+                                            L.NA_LAST if na_last else L.NA_FIRST, kmem, C.byref(h)))
+        return Result(self, h, [karr[i].stype for i in range(len(keys))], len(aggs))
+
+    # ---- S-red ------------------------------------------------------------
+    def reduce(self, op, values, rowindex, offsets, stype=None):
+        opc = OPS[op] if isinstance(op, str) else int(op)
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        ng = len(offsets) - 1
+        nrows = int(offsets[-1]) if ng >= 0 and len(offsets) else 0
+        ri = None
+        if rowindex is not None:
+            ri = np.ascontiguousarray(rowindex, np.int32)
+        if opc == L.COUNT0:
+            out = np.empty(ng, np.int64)
+            L.check(self._lib.dthip_reduce(self._h, opc, None, None, offsets.ctypes.data, ng, nrows, L.HOST,
+                                           out.ctypes.data))
+            return out
+        a, col = _host_col(values, stype)
+        ost = self._lib.dthip_reduce_out_stype(opc, col.stype)
+        out = np.empty(ng, ST2NP[ost])
+        L.check(self._lib.dthip_reduce(self._h, opc, C.byref(col), ri.ctypes.data if ri is not None else None,
+                                       offsets.ctypes.data, ng, nrows, L.HOST, out.ctypes.data))
+        return out
+
+    # ---- RowIndex ---------------------------------------------------------
+    def bool_to_rowindex(self, mask):
+        m = np.ascontiguousarray(mask)
+        if m.dtype == np.bool_:
+            m = m.view(np.int8)
+        out = np.empty(len(m), np.int32)
+        k = C.c_int64(0)
+        L.check(self._lib.dthip_bool_to_rowindex(self._h, m.ctypes.data, len(m), L.HOST, out.ctypes.data, C.byref(k)))
+        return out[:k.value].copy()
+
+    def filter_cmp(self, values, cmp, scalar, stype=None):
+        a, col = _host_col(values, stype)
+        out = np.empty(len(a), np.int32)
+        k = C.c_int64(0)
+        isf = col.stype in (L.FLOAT32, L.FLOAT64)
+        L.check(self._lib.dthip_filter_cmp(self._h, C.byref(col), len(a), CMP[cmp], float(scalar),
+                                           0 if isf else int(scalar), L.HOST, out.ctypes.data, C.byref(k)))
+        return out[:k.value].copy()
+
+    def gather(self, values, rowindex, stype=None):
+        a, col = _host_col(values, stype)
+        ri = np.ascontiguousarray(rowindex, np.int32)
+        out = np.empty(len(ri), a.dtype)
+        L.check(self._lib.dthip_gather(self._h, C.byref(col), ri.ctypes.data, len(ri), L.HOST, out.ctypes.data))
+        return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on device LOCAL_RANK (or 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        import os
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

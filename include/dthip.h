@@ -1,0 +1,195 @@
+/*
+ * dthip.h -- C ABI of libdthip.so: the MI355X (gfx950) implementation of
+ * datatable's DT[i, j, by()] hot path.
+ *
+ * Every entry point replaces (or is what a binding of) one seam of the
+ * reference, h2oai/datatable v1.2.0a (paths relative to the reference root):
+ *
+ *   dthip_groupby        <- RiGb group(columns, flags, na_pos)
+ *                           src/core/sort.h:56-58, src/core/sort.cc:1411-1495
+ *   dthip_reduce         <- FExpr_ReduceUnary::evaluate1(col, gby, is_grouped)
+ *                           src/core/expr/fexpr_reduce_unary.h:42 and the
+ *                           reducer columns src/core/column/sumprod.h:34-59,
+ *                           mean.h:33-52, minmax.h:33-62, count.h:35-88
+ *   dthip_groupby_agg    <- EvalContext::evaluate() for DT[:, {reducers}, by(keys)]
+ *                           src/core/expr/eval_context.cc:144-172,249-288,473-516
+ *                           (group + reducers fused; no RowIndex materialised)
+ *   dthip_bool_to_rowindex <- ArrayRowIndexImpl::init_from_boolean_column
+ *                           src/core/rowindex_array.cc:130-170
+ *   dthip_filter_cmp     <- DT[f.x <cmp> c, :] : comparison FExpr + the above
+ *                           src/core/expr/fexpr_func.cc:61-73
+ *   dthip_gather         <- ColumnImpl::_materialize_fw over an ArrayView
+ *                           src/core/column/column_impl.cc:78-101, view.cc:140-145
+ *
+ * Conventions (mirroring src/datatable/include/datatable.h:32-116, api.cc:34-38):
+ *   - plain C, no HIP/torch types in signatures; pointers + sizes only
+ *   - stype codes are the reference's SType values (src/core/stype.h:41-62)
+ *   - NA sentinels are the reference's (src/core/stype.h:186-197): INT*_MIN for
+ *     int8/16/32/64 and bool8 (-128), NaN for float32/64; no validity bitmaps
+ *   - RowIndex / group offsets are int32 (ARR32; src/core/sort.cc:464-465,
+ *     groupby.cc:43-48); nrows > INT32_MAX is rejected with DTHIP_EINVAL
+ *     (the reference silently overflows)
+ *   - every function returns 0 on success or a negative DTHIP_E* code and
+ *     records a message retrievable with dthip_last_error() (thread-local)
+ *   - `mem` says where ALL data pointers of that call live: DTHIP_HOST
+ *     (pageable/pinned host memory; the call stages through HBM) or
+ *     DTHIP_DEVICE (HBM pointers of the context's device; nothing is copied)
+ *   - a context owns one HIP stream; calls are asynchronous on that stream
+ *     for DTHIP_DEVICE data except where a result size must be known
+ *     (ngroups), thread-compatible but not thread-safe
+ */
+#ifndef DTHIP_H
+#define DTHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTHIP_ABI_VERSION 1
+
+/* error codes */
+#define DTHIP_OK        0
+#define DTHIP_EINVAL   -1   /* bad argument (maps to ValueError/TypeError) */
+#define DTHIP_ENOTIMPL -2   /* unsupported stype/op (maps to NotImplementedError) */
+#define DTHIP_ENOMEM   -3   /* device allocation failed (MemoryError) */
+#define DTHIP_EDEVICE  -4   /* HIP runtime error / kernel fault (RuntimeError) */
+
+/* reference SType codes, src/core/stype.h:41-62 */
+enum dthip_stype {
+  DTHIP_BOOL = 1, DTHIP_INT8 = 2, DTHIP_INT16 = 3, DTHIP_INT32 = 4,
+  DTHIP_INT64 = 5, DTHIP_FLOAT32 = 6, DTHIP_FLOAT64 = 7
+};
+
+/* reducers */
+enum dthip_op {
+  DTHIP_SUM = 0, DTHIP_MEAN = 1, DTHIP_MIN = 2, DTHIP_MAX = 3,
+  DTHIP_COUNT = 4,   /* count(col): non-NA rows per group   (count.h:35-58) */
+  DTHIP_COUNT0 = 5   /* count():    rows per group          (count.h:61-88) */
+};
+
+enum dthip_mem { DTHIP_HOST = 0, DTHIP_DEVICE = 1 };
+
+/* NaPosition, src/core/sort.h:46-50 (REMOVE is not implemented) */
+enum dthip_napos { DTHIP_NA_FIRST = 0, DTHIP_NA_LAST = 1 };
+
+/* SortFlag bits, src/core/sort.h:36-44 */
+#define DTHIP_FLAG_DESCENDING 1
+
+/* comparison codes for dthip_filter_cmp */
+enum dthip_cmp { DTHIP_GT = 0, DTHIP_GE = 1, DTHIP_LT = 2, DTHIP_LE = 3, DTHIP_EQ = 4, DTHIP_NE = 5 };
+
+/* one typed column buffer: contiguous T[nrows] with sentinel NAs
+ * (SentinelFw_ColumnImpl<T>, src/core/column/sentinel_fw.cc:141-181) */
+typedef struct dthip_col {
+  const void* data;
+  int32_t stype;   /* enum dthip_stype */
+  int32_t flags;   /* DTHIP_FLAG_* (keys only) */
+} dthip_col;
+
+/* one requested aggregate: op applied to values[col] (col ignored for COUNT0) */
+typedef struct dthip_agg {
+  int32_t op;      /* enum dthip_op */
+  int32_t col;
+} dthip_agg;
+
+typedef struct dthip_ctx dthip_ctx;       /* device + stream + workspace */
+typedef struct dthip_result dthip_result; /* device-resident result of a groupby */
+
+/* ---- library / context -------------------------------------------------- */
+int         dthip_abi_version(void);
+const char* dthip_last_error(void);
+int         dthip_device_count(void);
+/* stream: a hipStream_t to launch on (e.g. the caller's current stream), or NULL
+ * to let the context create its own non-blocking stream. */
+int  dthip_init(int device, void* stream, dthip_ctx** out);
+int  dthip_destroy(dthip_ctx* ctx);
+int  dthip_sync(dthip_ctx* ctx);
+/* release cached workspace back to the driver */
+int  dthip_trim(dthip_ctx* ctx);
+
+/* device memory helpers so a host-language binding needs no HIP runtime */
+int  dthip_malloc(dthip_ctx* ctx, size_t bytes, void** dptr);
+int  dthip_free(dthip_ctx* ctx, void* dptr);
+int  dthip_memcpy_h2d(dthip_ctx* ctx, void* dst, const void* src, size_t bytes);
+int  dthip_memcpy_d2h(dthip_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* stream timers (HIP events on the context's stream) */
+int  dthip_timer_start(dthip_ctx* ctx);
+int  dthip_timer_stop(dthip_ctx* ctx, float* elapsed_ms);   /* synchronises */
+/* per-kernel accounting: when enabled every launch of the library's kernels is
+ * bracketed by HIP events; dthip_profile_get() synchronises and returns the
+ * accumulated time and launch count of kernels whose name contains `name`. */
+int  dthip_profile_enable(dthip_ctx* ctx, int on);
+int  dthip_profile_reset(dthip_ctx* ctx);
+int  dthip_profile_get(dthip_ctx* ctx, const char* name, double* total_ms, int64_t* launches);
+/* names (newline separated) of all kernels seen since the last reset */
+int  dthip_profile_names(dthip_ctx* ctx, char* buf, size_t buflen);
+
+/* ---- S-grp: group() ------------------------------------------------------ */
+/* Stable sort of rows by keys[0..nkeys) (keys[0] most significant), NA first
+ * unless na_pos says otherwise, and the run-length grouping of equal keys.
+ * The result holds, on the device: rowindex int32[nrows] (only if
+ * want_rowindex) and offsets int32[ngroups+1]. */
+int  dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrows,
+                   int na_pos, int mem, int want_rowindex, dthip_result** out);
+
+/* ---- fused DT[:, aggs, by(keys)] ----------------------------------------- */
+/* Groups by keys and evaluates aggs without materialising the RowIndex.
+ * The result holds offsets, one group-key column per key (value of the key in
+ * each group, stype of the key) and one column per agg, typed by
+ * dthip_reduce_out_stype(). */
+int  dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys,
+                       const dthip_col* values, int nvalues,
+                       const dthip_agg* aggs, int naggs,
+                       int64_t nrows, int na_pos, int mem, dthip_result** out);
+
+/* ---- result accessors ---------------------------------------------------- */
+int64_t dthip_result_ngroups(const dthip_result* r);
+int64_t dthip_result_nrows(const dthip_result* r);
+/* device pointers owned by the result (NULL if absent) */
+const int32_t* dthip_result_rowindex(const dthip_result* r);
+const int32_t* dthip_result_offsets(const dthip_result* r);
+const void*    dthip_result_key(const dthip_result* r, int k);
+const void*    dthip_result_agg(const dthip_result* r, int a);
+int            dthip_result_agg_stype(const dthip_result* r, int a);
+/* copy out (dst in `mem` space, sized by the caller from ngroups/nrows) */
+int  dthip_result_copy_rowindex(dthip_ctx* ctx, const dthip_result* r, int32_t* dst, int mem);
+int  dthip_result_copy_offsets(dthip_ctx* ctx, const dthip_result* r, int32_t* dst, int mem);
+int  dthip_result_copy_key(dthip_ctx* ctx, const dthip_result* r, int k, void* dst, int mem);
+int  dthip_result_copy_agg(dthip_ctx* ctx, const dthip_result* r, int a, void* dst, int mem);
+/* fill the by-column k of a groupby (not _agg) result: key[rowindex[offsets[g]]]
+ * (EvalContext::update_groupby_columns, eval_context.cc:473-485) */
+int  dthip_result_group_keys(dthip_ctx* ctx, const dthip_result* r, const dthip_col* key,
+                             int mem, void* dst);
+int  dthip_result_free(dthip_ctx* ctx, dthip_result* r);
+
+/* ---- S-red: per-group reducers over an existing grouping ------------------ */
+/* output stype of op applied to a column of stype `stype`
+ * (fexpr_sumprod.cc:47-66, fexpr_mean.cc:45-74, fexpr_minmax.cc:47-68, fexpr_count.cc) */
+int  dthip_reduce_out_stype(int op, int stype);
+/* value[rowindex[i]] for i in [offsets[g], offsets[g+1]) reduced per group.
+ * rowindex may be NULL (identity: the column is already in grouped order).
+ * value may be NULL for DTHIP_COUNT0.  out: T_out[ngroups], NA as sentinel. */
+int  dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value,
+                  const int32_t* rowindex, const int32_t* offsets,
+                  int64_t ngroups, int64_t nrows, int mem, void* out);
+
+/* ---- RowIndex construction / application ---------------------------------- */
+/* ascending ARR32 of rows whose mask is 1 and not NA; out has room for n */
+int  dthip_bool_to_rowindex(dthip_ctx* ctx, const int8_t* mask, int64_t n, int mem,
+                            int32_t* out, int64_t* nout);
+/* rows where col[i] <cmp> scalar (NA compares false, except NE); scalar is cf
+ * for float columns and ci for integer columns */
+int  dthip_filter_cmp(dthip_ctx* ctx, const dthip_col* col, int64_t n, int cmp,
+                      double cf, int64_t ci, int mem, int32_t* out, int64_t* nout);
+/* out[i] = rowindex[i] < 0 ? NA : col[rowindex[i]] */
+int  dthip_gather(dthip_ctx* ctx, const dthip_col* col, const int32_t* rowindex,
+                  int64_t nout, int mem, void* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTHIP_H */

@@ -1,0 +1,292 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libdthip.so), against
+  (1) the committed golden fixtures = outputs of the unmodified reference, and
+  (2) the CPU oracle on seeded inputs at sizes it finishes in seconds.
+Bit-exact for RowIndex, offsets, group keys, counts, integer sums, min/max;
+float sums/means within 1e-6 relative (BASELINE.json's tolerance; the GPU
+re-associates the sum, the reference adds left to right)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, assert_same, golden_names
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+
+OPS = ("sum", "mean", "min", "max", "count")
+
+
+def group_abs_scale(v, ri, off):
+    """sum of |v| per group, for the absolute part of the float tolerance"""
+    if len(off) < 2:
+        return np.zeros(0)
+    a = np.abs(np.nan_to_num(v.astype(np.float64), nan=0.0, posinf=0.0, neginf=0.0))[ri]
+    return np.add.reduceat(a, off[:-1].astype(np.int64)) if len(a) else np.zeros(len(off) - 1)
+
+
+def check_agg(got, exp, opn, v, ri, off, what):
+    if exp.dtype.kind == "f" and opn in ("sum", "mean"):
+        sc = group_abs_scale(v, ri, off)
+        if v.dtype == np.float32 and opn == "sum":
+            # the reference accumulates float32 sums in float32 (sumprod.h:48-55); the GPU in float64
+            assert_close(got, exp, scale=sc * 1e6, rel=1e-4, what=what)
+        else:
+            assert_close(got, exp, scale=sc, rel=1e-6, what=what)
+    else:
+        assert_same(got, exp, what)
+
+
+# ---- golden fixtures (reference outputs) -----------------------------------------------
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_groupby(ctx, gold, name):
+    c = gold.by_name[name]
+    keys = gold.keys(name)
+    r = ctx.groupby(keys, stypes=c["key_stypes"])
+    assert r.ngroups == len(gold.get(name, "off")) - 1
+    assert_same(r.offsets(), gold.get(name, "off"), "offsets")
+    assert_same(r.rowindex(), gold.get(name, "ri"), "rowindex")
+    for i in range(len(keys)):
+        assert_same(r.group_keys(keys[i], c["key_stypes"][i]), gold.get(name, "gk%d" % i), "group key %d" % i)
+    r.free()
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_fused_agg(ctx, gold, name):
+    c = gold.by_name[name]
+    keys, vals = gold.keys(name), gold.vals(name)
+    aggs = [(opn, vi) for opn, vi, _ in c["aggs"]] + [("count0", None)]
+    r = ctx.groupby_agg(keys, vals, aggs, key_stypes=c["key_stypes"], value_stypes=c["val_stypes"])
+    ri, off = gold.get(name, "ri"), gold.get(name, "off")
+    assert_same(r.offsets(), off, "offsets")
+    for i in range(len(keys)):
+        assert_same(r.key(i), gold.get(name, "gk%d" % i), "group key %d" % i)
+    for a, (opn, vi, ost) in enumerate(c["aggs"]):
+        check_agg(r.agg(a), gold.get(name, "%s.v%d" % (opn, vi)), opn, vals[vi], ri, off, "%s(v%d)" % (opn, vi))
+    assert_same(r.agg(len(c["aggs"])), np.diff(off).astype(np.int64), "count()")
+    r.free()
+
+
+@pytest.mark.parametrize("name", ["appendixB", "keytype_4", "keytype_7", "c2_shape", "skewed", "all_na_value"])
+def test_golden_reduce_through_rowindex(ctx, gold, name):
+    """S-red seam: reducers over a caller-supplied RowIndex + offsets"""
+    c = gold.by_name[name]
+    vals = gold.vals(name)
+    ri, off = gold.get(name, "ri"), gold.get(name, "off")
+    for opn, vi, ost in c["aggs"]:
+        got = ctx.reduce(opn, vals[vi], ri, off, stype=c["val_stypes"][vi])
+        check_agg(got, gold.get(name, "%s.v%d" % (opn, vi)), opn, vals[vi], ri, off, "%s(v%d)" % (opn, vi))
+    assert_same(ctx.reduce("count0", None, None, off), np.diff(off).astype(np.int64), "count()")
+
+
+# ---- seeded random inputs vs the oracle ----------------------------------------------------
+
+def _vs_oracle(ctx, keys, vals, aggs=OPS, key_stypes=None, check_ri=True):
+    ri, off = o.group(keys, stypes=key_stypes)
+    if check_ri:
+        r = ctx.groupby(keys, stypes=key_stypes)
+        assert_same(r.offsets(), off, "offsets")
+        assert_same(r.rowindex(), ri, "rowindex")
+        r.free()
+    alist = [(opn, vi) for vi in range(len(vals)) for opn in aggs] + [("count0", None)]
+    r = ctx.groupby_agg(keys, vals, alist, key_stypes=key_stypes)
+    assert_same(r.offsets(), off, "fused offsets")
+    for i, k in enumerate(keys):
+        kk = k.view(np.int8) if k.dtype == np.bool_ else k
+        assert_same(r.key(i), kk[ri[off[:-1]]], "fused group key %d" % i)
+    for a, (opn, vi) in enumerate(alist[:-1]):
+        check_agg(r.agg(a), o.reduce(opn, vals[vi], ri, off), opn, vals[vi], ri, off, "%s(v%d)" % (opn, vi))
+    assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count()")
+    r.free()
+
+
+def test_config1_full_size(ctx):
+    """BASELINE config 1 at full size: 1e6 rows, int32 key (100 groups), sum(float64)"""
+    rng = np.random.default_rng(1234 + 1)
+    n = 1_000_000
+    k = rng.integers(0, 100, n).astype(np.int32)
+    v = rng.standard_normal(n)
+    _vs_oracle(ctx, [k], [v])
+
+
+def test_config2_shape(ctx):
+    """BASELINE config 2 shape (1e6 of the 1e8 rows): int64 key, 4 float64 columns, sum+mean+min+max"""
+    rng = np.random.default_rng(1234 + 2)
+    n = 1_000_000
+    k = rng.integers(0, 100_000, n).astype(np.int64)
+    vals = [rng.standard_normal(n) for _ in range(4)]
+    _vs_oracle(ctx, [k], vals, aggs=("sum", "mean", "min", "max"))
+
+
+def test_config3_shape(ctx):
+    """BASELINE config 3 shape scaled: 4e6 rows, int64 key with 4e4 groups (100 rows/group), 24-bit-like key"""
+    rng = np.random.default_rng(1234 + 3)
+    n = 4_000_000
+    k = rng.integers(0, 10_000_000, n).astype(np.int64)      # 24 significant bits -> three 8-bit passes
+    v = rng.standard_normal(n)
+    _vs_oracle(ctx, [k], [v], aggs=("sum",))
+
+
+def test_config3_hard_keys(ctx):
+    """full-range int64 keys drawn from a pool: the 64-significant-bit path (8 passes, 64-bit radix keys)"""
+    rng = np.random.default_rng(99)
+    n = 1_000_000
+    pool = rng.integers(-2**62, 2**62, 10_000)
+    k = rng.choice(pool, n).astype(np.int64)
+    v = rng.standard_normal(n)
+    _vs_oracle(ctx, [k], [v], aggs=("sum", "count"))
+
+
+def test_config4_shape(ctx):
+    """BASELINE config 4 shape scaled: 2-key composite (int32,int32), count + sum"""
+    rng = np.random.default_rng(1234 + 4)
+    n = 2_000_000
+    a = rng.integers(0, 3163, n).astype(np.int32)
+    b = rng.integers(0, 3163, n).astype(np.int32)
+    v = rng.standard_normal(n)
+    _vs_oracle(ctx, [a, b], [v], aggs=("sum", "count"))
+
+
+def test_config5_two_step_filter_then_group(ctx):
+    """BASELINE config 5 in the only form the reference supports:
+    V = DT[f.x > 0, :]; V[:, sum(f.x), by(f.k)]"""
+    rng = np.random.default_rng(1234 + 5)
+    n = 2_000_000
+    k = rng.integers(0, 200_000, n).astype(np.int64)
+    x = rng.standard_normal(n)
+    x[rng.random(n) < 0.01] = np.nan
+    ri_f = ctx.filter_cmp(x, ">", 0.0)
+    assert_same(ri_f, o.filter_cmp(x, ">", 0.0), "filter rowindex")
+    kv, xv = ctx.gather(k, ri_f), ctx.gather(x, ri_f)
+    assert_same(kv, o.gather(k, ri_f), "gathered key")
+    assert_same(xv, o.gather(x, ri_f), "gathered x")
+    _vs_oracle(ctx, [kv], [xv], aggs=("sum",))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 2047, 2048, 2049, 8191, 8192, 8193, 16385, 100_003])
+def test_tile_boundaries(ctx, n):
+    """sizes around the wave (64), reduce-tile (2048) and radix-tile (8192) boundaries"""
+    rng = np.random.default_rng(n)
+    k = rng.integers(-50, 50, n).astype(np.int32)
+    k[rng.random(n) < 0.05] = -2**31
+    v = rng.standard_normal(n)
+    v[rng.random(n) < 0.05] = np.nan
+    _vs_oracle(ctx, [k], [v])
+
+
+def test_giant_group_spanning_many_tiles(ctx):
+    """one group covering ~all rows (look-back carries, reducer side-buffer fixup over many tiles)"""
+    n = 300_000
+    k = np.full(n, 7, np.int64)
+    k[::50_000] = 3
+    k[-1] = 9
+    v = np.arange(n, dtype=np.float64)
+    iv = np.arange(n, dtype=np.int64) - 5
+    _vs_oracle(ctx, [k], [v, iv])
+
+
+def test_already_sorted_and_reverse(ctx):
+    n = 200_000
+    v = np.random.default_rng(5).standard_normal(n)
+    _vs_oracle(ctx, [np.arange(n, dtype=np.int32) // 7], [v])
+    _vs_oracle(ctx, [(np.arange(n, dtype=np.int32)[::-1] // 3).copy()], [v])
+
+
+def test_all_distinct_keys(ctx):
+    rng = np.random.default_rng(8)
+    n = 150_000
+    k = rng.permutation(n).astype(np.int64) * 1000003
+    _vs_oracle(ctx, [k], [rng.standard_normal(n)], aggs=("sum", "min"))
+
+
+def test_value_stypes_and_narrow_values(ctx):
+    """int8/int16 values take the RowIndex-gather reducer path; float32 stays float32"""
+    rng = np.random.default_rng(21)
+    n = 100_000
+    k = rng.integers(0, 300, n).astype(np.int32)
+    vals = [rng.integers(-100, 100, n).astype(np.int8), rng.integers(-30000, 30000, n).astype(np.int16),
+            rng.integers(-10**9, 10**9, n).astype(np.int32), rng.integers(-10**15, 10**15, n).astype(np.int64),
+            rng.standard_normal(n).astype(np.float32), rng.standard_normal(n)]
+    _vs_oracle(ctx, [k], vals, check_ri=False)
+
+
+def test_three_keys_over_64_bits(ctx):
+    rng = np.random.default_rng(31)
+    n = 200_000
+    k0 = rng.choice(rng.integers(-2**62, 2**62, 50), n).astype(np.int64)
+    k1 = rng.integers(0, 9, n).astype(np.float64) / 4
+    k1[rng.random(n) < 0.1] = np.nan
+    k2 = rng.integers(-3, 3, n).astype(np.int8)
+    _vs_oracle(ctx, [k0, k1, k2], [rng.standard_normal(n)], aggs=("sum", "max"))
+
+
+def test_descending_and_na_last(ctx):
+    rng = np.random.default_rng(41)
+    n = 50_000
+    k = rng.integers(-1000, 1000, n).astype(np.int32)
+    k[rng.random(n) < 0.1] = -2**31
+    f = (rng.integers(-20, 20, n) / 4).astype(np.float64)
+    f[rng.random(n) < 0.1] = np.nan
+    for keys, desc, na_last in (([k], [True], False), ([k], [False], True), ([f], [True], False), ([f, k], [True, False], True)):
+        ri, off = o.group(keys, desc=desc, na_last=na_last)
+        r = ctx.groupby(keys, desc=desc, na_last=na_last)
+        assert_same(r.offsets(), off, "offsets desc=%s na_last=%s" % (desc, na_last))
+        assert_same(r.rowindex(), ri, "rowindex desc=%s na_last=%s" % (desc, na_last))
+        r.free()
+
+
+def test_bool_mask_to_rowindex(ctx):
+    rng = np.random.default_rng(51)
+    for n in (0, 1, 100, 5000, 300_001):
+        m = rng.integers(0, 2, n).astype(np.int8)
+        m[rng.random(n) < 0.1] = -128
+        assert_same(ctx.bool_to_rowindex(m), o.bool_to_rowindex(m), "mask n=%d" % n)
+
+
+@pytest.mark.parametrize("cmp", [">", ">=", "<", "<=", "==", "!="])
+def test_filter_cmp(ctx, cmp):
+    rng = np.random.default_rng(61)
+    n = 70_000
+    x = rng.integers(-5, 5, n).astype(np.float64)
+    x[rng.random(n) < 0.1] = np.nan
+    i = rng.integers(-5, 5, n).astype(np.int32)
+    i[rng.random(n) < 0.1] = -2**31
+    assert_same(ctx.filter_cmp(x, cmp, 1.0), o.filter_cmp(x, cmp, 1.0), "float %s" % cmp)
+    assert_same(ctx.filter_cmp(i, cmp, 1), o.filter_cmp(i, cmp, 1), "int %s" % cmp)
+
+
+def test_gather_with_na_indices(ctx):
+    rng = np.random.default_rng(71)
+    for dt in (np.int8, np.int16, np.int32, np.int64, np.float32, np.float64):
+        v = rng.integers(-100, 100, 1000).astype(dt)
+        ri = rng.integers(0, 1000, 5000).astype(np.int32)
+        ri[::17] = -2**31
+        assert_same(ctx.gather(v, ri), o.gather(v, ri), "gather %s" % dt)
+
+
+def test_rejects_bad_arguments(ctx):
+    with pytest.raises(NotImplementedError):
+        ctx.groupby([np.zeros(4, np.int32)], stypes=[11])     # STR32 keys are out of scope
+    with pytest.raises(ValueError):
+        ctx.groupby_agg([np.zeros(4, np.int32)], [np.zeros(4)], [("sum", 3)])
+
+
+# ---- full-size properties (no oracle: size-independent invariants) ----------------------------
+
+def test_full_size_properties_1e8(ctx):
+    """1e8 rows / 1e6 groups through the fused path: keys strictly ascending, counts sum to n,
+    sum of group sums == total sum (1e-9 rel), sum(v=1) == count exactly."""
+    rng = np.random.default_rng(7)
+    n = 100_000_000
+    k = rng.integers(0, 1_000_000, n, dtype=np.int64)
+    v = rng.standard_normal(n)
+    r = ctx.groupby_agg([k], [v], [("sum", 0), ("count", 0), ("count0", None), ("min", 0), ("max", 0)])
+    keys, s, c, c0 = r.key(0), r.agg(0), r.agg(1), r.agg(2)
+    mn, mx = r.agg(3), r.agg(4)
+    r.free()
+    assert np.all(np.diff(keys) > 0)
+    assert c0.sum() == n and np.array_equal(c, c0)
+    assert np.array_equal(c0, np.bincount(k, minlength=keys.max() + 1)[keys])
+    assert abs(s.sum() - v.sum()) <= 1e-9 * np.abs(v).sum()
+    assert np.all(mn <= mx) and mn.min() == v.min() and mx.max() == v.max()
+    ref = np.bincount(k, weights=v, minlength=keys.max() + 1)[keys]
+    assert_close(s, ref, scale=np.bincount(k, weights=np.abs(v))[keys], rel=1e-6, what="sum vs bincount")
