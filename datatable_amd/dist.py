@@ -1,0 +1,140 @@
+"""Multi-GPU DT[:, aggs, by(keys)]: one process per GPU, torch.distributed (RCCL over xGMI).
+
+The reference is single-process; this exchange step is new.  Design
+(SURVEY §8e): rows are sharded by row block; every rank first runs the fused local
+groupby-aggregate (a combiner, so at most one partial per local group crosses the
+fabric), then partials are range-partitioned on the FIRST key column and exchanged
+with ONE all-to-all-v per column; the owner merges the <= world_size partials of
+each group with the same HIP groupby kernel (sum of sums, sum of counts, min of mins,
+max of maxes; mean = sum(mean_i*count_i)/sum(count_i)).
+
+Range (not hash) partitioning keeps the global group order equal to the
+concatenation of the ranks' outputs in rank order -- the order the reference
+returns (ascending keys, NA group first: NA is the smallest integer sentinel and
+lands on rank 0).  xGMI is point-to-point, so an all-to-all uses all 7 links of a
+GPU concurrently; the payload is partials (<= ngroups x 16..40 B per GPU), not rows.
+
+The local compute is injected as a backend so the exchange logic is testable on CPU
+(gloo, world_size 2) with a CPU reference backend supplied by the tests; the product backend is
+`HipBackend` (libdthip through torch_bridge).  Documented deviations of the merge from
+a single-GPU run: a partial int64 sum equal to INT64_MIN, or a NaN partial float sum
+(inf - inf inside one shard), is treated as NA by the merge.
+"""
+import torch
+import torch.distributed as dist
+
+INT_KEY_DTYPES = (torch.int8, torch.int16, torch.int32, torch.int64)
+
+
+class HipBackend:
+    """local groupby_agg on this rank's GPU through the C ABI"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def groupby_agg(self, keys, values, aggs):
+        from .torch_bridge import groupby_agg_tensors
+        _, gk, out = groupby_agg_tensors(self.ctx, keys, values, aggs)
+        return gk, out
+
+
+def _partials_for(aggs):
+    """requested aggs -> deduplicated list of local partial aggs + recipe per requested agg"""
+    partial, index = [], {}
+
+    def need(op, col):
+        key = (op, col)
+        if key not in index:
+            index[key] = len(partial)
+            partial.append(key)
+        return index[key]
+
+    recipe = []
+    for op, col in aggs:
+        if op == "mean":
+            recipe.append(("mean", need("mean", col), need("count", col)))
+        elif op in ("sum", "min", "max", "count"):
+            recipe.append((op, need(op, col)))
+        elif op == "count0":
+            recipe.append(("count0", need("count0", None)))
+        else:
+            raise ValueError("unknown reducer %r" % (op,))
+    return partial, recipe
+
+
+def _all_to_all_v(t, send_counts, recv_counts, group):
+    out = torch.empty(int(sum(recv_counts)), dtype=t.dtype, device=t.device)
+    dist.all_to_all_single(out, t.contiguous(), list(recv_counts), list(send_counts), group=group)
+    return out
+
+
+def range_boundaries(gmin, gmax, world):
+    """world-1 ascending key boundaries splitting [gmin, gmax] evenly (python ints, no overflow)"""
+    width = gmax - gmin + 1
+    return [gmin + (width * j) // world for j in range(1, world)]
+
+
+def sharded_groupby_agg(backend, keys, values, aggs, group=None):
+    """keys / values: this rank's row shard (tensors on the backend's device).
+    aggs: [(op, value_index)], op in sum/mean/min/max/count/count0 (value_index None for count0).
+    Returns (group_key_tensors, agg_tensors) for the key range this rank owns."""
+    world = dist.get_world_size(group)
+    if keys[0].dtype not in INT_KEY_DTYPES:
+        raise NotImplementedError("distributed groupby partitions on an integer first key column")
+    partial, recipe = _partials_for(aggs)
+    gk, parts = backend.groupby_agg(keys, values, partial)
+    dev = gk[0].device
+    # weighted sums for means (float64)
+    cols, merge_ops = [], []
+    for i, (op, col) in enumerate(partial):
+        p = parts[i]
+        if op == "mean":
+            cnt = parts[partial.index(("count", col))]
+            p64 = p.to(torch.float64)
+            p = torch.where(cnt > 0, p64 * cnt.to(torch.float64), torch.zeros_like(p64))
+            merge_ops.append("sum")
+        elif op in ("sum", "count", "count0"):
+            merge_ops.append("sum")
+        else:
+            merge_ops.append(op)
+        cols.append(p)
+
+    # global key range of the first key (valid keys only; NA sentinel = dtype min sorts first)
+    k0 = gk[0].to(torch.int64)
+    na = torch.iinfo(gk[0].dtype).min
+    valid = k0[gk[0] != na] if k0.numel() else k0
+    big = torch.iinfo(torch.int64)
+    lo = int(valid[0].item()) if valid.numel() else big.max
+    neg_hi = -int(valid[-1].item()) if valid.numel() else big.max
+    mm = torch.tensor([lo, neg_hi], dtype=torch.int64, device=dev)
+    dist.all_reduce(mm, op=dist.ReduceOp.MIN, group=group)
+    gmin, gmax = int(mm[0].item()), -int(mm[1].item())
+    if gmin > gmax:                       # no valid key anywhere: everything (NA groups) goes to rank 0
+        gmin, gmax = 0, 0
+    bounds = torch.tensor(range_boundaries(gmin, gmax, world), dtype=torch.int64, device=dev)
+    # NA rows (sentinel) must land on rank 0: the sentinel is below every boundary
+    cut = torch.searchsorted(k0.contiguous(), bounds) if world > 1 else bounds
+    edges = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), cut.to(torch.int64),
+                       torch.tensor([k0.numel()], dtype=torch.int64, device=dev)])
+    send_counts = (edges[1:] - edges[:-1])
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+
+    rk = [_all_to_all_v(k, sc, rc, group) for k in gk]
+    rp = [_all_to_all_v(c, sc, rc, group) for c in cols]
+
+    # merge the partials of each group on its owner
+    mk, merged = backend.groupby_agg(rk, rp, [(merge_ops[i], i) for i in range(len(rp))])
+
+    out = []
+    for r in recipe:
+        if r[0] == "mean":
+            s, c = merged[r[1]], merged[r[2]]
+            m = s / c.to(torch.float64)
+            m = torch.where(c > 0, m, torch.full_like(m, float("nan")))
+            src = partial[r[1]][1]
+            out.append(m.to(values[src].dtype) if values[src].dtype == torch.float32 else m)
+        else:
+            out.append(merged[r[1]])
+    return mk, out

@@ -114,6 +114,19 @@ class Result:
         L.check(self._ctx._lib.dthip_result_copy_agg(self._ctx._h, self._h, a, out.ctypes.data, L.HOST))
         return out
 
+    # device-to-device copies into caller-owned HBM (e.g. a torch tensor's data_ptr())
+    def rowindex_into(self, ptr):
+        L.check(self._ctx._lib.dthip_result_copy_rowindex(self._ctx._h, self._h, C.c_void_p(ptr), L.DEVICE))
+
+    def offsets_into(self, ptr):
+        L.check(self._ctx._lib.dthip_result_copy_offsets(self._ctx._h, self._h, C.c_void_p(ptr), L.DEVICE))
+
+    def key_into(self, k, ptr):
+        L.check(self._ctx._lib.dthip_result_copy_key(self._ctx._h, self._h, k, C.c_void_p(ptr), L.DEVICE))
+
+    def agg_into(self, a, ptr):
+        L.check(self._ctx._lib.dthip_result_copy_agg(self._ctx._h, self._h, a, C.c_void_p(ptr), L.DEVICE))
+
     def group_keys(self, key, stype=None):
         """by-column of a plain groupby result: key[rowindex[offsets[g]]]"""
         arr, mem, keep = _cols([key], [stype] if stype is not None else None)

@@ -1,0 +1,48 @@
+"""Plumbing between torch device tensors and the C ABI: torch is used only for
+device memory, streams and torch.distributed (RCCL); all compute is libdthip."""
+import torch
+
+from . import _lib as L
+from .engine import Context, DevCol
+
+T2ST = {torch.bool: L.BOOL, torch.int8: L.INT8, torch.int16: L.INT16, torch.int32: L.INT32,
+        torch.int64: L.INT64, torch.float32: L.FLOAT32, torch.float64: L.FLOAT64}
+ST2T = {L.BOOL: torch.int8, L.INT8: torch.int8, L.INT16: torch.int16, L.INT32: torch.int32,
+        L.INT64: torch.int64, L.FLOAT32: torch.float32, L.FLOAT64: torch.float64}
+
+
+def context_for_current_stream(device_index):
+    """A Context that launches on torch's current stream of that device, so torch ops and
+    libdthip kernels are ordered without extra synchronisation."""
+    with torch.cuda.device(device_index):
+        stream = torch.cuda.current_stream().cuda_stream
+    return Context(device_index, stream)
+
+
+def devcol(t, desc=False):
+    assert t.is_cuda and t.is_contiguous()
+    return DevCol(t.data_ptr(), T2ST[t.dtype], desc, keepalive=t)
+
+
+def groupby_agg_tensors(ctx, keys, values, aggs, na_last=False):
+    """keys/values: CUDA tensors.  Returns (offsets, [group key tensors], [agg tensors])."""
+    n = keys[0].numel()
+    r = ctx.groupby_agg([devcol(k) for k in keys], [devcol(v) for v in values], aggs, nrows=n, na_last=na_last)
+    ng = r.ngroups
+    dev = keys[0].device
+    off = torch.empty(ng + 1, dtype=torch.int32, device=dev)
+    r.offsets_into(off.data_ptr())
+    gk = []
+    for i, k in enumerate(keys):
+        t = torch.empty(ng, dtype=ST2T[T2ST[k.dtype]], device=dev)
+        if ng:
+            r.key_into(i, t.data_ptr())
+        gk.append(t)
+    out = []
+    for a in range(len(aggs)):
+        t = torch.empty(ng, dtype=ST2T[r.agg_stype(a)], device=dev)
+        if ng:
+            r.agg_into(a, t.data_ptr())
+        out.append(t)
+    r.free()
+    return off, gk, out
