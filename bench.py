@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--groups", type=int, default=10_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=100_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=250_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
