@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--groups", type=int, default=10_000_000)
     ap.add_argument("--cpu-sample", type=int, default=250_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the result sanity check (kernel timing experiments)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
 
@@ -135,9 +136,10 @@ def main():
         last.agg_into(0, sums.data_ptr()); last.key_into(0, gkeys.data_ptr()); last.offsets_into(off.data_ptr())
         release(last)
         torch.cuda.synchronize()
-        assert int(off[-1].item()) == n_local and bool((gkeys[1:] > gkeys[:-1]).all())
-        total, ref = float(sums.sum().item()), float(vals.sum().item())
-        assert abs(total - ref) <= 1e-9 * float(vals.abs().sum().item()), (total, ref)
+        if not args.no_check:
+            assert int(off[-1].item()) == n_local and bool((gkeys[1:] > gkeys[:-1]).all())
+            total, ref = float(sums.sum().item()), float(vals.sum().item())
+            assert abs(total - ref) <= 1e-9 * float(vals.abs().sum().item()), (total, ref)
     else:
         gk, out = last
         ng_t = torch.tensor([gk[0].numel()], dtype=torch.int64, device=dev)

@@ -284,7 +284,12 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
   for (int i = 0; i < nactive; i++) state_words += (size_t)ntiles << xa.pbits[active[i]];
   unsigned long long* state = nullptr;
   DTHIP_TRY(sc.get<unsigned long long>(state_words + 64, &state));
-  DTHIP_CHECK_HIP(hipMemsetAsync(state, 0, (state_words + 64) * 8, ctx->stream));
+  {
+    static int debug_calls = 0;
+    const bool reuse = (radix_debug_flags() & 2) && debug_calls++ >= 1;   // experiment: keep the previous run's prefixes
+    if (reuse) DTHIP_CHECK_HIP(hipMemsetAsync(state + state_words, 0, 64 * 8, ctx->stream));
+    else DTHIP_CHECK_HIP(hipMemsetAsync(state, 0, (state_words + 64) * 8, ctx->stream));
+  }
   uint32_t* tickets = reinterpret_cast<uint32_t*>(state + state_words);   // [MAX_PASSES] + err flag
   int* err = reinterpret_cast<int*>(tickets + 16);
   unsigned char* kB = nullptr;
@@ -379,14 +384,14 @@ static int heads_to_offsets(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
                             const uint8_t* heads, int64_t n, Grouping* g) {
   const uint32_t nt = (uint32_t)((n + SEG_TILE - 1) / SEG_TILE);
   uint32_t* tile_counts = nullptr;
-  DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 2, &tile_counts));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, &tile_counts));
   unsigned long long* bitmap = nullptr;
   DTHIP_TRY(sc.get<unsigned long long>((size_t)((n + 63) / 64) + 1, &bitmap));
   int64_t ng = 0;
   DTHIP_TRY(launch_count_heads(ctx, keys, key64, heads, n, tile_counts, bitmap, tile_counts + nt, &ng));
   void* off = nullptr;
   DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * (size_t)(ng + 1), &off));
-  DTHIP_TRY(launch_write_offsets(ctx, keys, key64, heads, n, tile_counts, ng, static_cast<int32_t*>(off)));
+  DTHIP_TRY(launch_write_offsets(ctx, bitmap, n, tile_counts, ng, static_cast<int32_t*>(off)));
   g->n = n; g->ngroups = ng; g->offsets = static_cast<int32_t*>(off);
   g->bitmap = bitmap; g->tile_first = tile_counts;
   return DTHIP_OK;
@@ -858,7 +863,7 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
     DTHIP_TRY(sc.get<unsigned long long>((size_t)((nrows + 63) / 64) + 1, &bitmap));
     const uint32_t nt = (uint32_t)((nrows + SEG_TILE - 1) / SEG_TILE);
     uint32_t* tile_counts = nullptr;
-    DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 2, &tile_counts));
+    DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, &tile_counts));
     DTHIP_TRY(launch_bitmap_from_offsets(ctx, static_cast<const int32_t*>(d_off), ngroups, nrows, bitmap, tile_counts,
                                          tile_counts + nt));
     ReduceOuts ro;

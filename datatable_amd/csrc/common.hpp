@@ -170,6 +170,7 @@ struct RadixPass {
   PayCols pay;
 };
 uint32_t radix_tile_items(int key64, int maxpaywidth);
+int radix_debug_flags();
 int launch_radix_pass(dthip_ctx* ctx, const RadixPass& p);
 
 // group.hip: run heads of a sorted key sequence -> offsets, head bitmap, tile head counts
@@ -181,7 +182,7 @@ int launch_scan_tiles(dthip_ctx* ctx, uint32_t* counts, uint32_t m, uint32_t* to
 int launch_count_heads(dthip_ctx* ctx, const void* keys, int key64, const uint8_t* heads, int64_t n,
                        uint32_t* tile_counts, unsigned long long* bitmap, uint32_t* d_total,
                        int64_t* ngroups_host);
-int launch_write_offsets(dthip_ctx* ctx, const void* keys, int key64, const uint8_t* heads, int64_t n,
+int launch_write_offsets(dthip_ctx* ctx, const unsigned long long* bitmap, int64_t n,
                          const uint32_t* tile_base, int64_t ngroups, int32_t* offsets);
 int launch_mark_heads(dthip_ctx* ctx, const void* keys, int key64, int64_t n, uint8_t* heads);
 int launch_bitmap_from_offsets(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n,

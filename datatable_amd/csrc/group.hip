@@ -15,45 +15,57 @@
 namespace dthip {
 
 constexpr int GB_BLOCK = 256;
-constexpr int GB_ITEMS = 8;                         // rounds of 64 per wave
+constexpr int GB_ITEMS = 8;                         // consecutive positions per thread = one bitmap byte
 constexpr int GB_TILE = GB_BLOCK * GB_ITEMS;        // 2048 positions per workgroup (== reduce tile)
-static_assert(GB_TILE == 2048, "reduce.hip assumes 2048-position tiles");
+static_assert(GB_TILE == SEG_TILE, "reduce.hip assumes 2048-position tiles");
 
-template <typename KeyT>
-__device__ __forceinline__ bool head_at(const KeyT* K, const uint8_t* H, uint32_t i) {
-  if (H) return H[i] != 0;
-  return i == 0 || K[i] != K[i - 1];
-}
+typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
 
-// sweep: per-lane bit k = head flag of position  tile_base + wave*512 + k*64 + lane
+// Head flags of 8 consecutive sorted positions -> one byte of the head bitmap, plus the
+// number of heads of every 2048-position tile.  Keys are read with 16-byte loads.
+//   KeyT = uint32_t / unsigned long long: head(i) = i==0 || K[i] != K[i-1]
+//   KeyT = uint8_t: K is a byte-per-position flag array (multi-stage sorts)
 template <typename KeyT>
-__device__ __forceinline__ uint32_t sweep_heads(const KeyT* K, const uint8_t* H, uint32_t n,
-                                                uint32_t wave_base, uint32_t* wave_count,
-                                                unsigned long long* bitmap) {
-  const int lane = lane_id();
-  uint32_t bits = 0, cnt = 0;
-#pragma unroll
-  for (int k = 0; k < GB_ITEMS; k++) {
-    const uint32_t idx = wave_base + 64u * k + lane;
-    const bool f = idx < n && head_at<KeyT>(K, H, idx);
-    const unsigned long long bal = __ballot(f);
-    bits |= (uint32_t)f << k;
-    cnt += (uint32_t)__popcll(bal);
-    if (bitmap && lane == 0 && (wave_base + 64u * k) < n) bitmap[(wave_base + 64u * k) >> 6] = bal;
-  }
-  *wave_count = cnt;
-  return bits;
-}
-
-template <typename KeyT>
-__global__ void __launch_bounds__(GB_BLOCK) count_heads_kernel(const KeyT* K, const uint8_t* H, uint32_t n,
-                                                               uint32_t* tile_counts,
-                                                               unsigned long long* bitmap) {
+__global__ void __launch_bounds__(GB_BLOCK) count_heads_kernel(const KeyT* __restrict__ K, uint32_t n,
+                                                               uint32_t* __restrict__ tile_counts,
+                                                               uint8_t* __restrict__ bitmap) {
   __shared__ uint32_t wc[GB_BLOCK / 64];
-  const uint32_t wave_base = blockIdx.x * GB_TILE + wave_id() * (64 * GB_ITEMS);
-  uint32_t cnt;
-  sweep_heads<KeyT>(K, H, n, wave_base, &cnt, bitmap);
-  if (lane_id() == 0) wc[wave_id()] = cnt;
+  const uint32_t p0 = blockIdx.x * GB_TILE + threadIdx.x * GB_ITEMS;
+  uint32_t hb = 0;
+  if (p0 < n) {
+    KeyT k[GB_ITEMS];
+    if (p0 + GB_ITEMS <= n) {
+      constexpr int NV = GB_ITEMS * (int)sizeof(KeyT) / 16;      // 0 for bytes, 2 for u32, 4 for u64
+      if (NV > 0) {
+        const gu32x4* src = reinterpret_cast<const gu32x4*>(K + p0);
+        gu32x4 v[NV > 0 ? NV : 1];
+#pragma unroll
+        for (int j = 0; j < NV; j++) v[j] = src[j];
+        const KeyT* vk = reinterpret_cast<const KeyT*>(v);
+#pragma unroll
+        for (int j = 0; j < GB_ITEMS; j++) k[j] = vk[j];
+      } else {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long*>(K + p0);
+#pragma unroll
+        for (int j = 0; j < GB_ITEMS; j++) k[j] = (KeyT)((w >> (8 * j)) & 0xFF);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < GB_ITEMS; j++) k[j] = (p0 + j < n) ? K[p0 + j] : KeyT(0);
+    }
+    if (sizeof(KeyT) == 1) {
+#pragma unroll
+      for (int j = 0; j < GB_ITEMS; j++) hb |= (uint32_t)((p0 + j < n) && k[j] != 0) << j;
+    } else {
+      const bool h0 = (p0 == 0) || (K[p0 - 1] != k[0]);
+      hb = h0 ? 1u : 0u;
+#pragma unroll
+      for (int j = 1; j < GB_ITEMS; j++) hb |= (uint32_t)((p0 + j < n) && k[j] != k[j - 1]) << j;
+    }
+    bitmap[p0 >> 3] = (uint8_t)hb;
+  }
+  const uint32_t c = wave_reduce_sum_u32((uint32_t)__popc(hb));
+  if (lane_id() == 0) wc[wave_id()] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t s = 0;
@@ -62,64 +74,93 @@ __global__ void __launch_bounds__(GB_BLOCK) count_heads_kernel(const KeyT* K, co
   }
 }
 
-// in-place exclusive scan of `counts[0..m)` by one workgroup; total -> *total
-__global__ void __launch_bounds__(1024) scan_tiles_kernel(uint32_t* counts, uint32_t m, uint32_t* total) {
+// In-place exclusive scan of counts[0..m) in three small launches: every workgroup scans
+// its own chunk of 8192 and records the chunk total; one workgroup scans the chunk totals;
+// every workgroup adds its chunk base.
+constexpr int SC_CHUNK = 1024 * 8;
+
+__global__ void __launch_bounds__(1024) scan_chunk_kernel(uint32_t* counts, uint32_t m, uint32_t* chunk_tot) {
+  __shared__ uint32_t scratch[16];
+  const uint32_t i0 = blockIdx.x * SC_CHUNK + threadIdx.x * 8;
+  uint32_t v[8], s = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { v[j] = (i0 + j < m) ? counts[i0 + j] : 0; s += v[j]; }
+  uint32_t tot;
+  uint32_t e = block_excl_scan_u32<1024>(s, scratch, &tot);
+#pragma unroll
+  for (int j = 0; j < 8; j++) { if (i0 + j < m) counts[i0 + j] = e; e += v[j]; }
+  if (threadIdx.x == 0) chunk_tot[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(1024) scan_chunk_totals_kernel(uint32_t* chunk_tot, uint32_t nchunks, uint32_t* total) {
   __shared__ uint32_t scratch[16];
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < m; base += 1024) {
+  for (uint32_t base = 0; base < nchunks; base += 1024) {
     const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < m ? counts[i] : 0;
+    const uint32_t v = i < nchunks ? chunk_tot[i] : 0;
     uint32_t tot;
     const uint32_t e = block_excl_scan_u32<1024>(v, scratch, &tot);
-    if (i < m) counts[i] = carry + e;
+    if (i < nchunks) chunk_tot[i] = carry + e;
     carry += tot;
   }
   if (threadIdx.x == 0) *total = carry;
 }
 
+__global__ void __launch_bounds__(1024) scan_add_base_kernel(uint32_t* counts, uint32_t m, const uint32_t* chunk_base) {
+  const uint32_t b = chunk_base[blockIdx.x];
+  if (b == 0) return;
+  const uint32_t i0 = blockIdx.x * SC_CHUNK + threadIdx.x * 8;
+#pragma unroll
+  for (int j = 0; j < 8; j++) if (i0 + j < m) counts[i0 + j] += b;
+}
+
+// counts must have room for m + 1 + ceil(m / 8192) words: [0,m) data, [m] total, then scratch
 int launch_scan_tiles(dthip_ctx* ctx, uint32_t* counts, uint32_t m, uint32_t* total) {
-  DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_tiles_kernel, 1, 1024, 0, counts, m, total);
+  const uint32_t nchunks = (m + SC_CHUNK - 1) / SC_CHUNK;
+  uint32_t* chunk_tot = counts + m + 1;
+  if (total != counts + m) { set_error("scan_tiles: total must be counts + m"); return DTHIP_EINVAL; }
+  DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_chunk_kernel, nchunks, 1024, 0, counts, m, chunk_tot);
+  DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_chunk_totals_kernel, 1, 1024, 0, chunk_tot, nchunks, total);
+  if (nchunks > 1) DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_add_base_kernel, nchunks, 1024, 0, counts, m, chunk_tot);
   return DTHIP_OK;
 }
 
-template <typename KeyT>
-__global__ void __launch_bounds__(GB_BLOCK) write_offsets_kernel(const KeyT* K, const uint8_t* H, uint32_t n,
-                                                                 const uint32_t* tile_base, uint32_t ngroups,
-                                                                 int32_t* offsets) {
-  __shared__ uint32_t wc[GB_BLOCK / 64];
-  const int lane = lane_id(), wave = wave_id();
-  const uint32_t wave_base = blockIdx.x * GB_TILE + wave * (64 * GB_ITEMS);
-  uint32_t cnt;
-  const uint32_t bits = sweep_heads<KeyT>(K, H, n, wave_base, &cnt, nullptr);
-  if (lane == 0) wc[wave] = cnt;
-  __syncthreads();
-  uint32_t running = tile_base[blockIdx.x];
-  for (int w = 0; w < wave; w++) running += wc[w];
-#pragma unroll
-  for (int k = 0; k < GB_ITEMS; k++) {
-    const bool f = (bits >> k) & 1u;
-    const unsigned long long bal = __ballot(f);
-    if (f) offsets[running + mbcnt64(bal)] = (int32_t)(wave_base + 64u * k + lane);
-    running += (uint32_t)__popcll(bal);
+// offsets[g] = sorted position of the g-th head, read back from the head bitmap
+__global__ void __launch_bounds__(GB_BLOCK) write_offsets_kernel(const uint8_t* __restrict__ bitmap, uint32_t n,
+                                                                 const uint32_t* __restrict__ tile_base,
+                                                                 uint32_t ngroups, int32_t* __restrict__ offsets) {
+  __shared__ uint32_t scratch[GB_BLOCK / 64];
+  const uint32_t p0 = blockIdx.x * GB_TILE + threadIdx.x * GB_ITEMS;
+  uint32_t hb = (p0 < n) ? bitmap[p0 >> 3] : 0u;
+  uint32_t r = tile_base[blockIdx.x] + block_excl_scan_u32<GB_BLOCK>((uint32_t)__popc(hb), scratch, nullptr);
+  while (hb) {
+    const int j = __ffs((int)hb) - 1;
+    offsets[r++] = (int32_t)(p0 + j);
+    hb &= hb - 1;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) offsets[ngroups] = (int32_t)n;
 }
 
 static uint32_t ntiles_of(int64_t n) { return (uint32_t)((n + GB_TILE - 1) / GB_TILE); }
 
-// tile_counts: [ntiles] (becomes the exclusive scan = index of the first head of each tile)
+// tile_counts[ntiles] <- exclusive scan of heads per tile (= index of the first head of each
+// tile); bitmap <- 1 bit per position (ceil(n/8) bytes, padded to 8); d_total <- ngroups
 int launch_count_heads(dthip_ctx* ctx, const void* keys, int key64, const uint8_t* heads, int64_t n,
                        uint32_t* tile_counts, unsigned long long* bitmap, uint32_t* d_total,
                        int64_t* ngroups_host) {
   const uint32_t nt = ntiles_of(n);
-  if (key64) {
+  uint8_t* bm = reinterpret_cast<uint8_t*>(bitmap);
+  if (heads) {
+    DTHIP_LAUNCH(ctx, "count_heads_kernel", count_heads_kernel<uint8_t>, nt, GB_BLOCK, 0,
+                 heads, (uint32_t)n, tile_counts, bm);
+  } else if (key64) {
     DTHIP_LAUNCH(ctx, "count_heads_kernel", count_heads_kernel<unsigned long long>, nt, GB_BLOCK, 0,
-                 static_cast<const unsigned long long*>(keys), heads, (uint32_t)n, tile_counts, bitmap);
+                 static_cast<const unsigned long long*>(keys), (uint32_t)n, tile_counts, bm);
   } else {
     DTHIP_LAUNCH(ctx, "count_heads_kernel", count_heads_kernel<uint32_t>, nt, GB_BLOCK, 0,
-                 static_cast<const uint32_t*>(keys), heads, (uint32_t)n, tile_counts, bitmap);
+                 static_cast<const uint32_t*>(keys), (uint32_t)n, tile_counts, bm);
   }
-  DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_tiles_kernel, 1, 1024, 0, tile_counts, nt, d_total);
+  DTHIP_TRY(launch_scan_tiles(ctx, tile_counts, nt, d_total));
   if (ngroups_host) {
     uint32_t t = 0;
     DTHIP_TRY(read_back(ctx, &t, d_total, sizeof(t)));
@@ -128,17 +169,11 @@ int launch_count_heads(dthip_ctx* ctx, const void* keys, int key64, const uint8_
   return DTHIP_OK;
 }
 
-int launch_write_offsets(dthip_ctx* ctx, const void* keys, int key64, const uint8_t* heads, int64_t n,
+int launch_write_offsets(dthip_ctx* ctx, const unsigned long long* bitmap, int64_t n,
                          const uint32_t* tile_base, int64_t ngroups, int32_t* offsets) {
   const uint32_t nt = ntiles_of(n);
-  if (key64) {
-    DTHIP_LAUNCH(ctx, "write_offsets_kernel", write_offsets_kernel<unsigned long long>, nt, GB_BLOCK, 0,
-                 static_cast<const unsigned long long*>(keys), heads, (uint32_t)n, tile_base, (uint32_t)ngroups,
-                 offsets);
-  } else {
-    DTHIP_LAUNCH(ctx, "write_offsets_kernel", write_offsets_kernel<uint32_t>, nt, GB_BLOCK, 0,
-                 static_cast<const uint32_t*>(keys), heads, (uint32_t)n, tile_base, (uint32_t)ngroups, offsets);
-  }
+  DTHIP_LAUNCH(ctx, "write_offsets_kernel", write_offsets_kernel, nt, GB_BLOCK, 0,
+               reinterpret_cast<const uint8_t*>(bitmap), (uint32_t)n, tile_base, (uint32_t)ngroups, offsets);
   return DTHIP_OK;
 }
 
@@ -198,7 +233,7 @@ int launch_bitmap_from_offsets(dthip_ctx* ctx, const int32_t* offsets, int64_t n
   }
   DTHIP_LAUNCH(ctx, "bitmap_tile_counts_kernel", bitmap_tile_counts_kernel, (nt + 3) / 4, 256, 0,
                bitmap, nwords, nt, tile_counts);
-  DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_tiles_kernel, 1, 1024, 0, tile_counts, nt, d_total);
+  DTHIP_TRY(launch_scan_tiles(ctx, tile_counts, nt, d_total));
   return DTHIP_OK;
 }
 

@@ -106,10 +106,98 @@ __global__ void __launch_bounds__(XH_BLOCK) xform_hist_kernel(XformArgs a) {
   }
 }
 
+typedef uint32_t xu32x4 __attribute__((ext_vector_type(4)));
+
+// Fast path of the above for ONE integer key column (int32 / int64) read in row order:
+// 4 consecutive rows per thread, 16-byte loads and stores.
+template <typename T, bool OUT64>
+__global__ void __launch_bounds__(XH_BLOCK) xform_hist_int_kernel(XformArgs a) {
+  typedef unsigned long long u64;
+  __shared__ uint32_t lhist[MAX_PASSES * HIST_STRIDE];
+  for (int i = threadIdx.x; i < a.npass * HIST_STRIDE; i += XH_BLOCK) lhist[i] = 0;
+  __syncthreads();
+  const KeyColDev c = a.cols[0];
+  const T* __restrict__ src = static_cast<const T*>(c.data);
+  const T na = (T)((u64)1 << (8 * sizeof(T) - 1));
+  const uint32_t ngrp = (a.n + 3) / 4;
+  const uint32_t stride = gridDim.x * XH_BLOCK;
+  for (uint32_t g = blockIdx.x * XH_BLOCK + threadIdx.x; g < ngrp; g += stride) {
+    const uint32_t r0 = g * 4;
+    const uint32_t nv = a.n - r0 < 4u ? a.n - r0 : 4u;
+    T v[4];
+    if (nv == 4) {
+      constexpr int NV = (int)sizeof(T) / 4;
+      xu32x4 w[NV];
+      const xu32x4* p = reinterpret_cast<const xu32x4*>(src + r0);
+#pragma unroll
+      for (int j = 0; j < NV; j++) w[j] = p[j];
+      const T* wt = reinterpret_cast<const T*>(w);
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = wt[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = (uint32_t)j < nv ? src[r0 + j] : na;
+    }
+    u64 k[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const u64 u = (u64)(long long)v[j];
+      k[j] = (v[j] == na) ? c.na_repl : (c.desc ? c.edge - u + c.inc : u - c.edge + c.inc);
+    }
+    if (nv == 4) {
+      if (OUT64) {
+        xu32x4* o = reinterpret_cast<xu32x4*>(static_cast<u64*>(a.out) + r0);
+        xu32x4 w0, w1;
+        w0.x = (uint32_t)k[0]; w0.y = (uint32_t)(k[0] >> 32); w0.z = (uint32_t)k[1]; w0.w = (uint32_t)(k[1] >> 32);
+        w1.x = (uint32_t)k[2]; w1.y = (uint32_t)(k[2] >> 32); w1.z = (uint32_t)k[3]; w1.w = (uint32_t)(k[3] >> 32);
+        o[0] = w0; o[1] = w1;
+      } else {
+        xu32x4 w0;
+        w0.x = (uint32_t)k[0]; w0.y = (uint32_t)k[1]; w0.z = (uint32_t)k[2]; w0.w = (uint32_t)k[3];
+        *reinterpret_cast<xu32x4*>(static_cast<uint32_t*>(a.out) + r0) = w0;
+      }
+    } else {
+      for (uint32_t j = 0; j < nv; j++) {
+        if (OUT64) static_cast<u64*>(a.out)[r0 + j] = k[j];
+        else static_cast<uint32_t*>(a.out)[r0 + j] = (uint32_t)k[j];
+      }
+    }
+    for (int p = 0; p < a.npass; p++) {
+      const int sh = a.pshift[p];
+      const uint32_t msk = (1u << a.pbits[p]) - 1u;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if ((uint32_t)j < nv) atomicAdd(&lhist[p * HIST_STRIDE + ((uint32_t)(k[j] >> sh) & msk)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.npass * HIST_STRIDE; i += XH_BLOCK) {
+    const uint32_t cnt = lhist[i];
+    if (cnt) atomicAdd(&a.hist[i], cnt);
+  }
+}
+
 int launch_xform_hist(dthip_ctx* ctx, const XformArgs& a) {
   if (a.n == 0) return DTHIP_OK;
-  long long blocks = ((long long)a.n + XH_BLOCK * 8 - 1) / (XH_BLOCK * 8);
   const long long maxb = (long long)ctx->num_cus * 8;
+  const bool fast = a.ncols == 1 && a.order == nullptr && a.cols[0].shift == 0 &&
+                    (a.cols[0].stype == DTHIP_INT32 || a.cols[0].stype == DTHIP_INT64) &&
+                    (reinterpret_cast<uintptr_t>(a.cols[0].data) & 15) == 0;
+  if (fast) {
+    long long blocks = ((long long)a.n + XH_BLOCK * 16 - 1) / (XH_BLOCK * 16);
+    if (blocks > maxb) blocks = maxb;
+    const unsigned g = (unsigned)blocks;
+    if (a.cols[0].stype == DTHIP_INT64) {
+      if (a.out64) { DTHIP_LAUNCH(ctx, "xform_hist_kernel", (xform_hist_int_kernel<long long, true>), g, XH_BLOCK, 0, a); }
+      else { DTHIP_LAUNCH(ctx, "xform_hist_kernel", (xform_hist_int_kernel<long long, false>), g, XH_BLOCK, 0, a); }
+    } else {
+      if (a.out64) { DTHIP_LAUNCH(ctx, "xform_hist_kernel", (xform_hist_int_kernel<int32_t, true>), g, XH_BLOCK, 0, a); }
+      else { DTHIP_LAUNCH(ctx, "xform_hist_kernel", (xform_hist_int_kernel<int32_t, false>), g, XH_BLOCK, 0, a); }
+    }
+    return DTHIP_OK;
+  }
+  long long blocks = ((long long)a.n + XH_BLOCK * 8 - 1) / (XH_BLOCK * 8);
   if (blocks > maxb) blocks = maxb;
   DTHIP_LAUNCH(ctx, "xform_hist_kernel", xform_hist_kernel, (unsigned)blocks, XH_BLOCK, 0, a);
   return DTHIP_OK;
@@ -132,8 +220,23 @@ int launch_hist_scan(dthip_ctx* ctx, const uint32_t* hist, uint32_t* base, int n
 // ---------------------------------------------------------------------------
 // one-sweep radix pass
 // ---------------------------------------------------------------------------
-constexpr int RP_BLOCK = 512;
-constexpr int RP_ITEMS = 16;
+// tile geometry variants (selected at run time by DTHIP_RP_VARIANT; default 0)
+struct RpGeom { int block, items; };
+static const RpGeom RP_GEOMS[] = {{512, 16}, {512, 8}, {256, 16}, {256, 8}, {1024, 16}, {1024, 8}};
+static int rp_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DTHIP_RP_VARIANT");
+    v = e ? atoi(e) : 0;
+    if (v < 0 || v >= (int)(sizeof(RP_GEOMS) / sizeof(RP_GEOMS[0]))) v = 0;
+  }
+  return v;
+}
+static int rp_debug() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DTHIP_RP_DEBUG"); v = e ? atoi(e) : 0; }
+  return v;
+}
 constexpr unsigned long long ST_AGG = 1ULL << 62;   // tile's own count is published
 constexpr unsigned long long ST_INCL = 2ULL << 62;  // inclusive prefix up to this tile is published
 constexpr unsigned long long ST_VAL = (1ULL << 62) - 1;
@@ -148,14 +251,44 @@ struct PassArgsT {
   uint32_t* ticket;
   int* err;
   int iota;
+  int debug;      // timing experiments only. bit0: skip the look-back (wrong results); bit1: reuse saved prefixes
   PayCols pay;
 };
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-B access
+
+// store 4 values of tile-sorted slots s0..s0+3 to their global positions: one 16-B
+// (or two, for 8-byte elements) store when the four land on consecutive addresses
+template <typename T>
+__device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t (&gp)[4], const T (&v)[4], uint32_t nv) {
+  const bool run = nv == 4 && gp[1] == gp[0] + 1 && gp[2] == gp[0] + 2 && gp[3] == gp[0] + 3;
+  if (run) {
+    if (sizeof(T) == 4) {
+      u32x4 w;
+      w.x = (uint32_t)v[0]; w.y = (uint32_t)v[1]; w.z = (uint32_t)v[2]; w.w = (uint32_t)v[3];
+      *reinterpret_cast<u32x4_u*>(out + gp[0]) = w;
+    } else {
+      u32x4 w0, w1;
+      w0.x = (uint32_t)v[0]; w0.y = (uint32_t)((unsigned long long)v[0] >> 32);
+      w0.z = (uint32_t)v[1]; w0.w = (uint32_t)((unsigned long long)v[1] >> 32);
+      w1.x = (uint32_t)v[2]; w1.y = (uint32_t)((unsigned long long)v[2] >> 32);
+      w1.z = (uint32_t)v[3]; w1.w = (uint32_t)((unsigned long long)v[3] >> 32);
+      u32x4_u* o = reinterpret_cast<u32x4_u*>(out + gp[0]);
+      o[0] = w0; o[1] = w1;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) if ((uint32_t)j < nv) out[gp[j]] = v[j];
+  }
+}
+
 // RB   = number of ballot rounds (>= bits of every pass run with this instance)
 // P0W  = byte width of payload column 0 when it is prefetched with the keys (0: none / iota)
-template <typename KeyT, int RB, int P0W>
-__global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a) {
-  constexpr int BLOCK = RP_BLOCK, ITEMS = RP_ITEMS, WAVES = BLOCK / 64, TILE = BLOCK * ITEMS;
+template <typename KeyT, int RB, int P0W, int BLOCK, int ITEMS>
+__global__ void __launch_bounds__(BLOCK) radix_pass_kernel(PassArgsT<KeyT> a) {
+  constexpr int WAVES = BLOCK / 64, TILE = BLOCK * ITEMS;
+  constexpr int GROUPS = ITEMS / 4;     // each thread owns GROUPS groups of 4 consecutive tile-sorted slots
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bins = 1 << a.bits;
   const uint32_t dmask = (uint32_t)bins - 1u;
@@ -173,15 +306,13 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a)
   const uint32_t tile = misc[15];
   const uint32_t tile_base = tile * (uint32_t)TILE;
   const uint32_t nvalid = (a.n - tile_base < (uint32_t)TILE) ? (a.n - tile_base) : (uint32_t)TILE;
+  const bool full = nvalid == (uint32_t)TILE;
   const uint32_t wbase = (uint32_t)wave * 64u * ITEMS + (uint32_t)lane;   // wave-striped: item i at wbase + 64*i
 
   // ---- load keys (and payload column 0) -----------------------------------
+  // Full tiles: 16-byte coalesced loads of the wave's 1024 consecutive keys, transposed
+  // through LDS into the wave-striped arrangement the stable ranking needs.
   KeyT key[ITEMS];
-#pragma unroll
-  for (int i = 0; i < ITEMS; i++) {
-    const uint32_t loc = wbase + 64u * i;
-    key[i] = (loc < nvalid) ? a.kin[tile_base + loc] : KeyT(0);
-  }
   typedef typename std::conditional<P0W == 8, unsigned long long, uint32_t>::type P0T;
   P0T pay0[P0W ? ITEMS : 1];
   if (P0W) {
@@ -190,6 +321,26 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a)
     for (int i = 0; i < ITEMS; i++) {
       const uint32_t loc = wbase + 64u * i;
       pay0[i] = (loc < nvalid) ? pin[tile_base + loc] : P0T(0);
+    }
+  }
+  if (full) {
+    constexpr int NV = ITEMS * (int)sizeof(KeyT) / 16;
+    const u32x4* gsrc = reinterpret_cast<const u32x4*>(a.kin + tile_base + (uint32_t)wave * 64u * ITEMS);
+    u32x4* wl = reinterpret_cast<u32x4*>(exch) + (size_t)wave * 64 * NV;
+    u32x4 tmp[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) tmp[j] = gsrc[j * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < NV; j++) wl[j * 64 + lane] = tmp[j];
+    __syncthreads();
+    const KeyT* wk = reinterpret_cast<const KeyT*>(wl);
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) key[i] = wk[i * 64 + lane];
+  } else {
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const uint32_t loc = wbase + 64u * i;
+      key[i] = (loc < nvalid) ? a.kin[tile_base + loc] : KeyT(0);
     }
   }
 
@@ -233,7 +384,10 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a)
     bin_excl[tid] = excl;
     unsigned long long* st = a.state + (size_t)tile * bins + tid;
     uint32_t prefix = 0;
-    if (tile == 0) {
+    if (a.debug & 2) {
+      // timing experiment: the inclusive prefixes of an identical previous run are still in `state`
+      prefix = (uint32_t)(ld_agent_u64(st) & ST_VAL) - tcount;
+    } else if (tile == 0 || (a.debug & 1)) {
       st_agent_u64(st, ST_INCL | tcount);
     } else {
       st_agent_u64(st, ST_AGG | tcount);
@@ -268,16 +422,22 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a)
     }
   }
   __syncthreads();
+  // thread owns slots (g*BLOCK + tid)*4 .. +3 for g in [0, GROUPS)
   uint32_t gpos[ITEMS];
 #pragma unroll
-  for (int k = 0; k < ITEMS; k++) {
-    const uint32_t slot = (uint32_t)k * BLOCK + tid;
-    if (slot < nvalid) {
-      const KeyT kk = ek[slot];
-      const uint32_t d = (uint32_t)(kk >> a.shift) & dmask;
-      gpos[k] = bin_delta[d] + slot;
-      a.kout[gpos[k]] = kk;
+  for (int g = 0; g < GROUPS; g++) {
+    const uint32_t s0 = ((uint32_t)g * BLOCK + tid) * 4u;
+    const uint32_t nv = s0 < nvalid ? (nvalid - s0 < 4u ? nvalid - s0 : 4u) : 0u;
+    KeyT kk[4];
+    uint32_t gp[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      kk[j] = ek[s0 + j];     // slots beyond nvalid hold stale data, never stored
+      const uint32_t d = (uint32_t)(kk[j] >> a.shift) & dmask;
+      gp[j] = bin_delta[d] + s0 + j;
+      gpos[g * 4 + j] = gp[j];
     }
+    if (nv) store_group4<KeyT>(a.kout, gp, kk, nv);
   }
 
   // ---- payload columns follow the same permutation --------------------------
@@ -300,9 +460,13 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a)
       }
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const uint32_t slot = (uint32_t)k * BLOCK + tid;
-        if (slot < nvalid) pout[gpos[k]] = e4[slot];
+      for (int g = 0; g < GROUPS; g++) {
+        const uint32_t s0 = ((uint32_t)g * BLOCK + tid) * 4u;
+        const uint32_t nv = s0 < nvalid ? (nvalid - s0 < 4u ? nvalid - s0 : 4u) : 0u;
+        uint32_t vv[4], gp[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { vv[j] = e4[s0 + j]; gp[j] = gpos[g * 4 + j]; }
+        if (nv) store_group4<uint32_t>(pout, gp, vv, nv);
       }
     } else {
       unsigned long long* e8 = reinterpret_cast<unsigned long long*>(exch);
@@ -320,65 +484,76 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a)
       }
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < ITEMS; k++) {
-        const uint32_t slot = (uint32_t)k * BLOCK + tid;
-        if (slot < nvalid) pout[gpos[k]] = e8[slot];
+      for (int g = 0; g < GROUPS; g++) {
+        const uint32_t s0 = ((uint32_t)g * BLOCK + tid) * 4u;
+        const uint32_t nv = s0 < nvalid ? (nvalid - s0 < 4u ? nvalid - s0 : 4u) : 0u;
+        unsigned long long vv[4];
+        uint32_t gp[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { vv[j] = e8[s0 + j]; gp[j] = gpos[g * 4 + j]; }
+        if (nv) store_group4<unsigned long long>(pout, gp, vv, nv);
       }
     }
   }
 }
 
-uint32_t radix_tile_items(int, int) { return RP_BLOCK * RP_ITEMS; }
+int radix_debug_flags() { return rp_debug(); }
+uint32_t radix_tile_items(int, int) { const RpGeom g = RP_GEOMS[rp_variant()]; return (uint32_t)(g.block * g.items); }
 
-static size_t pass_lds_bytes(int bits, int key64, int maxw) {
-  const int bins = 1 << bits;
-  const int w = (key64 ? 8 : 4) > maxw ? (key64 ? 8 : 4) : maxw;
-  return (size_t)((RP_BLOCK / 64) * bins + 2 * bins + 16) * 4 + (size_t)RP_BLOCK * RP_ITEMS * w;
-}
-
-template <typename KeyT, int RB, int P0W>
-static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p, size_t lds) {
+template <typename KeyT, int RB, int P0W, int BLOCK, int ITEMS>
+static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
   PassArgsT<KeyT> a;
   a.kin = static_cast<const KeyT*>(p.kin); a.kout = static_cast<KeyT*>(p.kout);
   a.n = p.n; a.shift = p.shift; a.bits = p.bits; a.base = p.base; a.state = p.state;
-  a.ticket = p.ticket; a.err = p.err; a.iota = p.iota; a.pay = p.pay;
-  auto kfn = radix_pass_kernel<KeyT, RB, P0W>;
+  a.ticket = p.ticket; a.err = p.err; a.iota = p.iota; a.debug = rp_debug(); a.pay = p.pay;
+  int maxw = (int)sizeof(KeyT);
+  for (int c = 0; c < p.pay.n; c++) maxw = p.pay.width[c] > maxw ? p.pay.width[c] : maxw;
+  const int bins = 1 << p.bits;
+  const size_t lds = (size_t)((BLOCK / 64) * bins + 2 * bins + 16) * 4 + (size_t)BLOCK * ITEMS * maxw;
+  auto kfn = radix_pass_kernel<KeyT, RB, P0W, BLOCK, ITEMS>;
   static bool attr_set = false;
   if (!attr_set) {
     DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     attr_set = true;
   }
-  const uint32_t tile = RP_BLOCK * RP_ITEMS;
+  const uint32_t tile = BLOCK * ITEMS;
   const uint32_t ntiles = (p.n + tile - 1) / tile;
-  DTHIP_LAUNCH(ctx, "radix_pass_kernel", kfn, ntiles, RP_BLOCK, lds, a);
+  DTHIP_LAUNCH(ctx, "radix_pass_kernel", kfn, ntiles, BLOCK, lds, a);
   return DTHIP_OK;
+}
+
+template <typename KeyT, int BLOCK, int ITEMS>
+static int launch_pass_g(dthip_ctx* ctx, const RadixPass& p) {
+  const int p0w = (p.pay.n > 0 && !p.iota) ? p.pay.width[0] : 0;
+  if (p.bits > 8) {
+    if (BLOCK < 512) { set_error("9-bit digits need a 512-thread tile"); return DTHIP_EINVAL; }
+    if (p0w == 8) return launch_pass_t<KeyT, 9, 8, (BLOCK < 512 ? 512 : BLOCK), ITEMS>(ctx, p);
+    if (p0w == 4) return launch_pass_t<KeyT, 9, 4, (BLOCK < 512 ? 512 : BLOCK), ITEMS>(ctx, p);
+    return launch_pass_t<KeyT, 9, 0, (BLOCK < 512 ? 512 : BLOCK), ITEMS>(ctx, p);
+  }
+  if (p0w == 8) return launch_pass_t<KeyT, 8, 8, BLOCK, ITEMS>(ctx, p);
+  if (p0w == 4) return launch_pass_t<KeyT, 8, 4, BLOCK, ITEMS>(ctx, p);
+  return launch_pass_t<KeyT, 8, 0, BLOCK, ITEMS>(ctx, p);
+}
+
+template <typename KeyT>
+static int launch_pass_k(dthip_ctx* ctx, const RadixPass& p) {
+  switch (rp_variant()) {
+    case 1: return launch_pass_g<KeyT, 512, 8>(ctx, p);
+    case 2: return launch_pass_g<KeyT, 256, 16>(ctx, p);
+    case 3: return launch_pass_g<KeyT, 256, 8>(ctx, p);
+    case 4: return launch_pass_g<KeyT, 1024, 16>(ctx, p);
+    case 5: return launch_pass_g<KeyT, 1024, 8>(ctx, p);
+    default: return launch_pass_g<KeyT, 512, 16>(ctx, p);
+  }
 }
 
 int launch_radix_pass(dthip_ctx* ctx, const RadixPass& p) {
   if (p.n == 0) return DTHIP_OK;
   if (p.bits < 1 || p.bits > 9) { set_error("radix pass: bad digit width %d", p.bits); return DTHIP_EINVAL; }
-  int maxw = 0;
-  for (int c = 0; c < p.pay.n; c++) maxw = p.pay.width[c] > maxw ? p.pay.width[c] : maxw;
-  const size_t lds = pass_lds_bytes(p.bits, p.key64, maxw);
-  const int p0w = (p.pay.n > 0 && !p.iota) ? p.pay.width[0] : 0;
-  const bool rb9 = p.bits > 8;
-#define DISPATCH(KT)                                                            \
-  do {                                                                          \
-    if (rb9) {                                                                  \
-      if (p0w == 8) return launch_pass_t<KT, 9, 8>(ctx, p, lds);                \
-      if (p0w == 4) return launch_pass_t<KT, 9, 4>(ctx, p, lds);                \
-      return launch_pass_t<KT, 9, 0>(ctx, p, lds);                              \
-    } else {                                                                    \
-      if (p0w == 8) return launch_pass_t<KT, 8, 8>(ctx, p, lds);                \
-      if (p0w == 4) return launch_pass_t<KT, 8, 4>(ctx, p, lds);                \
-      return launch_pass_t<KT, 8, 0>(ctx, p, lds);                              \
-    }                                                                           \
-  } while (0)
-  if (p.key64) DISPATCH(unsigned long long);
-  else DISPATCH(uint32_t);
-#undef DISPATCH
-  return DTHIP_OK;
+  if (p.key64) return launch_pass_k<unsigned long long>(ctx, p);
+  return launch_pass_k<uint32_t>(ctx, p);
 }
 
 }  // namespace dthip

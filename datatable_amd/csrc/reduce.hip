@@ -32,6 +32,7 @@ namespace dthip {
 constexpr int SR_BLOCK = 256;
 constexpr int SR_ITEMS = 8;
 constexpr int SR_TILE = SR_BLOCK * SR_ITEMS;   // 2048, must equal group.hip's GB_TILE
+typedef uint32_t ru32x4 __attribute__((ext_vector_type(4)));
 
 // ---- accumulator states ---------------------------------------------------
 struct StF {   // float32 / float64 values
@@ -189,24 +190,49 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
   uint32_t hb = 0;
   if (p0 < n) hb = bitmap[p0 >> 3];
 
-  // values (optionally gathered through the RowIndex), NA -> not accumulated
+  // values (optionally gathered through the RowIndex), NA -> not accumulated.
+  // Interior threads read their 8 consecutive elements with 16-byte loads.
   T x[SR_ITEMS];
   bool ok[SR_ITEMS];
+  const bool whole = p0 + SR_ITEMS <= n;
+  if (whole && !ri && sizeof(T) >= 2 && ((reinterpret_cast<uintptr_t>(vals) & 15) == 0)) {
+    constexpr int NV = SR_ITEMS * (int)sizeof(T) / 16 > 0 ? SR_ITEMS * (int)sizeof(T) / 16 : 1;
+    ru32x4 v[NV];
+    const ru32x4* src = reinterpret_cast<const ru32x4*>(vals + p0);
 #pragma unroll
-  for (int j = 0; j < SR_ITEMS; j++) {
-    const uint32_t p = p0 + j;
-    ok[j] = false;
-    x[j] = T(0);
-    if (p < n) {
-      if (ri) {
-        const int32_t r = ri[p];
-        if (r >= 0) { x[j] = vals[r]; ok[j] = true; }
-      } else {
-        x[j] = vals[p]; ok[j] = true;
-      }
+    for (int j = 0; j < NV; j++) v[j] = src[j];
+    const T* vt = reinterpret_cast<const T*>(v);
+#pragma unroll
+    for (int j = 0; j < SR_ITEMS; j++) { x[j] = vt[j]; ok[j] = !VT<T>::isna(x[j]); }
+  } else if (whole && ri && ((reinterpret_cast<uintptr_t>(ri) & 15) == 0)) {
+    ru32x4 rv[2];
+    const ru32x4* rsrc = reinterpret_cast<const ru32x4*>(ri + p0);
+    rv[0] = rsrc[0]; rv[1] = rsrc[1];
+    const int32_t* rr = reinterpret_cast<const int32_t*>(rv);
+#pragma unroll
+    for (int j = 0; j < SR_ITEMS; j++) {
+      const int32_t r = rr[j];
+      ok[j] = r >= 0;
+      x[j] = ok[j] ? vals[r] : T(0);
       if (ok[j] && VT<T>::isna(x[j])) ok[j] = false;
-    } else {
-      hb &= ~(1u << j);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < SR_ITEMS; j++) {
+      const uint32_t p = p0 + j;
+      ok[j] = false;
+      x[j] = T(0);
+      if (p < n) {
+        if (ri) {
+          const int32_t r = ri[p];
+          if (r >= 0) { x[j] = vals[r]; ok[j] = true; }
+        } else {
+          x[j] = vals[p]; ok[j] = true;
+        }
+        if (ok[j] && VT<T>::isna(x[j])) ok[j] = false;
+      } else {
+        hb &= ~(1u << j);
+      }
     }
   }
 

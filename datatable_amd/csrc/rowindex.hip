@@ -99,7 +99,7 @@ int launch_compact(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out, i
   const uint32_t nt = (uint32_t)((n + CP_TILE - 1) / CP_TILE);
   Scratch sc(ctx);
   uint32_t* tile_counts = nullptr;
-  DTHIP_TRY(sc.get<uint32_t>(nt + 1, &tile_counts));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, &tile_counts));
   DTHIP_LAUNCH(ctx, "compact_count_kernel", compact_count_kernel, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts);
   DTHIP_TRY(launch_scan_tiles(ctx, tile_counts, nt, tile_counts + nt));
   DTHIP_LAUNCH(ctx, "compact_write_kernel", compact_write_kernel, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts, out);
