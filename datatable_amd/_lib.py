@@ -38,6 +38,7 @@ SIGNATURES = {
     "dthip_destroy": (C.c_int, [C.c_void_p]),
     "dthip_sync": (C.c_int, [C.c_void_p]),
     "dthip_trim": (C.c_int, [C.c_void_p]),
+    "dthip_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "dthip_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dthip_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dthip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

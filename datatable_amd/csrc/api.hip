@@ -483,6 +483,205 @@ static int reduce_outs_for(int op, void* dst, ReduceOuts* o) {
   return DTHIP_OK;
 }
 
+// ---- bucketed aggregation (bucket.hip): DT[:, aggs, by(keys)] without a sort -------------
+// Accumulators each value column needs for the requested reducers.
+static int acc_flags_for(const dthip_agg* aggs, int naggs, int col, int vstype) {
+  int f = 0;
+  const bool isf = stype_is_float(vstype);
+  for (int a = 0; a < naggs; a++) {
+    if (aggs[a].op == DTHIP_COUNT0 || aggs[a].col != col) continue;
+    switch (aggs[a].op) {
+      case DTHIP_SUM: f |= ACC_SUM; break;
+      case DTHIP_MEAN: f |= ACC_VCNT | (isf ? ACC_SUM : ACC_FSUM); break;
+      case DTHIP_MIN: f |= ACC_MIN | ACC_VCNT; break;
+      case DTHIP_MAX: f |= ACC_MAX | ACC_VCNT; break;
+      case DTHIP_COUNT: f |= ACC_VCNT; break;
+      default: break;
+    }
+  }
+  return f;
+}
+
+static int floor_log2_sz(size_t v) { int b = -1; while (v) { b++; v >>= 1; } return b; }
+
+constexpr size_t BUCKET_LDS_TABLE = 128 * 1024;   // LDS bytes one aggregation table may take
+constexpr int BUCKET_MAX_R = 14;                  // slot keys are uint16
+constexpr int BUCKET_MAX_D = 11;                  // <= 2048 buckets in one partition pass
+
+// Decides whether the bucket path applies; fills the slot-bit count r.
+static bool bucket_eligible(const dthip_ctx* ctx, const KeyPlan& plan, const std::vector<dthip_col>& vd,
+                            const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int* r_out) {
+  if (ctx->agg_path == 1) return false;
+  if (plan.nstages != 1) return false;
+  const int B = plan.stage_bits[0];
+  if (B > 32 || B < 1) return false;
+  int r = BUCKET_MAX_R;
+  bool first = true;
+  for (int c : used) {
+    const int sz = stype_size(vd[c].stype);
+    if (sz != 4 && sz != 8) return false;
+    const int f = acc_flags_for(aggs, naggs, c, vd[c].stype) | (first ? ACC_CNT : 0);
+    first = false;
+    const int rc = floor_log2_sz(BUCKET_LDS_TABLE / table_agg_slot_bytes(f));
+    if (rc < r) r = rc;
+  }
+  if (r > B) r = B;
+  if (B - r > BUCKET_MAX_D) return false;
+  // the dense accumulator arrays have 2^B slots: only worth it when the key range is dense enough
+  if (ctx->agg_path != 2 && (1ULL << B) > 16ULL * (unsigned long long)n + 4096ULL) return false;
+  if (ctx->agg_path != 2 && n < 4096) return false;
+  *r_out = r;
+  return true;
+}
+
+static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const KeyPlan& plan,
+                              const std::vector<dthip_col>& kd, const std::vector<dthip_col>& vd,
+                              const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int r) {
+  const int nkeys = plan.nkeys;
+  const int B = plan.stage_bits[0];
+  KeyXform kx;
+  memset(&kx, 0, sizeof(kx));
+  kx.ncols = nkeys;
+  for (int k = 0; k < nkeys; k++) kx.cols[k] = plan.col[k];
+  // vector key loads need one aligned int32/int64 column and aligned value columns
+  int km = 0;
+  if (nkeys == 1 && kx.cols[0].shift == 0 && (reinterpret_cast<uintptr_t>(kx.cols[0].data) & 15) == 0) {
+    if (kx.cols[0].stype == DTHIP_INT64) km = 1;
+    else if (kx.cols[0].stype == DTHIP_INT32) km = 2;
+  }
+  for (int c : used) if (reinterpret_cast<uintptr_t>(vd[c].data) & 15) km = 0;
+  BucketGeom g;
+  bucket_geometry(ctx, n, B, r, km, &g);
+  const size_t nslots = (size_t)g.F * g.S;
+
+  // --- partition (skipped when one table holds the whole key range) ---
+  uint16_t* kpart = nullptr;
+  std::vector<const void*> vsrc(vd.size(), nullptr);
+  for (int c : used) vsrc[c] = vd[c].data;
+  uint32_t* bbase = nullptr; WorkItem* items = nullptr; uint32_t* nitems = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 2, &bbase));
+  nitems = bbase + g.F + 1;
+  uint32_t M;
+  {
+    const uint64_t denom = std::max<uint64_t>(g.F, (uint64_t)ctx->num_cus * 4);
+    uint64_t m = (2 * (uint64_t)n + denom - 1) / denom;
+    if (m < 65536) m = 65536;
+    m = (m + 7) & ~7ULL;
+    M = (uint32_t)std::min<uint64_t>(m, 0x7FFFFFF8ULL);
+  }
+  const uint32_t max_items = g.F + (uint32_t)((uint64_t)n / M) + 1;
+  DTHIP_TRY(sc.get<WorkItem>(max_items, &items));
+  if (g.d > 0) {
+    uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
+    DTHIP_TRY(sc.get<uint32_t>((size_t)g.ntiles * g.F, &P));
+    DTHIP_TRY(sc.get<uint32_t>((size_t)g.G * g.F, &gtot));
+    DTHIP_TRY(sc.get<uint32_t>((size_t)g.F, &tot));
+    DTHIP_TRY(launch_bucket_hist(ctx, kx, n, g, P, gtot));
+    DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot));
+    DTHIP_TRY(launch_bucket_plan(ctx, tot, g.F, 0, M, bbase, items, nitems));
+    DTHIP_TRY(sc.get<uint16_t>((size_t)n + 8, &kpart));
+    PayCols pc;
+    memset(&pc, 0, sizeof(pc));
+    for (int c : used) {
+      unsigned char* vb = nullptr;
+      const int w = stype_size(vd[c].stype);
+      DTHIP_TRY(sc.get<unsigned char>((size_t)n * w + 64, &vb));
+      pc.in[pc.n] = vd[c].data; pc.out[pc.n] = vb; pc.width[pc.n] = w; pc.n++;
+      vsrc[c] = vb;
+    }
+    DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, P, gtot, bbase, kpart, pc));
+  } else {
+    DTHIP_TRY(launch_bucket_plan(ctx, nullptr, 1, (uint32_t)n, M, bbase, items, nitems));
+  }
+
+  // --- dense accumulators + one aggregation launch per value column ---
+  uint32_t* d_cnt = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>(nslots, &d_cnt));
+  DTHIP_CHECK_HIP(hipMemsetAsync(d_cnt, 0, nslots * 4, ctx->stream));
+  std::vector<AggTable> tabs(vd.size());
+  std::vector<int> tflags(vd.size(), 0);
+  bool first = true;
+  for (int c : used) {
+    AggTable& t = tabs[c];
+    int f = acc_flags_for(aggs, naggs, c, vd[c].stype);
+    if (first) { f |= ACC_CNT; t.cnt = d_cnt; }
+    tflags[c] = f;
+    if (f & ACC_SUM) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.sum)); DTHIP_CHECK_HIP(hipMemsetAsync(t.sum, 0, nslots * 8, ctx->stream)); }
+    if (f & ACC_MIN) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.mn)); DTHIP_CHECK_HIP(hipMemsetAsync(t.mn, 0xFF, nslots * 8, ctx->stream)); }
+    if (f & ACC_MAX) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.mx)); DTHIP_CHECK_HIP(hipMemsetAsync(t.mx, 0, nslots * 8, ctx->stream)); }
+    if (f & ACC_FSUM) { DTHIP_TRY(sc.get<double>(nslots, &t.fsum)); DTHIP_CHECK_HIP(hipMemsetAsync(t.fsum, 0, nslots * 8, ctx->stream)); }
+    if (f & ACC_VCNT) { DTHIP_TRY(sc.get<uint32_t>(nslots, &t.vcnt)); DTHIP_CHECK_HIP(hipMemsetAsync(t.vcnt, 0, nslots * 4, ctx->stream)); }
+    TableAggArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.items = items; ta.nitems = nitems; ta.max_items = max_items;
+    ta.kpart = kpart; ta.kx = kx; ta.val = vsrc[c]; ta.vstype = vd[c].stype; ta.S = g.S; ta.flags = f; ta.tab = t;
+    DTHIP_TRY(launch_table_agg(ctx, ta));
+    first = false;
+  }
+  if (first) {   // no value column at all (only count()): row counts alone
+    TableAggArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.items = items; ta.nitems = nitems; ta.max_items = max_items;
+    ta.kpart = kpart; ta.kx = kx; ta.val = nullptr; ta.vstype = DTHIP_INT32; ta.S = g.S; ta.flags = ACC_CNT;
+    ta.tab.cnt = d_cnt;
+    DTHIP_TRY(launch_table_agg(ctx, ta));
+  }
+
+  // --- groups = non-empty slots in slot order ---
+  int32_t* idx = nullptr;
+  DTHIP_TRY(sc.get<int32_t>(std::min<size_t>(nslots, (size_t)n) + 1, &idx));
+  PredArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.data = d_cnt; pa.stype = DTHIP_INT32; pa.cmp = DTHIP_GT; pa.ci = 0; pa.is_mask = 0;
+  int64_t ng = 0;
+  DTHIP_TRY(launch_compact(ctx, pa, (int64_t)nslots, idx, &ng));
+  res->nrows = n; res->ngroups = ng;
+  // offsets = exclusive scan of the group sizes (Groupby offsets, groupby.h:54-91)
+  void* off = nullptr;
+  DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * ((size_t)ng + 2 + (size_t)ng / 8192 + 1), &off));
+  DTHIP_TRY(launch_gather(ctx, d_cnt, DTHIP_INT32, idx, ng, off));
+  DTHIP_TRY(launch_scan_tiles(ctx, static_cast<uint32_t*>(off), (uint32_t)ng, static_cast<uint32_t*>(off) + ng));
+  res->offsets = static_cast<int32_t*>(off);
+  // group-key columns: the slot index is the packed transformed key
+  for (int k = 0; k < nkeys; k++) {
+    void* kp = nullptr;
+    DTHIP_TRY(result_alloc(ctx, res, (size_t)ng * stype_size(kd[k].stype), &kp));
+    res->key[k] = kp;
+    DTHIP_TRY(launch_untransform_keys(ctx, idx, 0, nullptr, ng, plan.col[k], plan.nsig[k], kp));
+  }
+  for (int a = 0; a < naggs; a++) {
+    void* ap = nullptr;
+    DTHIP_TRY(result_alloc(ctx, res, (size_t)ng * stype_size(res->agg_stype[a]), &ap));
+    res->agg[a] = ap;
+  }
+  for (int c : used) {
+    TableFinArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.idx = idx; fa.ng = (uint32_t)ng; fa.tab = tabs[c]; fa.vstype = vd[c].stype;
+    std::vector<std::pair<int, int>> dups;
+    int first_of_op[6] = {-1, -1, -1, -1, -1, -1};
+    for (int a = 0; a < naggs; a++) {
+      if (aggs[a].op == DTHIP_COUNT0 || aggs[a].col != c) continue;
+      if (first_of_op[aggs[a].op] >= 0) { dups.push_back({a, first_of_op[aggs[a].op]}); continue; }
+      first_of_op[aggs[a].op] = a;
+      switch (aggs[a].op) {
+        case DTHIP_SUM: fa.o_sum = res->agg[a]; break;
+        case DTHIP_MEAN: fa.o_mean = res->agg[a]; break;
+        case DTHIP_MIN: fa.o_min = res->agg[a]; break;
+        case DTHIP_MAX: fa.o_max = res->agg[a]; break;
+        default: fa.o_count = static_cast<int64_t*>(res->agg[a]); break;
+      }
+    }
+    DTHIP_TRY(launch_table_finalize(ctx, fa));
+    for (auto& d : dups)
+      DTHIP_CHECK_HIP(hipMemcpyAsync(res->agg[d.first], res->agg[d.second], (size_t)ng * stype_size(res->agg_stype[d.first]),
+                                     hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  for (int a = 0; a < naggs; a++)
+    if (aggs[a].op == DTHIP_COUNT0) DTHIP_TRY(launch_count0(ctx, res->offsets, ng, static_cast<int64_t*>(res->agg[a])));
+  return DTHIP_OK;
+}
+
 }  // namespace dthip
 
 extern "C" {
@@ -518,6 +717,8 @@ int dthip_init(int device, void* stream, dthip_ctx** out) {
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  if (const char* e = getenv("DTHIP_AGG_PATH")) ctx->agg_path = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;
+  if (const char* e = getenv("DTHIP_BUCKET_VARIANT")) ctx->bucket_variant = atoi(e);
   (void)hipEventCreate(&ctx->t0);
   (void)hipEventCreate(&ctx->t1);
   *out = ctx;
@@ -547,6 +748,18 @@ int dthip_sync(dthip_ctx* ctx) {
 }
 
 int dthip_trim(dthip_ctx* ctx) { return ctx ? dev_trim(ctx) : DTHIP_EINVAL; }
+
+int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx || !name) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (!strcmp(name, "agg_path")) {
+    if (value < 0 || value > 2) { set_error("agg_path must be 0 (auto), 1 (sort) or 2 (bucket)"); return DTHIP_EINVAL; }
+    ctx->agg_path = (int)value;
+    return DTHIP_OK;
+  }
+  if (!strcmp(name, "bucket_variant")) { ctx->bucket_variant = (int)value; return DTHIP_OK; }
+  set_error("unknown option '%s'", name);
+  return DTHIP_EINVAL;
+}
 
 int dthip_malloc(dthip_ctx* ctx, size_t bytes, void** dptr) {
   if (!ctx || !dptr) { set_error("null argument"); return DTHIP_EINVAL; }
@@ -687,6 +900,11 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
     if (fused) {
       if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan)) != DTHIP_OK) break;
       if (plan.nstages != 1) fused = false;
+    }
+    int slot_bits = 0;
+    if (fused && bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &slot_bits)) {
+      rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits);
+      break;
     }
     if (fused) {
       // values ride through the sort; the RowIndex is never materialised

@@ -1,0 +1,735 @@
+// bucket.hip -- DT[:, {sum,mean,min,max,count}, by(keys)] for DENSE key ranges without a sort.
+//
+// What the reference computes (src/core/expr/eval_context.cc:144-172, sort.cc:1411-1495,
+// column/{sumprod,mean,minmax,count}.h): groups = distinct transformed keys in ascending
+// order (NA first), one reducer value per group.  The reference gets there with an MSD
+// radix sort producing an ordering vector (sort.cc:1128-1353) and then gathers every value
+// through it.  When the transformed key x = key - min + 1 has few significant bits
+// (B <= ~25: config C3 has 24, C2 17, C4 24), the groups can be produced with ONE scatter:
+//
+//   hist       per-tile digit counts of the top d = B - r bits (LDS atomics) -> the exact
+//              global position of every (tile, bucket) run: no look-back, no spinning
+//   partition  each 12288-row tile is ordered by bucket in LDS and written as runs; the
+//              slot key (low r bits, uint16) and the value columns move together.
+//              Tiles are dealt to XCDs in contiguous ranges so that the partially written
+//              128-B lines of a bucket are completed by the same XCD's L2.
+//   table_agg  one workgroup per bucket (or per <= M-row part of a big bucket) accumulates
+//              count / sum / min / max into an LDS table of S = 2^r slots with DS atomics
+//              (ds_add_u32, ds_add_f64 / ds_add_u64, ds_min_u64 / ds_max_u64 on an order-
+//              preserving image), then stores the table to the dense accumulator arrays
+//              (plain stores when the bucket has a single part, global atomics otherwise).
+//   finalize   non-empty slots, in slot order, are the groups in key order (the slot index
+//              IS the transformed key): compaction + gathers produce keys / offsets / aggs.
+//
+// HBM traffic for C3 (int64 key + float64 value): hist 8 B/row, partition 16 R + 10 W,
+// table_agg 10 R  => 44 B/row against 3 x 24 + 16 for the LSD sort path.
+// Integer results (counts, int sums, min/max, group keys/sizes) are exact and order
+// independent; float sums are accumulated in a data-dependent order (<= 1e-6 relative,
+// the tolerance BASELINE.json states).  Not usable when a RowIndex is requested.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "keyxform.hpp"
+
+namespace dthip {
+
+typedef uint32_t bu32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t bu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------------------
+// tile loaders.  KM = 1: one 16-B aligned int64 key column, 2 consecutive rows per lane per
+// load; KM = 2: one aligned int32 key column, 4 consecutive rows; KM = 0: anything, 1 row.
+// Item j of thread tid is row  tile_base + ((j / VW) * BLOCK + tid) * VW + j % VW.
+// ---------------------------------------------------------------------------------------
+template <int KM> struct KmVW { static constexpr int value = KM == 1 ? 2 : KM == 2 ? 4 : 1; };
+
+template <int BLOCK, int KM>
+__device__ __forceinline__ uint32_t item_row(int j, int tid) {
+  constexpr int VW = KmVW<KM>::value;
+  return ((uint32_t)(j / VW) * BLOCK + (uint32_t)tid) * VW + (uint32_t)(j % VW);
+}
+
+__device__ __forceinline__ uint32_t xf_int(const KeyColDev& c, long long v, long long na) {
+  const u64 u = (u64)v;
+  return (uint32_t)((v == na) ? c.na_repl : (c.desc ? c.edge - u + c.inc : u - c.edge + c.inc));
+}
+
+template <int BLOCK, int ITEMS, int KM>
+__device__ __forceinline__ void load_tile_x(const KeyXform& kx, uint32_t tile_base, uint32_t nvalid, bool full,
+                                            int tid, uint32_t (&x)[ITEMS]) {
+  if (KM == 1 && full) {
+    const KeyColDev& c = kx.cols[0];
+    const long long* src = static_cast<const long long*>(c.data) + tile_base;
+    bu32x4 w[ITEMS / 2];
+#pragma unroll
+    for (int q = 0; q < ITEMS / 2; q++) w[q] = *reinterpret_cast<const bu32x4*>(src + ((uint32_t)q * BLOCK + tid) * 2);
+#pragma unroll
+    for (int q = 0; q < ITEMS / 2; q++) {
+      x[2 * q] = xf_int(c, (long long)((u64)w[q].x | ((u64)w[q].y << 32)), INT64_MIN);
+      x[2 * q + 1] = xf_int(c, (long long)((u64)w[q].z | ((u64)w[q].w << 32)), INT64_MIN);
+    }
+  } else if (KM == 2 && full) {
+    const KeyColDev& c = kx.cols[0];
+    const int32_t* src = static_cast<const int32_t*>(c.data) + tile_base;
+    bu32x4 w[ITEMS / 4];
+#pragma unroll
+    for (int q = 0; q < ITEMS / 4; q++) w[q] = *reinterpret_cast<const bu32x4*>(src + ((uint32_t)q * BLOCK + tid) * 4);
+#pragma unroll
+    for (int q = 0; q < ITEMS / 4; q++) {
+      x[4 * q] = xf_int(c, (long long)(int32_t)w[q].x, INT32_MIN);
+      x[4 * q + 1] = xf_int(c, (long long)(int32_t)w[q].y, INT32_MIN);
+      x[4 * q + 2] = xf_int(c, (long long)(int32_t)w[q].z, INT32_MIN);
+      x[4 * q + 3] = xf_int(c, (long long)(int32_t)w[q].w, INT32_MIN);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+      const uint32_t rel = item_row<BLOCK, KM>(j, tid);
+      if (KM == 0) x[j] = rel < nvalid ? (uint32_t)packed_key(kx.cols, kx.ncols, tile_base + rel) : 0u;
+      else x[j] = rel < nvalid ? (uint32_t)xform_key(kx.cols[0], tile_base + rel) : 0u;
+    }
+  }
+}
+
+// payload column values of the thread's items (PT = uint32_t / u64), same row assignment
+template <int BLOCK, int ITEMS, int KM, typename PT>
+__device__ __forceinline__ void load_tile_vals(const PT* __restrict__ src, uint32_t nvalid, bool full, int tid,
+                                               PT (&v)[ITEMS]) {
+  constexpr int VW = KmVW<KM>::value;
+  if (full && VW > 1) {
+    constexpr int BYTES = VW * (int)sizeof(PT);       // contiguous bytes per lane per row group: 8, 16 or 32
+#pragma unroll
+    for (int q = 0; q < ITEMS / VW; q++) {
+      const PT* p = src + ((uint32_t)q * BLOCK + tid) * VW;
+      if (BYTES == 8) {
+        const bu32x2 w = *reinterpret_cast<const bu32x2*>(p);
+        v[VW * q] = (PT)w.x; v[VW * q + 1] = (PT)w.y;
+      } else if (BYTES == 16 && sizeof(PT) == 8) {
+        const bu32x4 w = *reinterpret_cast<const bu32x4*>(p);
+        v[VW * q] = (PT)((u64)w.x | ((u64)w.y << 32)); v[VW * q + 1] = (PT)((u64)w.z | ((u64)w.w << 32));
+      } else if (BYTES == 16) {
+        const bu32x4 w = *reinterpret_cast<const bu32x4*>(p);
+        v[VW * q] = (PT)w.x; v[VW * q + 1] = (PT)w.y; v[VW * q + 2] = (PT)w.z; v[VW * q + 3] = (PT)w.w;
+      } else {
+        const bu32x4 w0 = reinterpret_cast<const bu32x4*>(p)[0];
+        const bu32x4 w1 = reinterpret_cast<const bu32x4*>(p)[1];
+        v[VW * q] = (PT)((u64)w0.x | ((u64)w0.y << 32)); v[VW * q + 1] = (PT)((u64)w0.z | ((u64)w0.w << 32));
+        v[VW * q + 2] = (PT)((u64)w1.x | ((u64)w1.y << 32)); v[VW * q + 3] = (PT)((u64)w1.z | ((u64)w1.w << 32));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+      const uint32_t rel = item_row<BLOCK, KM>(j, tid);
+      v[j] = rel < nvalid ? src[rel] : PT(0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// hist: per-tile bucket counts -> P[tile][b] = rows of bucket b in the earlier tiles of the
+// same group; gtot[group][b] = rows of bucket b in the group.  One workgroup per group.
+// ---------------------------------------------------------------------------------------
+struct HistArgs {
+  KeyXform kx; uint32_t n; int r; uint32_t F;
+  uint32_t ntiles, tpg;
+  uint32_t* P; uint32_t* gtot;
+};
+
+template <int BLOCK, int ITEMS, int KM>
+__global__ void __launch_bounds__(BLOCK) bucket_hist_kernel(HistArgs a) {
+  constexpr uint32_t TILE = BLOCK * ITEMS;
+  constexpr int NB = 2048 / BLOCK;          // bins per thread (F <= 2048)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);
+  const int tid = threadIdx.x;
+  uint32_t run[NB];
+#pragma unroll
+  for (int k = 0; k < NB; k++) { run[k] = 0; const uint32_t b = (uint32_t)k * BLOCK + tid; if (b < a.F) cnt[b] = 0; }
+  __syncthreads();
+  const uint32_t t0 = blockIdx.x * a.tpg;
+  const uint32_t t1 = (t0 + a.tpg < a.ntiles) ? t0 + a.tpg : a.ntiles;
+  for (uint32_t t = t0; t < t1; t++) {
+    const uint32_t tile_base = t * TILE;
+    const uint32_t nvalid = (a.n - tile_base < TILE) ? (a.n - tile_base) : TILE;
+    const bool full = nvalid == TILE;
+    uint32_t x[ITEMS];
+    load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x);
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++)
+      if (full || item_row<BLOCK, KM>(j, tid) < nvalid) atomicAdd(&cnt[x[j] >> a.r], 1u);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      const uint32_t b = (uint32_t)k * BLOCK + tid;
+      if (b < a.F) {
+        const uint32_t c = cnt[b];
+        cnt[b] = 0;
+        a.P[(size_t)t * a.F + b] = run[k];
+        run[k] += c;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < NB; k++) {
+    const uint32_t b = (uint32_t)k * BLOCK + tid;
+    if (b < a.F) a.gtot[(size_t)blockIdx.x * a.F + b] = run[k];
+  }
+}
+
+// gtot[g][b] -> exclusive prefix over g (in place); tot[b] = column total.
+// One workgroup per 64 buckets: lane = bucket, each of the 16 waves owns a range of groups.
+__global__ void __launch_bounds__(1024) bucket_gscan_kernel(uint32_t* gtot, uint32_t G, uint32_t F, uint32_t* tot) {
+  __shared__ uint32_t part[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t b = blockIdx.x * 64 + lane;
+  const uint32_t per = (G + 15) / 16;
+  const uint32_t g0 = wave * per, g1 = (g0 + per < G) ? g0 + per : G;
+  uint32_t s = 0;
+  if (b < F) for (uint32_t g = g0; g < g1; g++) s += gtot[(size_t)g * F + b];
+  part[wave][lane] = s;
+  __syncthreads();
+  uint32_t off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) { const uint32_t v = part[w][lane]; if (w < wave) off += v; total += v; }
+  if (b < F) {
+    for (uint32_t g = g0; g < g1; g++) {
+      const uint32_t v = gtot[(size_t)g * F + b];
+      gtot[(size_t)g * F + b] = off;
+      off += v;
+    }
+    if (wave == 0) tot[b] = total;
+  }
+}
+
+// bucket sizes -> bucket starts + the aggregation work list (parts of <= M rows)
+__global__ void __launch_bounds__(1024) bucket_plan_kernel(const uint32_t* tot, uint32_t F, uint32_t n_raw, uint32_t M,
+                                                           uint32_t* bbase, WorkItem* items, uint32_t* nitems) {
+  __shared__ uint32_t scratch[16];
+  const int tid = threadIdx.x;
+  uint32_t sz[2], np[2], s = 0, ps = 0;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint32_t b = (uint32_t)tid * 2 + k;
+    sz[k] = b < F ? (tot ? tot[b] : n_raw) : 0u;
+    np[k] = (sz[k] + M - 1) / M;
+    s += sz[k]; ps += np[k];
+  }
+  uint32_t stot, ptot;
+  uint32_t e = block_excl_scan_u32<1024>(s, scratch, &stot);
+  uint32_t pe = block_excl_scan_u32<1024>(ps, scratch, &ptot);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint32_t b = (uint32_t)tid * 2 + k;
+    if (b < F) {
+      bbase[b] = e;
+      for (uint32_t i = 0; i < np[k]; i++) {
+        WorkItem it;
+        it.bucket = b;
+        it.begin = e + i * M;
+        it.end = (i + 1 == np[k]) ? e + sz[k] : e + (i + 1) * M;
+        it.single = np[k] == 1 ? 1u : 0u;
+        items[pe + i] = it;
+      }
+      e += sz[k]; pe += np[k];
+    }
+  }
+  if (tid == 0) { bbase[F] = stot; *nitems = ptot; }
+}
+
+// ---------------------------------------------------------------------------------------
+// partition
+// ---------------------------------------------------------------------------------------
+struct PartArgs {
+  KeyXform kx; uint32_t n; int r; uint32_t F;
+  uint32_t tpg;
+  const uint32_t* P; const uint32_t* gpre; const uint32_t* bbase;
+  uint16_t* kout;
+  PayCols pay;
+};
+
+template <int BLOCK, int ITEMS, int KM, typename PT>
+__device__ __forceinline__ void move_payload(const PT* __restrict__ pin, PT* __restrict__ pout, unsigned char* stage,
+                                             uint32_t nvalid, bool full, int tid, const uint32_t (&lpos)[ITEMS],
+                                             const uint32_t (&gpos)[ITEMS]) {
+  PT v[ITEMS];
+  load_tile_vals<BLOCK, ITEMS, KM, PT>(pin, nvalid, full, tid, v);
+  PT* st = reinterpret_cast<PT*>(stage);
+  __syncthreads();                                   // previous users of `stage` are done
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++)
+    if (full || item_row<BLOCK, KM>(j, tid) < nvalid) st[lpos[j]] = v[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    const uint32_t s = (uint32_t)j * BLOCK + tid;
+    if (s < nvalid) pout[gpos[j]] = st[s];
+  }
+}
+
+template <int BLOCK, int ITEMS, int KM>
+__global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
+  constexpr uint32_t TILE = BLOCK * ITEMS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t F = a.F, Fp = (F + 3u) & ~3u;
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);     // [Fp] bucket counts, then tile-local exclusive starts
+  uint32_t* delta = cnt + Fp;                            // [Fp] global start - local start
+  uint32_t* misc = delta + Fp;                           // [32]
+  unsigned char* stage = reinterpret_cast<unsigned char*>(misc + 32);
+  const int tid = threadIdx.x;
+
+  // tiles are dealt to XCDs (block b runs on XCD b % 8: speed only) in contiguous ranges
+  const uint32_t nt = gridDim.x, bi = blockIdx.x;
+  const uint32_t xq = nt / 8, xr = nt % 8, xc = bi % 8, q = bi / 8;
+  const uint32_t tile = xc * xq + (xc < xr ? xc : xr) + q;
+  const uint32_t tile_base = tile * TILE;
+  const uint32_t nvalid = (a.n - tile_base < TILE) ? (a.n - tile_base) : TILE;
+  const bool full = nvalid == TILE;
+
+  for (uint32_t b = tid; b < F; b += BLOCK) cnt[b] = 0;
+  uint32_t x[ITEMS];
+  load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x);
+  __syncthreads();
+
+  // rank of every row inside its bucket (arrival order: buckets are unordered sets)
+  uint32_t lpos[ITEMS];
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    lpos[j] = 0;
+    if (full || item_row<BLOCK, KM>(j, tid) < nvalid) lpos[j] = atomicAdd(&cnt[x[j] >> a.r], 1u);
+  }
+  __syncthreads();
+
+  // exclusive scan of the bucket counts; global position of every bucket's run
+  {
+    const uint32_t K = (F + BLOCK - 1) / BLOCK;          // consecutive bins per thread
+    uint32_t c[2048 / BLOCK], s = 0;
+#pragma unroll
+    for (int k = 0; k < 2048 / BLOCK; k++) {
+      const uint32_t b = (uint32_t)tid * K + k;
+      c[k] = ((uint32_t)k < K && b < F) ? cnt[b] : 0u;
+      s += c[k];
+    }
+    uint32_t e = block_excl_scan_u32<BLOCK>(s, misc, nullptr);
+    const uint32_t g = tile / a.tpg;
+#pragma unroll
+    for (int k = 0; k < 2048 / BLOCK; k++) {
+      const uint32_t b = (uint32_t)tid * K + k;
+      if ((uint32_t)k < K && b < F) {
+        cnt[b] = e;
+        delta[b] = a.bbase[b] + a.gpre[(size_t)g * F + b] + a.P[(size_t)tile * F + b] - e;
+        e += c[k];
+      }
+    }
+  }
+  __syncthreads();
+
+  // keys: registers -> LDS in bucket order -> global runs of uint16 slot keys
+  uint32_t* st32 = reinterpret_cast<uint32_t*>(stage);
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    if (full || item_row<BLOCK, KM>(j, tid) < nvalid) {
+      lpos[j] += cnt[x[j] >> a.r];
+      st32[lpos[j]] = x[j];
+    }
+  }
+  __syncthreads();
+  uint32_t gpos[ITEMS];
+  const uint32_t smask = (1u << a.r) - 1u;
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    const uint32_t s = (uint32_t)j * BLOCK + tid;
+    gpos[j] = 0;
+    if (s < nvalid) {
+      const uint32_t xs = st32[s];
+      gpos[j] = delta[xs >> a.r] + s;
+      a.kout[gpos[j]] = (uint16_t)(xs & smask);
+    }
+  }
+
+  // value columns follow the same permutation
+  for (int c = 0; c < a.pay.n; c++) {
+    if (a.pay.width[c] == 8)
+      move_payload<BLOCK, ITEMS, KM, u64>(static_cast<const u64*>(a.pay.in[c]) + tile_base,
+                                          static_cast<u64*>(a.pay.out[c]), stage, nvalid, full, tid, lpos, gpos);
+    else
+      move_payload<BLOCK, ITEMS, KM, uint32_t>(static_cast<const uint32_t*>(a.pay.in[c]) + tile_base,
+                                               static_cast<uint32_t*>(a.pay.out[c]), stage, nvalid, full, tid, lpos, gpos);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// geometry + launchers
+// ---------------------------------------------------------------------------------------
+struct BkGeomV { uint32_t block, items; };
+static const BkGeomV BK_GEOMS[] = {{1024, 12}, {512, 12}, {1024, 8}, {512, 16}};
+
+void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom* g) {
+  int v = ctx->bucket_variant;
+  if (v < 0 || v >= (int)(sizeof(BK_GEOMS) / sizeof(BK_GEOMS[0]))) v = 0;
+  if (r > B) r = B;
+  g->B = B; g->r = r; g->d = B - r;
+  g->F = 1u << g->d; g->S = 1u << r;
+  g->block = BK_GEOMS[v].block; g->items = BK_GEOMS[v].items;
+  g->tile = g->block * g->items;
+  g->ntiles = (uint32_t)((n + g->tile - 1) / g->tile);
+  const uint32_t gmax = (uint32_t)ctx->num_cus * (g->block == 1024 ? 2u : 4u);
+  g->tpg = (g->ntiles + gmax - 1) / gmax;
+  if (g->tpg == 0) g->tpg = 1;
+  g->G = (g->ntiles + g->tpg - 1) / g->tpg;
+  g->km = km;
+}
+
+#define BK_DISPATCH(FN, g, ...)                                                                   \
+  do {                                                                                            \
+    const int _km = (g).km;                                                                       \
+    if ((g).block == 1024 && (g).items == 12) {                                                   \
+      if (_km == 1) return FN<1024, 12, 1>(__VA_ARGS__);                                          \
+      if (_km == 2) return FN<1024, 12, 2>(__VA_ARGS__);                                          \
+      return FN<1024, 12, 0>(__VA_ARGS__);                                                        \
+    } else if ((g).block == 512 && (g).items == 12) {                                             \
+      if (_km == 1) return FN<512, 12, 1>(__VA_ARGS__);                                           \
+      if (_km == 2) return FN<512, 12, 2>(__VA_ARGS__);                                           \
+      return FN<512, 12, 0>(__VA_ARGS__);                                                         \
+    } else if ((g).block == 1024 && (g).items == 8) {                                             \
+      if (_km == 1) return FN<1024, 8, 1>(__VA_ARGS__);                                           \
+      if (_km == 2) return FN<1024, 8, 2>(__VA_ARGS__);                                           \
+      return FN<1024, 8, 0>(__VA_ARGS__);                                                         \
+    } else {                                                                                      \
+      if (_km == 1) return FN<512, 16, 1>(__VA_ARGS__);                                           \
+      if (_km == 2) return FN<512, 16, 2>(__VA_ARGS__);                                           \
+      return FN<512, 16, 0>(__VA_ARGS__);                                                         \
+    }                                                                                             \
+  } while (0)
+
+template <int BLOCK, int ITEMS, int KM>
+static int hist_t(dthip_ctx* ctx, const HistArgs& a, uint32_t G) {
+  DTHIP_LAUNCH(ctx, "bucket_hist_kernel", (bucket_hist_kernel<BLOCK, ITEMS, KM>), G, BLOCK, (size_t)a.F * 4 + 16, a);
+  return DTHIP_OK;
+}
+
+int launch_bucket_hist(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, uint32_t* P, uint32_t* gtot) {
+  HistArgs a;
+  a.kx = kx; a.n = (uint32_t)n; a.r = g.r; a.F = g.F; a.ntiles = g.ntiles; a.tpg = g.tpg; a.P = P; a.gtot = gtot;
+  BK_DISPATCH(hist_t, g, ctx, a, g.G);
+}
+
+int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uint32_t* tot) {
+  DTHIP_LAUNCH(ctx, "bucket_gscan_kernel", bucket_gscan_kernel, (g.F + 63) / 64, 1024, 0, gtot, g.G, g.F, tot);
+  return DTHIP_OK;
+}
+
+int launch_bucket_plan(dthip_ctx* ctx, const uint32_t* tot, uint32_t F, uint32_t n_raw, uint32_t M,
+                       uint32_t* bbase, WorkItem* items, uint32_t* nitems) {
+  if (F > 2048) { set_error("bucket plan: F=%u > 2048", F); return DTHIP_EINVAL; }
+  DTHIP_LAUNCH(ctx, "bucket_plan_kernel", bucket_plan_kernel, 1, 1024, 0, tot, F, n_raw, M, bbase, items, nitems);
+  return DTHIP_OK;
+}
+
+template <int BLOCK, int ITEMS, int KM>
+static int part_t(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds) {
+  auto kfn = bucket_partition_kernel<BLOCK, ITEMS, KM>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    attr_set = true;
+  }
+  DTHIP_LAUNCH(ctx, "bucket_partition_kernel", kfn, ntiles, BLOCK, lds, a);
+  return DTHIP_OK;
+}
+
+int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
+                            const uint32_t* gpre, const uint32_t* bbase, uint16_t* kout, const PayCols& pay) {
+  PartArgs a;
+  a.kx = kx; a.n = (uint32_t)n; a.r = g.r; a.F = g.F; a.tpg = g.tpg; a.P = P; a.gpre = gpre; a.bbase = bbase;
+  a.kout = kout; a.pay = pay;
+  int maxw = 4;
+  for (int c = 0; c < pay.n; c++) maxw = pay.width[c] > maxw ? pay.width[c] : maxw;
+  const uint32_t Fp = (g.F + 3u) & ~3u;
+  const size_t lds = (size_t)(2 * Fp + 32) * 4 + (size_t)g.tile * maxw;
+  BK_DISPATCH(part_t, g, ctx, a, g.ntiles, lds);
+}
+
+// ---------------------------------------------------------------------------------------
+// table aggregation
+// ---------------------------------------------------------------------------------------
+constexpr int TA_BLOCK = 1024;
+
+size_t table_agg_slot_bytes(int flags) {
+  size_t b = 0;
+  if (flags & ACC_CNT) b += 4;
+  if (flags & ACC_VCNT) b += 4;
+  if (flags & ACC_SUM) b += 8;
+  if (flags & ACC_MIN) b += 8;
+  if (flags & ACC_MAX) b += 8;
+  if (flags & ACC_FSUM) b += 8;
+  return b;
+}
+
+template <typename VT> struct ValTraits;
+template <> struct ValTraits<double> {
+  static constexpr bool is_float = true;
+  static __device__ __forceinline__ bool isna(double v) { return v != v; }
+};
+template <> struct ValTraits<float> {
+  static constexpr bool is_float = true;
+  static __device__ __forceinline__ bool isna(float v) { return v != v; }
+};
+template <> struct ValTraits<int32_t> {
+  static constexpr bool is_float = false;
+  static __device__ __forceinline__ bool isna(int32_t v) { return v == INT32_MIN; }
+};
+template <> struct ValTraits<long long> {
+  static constexpr bool is_float = false;
+  static __device__ __forceinline__ bool isna(long long v) { return v == INT64_MIN; }
+};
+
+// order-preserving unsigned images (the reference's float key transform, sort.cc:808-845)
+__device__ __forceinline__ u64 sortable_f64(double d) {
+  const u64 t = (u64)__double_as_longlong(d);
+  return t ^ (0x8000000000000000ULL | (0ULL - (t >> 63)));
+}
+__device__ __forceinline__ double unsortable_f64(u64 k) {
+  const u64 t = (k & 0x8000000000000000ULL) ? (k ^ 0x8000000000000000ULL) : ~k;
+  return __longlong_as_double((long long)t);
+}
+__device__ __forceinline__ u64 sortable_i64(long long v) { return (u64)v ^ 0x8000000000000000ULL; }
+
+struct LdsTab {
+  u64* sum; u64* mn; u64* mx; double* fsum; uint32_t* cnt; uint32_t* vcnt;
+};
+
+__device__ __forceinline__ LdsTab carve_tab(unsigned char* smem, uint32_t S, int flags) {
+  LdsTab t;
+  unsigned char* p = smem;
+  t.sum = reinterpret_cast<u64*>(p); if (flags & ACC_SUM) p += (size_t)S * 8;
+  t.mn = reinterpret_cast<u64*>(p); if (flags & ACC_MIN) p += (size_t)S * 8;
+  t.mx = reinterpret_cast<u64*>(p); if (flags & ACC_MAX) p += (size_t)S * 8;
+  t.fsum = reinterpret_cast<double*>(p); if (flags & ACC_FSUM) p += (size_t)S * 8;
+  t.cnt = reinterpret_cast<uint32_t*>(p); if (flags & ACC_CNT) p += (size_t)S * 4;
+  t.vcnt = reinterpret_cast<uint32_t*>(p);
+  return t;
+}
+
+__device__ __forceinline__ void lds_fadd(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <typename VT>
+__device__ __forceinline__ void acc_row(const LdsTab& t, int flags, uint32_t slot, VT v) {
+  if (flags & ACC_CNT) atomicAdd(&t.cnt[slot], 1u);
+  if (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) {
+    if (!ValTraits<VT>::isna(v)) {
+      if (flags & ACC_VCNT) atomicAdd(&t.vcnt[slot], 1u);
+      if (ValTraits<VT>::is_float) {
+        const double d = (double)v;
+        if (flags & ACC_SUM) lds_fadd(reinterpret_cast<double*>(&t.sum[slot]), d);
+        if (flags & (ACC_MIN | ACC_MAX)) {
+          const u64 k = sortable_f64(d);
+          if (flags & ACC_MIN) atomicMin(&t.mn[slot], k);
+          if (flags & ACC_MAX) atomicMax(&t.mx[slot], k);
+        }
+      } else {
+        const long long iv = (long long)v;
+        if (flags & ACC_SUM) atomicAdd(&t.sum[slot], (u64)iv);
+        if (flags & ACC_FSUM) lds_fadd(&t.fsum[slot], (double)iv);
+        if (flags & (ACC_MIN | ACC_MAX)) {
+          const u64 k = sortable_i64(iv);
+          if (flags & ACC_MIN) atomicMin(&t.mn[slot], k);
+          if (flags & ACC_MAX) atomicMax(&t.mx[slot], k);
+        }
+      }
+    }
+  }
+}
+
+struct TableAggDev {
+  const WorkItem* items; const uint32_t* nitems;
+  const uint16_t* kpart; KeyXform kx;
+  const void* val;
+  uint32_t S; int flags; int isfloat;
+  AggTable tab;
+};
+
+template <typename VT, bool RAW>
+__global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (blockIdx.x >= *a.nitems) return;
+  const WorkItem it = a.items[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int flags = a.flags;
+  const uint32_t S = a.S;
+  const LdsTab t = carve_tab(smem, S, flags);
+  for (uint32_t s = tid; s < S; s += TA_BLOCK) {
+    if (flags & ACC_SUM) t.sum[s] = 0;
+    if (flags & ACC_MIN) t.mn[s] = ~0ULL;
+    if (flags & ACC_MAX) t.mx[s] = 0;
+    if (flags & ACC_FSUM) t.fsum[s] = 0.0;
+    if (flags & ACC_CNT) t.cnt[s] = 0;
+    if (flags & ACC_VCNT) t.vcnt[s] = 0;
+  }
+  __syncthreads();
+  const VT* __restrict__ val = static_cast<const VT*>(a.val);
+  const bool hasval = (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) != 0;
+  if (RAW) {
+    for (uint32_t row = it.begin + tid; row < it.end; row += TA_BLOCK) {
+      const uint32_t slot = (uint32_t)packed_key(a.kx.cols, a.kx.ncols, row);
+      const VT v = hasval ? val[row] : VT(0);
+      acc_row<VT>(t, flags, slot, v);
+    }
+  } else {
+    const uint16_t* __restrict__ kp = a.kpart;
+    uint32_t a0 = (it.begin + 7u) & ~7u; if (a0 > it.end) a0 = it.end;
+    uint32_t a1 = it.end & ~7u; if (a1 < a0) a1 = a0;
+    // ragged head [begin, a0) and tail [a1, end): fewer than 8 rows each
+    {
+      const uint32_t nh = a0 - it.begin, ntl = it.end - a1;
+      if ((uint32_t)tid < nh) {
+        const uint32_t row = it.begin + tid;
+        acc_row<VT>(t, flags, kp[row], hasval ? val[row] : VT(0));
+      } else if ((uint32_t)tid >= 64u && (uint32_t)tid - 64u < ntl) {
+        const uint32_t row = a1 + ((uint32_t)tid - 64u);
+        acc_row<VT>(t, flags, kp[row], hasval ? val[row] : VT(0));
+      }
+    }
+    const uint32_t ngr = (a1 - a0) >> 3;
+    for (uint32_t g = tid; g < ngr; g += TA_BLOCK) {
+      const uint32_t row = a0 + g * 8u;
+      const bu32x4 kw = *reinterpret_cast<const bu32x4*>(kp + row);
+      uint32_t slot[8];
+      slot[0] = kw.x & 0xFFFFu; slot[1] = kw.x >> 16; slot[2] = kw.y & 0xFFFFu; slot[3] = kw.y >> 16;
+      slot[4] = kw.z & 0xFFFFu; slot[5] = kw.z >> 16; slot[6] = kw.w & 0xFFFFu; slot[7] = kw.w >> 16;
+      VT v[8];
+      if (hasval) {
+        constexpr int NV = (int)sizeof(VT) / 2;     // 16-B loads for 8 values: 2 (4-byte) or 4 (8-byte)
+        bu32x4 w[NV];
+        const bu32x4* vp = reinterpret_cast<const bu32x4*>(val + row);
+#pragma unroll
+        for (int j = 0; j < NV; j++) w[j] = vp[j];
+        const VT* wv = reinterpret_cast<const VT*>(w);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = wv[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = VT(0);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc_row<VT>(t, flags, slot[j], v[j]);
+    }
+  }
+  __syncthreads();
+  // table -> dense accumulators
+  const size_t base = (size_t)it.bucket * S;
+  if (it.single) {
+    for (uint32_t s = tid; s < S; s += TA_BLOCK) {
+      if (flags & ACC_CNT) a.tab.cnt[base + s] = t.cnt[s];
+      if (flags & ACC_VCNT) a.tab.vcnt[base + s] = t.vcnt[s];
+      if (flags & ACC_SUM) a.tab.sum[base + s] = t.sum[s];
+      if (flags & ACC_MIN) a.tab.mn[base + s] = t.mn[s];
+      if (flags & ACC_MAX) a.tab.mx[base + s] = t.mx[s];
+      if (flags & ACC_FSUM) a.tab.fsum[base + s] = t.fsum[s];
+    }
+  } else {
+    for (uint32_t s = tid; s < S; s += TA_BLOCK) {
+      if (flags & ACC_CNT) { const uint32_t c = t.cnt[s]; if (c) atomicAdd(&a.tab.cnt[base + s], c); }
+      if (flags & ACC_VCNT) { const uint32_t c = t.vcnt[s]; if (c) atomicAdd(&a.tab.vcnt[base + s], c); }
+      if (flags & ACC_SUM) {
+        const u64 w = t.sum[s];
+        if (w) {
+          if (a.isfloat) atomicAdd(reinterpret_cast<double*>(&a.tab.sum[base + s]), __longlong_as_double((long long)w));
+          else atomicAdd(&a.tab.sum[base + s], w);
+        }
+      }
+      if (flags & ACC_MIN) { const u64 w = t.mn[s]; if (w != ~0ULL) atomicMin(&a.tab.mn[base + s], w); }
+      if (flags & ACC_MAX) { const u64 w = t.mx[s]; if (w) atomicMax(&a.tab.mx[base + s], w); }
+      if (flags & ACC_FSUM) { const double w = t.fsum[s]; if (w != 0.0) atomicAdd(&a.tab.fsum[base + s], w); }
+    }
+  }
+}
+
+template <typename VT, bool RAW>
+static int table_agg_t(dthip_ctx* ctx, const TableAggDev& d, uint32_t grid, size_t lds) {
+  auto kfn = table_agg_kernel<VT, RAW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    attr_set = true;
+  }
+  DTHIP_LAUNCH(ctx, "table_agg_kernel", kfn, grid, TA_BLOCK, lds, d);
+  return DTHIP_OK;
+}
+
+int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a) {
+  if (a.max_items == 0) return DTHIP_OK;
+  TableAggDev d;
+  d.items = a.items; d.nitems = a.nitems; d.kpart = a.kpart; d.kx = a.kx; d.val = a.val;
+  d.S = a.S; d.flags = a.flags; d.isfloat = stype_is_float(a.vstype) ? 1 : 0; d.tab = a.tab;
+  const size_t lds = (size_t)a.S * table_agg_slot_bytes(a.flags) + 16;
+  if (lds > 160 * 1024 - 256) { set_error("table_agg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
+  const bool raw = a.kpart == nullptr;
+  const int st = a.val ? a.vstype : DTHIP_INT32;
+#define TA_GO(VT)                                                             \
+  do {                                                                        \
+    if (raw) return table_agg_t<VT, true>(ctx, d, a.max_items, lds);          \
+    return table_agg_t<VT, false>(ctx, d, a.max_items, lds);                  \
+  } while (0)
+  switch (st) {
+    case DTHIP_INT32: TA_GO(int32_t);
+    case DTHIP_INT64: TA_GO(long long);
+    case DTHIP_FLOAT32: TA_GO(float);
+    case DTHIP_FLOAT64: TA_GO(double);
+    default: set_error("table_agg: unsupported value stype %d", a.vstype); return DTHIP_ENOTIMPL;
+  }
+#undef TA_GO
+}
+
+// ---------------------------------------------------------------------------------------
+// finalize: dense accumulators at the non-empty slots -> reducer columns
+// (output stypes: fexpr_sumprod.cc:47-66, fexpr_mean.cc:45-74, fexpr_minmax.cc:47-68)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) table_finalize_kernel(TableFinArgs a) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= a.ng) return;
+  const uint32_t s = (uint32_t)a.idx[g];
+  const uint32_t vc = a.tab.vcnt ? a.tab.vcnt[s] : 0u;
+  const int st = a.vstype;
+  const bool isf = st == DTHIP_FLOAT32 || st == DTHIP_FLOAT64;
+  if (a.o_sum) {
+    const u64 w = a.tab.sum[s];
+    if (st == DTHIP_FLOAT64) static_cast<double*>(a.o_sum)[g] = __longlong_as_double((long long)w);
+    else if (st == DTHIP_FLOAT32) static_cast<float*>(a.o_sum)[g] = (float)__longlong_as_double((long long)w);
+    else static_cast<long long*>(a.o_sum)[g] = (long long)w;
+  }
+  if (a.o_mean) {
+    double m = __builtin_nan("");
+    if (vc) m = (isf ? __longlong_as_double((long long)a.tab.sum[s]) : a.tab.fsum[s]) / (double)vc;
+    if (st == DTHIP_FLOAT32) static_cast<float*>(a.o_mean)[g] = vc ? (float)m : __builtin_nanf("");
+    else static_cast<double*>(a.o_mean)[g] = m;
+  }
+  for (int which = 0; which < 2; which++) {
+    void* o = which ? a.o_max : a.o_min;
+    if (!o) continue;
+    const u64 k = which ? a.tab.mx[s] : a.tab.mn[s];
+    if (isf) {
+      const double d = vc ? unsortable_f64(k) : __builtin_nan("");
+      if (st == DTHIP_FLOAT64) static_cast<double*>(o)[g] = d;
+      else static_cast<float*>(o)[g] = vc ? (float)d : __builtin_nanf("");
+    } else {
+      const long long v = (long long)(k ^ 0x8000000000000000ULL);
+      if (st == DTHIP_INT64) static_cast<long long*>(o)[g] = vc ? v : INT64_MIN;
+      else static_cast<int32_t*>(o)[g] = vc ? (int32_t)v : INT32_MIN;
+    }
+  }
+  if (a.o_count) a.o_count[g] = (int64_t)vc;
+}
+
+int launch_table_finalize(dthip_ctx* ctx, const TableFinArgs& a) {
+  if (a.ng == 0) return DTHIP_OK;
+  DTHIP_LAUNCH(ctx, "table_finalize_kernel", table_finalize_kernel, (a.ng + 255) / 256, 256, 0, a);
+  return DTHIP_OK;
+}
+
+}  // namespace dthip

@@ -67,6 +67,8 @@ struct dthip_ctx {
   std::vector<hipEvent_t> event_pool;
   std::map<std::string, dthip::ProfAcc> acc;
   int num_cus = 256;
+  int agg_path = 0;          // 0 auto, 1 sort path, 2 bucket path whenever eligible
+  int bucket_variant = 0;    // partition tile geometry (experiments)
 };
 
 namespace dthip {
@@ -190,6 +192,55 @@ int launch_bitmap_from_offsets(dthip_ctx* ctx, const int32_t* offsets, int64_t n
 int launch_iota(dthip_ctx* ctx, int32_t* out, int64_t n);
 int launch_untransform_keys(dthip_ctx* ctx, const void* sorted_keys, int key64, const int32_t* offsets,
                             int64_t ngroups, const KeyColDev& col, int bits, void* out);
+
+// bucket.hip: dense-key-range aggregation without a sort.  Rows are partitioned ONCE by the
+// top `d` bits of the packed transformed key into F = 2^d buckets (any order inside a
+// bucket), then every bucket is aggregated into an LDS-resident table of S = 2^r slots
+// addressed by the low r bits; non-empty slots, in slot order, ARE the groups in key order.
+struct KeyXform { KeyColDev cols[MAX_KEYCOLS]; int ncols; };
+struct BucketGeom {
+  int B, r, d;            // significant key bits, slot bits, bucket bits
+  uint32_t F, S;          // 1 << d, 1 << r
+  uint32_t block, items;  // partition / histogram tile geometry
+  uint32_t tile, ntiles;  // rows per tile, number of tiles
+  uint32_t tpg, G;        // tiles per histogram group, number of groups
+  int km;                 // key load mode: 0 generic, 1 one aligned int64 column, 2 one aligned int32 column
+};
+struct WorkItem { uint32_t bucket, begin, end, single; };
+enum { ACC_CNT = 1, ACC_SUM = 2, ACC_MIN = 4, ACC_MAX = 8, ACC_VCNT = 16, ACC_FSUM = 32 };
+// dense accumulator arrays of F*S slots (slot index == transformed key)
+struct AggTable {
+  uint32_t* cnt = nullptr;              // rows per slot
+  unsigned long long* sum = nullptr;    // int64 sum (integer values) or float64 sum bits (float values)
+  unsigned long long* mn = nullptr;     // order-preserving unsigned image of the minimum
+  unsigned long long* mx = nullptr;
+  uint32_t* vcnt = nullptr;             // non-NA rows per slot
+  double* fsum = nullptr;               // float64 sum of integer values (mean)
+};
+void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom* g);
+int launch_bucket_hist(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, uint32_t* P, uint32_t* gtot);
+// gtot -> exclusive prefix over groups (in place), tot[F]
+int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uint32_t* tot);
+// tot (nullable: one bucket of n_raw rows) -> bbase[F+1], work items of <= M rows, *nitems
+int launch_bucket_plan(dthip_ctx* ctx, const uint32_t* tot, uint32_t F, uint32_t n_raw, uint32_t M,
+                       uint32_t* bbase, WorkItem* items, uint32_t* nitems);
+int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
+                            const uint32_t* gpre, const uint32_t* bbase, uint16_t* kout, const PayCols& pay);
+struct TableAggArgs {
+  const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
+  const uint16_t* kpart;      // slot keys of the partitioned rows (null: raw mode, keys transformed on the fly)
+  KeyXform kx;
+  const void* val; int vstype; // value column in the same row order as the keys (null: row counts only)
+  uint32_t S; int flags;
+  AggTable tab;
+};
+int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a);
+size_t table_agg_slot_bytes(int flags);
+struct TableFinArgs {
+  const int32_t* idx; uint32_t ng; AggTable tab; int vstype;
+  void* o_sum; void* o_mean; void* o_min; void* o_max; int64_t* o_count;
+};
+int launch_table_finalize(dthip_ctx* ctx, const TableFinArgs& a);
 
 // reduce.hip
 struct ReduceOuts {

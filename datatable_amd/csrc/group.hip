@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256) untransform_kernel(UntransformArgs a) {
   typedef unsigned long long u64;
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
   if (g >= a.ngroups) return;
-  const uint32_t p = (uint32_t)a.offsets[g];
+  const uint32_t p = a.offsets ? (uint32_t)a.offsets[g] : g;   // null offsets: keys[g] is the group's key
   u64 k = a.key64 ? static_cast<const u64*>(a.keys)[p] : (u64)static_cast<const uint32_t*>(a.keys)[p];
   k >>= a.shift;
   if (a.bits < 64) k &= (1ULL << a.bits) - 1ULL;

@@ -16,60 +16,9 @@
 //                 stores are runs of consecutive addresses per digit.
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "keyxform.hpp"
 
 namespace dthip {
-
-// ---------------------------------------------------------------------------
-// key transform: column value -> unsigned key (sort.cc:689-720 _initB,
-// :728-776 _initI, :808-845 _initF), evaluated on the fly from the raw column
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long xform_key(const KeyColDev& c, uint32_t row) {
-  typedef unsigned long long u64;
-  switch (c.stype) {
-    case DTHIP_BOOL: {
-      const uint8_t t = static_cast<const uint8_t*>(c.data)[row];
-      if (t == 128) return c.na_repl;
-      return c.desc ? (u64)(uint8_t)((uint8_t)(128 - t) >> 6) : (u64)(uint8_t)(t + 1);
-    }
-    case DTHIP_INT8: {
-      const int8_t v = static_cast<const int8_t*>(c.data)[row];
-      if (v == INT8_MIN) return c.na_repl;
-      const u64 u = (u64)(long long)v;
-      return c.desc ? c.edge - u + c.inc : u - c.edge + c.inc;
-    }
-    case DTHIP_INT16: {
-      const int16_t v = static_cast<const int16_t*>(c.data)[row];
-      if (v == INT16_MIN) return c.na_repl;
-      const u64 u = (u64)(long long)v;
-      return c.desc ? c.edge - u + c.inc : u - c.edge + c.inc;
-    }
-    case DTHIP_INT32: {
-      const int32_t v = static_cast<const int32_t*>(c.data)[row];
-      if (v == INT32_MIN) return c.na_repl;
-      const u64 u = (u64)(long long)v;
-      return c.desc ? c.edge - u + c.inc : u - c.edge + c.inc;
-    }
-    case DTHIP_INT64: {
-      const long long v = static_cast<const long long*>(c.data)[row];
-      if (v == INT64_MIN) return c.na_repl;
-      const u64 u = (u64)v;
-      return c.desc ? c.edge - u + c.inc : u - c.edge + c.inc;
-    }
-    case DTHIP_FLOAT32: {
-      const uint32_t t = static_cast<const uint32_t*>(c.data)[row];
-      if ((t & 0x7F800000u) == 0x7F800000u && (t & 0x007FFFFFu) != 0) return c.na_repl;
-      return c.desc ? (u64)(uint32_t)(t ^ (0x7FFFFFFFu & ((t >> 31) - 1u)))
-                    : (u64)(uint32_t)(t ^ (0x80000000u | (0u - (t >> 31))));
-    }
-    default: {  // FLOAT64
-      const u64 t = static_cast<const u64*>(c.data)[row];
-      if ((t & 0x7FF0000000000000ULL) == 0x7FF0000000000000ULL && (t & 0x000FFFFFFFFFFFFFULL) != 0)
-        return c.na_repl;
-      return c.desc ? t ^ (0x7FFFFFFFFFFFFFFFULL & ((t >> 63) - 1ULL))
-                    : t ^ (0x8000000000000000ULL | (0ULL - (t >> 63)));
-    }
-  }
-}
 
 constexpr int XH_BLOCK = 256;
 

@@ -178,6 +178,10 @@ class Context:
     def trim(self):
         L.check(self._lib.dthip_trim(self._h))
 
+    def set_option(self, name, value):
+        """tuning knobs of dthip_set_option(): 'agg_path' (0 auto / 1 sort / 2 bucketed), 'bucket_variant'"""
+        L.check(self._lib.dthip_set_option(self._h, name.encode(), int(value)))
+
     # ---- timing -----------------------------------------------------------
     def timer_start(self):
         L.check(self._lib.dthip_timer_start(self._h))

@@ -109,6 +109,11 @@ int  dthip_destroy(dthip_ctx* ctx);
 int  dthip_sync(dthip_ctx* ctx);
 /* release cached workspace back to the driver */
 int  dthip_trim(dthip_ctx* ctx);
+/* tuning knobs (defaults are right for production):
+ *   "agg_path"       0 = choose per call (default), 1 = always the sort path,
+ *                    2 = the bucketed (sort-free) aggregation whenever its preconditions hold
+ *   "bucket_variant" partition tile geometry of the bucketed aggregation (0 = default) */
+int  dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value);
 
 /* device memory helpers so a host-language binding needs no HIP runtime */
 int  dthip_malloc(dthip_ctx* ctx, size_t bytes, void** dptr);

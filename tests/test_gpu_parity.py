@@ -13,6 +13,9 @@ from oracle import oracle as o
 pytestmark = pytest.mark.gpu
 
 OPS = ("sum", "mean", "min", "max", "count")
+# fused aggregation is checked on every path of dthip_groupby_agg: 0 = the library's own choice,
+# 1 = sort + segmented reduce, 2 = bucketed (sort-free) aggregation wherever its preconditions hold
+AGG_PATHS = (0, 1, 2)
 
 
 def group_abs_scale(v, ri, off):
@@ -55,15 +58,21 @@ def test_golden_fused_agg(ctx, gold, name):
     c = gold.by_name[name]
     keys, vals = gold.keys(name), gold.vals(name)
     aggs = [(opn, vi) for opn, vi, _ in c["aggs"]] + [("count0", None)]
-    r = ctx.groupby_agg(keys, vals, aggs, key_stypes=c["key_stypes"], value_stypes=c["val_stypes"])
     ri, off = gold.get(name, "ri"), gold.get(name, "off")
-    assert_same(r.offsets(), off, "offsets")
-    for i in range(len(keys)):
-        assert_same(r.key(i), gold.get(name, "gk%d" % i), "group key %d" % i)
-    for a, (opn, vi, ost) in enumerate(c["aggs"]):
-        check_agg(r.agg(a), gold.get(name, "%s.v%d" % (opn, vi)), opn, vals[vi], ri, off, "%s(v%d)" % (opn, vi))
-    assert_same(r.agg(len(c["aggs"])), np.diff(off).astype(np.int64), "count()")
-    r.free()
+    for path in AGG_PATHS:
+        ctx.set_option("agg_path", path)
+        try:
+            r = ctx.groupby_agg(keys, vals, aggs, key_stypes=c["key_stypes"], value_stypes=c["val_stypes"])
+        finally:
+            ctx.set_option("agg_path", 0)
+        tag = " [agg_path=%d]" % path
+        assert_same(r.offsets(), off, "offsets" + tag)
+        for i in range(len(keys)):
+            assert_same(r.key(i), gold.get(name, "gk%d" % i), "group key %d%s" % (i, tag))
+        for a, (opn, vi, ost) in enumerate(c["aggs"]):
+            check_agg(r.agg(a), gold.get(name, "%s.v%d" % (opn, vi)), opn, vals[vi], ri, off, "%s(v%d)%s" % (opn, vi, tag))
+        assert_same(r.agg(len(c["aggs"])), np.diff(off).astype(np.int64), "count()" + tag)
+        r.free()
 
 
 @pytest.mark.parametrize("name", ["appendixB", "keytype_4", "keytype_7", "c2_shape", "skewed", "all_na_value"])
@@ -88,15 +97,22 @@ def _vs_oracle(ctx, keys, vals, aggs=OPS, key_stypes=None, check_ri=True):
         assert_same(r.rowindex(), ri, "rowindex")
         r.free()
     alist = [(opn, vi) for vi in range(len(vals)) for opn in aggs] + [("count0", None)]
-    r = ctx.groupby_agg(keys, vals, alist, key_stypes=key_stypes)
-    assert_same(r.offsets(), off, "fused offsets")
-    for i, k in enumerate(keys):
-        kk = k.view(np.int8) if k.dtype == np.bool_ else k
-        assert_same(r.key(i), kk[ri[off[:-1]]], "fused group key %d" % i)
-    for a, (opn, vi) in enumerate(alist[:-1]):
-        check_agg(r.agg(a), o.reduce(opn, vals[vi], ri, off), opn, vals[vi], ri, off, "%s(v%d)" % (opn, vi))
-    assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count()")
-    r.free()
+    expected = [o.reduce(opn, vals[vi], ri, off) for opn, vi in alist[:-1]]
+    for path in AGG_PATHS:
+        ctx.set_option("agg_path", path)
+        try:
+            r = ctx.groupby_agg(keys, vals, alist, key_stypes=key_stypes)
+        finally:
+            ctx.set_option("agg_path", 0)
+        tag = " [agg_path=%d]" % path
+        assert_same(r.offsets(), off, "fused offsets" + tag)
+        for i, k in enumerate(keys):
+            kk = k.view(np.int8) if k.dtype == np.bool_ else k
+            assert_same(r.key(i), kk[ri[off[:-1]]], "fused group key %d%s" % (i, tag))
+        for a, (opn, vi) in enumerate(alist[:-1]):
+            check_agg(r.agg(a), expected[a], opn, vals[vi], ri, off, "%s(v%d)%s" % (opn, vi, tag))
+        assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count()" + tag)
+        r.free()
 
 
 def test_config1_full_size(ctx):
