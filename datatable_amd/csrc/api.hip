@@ -142,13 +142,29 @@ struct KeyPlan {
   // stages of consecutive keys whose packed width is <= 64 bits; stage 0 holds the most significant keys
   int nstages = 0;
   int stage_first[MAX_KEYCOLS], stage_last[MAX_KEYCOLS], stage_bits[MAX_KEYCOLS];
+  bool speculative = false;   // integer key ranges are widened guesses from a sample (bucketed aggregation only)
 };
 
-// min/max of integer keys -> transform parameters (sort.cc:728-776), packing layout
+constexpr uint32_t SPEC_SAMPLES = 1u << 17;
+
+static void stype_int_limits(int st, long long* lo, long long* hi) {
+  switch (st) {
+    case DTHIP_BOOL: case DTHIP_INT8: *lo = INT8_MIN + 1; *hi = INT8_MAX; break;
+    case DTHIP_INT16: *lo = INT16_MIN + 1; *hi = INT16_MAX; break;
+    case DTHIP_INT32: *lo = (long long)INT32_MIN + 1; *hi = INT32_MAX; break;
+    default: *lo = INT64_MIN + 1; *hi = INT64_MAX; break;
+  }
+}
+
+// min/max of integer keys -> transform parameters (sort.cc:728-776), packing layout.
+// speculative: the range of big integer columns is GUESSED from a sample and widened; only the
+// bucketed aggregation may use such a plan, because its histogram pass verifies every row.
 static int plan_keys(dthip_ctx* ctx, Scratch& sc, const dthip_col* keys_dev, int nkeys, int64_t n, int na_pos,
-                     KeyPlan* plan) {
+                     KeyPlan* plan, bool speculative = false) {
   if (nkeys < 1 || nkeys > MAX_KEYCOLS) { set_error("number of key columns must be 1..%d", MAX_KEYCOLS); return DTHIP_EINVAL; }
   plan->nkeys = nkeys;
+  plan->speculative = false;
+  if (n < ctx->spec_min_rows) speculative = false;   // below this the exact range scan is cheap enough
   MinMax* d_mm = nullptr;
   DTHIP_TRY(sc.get<MinMax>(nkeys, &d_mm));
   bool any_int = false;
@@ -156,7 +172,8 @@ static int plan_keys(dthip_ctx* ctx, Scratch& sc, const dthip_col* keys_dev, int
     const int st = keys_dev[k].stype;
     if (stype_size(st) == 0) { set_error("unsupported key stype %d", st); return DTHIP_ENOTIMPL; }
     if (st >= DTHIP_INT8 && st <= DTHIP_INT64) {
-      DTHIP_TRY(launch_minmax(ctx, keys_dev[k].data, st, n, d_mm + k));
+      if (speculative) DTHIP_TRY(launch_minmax_sample(ctx, keys_dev[k].data, st, n, SPEC_SAMPLES, d_mm + k));
+      else DTHIP_TRY(launch_minmax(ctx, keys_dev[k].data, st, n, d_mm + k));
       any_int = true;
     }
   }
@@ -170,21 +187,32 @@ static int plan_keys(dthip_ctx* ctx, Scratch& sc, const dthip_col* keys_dev, int
     c.desc = (keys_dev[k].flags & DTHIP_FLAG_DESCENDING) ? 1 : 0;
     c.shift = 0;
     if (st == DTHIP_BOOL) {
-      c.edge = 0; c.inc = 0; c.na_repl = (na_pos == DTHIP_NA_LAST) ? 3 : 0;
+      c.edge = 0; c.inc = 0; c.na_repl = (na_pos == DTHIP_NA_LAST) ? 3 : 0; c.xmax = ~0ULL;
       plan->nsig[k] = 2;
     } else if (st == DTHIP_FLOAT32) {
-      c.edge = 0; c.inc = 0; c.na_repl = (na_pos == DTHIP_NA_LAST) ? 0xFFFFFFFFULL : 0;
+      c.edge = 0; c.inc = 0; c.na_repl = (na_pos == DTHIP_NA_LAST) ? 0xFFFFFFFFULL : 0; c.xmax = ~0ULL;
       plan->nsig[k] = 32;
     } else if (st == DTHIP_FLOAT64) {
-      c.edge = 0; c.inc = 0; c.na_repl = (na_pos == DTHIP_NA_LAST) ? 0xFFFFFFFFFFFFFFFFULL : 0;
+      c.edge = 0; c.inc = 0; c.na_repl = (na_pos == DTHIP_NA_LAST) ? 0xFFFFFFFFFFFFFFFFULL : 0; c.xmax = ~0ULL;
       plan->nsig[k] = 64;
     } else {
       long long mn = mm[k].mn, mx = mm[k].mx;
       if (mm[k].nvalid == 0) { mn = 0; mx = 0; }
+      if (speculative && mm[k].nvalid > 0) {
+        // widen the sampled range by 1/64 of its width (+64) on both sides, inside the stype's range
+        long long tlo, thi;
+        stype_int_limits(st, &tlo, &thi);
+        const unsigned long long width = (unsigned long long)mx - (unsigned long long)mn;
+        const unsigned long long margin = width / 64 + 64;
+        mn = ((unsigned long long)mn - (unsigned long long)tlo > margin) ? (long long)((unsigned long long)mn - margin) : tlo;
+        mx = ((unsigned long long)thi - (unsigned long long)mx > margin) ? (long long)((unsigned long long)mx + margin) : thi;
+        plan->speculative = true;
+      }
       const unsigned long long range1 = (unsigned long long)mx - (unsigned long long)mn + 1ULL;
       c.edge = c.desc ? (unsigned long long)mx : (unsigned long long)mn;
       c.inc = (na_pos == DTHIP_NA_LAST) ? 0 : 1;
       c.na_repl = (na_pos == DTHIP_NA_LAST) ? range1 : 0;
+      c.xmax = range1 ? range1 : ~0ULL;    // range1 == 0: the range covers all 2^64 values
       const int nb = nbits_u64(range1);
       plan->nsig[k] = nb ? nb : 64;
     }
@@ -507,6 +535,7 @@ static int floor_log2_sz(size_t v) { int b = -1; while (v) { b++; v >>= 1; } ret
 constexpr size_t BUCKET_LDS_TABLE = 128 * 1024;   // LDS bytes one aggregation table may take
 constexpr int BUCKET_MAX_R = 14;                  // slot keys are uint16
 constexpr int BUCKET_MAX_D = 11;                  // <= 2048 buckets in one partition pass
+constexpr int DTHIP_RETRY_EXACT = 1;              // internal: a guessed key range was wrong, redo with the exact one
 
 // Decides whether the bucket path applies; fills the slot-bit count r.
 static bool bucket_eligible(const dthip_ctx* ctx, const KeyPlan& plan, const std::vector<dthip_col>& vd,
@@ -559,8 +588,10 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   std::vector<const void*> vsrc(vd.size(), nullptr);
   for (int c : used) vsrc[c] = vd[c].data;
   uint32_t* bbase = nullptr; WorkItem* items = nullptr; uint32_t* nitems = nullptr;
-  DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 2, &bbase));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 3, &bbase));
   nitems = bbase + g.F + 1;
+  uint32_t* d_bad = bbase + g.F + 2;
+  DTHIP_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
   uint32_t M;
   {
     const uint64_t denom = std::max<uint64_t>(g.F, (uint64_t)ctx->num_cus * 4);
@@ -576,9 +607,10 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.ntiles * g.F, &P));
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.G * g.F, &gtot));
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.F, &tot));
-    DTHIP_TRY(launch_bucket_hist(ctx, kx, n, g, P, gtot));
-    DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot));
+    DTHIP_TRY(launch_bucket_hist(ctx, kx, n, g, P, gtot, d_bad));
+    DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, nullptr, 0));
     DTHIP_TRY(launch_bucket_plan(ctx, tot, g.F, 0, M, bbase, items, nitems));
+    DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, bbase, 1));
     DTHIP_TRY(sc.get<uint16_t>((size_t)n + 8, &kpart));
     PayCols pc;
     memset(&pc, 0, sizeof(pc));
@@ -589,7 +621,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
       pc.in[pc.n] = vd[c].data; pc.out[pc.n] = vb; pc.width[pc.n] = w; pc.n++;
       vsrc[c] = vb;
     }
-    DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, P, gtot, bbase, kpart, pc));
+    DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, P, gtot, kpart, pc));
   } else {
     DTHIP_TRY(launch_bucket_plan(ctx, nullptr, 1, (uint32_t)n, M, bbase, items, nitems));
   }
@@ -614,7 +646,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     TableAggArgs ta;
     memset(&ta, 0, sizeof(ta));
     ta.items = items; ta.nitems = nitems; ta.max_items = max_items;
-    ta.kpart = kpart; ta.kx = kx; ta.val = vsrc[c]; ta.vstype = vd[c].stype; ta.S = g.S; ta.flags = f; ta.tab = t;
+    ta.kpart = kpart; ta.kx = kx; ta.val = vsrc[c]; ta.vstype = vd[c].stype; ta.S = g.S; ta.flags = f; ta.tab = t; ta.bad = d_bad;
     DTHIP_TRY(launch_table_agg(ctx, ta));
     first = false;
   }
@@ -623,7 +655,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     memset(&ta, 0, sizeof(ta));
     ta.items = items; ta.nitems = nitems; ta.max_items = max_items;
     ta.kpart = kpart; ta.kx = kx; ta.val = nullptr; ta.vstype = DTHIP_INT32; ta.S = g.S; ta.flags = ACC_CNT;
-    ta.tab.cnt = d_cnt;
+    ta.tab.cnt = d_cnt; ta.bad = d_bad;
     DTHIP_TRY(launch_table_agg(ctx, ta));
   }
 
@@ -635,6 +667,11 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   pa.data = d_cnt; pa.stype = DTHIP_INT32; pa.cmp = DTHIP_GT; pa.ci = 0; pa.is_mask = 0;
   int64_t ng = 0;
   DTHIP_TRY(launch_compact(ctx, pa, (int64_t)nslots, idx, &ng));
+  if (plan.speculative) {
+    uint32_t bad = 0;
+    DTHIP_TRY(read_back(ctx, &bad, d_bad, sizeof(bad)));
+    if (bad) return DTHIP_RETRY_EXACT;
+  }
   res->nrows = n; res->ngroups = ng;
   // offsets = exclusive scan of the group sizes (Groupby offsets, groupby.h:54-91)
   void* off = nullptr;
@@ -757,6 +794,7 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
     return DTHIP_OK;
   }
   if (!strcmp(name, "bucket_variant")) { ctx->bucket_variant = (int)value; return DTHIP_OK; }
+  if (!strcmp(name, "spec_min_rows")) { ctx->spec_min_rows = value; return DTHIP_OK; }
   set_error("unknown option '%s'", name);
   return DTHIP_EINVAL;
 }
@@ -898,13 +936,22 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
     std::vector<const void*> sorted_val(nvalues, nullptr);
     const int32_t* gather_ri = nullptr;
     if (fused) {
-      if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan)) != DTHIP_OK) break;
+      // first attempt: key ranges guessed from a sample (verified by the bucketed path); if that
+      // path does not apply, or the guess was wrong, plan again with the exact ranges
+      int slot_bits = 0;
+      bool done = false;
+      for (int attempt = (ctx->agg_path == 1 ? 1 : 0); attempt < 2 && !done; attempt++) {
+        if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan, attempt == 0)) != DTHIP_OK) break;
+        if (attempt == 0 && !plan.speculative) attempt = 1;      // nothing was guessed: this IS the exact plan
+        if (bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &slot_bits)) {
+          rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits);
+          if (rc == DTHIP_RETRY_EXACT && attempt == 0) { rc = DTHIP_OK; continue; }
+          if (rc == DTHIP_RETRY_EXACT) { set_error("bucketed aggregation: exact key range violated"); rc = DTHIP_EDEVICE; }
+          done = true;
+        }
+      }
+      if (rc != DTHIP_OK || done) break;
       if (plan.nstages != 1) fused = false;
-    }
-    int slot_bits = 0;
-    if (fused && bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &slot_bits)) {
-      rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits);
-      break;
     }
     if (fused) {
       // values ride through the sort; the RowIndex is never materialised

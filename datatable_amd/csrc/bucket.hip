@@ -49,14 +49,19 @@ __device__ __forceinline__ uint32_t item_row(int j, int tid) {
   return ((uint32_t)(j / VW) * BLOCK + (uint32_t)tid) * VW + (uint32_t)(j % VW);
 }
 
-__device__ __forceinline__ uint32_t xf_int(const KeyColDev& c, long long v, long long na) {
-  const u64 u = (u64)v;
-  return (uint32_t)((v == na) ? c.na_repl : (c.desc ? c.edge - u + c.inc : u - c.edge + c.inc));
+// integer key transform (sort.cc:728-776) without branches: ascending u - edge, descending edge - u
+__device__ __forceinline__ uint32_t xf_int(const KeyColDev& c, long long v, long long na, bool& bad) {
+  const u64 m = 0ULL - (u64)c.desc;              // all-ones when descending
+  const u64 d = ((((u64)v - c.edge) ^ m) - m) + c.inc;
+  const u64 t = (v == na) ? c.na_repl : d;
+  const bool b = t > c.xmax;                     // only possible when the key range was guessed from a sample
+  bad |= b;
+  return b ? 0u : (uint32_t)t;
 }
 
 template <int BLOCK, int ITEMS, int KM>
 __device__ __forceinline__ void load_tile_x(const KeyXform& kx, uint32_t tile_base, uint32_t nvalid, bool full,
-                                            int tid, uint32_t (&x)[ITEMS]) {
+                                            int tid, uint32_t (&x)[ITEMS], bool& bad) {
   if (KM == 1 && full) {
     const KeyColDev& c = kx.cols[0];
     const long long* src = static_cast<const long long*>(c.data) + tile_base;
@@ -65,8 +70,8 @@ __device__ __forceinline__ void load_tile_x(const KeyXform& kx, uint32_t tile_ba
     for (int q = 0; q < ITEMS / 2; q++) w[q] = *reinterpret_cast<const bu32x4*>(src + ((uint32_t)q * BLOCK + tid) * 2);
 #pragma unroll
     for (int q = 0; q < ITEMS / 2; q++) {
-      x[2 * q] = xf_int(c, (long long)((u64)w[q].x | ((u64)w[q].y << 32)), INT64_MIN);
-      x[2 * q + 1] = xf_int(c, (long long)((u64)w[q].z | ((u64)w[q].w << 32)), INT64_MIN);
+      x[2 * q] = xf_int(c, (long long)((u64)w[q].x | ((u64)w[q].y << 32)), INT64_MIN, bad);
+      x[2 * q + 1] = xf_int(c, (long long)((u64)w[q].z | ((u64)w[q].w << 32)), INT64_MIN, bad);
     }
   } else if (KM == 2 && full) {
     const KeyColDev& c = kx.cols[0];
@@ -76,17 +81,25 @@ __device__ __forceinline__ void load_tile_x(const KeyXform& kx, uint32_t tile_ba
     for (int q = 0; q < ITEMS / 4; q++) w[q] = *reinterpret_cast<const bu32x4*>(src + ((uint32_t)q * BLOCK + tid) * 4);
 #pragma unroll
     for (int q = 0; q < ITEMS / 4; q++) {
-      x[4 * q] = xf_int(c, (long long)(int32_t)w[q].x, INT32_MIN);
-      x[4 * q + 1] = xf_int(c, (long long)(int32_t)w[q].y, INT32_MIN);
-      x[4 * q + 2] = xf_int(c, (long long)(int32_t)w[q].z, INT32_MIN);
-      x[4 * q + 3] = xf_int(c, (long long)(int32_t)w[q].w, INT32_MIN);
+      x[4 * q] = xf_int(c, (long long)(int32_t)w[q].x, INT32_MIN, bad);
+      x[4 * q + 1] = xf_int(c, (long long)(int32_t)w[q].y, INT32_MIN, bad);
+      x[4 * q + 2] = xf_int(c, (long long)(int32_t)w[q].z, INT32_MIN, bad);
+      x[4 * q + 3] = xf_int(c, (long long)(int32_t)w[q].w, INT32_MIN, bad);
     }
   } else {
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
       const uint32_t rel = item_row<BLOCK, KM>(j, tid);
-      if (KM == 0) x[j] = rel < nvalid ? (uint32_t)packed_key(kx.cols, kx.ncols, tile_base + rel) : 0u;
-      else x[j] = rel < nvalid ? (uint32_t)xform_key(kx.cols[0], tile_base + rel) : 0u;
+      x[j] = 0u;
+      if (rel < nvalid) {
+        if (KM == 0) x[j] = (uint32_t)packed_key_checked(kx.cols, kx.ncols, tile_base + rel, bad);
+        else {
+          const u64 t = xform_key(kx.cols[0], tile_base + rel);
+          const bool b = t > kx.cols[0].xmax;
+          bad |= b;
+          x[j] = b ? 0u : (uint32_t)t;
+        }
+      }
     }
   }
 }
@@ -133,7 +146,7 @@ __device__ __forceinline__ void load_tile_vals(const PT* __restrict__ src, uint3
 struct HistArgs {
   KeyXform kx; uint32_t n; int r; uint32_t F;
   uint32_t ntiles, tpg;
-  uint32_t* P; uint32_t* gtot;
+  uint32_t* P; uint32_t* gtot; uint32_t* bad;
 };
 
 template <int BLOCK, int ITEMS, int KM>
@@ -144,6 +157,7 @@ __global__ void __launch_bounds__(BLOCK) bucket_hist_kernel(HistArgs a) {
   uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);
   const int tid = threadIdx.x;
   uint32_t run[NB];
+  bool bad = false;
 #pragma unroll
   for (int k = 0; k < NB; k++) { run[k] = 0; const uint32_t b = (uint32_t)k * BLOCK + tid; if (b < a.F) cnt[b] = 0; }
   __syncthreads();
@@ -154,7 +168,7 @@ __global__ void __launch_bounds__(BLOCK) bucket_hist_kernel(HistArgs a) {
     const uint32_t nvalid = (a.n - tile_base < TILE) ? (a.n - tile_base) : TILE;
     const bool full = nvalid == TILE;
     uint32_t x[ITEMS];
-    load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x);
+    load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x, bad);
 #pragma unroll
     for (int j = 0; j < ITEMS; j++)
       if (full || item_row<BLOCK, KM>(j, tid) < nvalid) atomicAdd(&cnt[x[j] >> a.r], 1u);
@@ -176,11 +190,15 @@ __global__ void __launch_bounds__(BLOCK) bucket_hist_kernel(HistArgs a) {
     const uint32_t b = (uint32_t)k * BLOCK + tid;
     if (b < a.F) a.gtot[(size_t)blockIdx.x * a.F + b] = run[k];
   }
+  if (__ballot(bad) && (tid & 63) == 0) atomicOr(a.bad, 1u);
 }
 
-// gtot[g][b] -> exclusive prefix over g (in place); tot[b] = column total.
+// phase 0: tot[b] = rows of bucket b (column totals of gtot[g][b]).
+// phase 1: gtot[g][b] <- bbase[b] + rows of bucket b in the groups before g (in place): the global
+//          position of group g's first row of bucket b.
 // One workgroup per 64 buckets: lane = bucket, each of the 16 waves owns a range of groups.
-__global__ void __launch_bounds__(1024) bucket_gscan_kernel(uint32_t* gtot, uint32_t G, uint32_t F, uint32_t* tot) {
+__global__ void __launch_bounds__(1024) bucket_gscan_kernel(uint32_t* gtot, uint32_t G, uint32_t F, uint32_t* tot,
+                                                            const uint32_t* bbase, int phase) {
   __shared__ uint32_t part[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t b = blockIdx.x * 64 + lane;
@@ -194,12 +212,16 @@ __global__ void __launch_bounds__(1024) bucket_gscan_kernel(uint32_t* gtot, uint
 #pragma unroll
   for (int w = 0; w < 16; w++) { const uint32_t v = part[w][lane]; if (w < wave) off += v; total += v; }
   if (b < F) {
-    for (uint32_t g = g0; g < g1; g++) {
-      const uint32_t v = gtot[(size_t)g * F + b];
-      gtot[(size_t)g * F + b] = off;
-      off += v;
+    if (phase == 0) {
+      if (wave == 0) tot[b] = total;
+    } else {
+      off += bbase[b];
+      for (uint32_t g = g0; g < g1; g++) {
+        const uint32_t v = gtot[(size_t)g * F + b];
+        gtot[(size_t)g * F + b] = off;
+        off += v;
+      }
     }
-    if (wave == 0) tot[b] = total;
   }
 }
 
@@ -244,7 +266,7 @@ __global__ void __launch_bounds__(1024) bucket_plan_kernel(const uint32_t* tot, 
 struct PartArgs {
   KeyXform kx; uint32_t n; int r; uint32_t F;
   uint32_t tpg;
-  const uint32_t* P; const uint32_t* gpre; const uint32_t* bbase;
+  const uint32_t* P; const uint32_t* gpre;      // gpre[g][b]: global position of group g's first row of bucket b
   uint16_t* kout;
   PayCols pay;
 };
@@ -289,7 +311,8 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
 
   for (uint32_t b = tid; b < F; b += BLOCK) cnt[b] = 0;
   uint32_t x[ITEMS];
-  load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x);
+  bool bad = false;     // out-of-range keys were reported by the histogram pass; here they are just key 0 again
+  load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x, bad);
   __syncthreads();
 
   // rank of every row inside its bucket (arrival order: buckets are unordered sets)
@@ -318,7 +341,7 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
       const uint32_t b = (uint32_t)tid * K + k;
       if ((uint32_t)k < K && b < F) {
         cnt[b] = e;
-        delta[b] = a.bbase[b] + a.gpre[(size_t)g * F + b] + a.P[(size_t)tile * F + b] - e;
+        delta[b] = a.gpre[(size_t)g * F + b] + a.P[(size_t)tile * F + b] - e;
         e += c[k];
       }
     }
@@ -409,14 +432,15 @@ static int hist_t(dthip_ctx* ctx, const HistArgs& a, uint32_t G) {
   return DTHIP_OK;
 }
 
-int launch_bucket_hist(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, uint32_t* P, uint32_t* gtot) {
+int launch_bucket_hist(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, uint32_t* P, uint32_t* gtot,
+                       uint32_t* bad) {
   HistArgs a;
-  a.kx = kx; a.n = (uint32_t)n; a.r = g.r; a.F = g.F; a.ntiles = g.ntiles; a.tpg = g.tpg; a.P = P; a.gtot = gtot;
+  a.kx = kx; a.n = (uint32_t)n; a.r = g.r; a.F = g.F; a.ntiles = g.ntiles; a.tpg = g.tpg; a.P = P; a.gtot = gtot; a.bad = bad;
   BK_DISPATCH(hist_t, g, ctx, a, g.G);
 }
 
-int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uint32_t* tot) {
-  DTHIP_LAUNCH(ctx, "bucket_gscan_kernel", bucket_gscan_kernel, (g.F + 63) / 64, 1024, 0, gtot, g.G, g.F, tot);
+int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uint32_t* tot, const uint32_t* bbase, int phase) {
+  DTHIP_LAUNCH(ctx, "bucket_gscan_kernel", bucket_gscan_kernel, (g.F + 63) / 64, 1024, 0, gtot, g.G, g.F, tot, bbase, phase);
   return DTHIP_OK;
 }
 
@@ -441,9 +465,9 @@ static int part_t(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds
 }
 
 int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
-                            const uint32_t* gpre, const uint32_t* bbase, uint16_t* kout, const PayCols& pay) {
+                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay) {
   PartArgs a;
-  a.kx = kx; a.n = (uint32_t)n; a.r = g.r; a.F = g.F; a.tpg = g.tpg; a.P = P; a.gpre = gpre; a.bbase = bbase;
+  a.kx = kx; a.n = (uint32_t)n; a.r = g.r; a.F = g.F; a.tpg = g.tpg; a.P = P; a.gpre = gpre;
   a.kout = kout; a.pay = pay;
   int maxw = 4;
   for (int c = 0; c < pay.n; c++) maxw = pay.width[c] > maxw ? pay.width[c] : maxw;
@@ -551,6 +575,7 @@ struct TableAggDev {
   const void* val;
   uint32_t S; int flags; int isfloat;
   AggTable tab;
+  uint32_t* bad;
 };
 
 template <typename VT, bool RAW>
@@ -574,11 +599,13 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
   const VT* __restrict__ val = static_cast<const VT*>(a.val);
   const bool hasval = (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) != 0;
   if (RAW) {
+    bool bad = false;
     for (uint32_t row = it.begin + tid; row < it.end; row += TA_BLOCK) {
-      const uint32_t slot = (uint32_t)packed_key(a.kx.cols, a.kx.ncols, row);
+      const uint32_t slot = (uint32_t)packed_key_checked(a.kx.cols, a.kx.ncols, row, bad);
       const VT v = hasval ? val[row] : VT(0);
       acc_row<VT>(t, flags, slot, v);
     }
+    if (__ballot(bad) && (tid & 63) == 0) atomicOr(a.bad, 1u);
   } else {
     const uint16_t* __restrict__ kp = a.kpart;
     uint32_t a0 = (it.begin + 7u) & ~7u; if (a0 > it.end) a0 = it.end;
@@ -666,9 +693,11 @@ int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a) {
   if (a.max_items == 0) return DTHIP_OK;
   TableAggDev d;
   d.items = a.items; d.nitems = a.nitems; d.kpart = a.kpart; d.kx = a.kx; d.val = a.val;
-  d.S = a.S; d.flags = a.flags; d.isfloat = stype_is_float(a.vstype) ? 1 : 0; d.tab = a.tab;
+  d.S = a.S; d.flags = a.flags; d.isfloat = stype_is_float(a.vstype) ? 1 : 0; d.tab = a.tab; d.bad = a.bad;
   const size_t lds = (size_t)a.S * table_agg_slot_bytes(a.flags) + 16;
-  if (lds > 160 * 1024 - 256) { set_error("table_agg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
+  if (lds > 160 * 1024 - 256) {
+    set_error("table_agg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL;
+  }
   const bool raw = a.kpart == nullptr;
   const int st = a.val ? a.vstype : DTHIP_INT32;
 #define TA_GO(VT)                                                             \

@@ -69,6 +69,7 @@ struct dthip_ctx {
   int num_cus = 256;
   int agg_path = 0;          // 0 auto, 1 sort path, 2 bucket path whenever eligible
   int bucket_variant = 0;    // partition tile geometry (experiments)
+  int64_t spec_min_rows = 1 << 23;   // key ranges are guessed from a sample only at or above this many rows
 };
 
 namespace dthip {
@@ -125,6 +126,9 @@ int read_back(dthip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes)
 // stats.hip: min / max / valid-count of an integer column (NumericStats::compute_minmax)
 struct MinMax { long long mn, mx, nvalid; };
 int launch_minmax(dthip_ctx* ctx, const void* data, int stype, int64_t n, MinMax* d_out);
+// the same over nsamp evenly spaced 16-byte pieces of the column (plus its first and last rows):
+// a GUESS of the key range that the histogram pass of the bucketed aggregation verifies
+int launch_minmax_sample(dthip_ctx* ctx, const void* data, int stype, int64_t n, uint32_t nsamp, MinMax* d_out);
 
 // radix.hip
 constexpr int MAX_KEYCOLS = 8;
@@ -137,6 +141,7 @@ struct KeyColDev {
   unsigned long long edge;     // min (ascending) or max (descending), as the column's unsigned image
   unsigned long long na_repl;  // transformed value of NA
   unsigned long long inc;      // 1 when NA is first, else 0
+  unsigned long long xmax;     // largest legal transformed value (rows beyond it: the key range was a guess and is wrong)
   int shift;                   // bit position of this key inside the packed key
 };
 struct XformArgs {
@@ -218,14 +223,16 @@ struct AggTable {
   double* fsum = nullptr;               // float64 sum of integer values (mean)
 };
 void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom* g);
-int launch_bucket_hist(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, uint32_t* P, uint32_t* gtot);
-// gtot -> exclusive prefix over groups (in place), tot[F]
-int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uint32_t* tot);
+// *bad is set when a row's transformed key exceeds its column's xmax (such rows are counted as key 0)
+int launch_bucket_hist(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, uint32_t* P, uint32_t* gtot,
+                       uint32_t* bad);
+// phase 0: tot[F] <- bucket sizes; phase 1: gtot <- bbase + exclusive prefix over groups (in place)
+int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uint32_t* tot, const uint32_t* bbase, int phase);
 // tot (nullable: one bucket of n_raw rows) -> bbase[F+1], work items of <= M rows, *nitems
 int launch_bucket_plan(dthip_ctx* ctx, const uint32_t* tot, uint32_t F, uint32_t n_raw, uint32_t M,
                        uint32_t* bbase, WorkItem* items, uint32_t* nitems);
 int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
-                            const uint32_t* gpre, const uint32_t* bbase, uint16_t* kout, const PayCols& pay);
+                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay);
 struct TableAggArgs {
   const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
   const uint16_t* kpart;      // slot keys of the partitioned rows (null: raw mode, keys transformed on the fly)
@@ -233,6 +240,7 @@ struct TableAggArgs {
   const void* val; int vstype; // value column in the same row order as the keys (null: row counts only)
   uint32_t S; int flags;
   AggTable tab;
+  uint32_t* bad;              // raw mode: set when a key exceeds its column's xmax
 };
 int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a);
 size_t table_agg_slot_bytes(int flags);

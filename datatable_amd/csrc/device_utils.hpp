@@ -14,14 +14,17 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// wave64 inclusive prefix sum with DPP row shifts + row broadcasts (gfx9 encodings): no lane-index
+// registers and no LDS traffic, unlike a ds_bpermute ladder
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t t = __shfl_up(v, o, 64);
-    if (lane >= o) v += t;
-  }
-  return v;
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
+  return (uint32_t)x;
 }
 
 __device__ __forceinline__ uint32_t wave_reduce_sum_u32(uint32_t v) {

@@ -119,6 +119,7 @@ int launch_scan_tiles(dthip_ctx* ctx, uint32_t* counts, uint32_t m, uint32_t* to
   const uint32_t nchunks = (m + SC_CHUNK - 1) / SC_CHUNK;
   uint32_t* chunk_tot = counts + m + 1;
   if (total != counts + m) { set_error("scan_tiles: total must be counts + m"); return DTHIP_EINVAL; }
+  if (m == 0) { DTHIP_CHECK_HIP(hipMemsetAsync(total, 0, sizeof(uint32_t), ctx->stream)); return DTHIP_OK; }
   DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_chunk_kernel, nchunks, 1024, 0, counts, m, chunk_tot);
   DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_chunk_totals_kernel, 1, 1024, 0, chunk_tot, nchunks, total);
   if (nchunks > 1) DTHIP_LAUNCH(ctx, "scan_tiles_kernel", scan_add_base_kernel, nchunks, 1024, 0, counts, m, chunk_tot);

@@ -68,4 +68,21 @@ __device__ __forceinline__ unsigned long long packed_key(const KeyColDev* cols, 
   return k;
 }
 
+// the same, verifying every column's transformed key against its xmax (speculative key ranges):
+// an out-of-range key makes the whole packed key 0 and sets `bad`
+__device__ __forceinline__ unsigned long long packed_key_checked(const KeyColDev* cols, int ncols, uint32_t row, bool& bad) {
+  unsigned long long k = 0;
+  bool b = false;
+#pragma unroll
+  for (int j = 0; j < MAX_KEYCOLS; j++) {
+    if (j < ncols) {
+      const unsigned long long x = xform_key(cols[j], row);
+      b |= x > cols[j].xmax;
+      k |= x << cols[j].shift;
+    }
+  }
+  bad |= b;
+  return b ? 0ULL : k;
+}
+
 }  // namespace dthip

@@ -112,7 +112,9 @@ int  dthip_trim(dthip_ctx* ctx);
 /* tuning knobs (defaults are right for production):
  *   "agg_path"       0 = choose per call (default), 1 = always the sort path,
  *                    2 = the bucketed (sort-free) aggregation whenever its preconditions hold
- *   "bucket_variant" partition tile geometry of the bucketed aggregation (0 = default) */
+ *   "bucket_variant" partition tile geometry of the bucketed aggregation (0 = default)
+ *   "spec_min_rows"  from this many rows on, integer key ranges are first guessed from a sample
+ *                    and verified by the bucketed aggregation (default 2^23) */
 int  dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value);
 
 /* device memory helpers so a host-language binding needs no HIP runtime */

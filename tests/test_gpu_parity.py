@@ -286,6 +286,31 @@ def test_rejects_bad_arguments(ctx):
         ctx.groupby_agg([np.zeros(4, np.int32)], [np.zeros(4)], [("sum", 3)])
 
 
+def test_speculative_key_range(ctx):
+    """bucketed path with the key range GUESSED from a sample (the default from 2^23 rows on):
+    a guess that holds, and one that a single unsampled outlier breaks (-> retried with the exact range)"""
+    rng = np.random.default_rng(77)
+    n = 3_000_000
+    k = rng.integers(1000, 300_000, n).astype(np.int64)
+    v = rng.standard_normal(n)
+    iv = rng.integers(-1000, 1000, n).astype(np.int32)
+    ctx.set_option("spec_min_rows", 1)
+    try:
+        _vs_oracle(ctx, [k], [v, iv], check_ri=False)
+        for hi, lo in ((600_000, -100_000),          # retried with the exact range on the bucketed path
+                       (40_000_000, -5_000_000)):    # exact range too wide for it: retried on the sort path
+            k2 = k.copy()
+            k2[1_234_567] = hi                       # rows the sample does not visit
+            k2[2_000_001] = lo
+            _vs_oracle(ctx, [k2], [v, iv], check_ri=False)
+        a = rng.integers(0, 500, n).astype(np.int32)
+        b = rng.integers(-7, 90, n).astype(np.int16)
+        b[rng.random(n) < 0.01] = -2**15
+        _vs_oracle(ctx, [a, b], [v], aggs=("sum", "count"), check_ri=False)
+    finally:
+        ctx.set_option("spec_min_rows", 1 << 23)
+
+
 # ---- full-size properties (no oracle: size-independent invariants) ----------------------------
 
 def test_full_size_properties_1e8(ctx):
