@@ -27,6 +27,8 @@ def devcol(t, desc=False):
 def groupby_agg_tensors(ctx, keys, values, aggs, na_last=False):
     """keys/values: CUDA tensors.  Returns (offsets, [group key tensors], [agg tensors])."""
     n = keys[0].numel()
+    # the context may launch on its own (non-blocking) stream: order it after torch's producers ...
+    torch.cuda.current_stream(keys[0].device).synchronize()
     r = ctx.groupby_agg([devcol(k) for k in keys], [devcol(v) for v in values], aggs, nrows=n, na_last=na_last)
     ng = r.ngroups
     dev = keys[0].device
@@ -44,5 +46,6 @@ def groupby_agg_tensors(ctx, keys, values, aggs, na_last=False):
         if ng:
             r.agg_into(a, t.data_ptr())
         out.append(t)
+    ctx.sync()          # ... and torch's consumers after the copies out of the result
     r.free()
     return off, gk, out
