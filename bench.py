@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--agg-path", type=int, default=0, help="dthip option agg_path: 0 auto, 1 sort, 2 bucketed")
     ap.add_argument("--bucket-variant", type=int, default=0)
+    ap.add_argument("--agg-offsets", type=int, default=0,
+                    help="1: the result also carries group sizes (not part of DT[:, sum(f.v), by(f.k)]'s result Frame)")
     args = ap.parse_args()
 
     import torch
@@ -82,6 +84,8 @@ def main():
     ctx = context_for_current_stream(local_rank)
     ctx.set_option("agg_path", args.agg_path)
     ctx.set_option("bucket_variant", args.bucket_variant)
+    if world == 1:
+        ctx.set_option("agg_offsets", args.agg_offsets)
 
     n_total = args.rows
     lo, hi = rank * n_total // world, (rank + 1) * n_total // world
@@ -131,19 +135,27 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # sanity of the last result (outside the timed region): every row counted once, totals agree
+    # sanity of the last result (outside the timed region): keys strictly ascending, totals agree,
+    # and (one extra untimed call with count()) every row counted exactly once
     if world == 1:
         ng = last.ngroups
         sums = torch.empty(ng, dtype=torch.float64, device=dev)
         gkeys = torch.empty(ng, dtype=torch.int64, device=dev)
-        off = torch.empty(ng + 1, dtype=torch.int32, device=dev)
-        last.agg_into(0, sums.data_ptr()); last.key_into(0, gkeys.data_ptr()); last.offsets_into(off.data_ptr())
+        last.agg_into(0, sums.data_ptr()); last.key_into(0, gkeys.data_ptr())
         release(last)
         torch.cuda.synchronize()
         if not args.no_check:
-            assert int(off[-1].item()) == n_local and bool((gkeys[1:] > gkeys[:-1]).all())
+            assert bool((gkeys[1:] > gkeys[:-1]).all())
             total, ref = float(sums.sum().item()), float(vals.sum().item())
             assert abs(total - ref) <= 1e-9 * float(vals.abs().sum().item()), (total, ref)
+            rc = ctx.groupby_agg([kcol], [vcol], [("count0", None), ("sum", 0)], nrows=n_local)
+            cnt = torch.empty(rc.ngroups, dtype=torch.int64, device=dev)
+            s2 = torch.empty(rc.ngroups, dtype=torch.float64, device=dev)
+            rc.agg_into(0, cnt.data_ptr()); rc.agg_into(1, s2.data_ptr())
+            rc.free()
+            torch.cuda.synchronize()
+            assert rc.ngroups == ng and int(cnt.sum().item()) == n_local
+            assert bool(torch.allclose(s2, sums, rtol=1e-9, atol=1e-9))
     else:
         gk, out = last
         ng_t = torch.tensor([gk[0].numel()], dtype=torch.int64, device=dev)

@@ -532,10 +532,16 @@ static int acc_flags_for(const dthip_agg* aggs, int naggs, int col, int vstype) 
 
 static int floor_log2_sz(size_t v) { int b = -1; while (v) { b++; v >>= 1; } return b; }
 
-constexpr size_t BUCKET_LDS_TABLE = 128 * 1024;   // LDS bytes one aggregation table may take
+constexpr size_t BUCKET_LDS_TABLE = 144 * 1024;   // LDS bytes one aggregation table may take
 constexpr int BUCKET_MAX_R = 14;                  // slot keys are uint16
 constexpr int BUCKET_MAX_D = 11;                  // <= 2048 buckets in one partition pass
 constexpr int DTHIP_RETRY_EXACT = 1;              // internal: a guessed key range was wrong, redo with the exact one
+
+static bool bucket_need_counts(const dthip_ctx* ctx, const dthip_agg* aggs, int naggs) {
+  if (ctx->agg_offsets) return true;
+  for (int a = 0; a < naggs; a++) if (aggs[a].op == DTHIP_COUNT0) return true;
+  return false;
+}
 
 // Decides whether the bucket path applies; fills the slot-bit count r.
 static bool bucket_eligible(const dthip_ctx* ctx, const KeyPlan& plan, const std::vector<dthip_col>& vd,
@@ -544,16 +550,18 @@ static bool bucket_eligible(const dthip_ctx* ctx, const KeyPlan& plan, const std
   if (plan.nstages != 1) return false;
   const int B = plan.stage_bits[0];
   if (B > 32 || B < 1) return false;
+  const int first_flag = bucket_need_counts(ctx, aggs, naggs) ? ACC_CNT : ACC_PRES;
   int r = BUCKET_MAX_R;
   bool first = true;
+  auto fit = [&](int f) { int rc = BUCKET_MAX_R; while (rc > 0 && table_agg_lds_bytes(f, 1u << rc) > BUCKET_LDS_TABLE) rc--; return rc; };
   for (int c : used) {
     const int sz = stype_size(vd[c].stype);
     if (sz != 4 && sz != 8) return false;
-    const int f = acc_flags_for(aggs, naggs, c, vd[c].stype) | (first ? ACC_CNT : 0);
+    const int f = acc_flags_for(aggs, naggs, c, vd[c].stype) | (first ? first_flag : 0);
     first = false;
-    const int rc = floor_log2_sz(BUCKET_LDS_TABLE / table_agg_slot_bytes(f));
-    if (rc < r) r = rc;
+    r = std::min(r, fit(f));
   }
+  if (first) r = std::min(r, fit(first_flag));
   if (r > B) r = B;
   if (B - r > BUCKET_MAX_D) return false;
   // the dense accumulator arrays have 2^B slots: only worth it when the key range is dense enough
@@ -583,6 +591,8 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   bucket_geometry(ctx, n, B, r, km, &g);
   const size_t nslots = (size_t)g.F * g.S;
 
+  const bool need_cnt = bucket_need_counts(ctx, aggs, naggs);
+  const int first_flag = need_cnt ? ACC_CNT : ACC_PRES;
   // --- partition (skipped when one table holds the whole key range) ---
   uint16_t* kpart = nullptr;
   std::vector<const void*> vsrc(vd.size(), nullptr);
@@ -602,6 +612,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   }
   const uint32_t max_items = g.F + (uint32_t)((uint64_t)n / M) + 1;
   DTHIP_TRY(sc.get<WorkItem>(max_items, &items));
+  int src = 1;
   if (g.d > 0) {
     uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.ntiles * g.F, &P));
@@ -611,9 +622,9 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, nullptr, 0));
     DTHIP_TRY(launch_bucket_plan(ctx, tot, g.F, 0, M, bbase, items, nitems));
     DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, bbase, 1));
-    DTHIP_TRY(sc.get<uint16_t>((size_t)n + 8, &kpart));
     PayCols pc;
     memset(&pc, 0, sizeof(pc));
+    DTHIP_TRY(sc.get<uint16_t>((size_t)n + 8, &kpart));
     for (int c : used) {
       unsigned char* vb = nullptr;
       const int w = stype_size(vd[c].stype);
@@ -621,22 +632,24 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
       pc.in[pc.n] = vd[c].data; pc.out[pc.n] = vb; pc.width[pc.n] = w; pc.n++;
       vsrc[c] = vb;
     }
+    src = 0;
     DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, P, gtot, kpart, pc));
   } else {
     DTHIP_TRY(launch_bucket_plan(ctx, nullptr, 1, (uint32_t)n, M, bbase, items, nitems));
   }
 
   // --- dense accumulators + one aggregation launch per value column ---
-  uint32_t* d_cnt = nullptr;
-  DTHIP_TRY(sc.get<uint32_t>(nslots, &d_cnt));
-  DTHIP_CHECK_HIP(hipMemsetAsync(d_cnt, 0, nslots * 4, ctx->stream));
+  uint32_t* d_cnt = nullptr;      // rows per slot, or (no counts wanted) one presence bit per slot
+  const size_t cnt_words = need_cnt ? nslots : (nslots + 31) / 32;
+  DTHIP_TRY(sc.get<uint32_t>(cnt_words, &d_cnt));
+  DTHIP_CHECK_HIP(hipMemsetAsync(d_cnt, 0, cnt_words * 4, ctx->stream));
   std::vector<AggTable> tabs(vd.size());
   std::vector<int> tflags(vd.size(), 0);
   bool first = true;
   for (int c : used) {
     AggTable& t = tabs[c];
     int f = acc_flags_for(aggs, naggs, c, vd[c].stype);
-    if (first) { f |= ACC_CNT; t.cnt = d_cnt; }
+    if (first) { f |= first_flag; if (need_cnt) t.cnt = d_cnt; else t.pres = d_cnt; }
     tflags[c] = f;
     if (f & ACC_SUM) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.sum)); DTHIP_CHECK_HIP(hipMemsetAsync(t.sum, 0, nslots * 8, ctx->stream)); }
     if (f & ACC_MIN) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.mn)); DTHIP_CHECK_HIP(hipMemsetAsync(t.mn, 0xFF, nslots * 8, ctx->stream)); }
@@ -645,17 +658,18 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     if (f & ACC_VCNT) { DTHIP_TRY(sc.get<uint32_t>(nslots, &t.vcnt)); DTHIP_CHECK_HIP(hipMemsetAsync(t.vcnt, 0, nslots * 4, ctx->stream)); }
     TableAggArgs ta;
     memset(&ta, 0, sizeof(ta));
-    ta.items = items; ta.nitems = nitems; ta.max_items = max_items;
+    ta.items = items; ta.nitems = nitems; ta.max_items = max_items; ta.src = src;
     ta.kpart = kpart; ta.kx = kx; ta.val = vsrc[c]; ta.vstype = vd[c].stype; ta.S = g.S; ta.flags = f; ta.tab = t; ta.bad = d_bad;
     DTHIP_TRY(launch_table_agg(ctx, ta));
     first = false;
   }
-  if (first) {   // no value column at all (only count()): row counts alone
+  if (first) {   // no value column at all: row counts (or key presence) alone
     TableAggArgs ta;
     memset(&ta, 0, sizeof(ta));
-    ta.items = items; ta.nitems = nitems; ta.max_items = max_items;
-    ta.kpart = kpart; ta.kx = kx; ta.val = nullptr; ta.vstype = DTHIP_INT32; ta.S = g.S; ta.flags = ACC_CNT;
-    ta.tab.cnt = d_cnt; ta.bad = d_bad;
+    ta.items = items; ta.nitems = nitems; ta.max_items = max_items; ta.src = src;
+    ta.kpart = kpart; ta.kx = kx; ta.val = nullptr; ta.vstype = DTHIP_INT32; ta.S = g.S; ta.flags = first_flag;
+    if (need_cnt) ta.tab.cnt = d_cnt; else ta.tab.pres = d_cnt;
+    ta.bad = d_bad;
     DTHIP_TRY(launch_table_agg(ctx, ta));
   }
 
@@ -664,7 +678,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   DTHIP_TRY(sc.get<int32_t>(std::min<size_t>(nslots, (size_t)n) + 1, &idx));
   PredArgs pa;
   memset(&pa, 0, sizeof(pa));
-  pa.data = d_cnt; pa.stype = DTHIP_INT32; pa.cmp = DTHIP_GT; pa.ci = 0; pa.is_mask = 0;
+  pa.data = d_cnt; pa.stype = DTHIP_INT32; pa.cmp = DTHIP_GT; pa.ci = 0; pa.is_mask = need_cnt ? 0 : 2;
   int64_t ng = 0;
   DTHIP_TRY(launch_compact(ctx, pa, (int64_t)nslots, idx, &ng));
   if (plan.speculative) {
@@ -673,12 +687,14 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     if (bad) return DTHIP_RETRY_EXACT;
   }
   res->nrows = n; res->ngroups = ng;
-  // offsets = exclusive scan of the group sizes (Groupby offsets, groupby.h:54-91)
-  void* off = nullptr;
-  DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * ((size_t)ng + 2 + (size_t)ng / 8192 + 1), &off));
-  DTHIP_TRY(launch_gather(ctx, d_cnt, DTHIP_INT32, idx, ng, off));
-  DTHIP_TRY(launch_scan_tiles(ctx, static_cast<uint32_t*>(off), (uint32_t)ng, static_cast<uint32_t*>(off) + ng));
-  res->offsets = static_cast<int32_t*>(off);
+  if (need_cnt) {
+    // offsets = exclusive scan of the group sizes (Groupby offsets, groupby.h:54-91)
+    void* off = nullptr;
+    DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * ((size_t)ng + 2 + (size_t)ng / 8192 + 1), &off));
+    DTHIP_TRY(launch_gather(ctx, d_cnt, DTHIP_INT32, idx, ng, off));
+    DTHIP_TRY(launch_scan_tiles(ctx, static_cast<uint32_t*>(off), (uint32_t)ng, static_cast<uint32_t*>(off) + ng));
+    res->offsets = static_cast<int32_t*>(off);
+  }
   // group-key columns: the slot index is the packed transformed key
   for (int k = 0; k < nkeys; k++) {
     void* kp = nullptr;
@@ -795,6 +811,7 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
   }
   if (!strcmp(name, "bucket_variant")) { ctx->bucket_variant = (int)value; return DTHIP_OK; }
   if (!strcmp(name, "spec_min_rows")) { ctx->spec_min_rows = value; return DTHIP_OK; }
+  if (!strcmp(name, "agg_offsets")) { ctx->agg_offsets = value != 0; return DTHIP_OK; }
   set_error("unknown option '%s'", name);
   return DTHIP_EINVAL;
 }
@@ -1040,6 +1057,7 @@ int dthip_result_copy_rowindex(dthip_ctx* ctx, const dthip_result* r, int32_t* d
 }
 int dthip_result_copy_offsets(dthip_ctx* ctx, const dthip_result* r, int32_t* dst, int mem) {
   if (!ctx || !r) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (!r->offsets) { set_error("result holds no group offsets (option agg_offsets=0 and no count() requested)"); return DTHIP_EINVAL; }
   return copy_out(ctx, dst, r->offsets, sizeof(int32_t) * (size_t)(r->ngroups + 1), mem);
 }
 int dthip_result_copy_key(dthip_ctx* ctx, const dthip_result* r, int k, void* dst, int mem) {

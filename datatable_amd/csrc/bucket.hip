@@ -492,6 +492,11 @@ size_t table_agg_slot_bytes(int flags) {
   return b;
 }
 
+// LDS bytes of one aggregation table of S slots (ACC_PRES: one presence bit per slot)
+size_t table_agg_lds_bytes(int flags, uint32_t S) {
+  return (size_t)S * table_agg_slot_bytes(flags) + ((flags & ACC_PRES) ? (size_t)((S + 31) / 32) * 4 : 0) + 16;
+}
+
 template <typename VT> struct ValTraits;
 template <> struct ValTraits<double> {
   static constexpr bool is_float = true;
@@ -522,7 +527,7 @@ __device__ __forceinline__ double unsortable_f64(u64 k) {
 __device__ __forceinline__ u64 sortable_i64(long long v) { return (u64)v ^ 0x8000000000000000ULL; }
 
 struct LdsTab {
-  u64* sum; u64* mn; u64* mx; double* fsum; uint32_t* cnt; uint32_t* vcnt;
+  u64* sum; u64* mn; u64* mx; double* fsum; uint32_t* cnt; uint32_t* vcnt; uint32_t* pres;
 };
 
 __device__ __forceinline__ LdsTab carve_tab(unsigned char* smem, uint32_t S, int flags) {
@@ -533,7 +538,8 @@ __device__ __forceinline__ LdsTab carve_tab(unsigned char* smem, uint32_t S, int
   t.mx = reinterpret_cast<u64*>(p); if (flags & ACC_MAX) p += (size_t)S * 8;
   t.fsum = reinterpret_cast<double*>(p); if (flags & ACC_FSUM) p += (size_t)S * 8;
   t.cnt = reinterpret_cast<uint32_t*>(p); if (flags & ACC_CNT) p += (size_t)S * 4;
-  t.vcnt = reinterpret_cast<uint32_t*>(p);
+  t.vcnt = reinterpret_cast<uint32_t*>(p); if (flags & ACC_VCNT) p += (size_t)S * 4;
+  t.pres = reinterpret_cast<uint32_t*>(p);
   return t;
 }
 
@@ -544,6 +550,7 @@ __device__ __forceinline__ void lds_fadd(double* p, double v) {
 template <typename VT>
 __device__ __forceinline__ void acc_row(const LdsTab& t, int flags, uint32_t slot, VT v) {
   if (flags & ACC_CNT) atomicAdd(&t.cnt[slot], 1u);
+  if (flags & ACC_PRES) atomicOr(&t.pres[slot >> 5], 1u << (slot & 31));
   if (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) {
     if (!ValTraits<VT>::isna(v)) {
       if (flags & ACC_VCNT) atomicAdd(&t.vcnt[slot], 1u);
@@ -578,8 +585,11 @@ struct TableAggDev {
   uint32_t* bad;
 };
 
-template <typename VT, bool RAW>
+// SRC: 0 = slot keys (uint16) + value column of the partitioned rows, 1 = raw rows (keys transformed
+// on the fly; one table holds the whole key range)
+template <typename VT, int SRC>
 __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
+  constexpr bool RAW = SRC == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (blockIdx.x >= *a.nitems) return;
   const WorkItem it = a.items[blockIdx.x];
@@ -595,6 +605,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
     if (flags & ACC_CNT) t.cnt[s] = 0;
     if (flags & ACC_VCNT) t.vcnt[s] = 0;
   }
+  if (flags & ACC_PRES) for (uint32_t s = tid; s < (S + 31) / 32; s += TA_BLOCK) t.pres[s] = 0;
   __syncthreads();
   const VT* __restrict__ val = static_cast<const VT*>(a.val);
   const bool hasval = (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) != 0;
@@ -658,7 +669,10 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
       if (flags & ACC_MAX) a.tab.mx[base + s] = t.mx[s];
       if (flags & ACC_FSUM) a.tab.fsum[base + s] = t.fsum[s];
     }
+    if (flags & ACC_PRES) for (uint32_t s = tid; s < (S + 31) / 32; s += TA_BLOCK) a.tab.pres[base / 32 + s] = t.pres[s];
   } else {
+    if (flags & ACC_PRES)
+      for (uint32_t s = tid; s < (S + 31) / 32; s += TA_BLOCK) { const uint32_t w = t.pres[s]; if (w) atomicOr(&a.tab.pres[base / 32 + s], w); }
     for (uint32_t s = tid; s < S; s += TA_BLOCK) {
       if (flags & ACC_CNT) { const uint32_t c = t.cnt[s]; if (c) atomicAdd(&a.tab.cnt[base + s], c); }
       if (flags & ACC_VCNT) { const uint32_t c = t.vcnt[s]; if (c) atomicAdd(&a.tab.vcnt[base + s], c); }
@@ -676,9 +690,9 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
   }
 }
 
-template <typename VT, bool RAW>
+template <typename VT, int SRC>
 static int table_agg_t(dthip_ctx* ctx, const TableAggDev& d, uint32_t grid, size_t lds) {
-  auto kfn = table_agg_kernel<VT, RAW>;
+  auto kfn = table_agg_kernel<VT, SRC>;
   static bool attr_set = false;
   if (!attr_set) {
     DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -694,16 +708,14 @@ int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a) {
   TableAggDev d;
   d.items = a.items; d.nitems = a.nitems; d.kpart = a.kpart; d.kx = a.kx; d.val = a.val;
   d.S = a.S; d.flags = a.flags; d.isfloat = stype_is_float(a.vstype) ? 1 : 0; d.tab = a.tab; d.bad = a.bad;
-  const size_t lds = (size_t)a.S * table_agg_slot_bytes(a.flags) + 16;
-  if (lds > 160 * 1024 - 256) {
-    set_error("table_agg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL;
-  }
-  const bool raw = a.kpart == nullptr;
+  const size_t lds = table_agg_lds_bytes(a.flags, a.S);
+  if (lds > 160 * 1024 - 256) { set_error("table_agg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
+  if ((a.flags & ACC_PRES) && (a.S & 31) && a.src != 1) { set_error("table_agg: presence bitmaps need S %% 32 == 0"); return DTHIP_EINVAL; }
   const int st = a.val ? a.vstype : DTHIP_INT32;
-#define TA_GO(VT)                                                             \
-  do {                                                                        \
-    if (raw) return table_agg_t<VT, true>(ctx, d, a.max_items, lds);          \
-    return table_agg_t<VT, false>(ctx, d, a.max_items, lds);                  \
+#define TA_GO(VT)                                                                 \
+  do {                                                                            \
+    if (a.src == 1) return table_agg_t<VT, 1>(ctx, d, a.max_items, lds);          \
+    return table_agg_t<VT, 0>(ctx, d, a.max_items, lds);                          \
   } while (0)
   switch (st) {
     case DTHIP_INT32: TA_GO(int32_t);

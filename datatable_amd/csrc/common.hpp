@@ -70,6 +70,7 @@ struct dthip_ctx {
   int agg_path = 0;          // 0 auto, 1 sort path, 2 bucket path whenever eligible
   int bucket_variant = 0;    // partition tile geometry (experiments)
   int64_t spec_min_rows = 1 << 23;   // key ranges are guessed from a sample only at or above this many rows
+  int agg_offsets = 1;       // dthip_groupby_agg results carry group offsets (= sizes) even when no count() asks for them
 };
 
 namespace dthip {
@@ -212,7 +213,7 @@ struct BucketGeom {
   int km;                 // key load mode: 0 generic, 1 one aligned int64 column, 2 one aligned int32 column
 };
 struct WorkItem { uint32_t bucket, begin, end, single; };
-enum { ACC_CNT = 1, ACC_SUM = 2, ACC_MIN = 4, ACC_MAX = 8, ACC_VCNT = 16, ACC_FSUM = 32 };
+enum { ACC_CNT = 1, ACC_SUM = 2, ACC_MIN = 4, ACC_MAX = 8, ACC_VCNT = 16, ACC_FSUM = 32, ACC_PRES = 64 };
 // dense accumulator arrays of F*S slots (slot index == transformed key)
 struct AggTable {
   uint32_t* cnt = nullptr;              // rows per slot
@@ -221,6 +222,7 @@ struct AggTable {
   unsigned long long* mx = nullptr;
   uint32_t* vcnt = nullptr;             // non-NA rows per slot
   double* fsum = nullptr;               // float64 sum of integer values (mean)
+  uint32_t* pres = nullptr;             // 1 bit per slot: some row has this key (when row counts are not wanted)
 };
 void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom* g);
 // *bad is set when a row's transformed key exceeds its column's xmax (such rows are counted as key 0)
@@ -235,7 +237,8 @@ int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const
                             const uint32_t* gpre, uint16_t* kout, const PayCols& pay);
 struct TableAggArgs {
   const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
-  const uint16_t* kpart;      // slot keys of the partitioned rows (null: raw mode, keys transformed on the fly)
+  int src;                    // 0: kpart + val of the partitioned rows, 1: raw rows (kx + val)
+  const uint16_t* kpart;      // slot keys of the partitioned rows (src 0)
   KeyXform kx;
   const void* val; int vstype; // value column in the same row order as the keys (null: row counts only)
   uint32_t S; int flags;
@@ -244,6 +247,7 @@ struct TableAggArgs {
 };
 int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a);
 size_t table_agg_slot_bytes(int flags);
+size_t table_agg_lds_bytes(int flags, uint32_t S);
 struct TableFinArgs {
   const int32_t* idx; uint32_t ng; AggTable tab; int vstype;
   void* o_sum; void* o_mean; void* o_min; void* o_max; int64_t* o_count;
@@ -265,7 +269,7 @@ int launch_count0(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64
 
 // rowindex.hip
 struct PredArgs {
-  const void* data; int stype; int cmp; double cf; long long ci; int is_mask;
+  const void* data; int stype; int cmp; double cf; long long ci; int is_mask;   // is_mask 2: data is a bitmap (uint32 words)
 };
 int launch_compact(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out, int64_t* nout_host);
 int launch_gather(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, int64_t nout, void* out);

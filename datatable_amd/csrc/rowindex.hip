@@ -19,6 +19,7 @@ constexpr int CP_TILE = CP_BLOCK * CP_ITEMS;
 // comparison of a column element with a scalar; NA compares false (NE: true),
 // like the reference's comparison FExprs feed init_from_boolean_column
 __device__ __forceinline__ bool pred_at(const PredArgs& p, uint32_t i) {
+  if (p.is_mask == 2) return (static_cast<const uint32_t*>(p.data)[i >> 5] >> (i & 31)) & 1u;
   if (p.is_mask) {
     const int8_t v = static_cast<const int8_t*>(p.data)[i];
     return v != INT8_MIN && v != 0;

@@ -113,6 +113,10 @@ int  dthip_trim(dthip_ctx* ctx);
  *   "agg_path"       0 = choose per call (default), 1 = always the sort path,
  *                    2 = the bucketed (sort-free) aggregation whenever its preconditions hold
  *   "bucket_variant" partition tile geometry of the bucketed aggregation (0 = default)
+ *   "agg_offsets"    1 (default): dthip_groupby_agg results always carry the group offsets;
+ *                    0: only when a count() aggregate asks for group sizes -- the reference's result
+ *                    Frame of DT[:, sum(f.v), by(f.k)] holds keys and sums only, and not counting rows
+ *                    lets the bucketed aggregation use twice as many table slots per bucket
  *   "spec_min_rows"  from this many rows on, integer key ranges are first guessed from a sample
  *                    and verified by the bucketed aggregation (default 2^23) */
 int  dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value);

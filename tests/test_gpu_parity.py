@@ -98,6 +98,7 @@ def _vs_oracle(ctx, keys, vals, aggs=OPS, key_stypes=None, check_ri=True):
         r.free()
     alist = [(opn, vi) for vi in range(len(vals)) for opn in aggs] + [("count0", None)]
     expected = [o.reduce(opn, vals[vi], ri, off) for opn, vi in alist[:-1]]
+    gkeys = [(k.view(np.int8) if k.dtype == np.bool_ else k)[ri[off[:-1]]] for k in keys]
     for path in AGG_PATHS:
         ctx.set_option("agg_path", path)
         try:
@@ -106,13 +107,27 @@ def _vs_oracle(ctx, keys, vals, aggs=OPS, key_stypes=None, check_ri=True):
             ctx.set_option("agg_path", 0)
         tag = " [agg_path=%d]" % path
         assert_same(r.offsets(), off, "fused offsets" + tag)
-        for i, k in enumerate(keys):
-            kk = k.view(np.int8) if k.dtype == np.bool_ else k
-            assert_same(r.key(i), kk[ri[off[:-1]]], "fused group key %d%s" % (i, tag))
+        for i in range(len(keys)):
+            assert_same(r.key(i), gkeys[i], "fused group key %d%s" % (i, tag))
         for a, (opn, vi) in enumerate(alist[:-1]):
             check_agg(r.agg(a), expected[a], opn, vals[vi], ri, off, "%s(v%d)%s" % (opn, vi, tag))
         assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count()" + tag)
         r.free()
+    # the same without group sizes in the result (option agg_offsets=0, no count()): the bucketed
+    # path then tracks key presence only and uses larger tables / fewer buckets
+    ctx.set_option("agg_path", 2)
+    ctx.set_option("agg_offsets", 0)
+    try:
+        r = ctx.groupby_agg(keys, vals, alist[:-1], key_stypes=key_stypes)
+    finally:
+        ctx.set_option("agg_path", 0)
+        ctx.set_option("agg_offsets", 1)
+    assert r.ngroups == len(off) - 1
+    for i in range(len(keys)):
+        assert_same(r.key(i), gkeys[i], "group key %d [no offsets]" % i)
+    for a, (opn, vi) in enumerate(alist[:-1]):
+        check_agg(r.agg(a), expected[a], opn, vals[vi], ri, off, "%s(v%d) [no offsets]" % (opn, vi))
+    r.free()
 
 
 def test_config1_full_size(ctx):
