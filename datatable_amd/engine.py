@@ -274,6 +274,20 @@ class Context:
                                            0 if isf else int(scalar), L.HOST, out.ctypes.data, C.byref(k)))
         return out[:k.value].copy()
 
+    # device-resident variants (raw HBM pointers in, raw HBM pointers out)
+    def filter_cmp_dev(self, col, nrows, cmp, scalar, out_ptr):
+        """rows of DevCol `col` with col <cmp> scalar -> ascending int32 RowIndex at out_ptr (room for nrows); returns the count"""
+        c = L.Col(col.ptr, col.stype, 0)
+        k = C.c_int64(0)
+        isf = col.stype in (L.FLOAT32, L.FLOAT64)
+        L.check(self._lib.dthip_filter_cmp(self._h, C.byref(c), nrows, CMP[cmp], float(scalar), 0 if isf else int(scalar),
+                                           L.DEVICE, C.c_void_p(out_ptr), C.byref(k)))
+        return k.value
+
+    def gather_dev(self, col, rowindex_ptr, nout, out_ptr):
+        c = L.Col(col.ptr, col.stype, 0)
+        L.check(self._lib.dthip_gather(self._h, C.byref(c), C.c_void_p(rowindex_ptr), nout, L.DEVICE, C.c_void_p(out_ptr)))
+
     def gather(self, values, rowindex, stype=None):
         a, col = _host_col(values, stype)
         ri = np.ascontiguousarray(rowindex, np.int32)

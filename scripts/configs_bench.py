@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Single-GPU timing of BASELINE.json's five configurations through the C ABI with
+HBM-resident inputs (the parity of the same shapes is in tests/).  Prints one line per config."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0, help="multiply every row count")
+    ap.add_argument("--configs", default="1,2,3,4,5")
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+    from datatable_amd import _lib as L
+    from datatable_amd.torch_bridge import context_for_current_stream, devcol
+    dev = torch.device("cuda", 0)
+    ctx = context_for_current_stream(0)
+    g = torch.Generator(device=dev)
+
+    def timed(fn):
+        fn()                                   # warm-up (allocator, first-touch)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(args.reps):
+            t0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best, r
+
+    out = []
+    for c in [int(x) for x in args.configs.split(",")]:
+        g.manual_seed(1234 + c)
+        if c == 1:
+            n = int(1e6 * args.scale)
+            k = torch.randint(0, 100, (n,), dtype=torch.int32, device=dev, generator=g)
+            v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            def run():
+                r = ctx.groupby_agg([devcol(k)], [devcol(v)], [("sum", 0)], nrows=n); ng = r.ngroups; r.free(); return ng
+            alg = n * 12
+        elif c == 2:
+            n = int(1e8 * args.scale)
+            k = torch.randint(0, 100_000, (n,), dtype=torch.int64, device=dev, generator=g)
+            vs = [torch.randn(n, dtype=torch.float64, device=dev, generator=g) for _ in range(4)]
+            aggs = [(op, i) for op in ("sum", "mean", "min", "max") for i in range(4)]
+            def run():
+                r = ctx.groupby_agg([devcol(k)], [devcol(x) for x in vs], aggs, nrows=n); ng = r.ngroups; r.free(); return ng
+            alg = n * 40
+        elif c == 3:
+            n = int(1e9 * args.scale)
+            k = torch.randint(0, 10_000_000, (n,), dtype=torch.int64, device=dev, generator=g)
+            v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            def run():
+                r = ctx.groupby_agg([devcol(k)], [devcol(v)], [("sum", 0)], nrows=n); ng = r.ngroups; r.free(); return ng
+            alg = n * 16
+        elif c == 4:
+            n = int(1e9 * args.scale)
+            a = torch.randint(0, 3163, (n,), dtype=torch.int32, device=dev, generator=g)
+            b = torch.randint(0, 3163, (n,), dtype=torch.int32, device=dev, generator=g)
+            v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            def run():
+                r = ctx.groupby_agg([devcol(a), devcol(b)], [devcol(v)], [("count0", None), ("sum", 0)], nrows=n)
+                ng = r.ngroups; r.free(); return ng
+            alg = n * 16
+        else:
+            n = int(1e9 * args.scale)
+            k = torch.randint(0, 100_000_000, (n,), dtype=torch.int64, device=dev, generator=g)
+            x = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            ri = torch.empty(n, dtype=torch.int32, device=dev)
+            def run():
+                # V = DT[f.x > 0, :]; V[:, :, by(f.k)]: filter -> RowIndex -> view gather -> group -> rows in grouped order
+                npass = ctx.filter_cmp_dev(devcol(x), n, ">", 0.0, ri.data_ptr())
+                kv = torch.empty(npass, dtype=torch.int64, device=dev)
+                ctx.gather_dev(devcol(k), ri.data_ptr(), npass, kv.data_ptr())
+                r = ctx.groupby([devcol(kv)], nrows=npass, want_rowindex=True)
+                ng = r.ngroups
+                # compose the grouped order with the filter RowIndex, then materialise both columns in that order
+                order = torch.empty(npass, dtype=torch.int32, device=dev)
+                ctx.gather_dev(devcol(ri[:npass]), r.rowindex_ptr, npass, order.data_ptr())
+                ko = torch.empty(npass, dtype=torch.int64, device=dev)
+                xo = torch.empty(npass, dtype=torch.float64, device=dev)
+                ctx.gather_dev(devcol(k), order.data_ptr(), npass, ko.data_ptr())
+                ctx.gather_dev(devcol(x), order.data_ptr(), npass, xo.data_ptr())
+                r.free()
+                return ng
+            alg = int(n * 30.4)
+        t, ng = timed(run)
+        line = {"config": c, "rows": n, "groups": ng, "ms": t * 1e3, "rows_per_s": n / t,
+                "alg_GBps": alg / t / 1e9, "frac_of_8TBps": alg / t / 8e12}
+        out.append(line)
+        print(json.dumps(line), flush=True)
+        del run
+        torch.cuda.empty_cache()
+        ctx.trim()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

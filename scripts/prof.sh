@@ -6,9 +6,9 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile "$@" > $OUT/bench_stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile "$@" > $OUT/bench_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o bench -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile "$@" > $OUT/bench_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o bench -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-check "$@" > $OUT/bench_stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-check "$@" > $OUT/bench_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o bench -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-check "$@" > $OUT/bench_write.log 2>&1
 cd $REPO
 for d in stats pmc_fetch pmc_write; do
   db=$(find $OUT/$d -name "*.db" | head -1)
