@@ -11,12 +11,16 @@ the N=1 workload too; for N>1 the SAME 1e9 rows are row-sharded over the ranks (
 scaling, as the north star states "1e9 rows at 1/2/4/8"): local fused groupby-sum,
 range-partitioned all-to-all of partials over RCCL, merge on the owner (datatable_amd/dist.py).
 
-A step = one full pass of the hot path over the (HBM-resident) batch: key range scan,
-key transform + digit histograms, radix passes carrying the value, run heads -> offsets,
-segmented sum, group keys.  Inputs are in HBM before the timed region; outputs stay in HBM.
-One JSON line on rank 0.  `roofline` is for the dominant kernel (radix_pass_kernel),
-timed with HIP events around every launch inside the timed region; `cpu_baseline` is the
-CPU oracle (oracle/, a port of the reference's algorithm) on a bounded sample, rank 0, N=1.
+A step = one full pass of the hot path over the (HBM-resident) batch.  Default path (dense
+integer key range): sampled key range, per-tile bucket histogram (which verifies the range),
+one 1024-way partition of (slot key, value), LDS-table aggregation per bucket, compaction of
+the non-empty slots into (group key, sum) columns.  `--agg-path 1` takes the general path:
+exact key range, key transform + digit histograms, stable LSD radix passes carrying the value,
+run heads -> offsets, segmented sum.  Inputs are in HBM before the timed region; outputs stay in HBM.
+One JSON line on rank 0.  `roofline` is for the dominant kernel of the timed region (the one
+with the largest total time: bucket_partition_kernel on the default path), timed with HIP events
+around every launch; `cpu_baseline` is the CPU oracle (oracle/, a port of the reference's
+algorithm) on a bounded sample, rank 0, N=1.
 """
 import argparse
 import json
@@ -63,6 +67,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--agg-path", type=int, default=0, help="dthip option agg_path: 0 auto, 1 sort, 2 bucketed")
     ap.add_argument("--bucket-variant", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path (RCCL collectives, merge) even with one rank")
     ap.add_argument("--agg-offsets", type=int, default=0,
                     help="1: the result also carries group sizes (not part of DT[:, sum(f.v), by(f.k)]'s result Frame)")
     args = ap.parse_args()
@@ -79,12 +85,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run for N>1" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    sharded = world > 1 or args.force_dist
+    if sharded:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     ctx = context_for_current_stream(local_rank)
     ctx.set_option("agg_path", args.agg_path)
     ctx.set_option("bucket_variant", args.bucket_variant)
-    if world == 1:
+    if not sharded:
         ctx.set_option("agg_offsets", args.agg_offsets)
 
     n_total = args.rows
@@ -100,18 +111,18 @@ def main():
     kcol, vcol = devcol(keys), devcol(vals)
 
     def step():
-        if world == 1:
+        if not sharded:
             r = ctx.groupby_agg([kcol], [vcol], aggs, nrows=n_local)
             return r
         return sharded_groupby_agg(backend, [keys], [vals], aggs)
 
     def release(r):
-        if world == 1:
+        if not sharded:
             r.free()
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -131,13 +142,13 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
     # sanity of the last result (outside the timed region): keys strictly ascending, totals agree,
     # and (one extra untimed call with count()) every row counted exactly once
-    if world == 1:
+    if not sharded:
         ng = last.ngroups
         sums = torch.empty(ng, dtype=torch.float64, device=dev)
         gkeys = torch.empty(ng, dtype=torch.int64, device=dev)
@@ -178,18 +189,24 @@ def main():
         alg_bytes_launch = ALG_BYTES_PER_ROW * n_local          # algorithmic bytes of the rows one launch processes
         roof = None
         if rp_n:
-            avg_s = rp_ms / rp_n * 1e-3
+            # single GPU: one launch of the dominant kernel per step.  Sharded: the merge of the exchanged
+            # partials launches it a second time on a few rows; its time is charged, its bytes are not.
+            per_step = max(1, round(rp_n / args.steps))
+            avg_s = rp_ms / rp_n * per_step * 1e-3
             ach = alg_bytes_launch / avg_s / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and not sharded:
                 try:
                     traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch_at_rows", {}).get(str(n_local))
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launches": rp_n, "avg_launch_ms": rp_ms / rp_n,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launches": rp_n, "launches_per_step": per_step,
+                    "avg_launch_ms": rp_ms / rp_n * per_step,
                     "alg_bytes_per_launch": alg_bytes_launch,
+                    "note": "achieved = 16 B/row (SURVEY 8d, C3) x rows of one launch / HIP-event time of that launch; "
+                            "traffic = HBM bytes of one launch from rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/)",
                     "whole_step_alg_GBs": (ALG_BYTES_PER_ROW * n_total + 16 * ng) / (dt / args.steps) / 1e9,
                     "whole_step_frac": (ALG_BYTES_PER_ROW * n_total + 16 * ng) / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world)}
         line = {
@@ -209,7 +226,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -53,6 +53,10 @@ SIGNATURES = {
                                 C.POINTER(C.c_void_p)]),
     "dthip_groupby_agg": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int, C.POINTER(Col), C.c_int,
                                     C.POINTER(Agg), C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dthip_groupby_rows": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int, C.POINTER(Col), C.c_int, C.c_int64, C.c_int,
+                                     C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dthip_result_col": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "dthip_result_copy_col": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "dthip_result_ngroups": (C.c_int64, [C.c_void_p]),
     "dthip_result_nrows": (C.c_int64, [C.c_void_p]),
     "dthip_result_rowindex": (C.c_void_p, [C.c_void_p]),

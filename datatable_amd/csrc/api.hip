@@ -260,7 +260,8 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
   const int key64 = bits > 32;
   const size_t ksz = key64 ? 8 : 4;
   out->key64 = key64;
-  int npass = (bits + 7) / 8;
+  // digits of up to 9 bits: 27 significant bits are 3 passes, not 4 (64 bits still 8 passes of 8)
+  int npass = (bits + 8) / 9;
   if (npass > MAX_PASSES) npass = MAX_PASSES;
   XformArgs xa;
   memset(&xa, 0, sizeof(xa));
@@ -376,6 +377,8 @@ struct dthip_result {
   int naggs = 0;
   std::vector<void*> agg;
   std::vector<int> agg_stype;
+  std::vector<void*> col;        // dthip_groupby_rows: columns permuted into grouped order
+  std::vector<int> col_stype;
   std::vector<void*> owned;
 };
 
@@ -580,11 +583,17 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   memset(&kx, 0, sizeof(kx));
   kx.ncols = nkeys;
   for (int k = 0; k < nkeys; k++) kx.cols[k] = plan.col[k];
-  // vector key loads need one aligned int32/int64 column and aligned value columns
+  // vector key loads: up to 4 aligned key columns, all int64 or all int32, and aligned value columns
   int km = 0;
-  if (nkeys == 1 && kx.cols[0].shift == 0 && (reinterpret_cast<uintptr_t>(kx.cols[0].data) & 15) == 0) {
-    if (kx.cols[0].stype == DTHIP_INT64) km = 1;
-    else if (kx.cols[0].stype == DTHIP_INT32) km = 2;
+  if (nkeys <= 4) {
+    bool all64 = true, all32 = true, aligned = true;
+    for (int k = 0; k < nkeys; k++) {
+      all64 &= kx.cols[k].stype == DTHIP_INT64;
+      all32 &= kx.cols[k].stype == DTHIP_INT32;
+      aligned &= (reinterpret_cast<uintptr_t>(kx.cols[k].data) & 15) == 0;
+    }
+    if (aligned && all64) km = 1;
+    else if (aligned && all32) km = 2;
   }
   for (int c : used) if (reinterpret_cast<uintptr_t>(vd[c].data) & 15) km = 0;
   BucketGeom g;
@@ -919,6 +928,85 @@ int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrow
   return DTHIP_OK;
 }
 
+int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dthip_col* cols, int ncols,
+                       int64_t nrows, int na_pos, int mem, int want_rowindex, dthip_result** out) {
+  DTHIP_TRY(check_common(ctx, nrows, mem));
+  if (!keys || !out || (ncols > 0 && !cols) || ncols < 0) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (na_pos != DTHIP_NA_FIRST && na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", na_pos); return DTHIP_ENOTIMPL; }
+  dthip_result* res = new dthip_result();
+  res->nkeys = nkeys;
+  res->col.assign(ncols, nullptr); res->col_stype.assign(ncols, 0);
+  for (int c = 0; c < ncols; c++) res->col_stype[c] = cols[c].stype;
+  int rc = DTHIP_OK;
+  do {
+    Scratch sc(ctx);
+    std::vector<dthip_col> kd, cd;
+    if ((rc = stage_cols(ctx, sc, keys, nkeys, nrows, mem, &kd)) != DTHIP_OK) break;
+    if ((rc = stage_cols(ctx, sc, cols, ncols, nrows, mem, &cd)) != DTHIP_OK) break;
+    if (nrows == 0) { rc = empty_result(ctx, res); break; }
+    KeyPlan plan; Grouping g;
+    if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan)) != DTHIP_OK) break;
+    bool ride = plan.nstages == 1 && ncols + (want_rowindex ? 1 : 0) <= MAX_PAYCOLS && ncols > 0;
+    for (int c = 0; c < ncols; c++) if (stype_size(cd[c].stype) < 4) ride = false;
+    if (ride) {
+      // the columns (and the row ids) ride through the radix passes: streaming reads and run-wise
+      // writes instead of one random gather per column through the finished RowIndex
+      PaySpec ps;
+      ps.n = 0;
+      if (want_rowindex) { ps.in[0] = nullptr; ps.width[0] = 4; ps.iota = true; ps.n = 1; }
+      // a requested column that IS a key column does not ride along: the sorted packed keys are
+      // turned back into it afterwards (streaming), which saves its bytes in every pass
+      std::vector<int> slot(ncols, -1), is_key(ncols, -1);
+      for (int c = 0; c < ncols; c++) {
+        for (int k = 0; k < nkeys; k++)
+          if (cols[c].data == keys[k].data && cols[c].stype == keys[k].stype) is_key[c] = k;
+        if (is_key[c] >= 0) continue;
+        slot[c] = ps.n;
+        ps.in[ps.n] = cd[c].data; ps.width[ps.n] = stype_size(cd[c].stype); ps.n++;
+      }
+      SortOut so;
+      if ((rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so)) != DTHIP_OK) break;
+      if ((rc = heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, nrows, &g)) != DTHIP_OK) break;
+      if (want_rowindex) { result_adopt(sc, res, so.pay[0]); res->rowindex = static_cast<int32_t*>(so.pay[0]); }
+      for (int c = 0; c < ncols && rc == DTHIP_OK; c++) {
+        if (is_key[c] >= 0) {
+          void* q = nullptr;
+          if ((rc = result_alloc(ctx, res, (size_t)nrows * stype_size(cd[c].stype), &q)) != DTHIP_OK) break;
+          rc = launch_untransform_keys(ctx, so.keys, so.key64, nullptr, nrows, plan.col[is_key[c]], plan.nsig[is_key[c]], q);
+          res->col[c] = q;
+          continue;
+        }
+        void* p = so.pay[slot[c]];
+        if (p == cd[c].data) {       // nothing moved (single group / already ordered passes skipped): copy
+          void* q = nullptr;
+          const size_t bytes = (size_t)nrows * stype_size(cd[c].stype);
+          if ((rc = result_alloc(ctx, res, bytes, &q)) != DTHIP_OK) break;
+          if (hipMemcpyAsync(q, p, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { set_error("D2D copy failed"); rc = DTHIP_EDEVICE; break; }
+          res->col[c] = q;
+        } else {
+          result_adopt(sc, res, p);
+          res->col[c] = p;
+        }
+      }
+      if (rc != DTHIP_OK) break;
+    } else {
+      if ((rc = group_core(ctx, sc, res, kd.data(), nkeys, nrows, na_pos, &plan, &g)) != DTHIP_OK) break;
+      for (int c = 0; c < ncols; c++) {
+        void* q = nullptr;
+        if ((rc = result_alloc(ctx, res, (size_t)nrows * stype_size(cd[c].stype), &q)) != DTHIP_OK) break;
+        if ((rc = launch_gather(ctx, cd[c].data, cd[c].stype, g.rowindex, nrows, q)) != DTHIP_OK) break;
+        res->col[c] = q;
+      }
+      if (rc != DTHIP_OK) break;
+      if (want_rowindex) { result_adopt(sc, res, g.rowindex); res->rowindex = g.rowindex; }
+    }
+    res->nrows = nrows; res->ngroups = g.ngroups; res->offsets = g.offsets;
+  } while (0);
+  if (rc != DTHIP_OK) { result_destroy(ctx, res); return rc; }
+  *out = res;
+  return DTHIP_OK;
+}
+
 int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dthip_col* values, int nvalues,
                       const dthip_agg* aggs, int naggs, int64_t nrows, int na_pos, int mem, dthip_result** out) {
   DTHIP_TRY(check_common(ctx, nrows, mem));
@@ -1047,6 +1135,12 @@ const int32_t* dthip_result_rowindex(const dthip_result* r) { return r ? r->rowi
 const int32_t* dthip_result_offsets(const dthip_result* r) { return r ? r->offsets : nullptr; }
 const void* dthip_result_key(const dthip_result* r, int k) { return (r && k >= 0 && k < r->nkeys) ? r->key[k] : nullptr; }
 const void* dthip_result_agg(const dthip_result* r, int a) { return (r && a >= 0 && a < r->naggs) ? r->agg[a] : nullptr; }
+const void* dthip_result_col(const dthip_result* r, int c) { return (r && c >= 0 && c < (int)r->col.size()) ? r->col[c] : nullptr; }
+int dthip_result_copy_col(dthip_ctx* ctx, const dthip_result* r, int c, void* dst, int mem) {
+  if (!ctx || !r || c < 0 || c >= (int)r->col.size()) { set_error("bad column index"); return DTHIP_EINVAL; }
+  if (r->nrows == 0) return DTHIP_OK;
+  return copy_out(ctx, dst, r->col[c], (size_t)r->nrows * stype_size(r->col_stype[c]), mem);
+}
 int dthip_result_agg_stype(const dthip_result* r, int a) { return (r && a >= 0 && a < r->naggs) ? r->agg_stype[a] : 0; }
 
 int dthip_result_copy_rowindex(dthip_ctx* ctx, const dthip_result* r, int32_t* dst, int mem) {

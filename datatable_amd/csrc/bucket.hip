@@ -37,8 +37,8 @@ typedef uint32_t bu32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
 // ---------------------------------------------------------------------------------------
-// tile loaders.  KM = 1: one 16-B aligned int64 key column, 2 consecutive rows per lane per
-// load; KM = 2: one aligned int32 key column, 4 consecutive rows; KM = 0: anything, 1 row.
+// tile loaders.  KM = 1: 16-B aligned int64 key column(s), 2 consecutive rows per lane per
+// load; KM = 2: aligned int32 key column(s), 4 consecutive rows; KM = 0: anything, 1 row.
 // Item j of thread tid is row  tile_base + ((j / VW) * BLOCK + tid) * VW + j % VW.
 // ---------------------------------------------------------------------------------------
 template <int KM> struct KmVW { static constexpr int value = KM == 1 ? 2 : KM == 2 ? 4 : 1; };
@@ -59,47 +59,56 @@ __device__ __forceinline__ uint32_t xf_int(const KeyColDev& c, long long v, long
   return b ? 0u : (uint32_t)t;
 }
 
+constexpr int VEC_KEYCOLS = 4;      // KM 1 / 2 handle up to this many key columns, all of the mode's type
+
 template <int BLOCK, int ITEMS, int KM>
 __device__ __forceinline__ void load_tile_x(const KeyXform& kx, uint32_t tile_base, uint32_t nvalid, bool full,
                                             int tid, uint32_t (&x)[ITEMS], bool& bad) {
   if (KM == 1 && full) {
-    const KeyColDev& c = kx.cols[0];
-    const long long* src = static_cast<const long long*>(c.data) + tile_base;
-    bu32x4 w[ITEMS / 2];
 #pragma unroll
-    for (int q = 0; q < ITEMS / 2; q++) w[q] = *reinterpret_cast<const bu32x4*>(src + ((uint32_t)q * BLOCK + tid) * 2);
+    for (int j = 0; j < ITEMS; j++) x[j] = 0;
 #pragma unroll
-    for (int q = 0; q < ITEMS / 2; q++) {
-      x[2 * q] = xf_int(c, (long long)((u64)w[q].x | ((u64)w[q].y << 32)), INT64_MIN, bad);
-      x[2 * q + 1] = xf_int(c, (long long)((u64)w[q].z | ((u64)w[q].w << 32)), INT64_MIN, bad);
+    for (int ci = 0; ci < VEC_KEYCOLS; ci++) {
+      if (ci < kx.ncols) {
+        const KeyColDev& c = kx.cols[ci];
+        const long long* src = static_cast<const long long*>(c.data) + tile_base;
+        bu32x4 w[ITEMS / 2];
+#pragma unroll
+        for (int q = 0; q < ITEMS / 2; q++) w[q] = *reinterpret_cast<const bu32x4*>(src + ((uint32_t)q * BLOCK + tid) * 2);
+#pragma unroll
+        for (int q = 0; q < ITEMS / 2; q++) {
+          x[2 * q] |= xf_int(c, (long long)((u64)w[q].x | ((u64)w[q].y << 32)), INT64_MIN, bad) << c.shift;
+          x[2 * q + 1] |= xf_int(c, (long long)((u64)w[q].z | ((u64)w[q].w << 32)), INT64_MIN, bad) << c.shift;
+        }
+      }
     }
   } else if (KM == 2 && full) {
-    const KeyColDev& c = kx.cols[0];
-    const int32_t* src = static_cast<const int32_t*>(c.data) + tile_base;
-    bu32x4 w[ITEMS / 4];
 #pragma unroll
-    for (int q = 0; q < ITEMS / 4; q++) w[q] = *reinterpret_cast<const bu32x4*>(src + ((uint32_t)q * BLOCK + tid) * 4);
+    for (int j = 0; j < ITEMS; j++) x[j] = 0;
 #pragma unroll
-    for (int q = 0; q < ITEMS / 4; q++) {
-      x[4 * q] = xf_int(c, (long long)(int32_t)w[q].x, INT32_MIN, bad);
-      x[4 * q + 1] = xf_int(c, (long long)(int32_t)w[q].y, INT32_MIN, bad);
-      x[4 * q + 2] = xf_int(c, (long long)(int32_t)w[q].z, INT32_MIN, bad);
-      x[4 * q + 3] = xf_int(c, (long long)(int32_t)w[q].w, INT32_MIN, bad);
+    for (int ci = 0; ci < VEC_KEYCOLS; ci++) {
+      if (ci < kx.ncols) {
+        const KeyColDev& c = kx.cols[ci];
+        const int32_t* src = static_cast<const int32_t*>(c.data) + tile_base;
+        bu32x4 w[ITEMS / 4];
+#pragma unroll
+        for (int q = 0; q < ITEMS / 4; q++) w[q] = *reinterpret_cast<const bu32x4*>(src + ((uint32_t)q * BLOCK + tid) * 4);
+#pragma unroll
+        for (int q = 0; q < ITEMS / 4; q++) {
+          x[4 * q] |= xf_int(c, (long long)(int32_t)w[q].x, INT32_MIN, bad) << c.shift;
+          x[4 * q + 1] |= xf_int(c, (long long)(int32_t)w[q].y, INT32_MIN, bad) << c.shift;
+          x[4 * q + 2] |= xf_int(c, (long long)(int32_t)w[q].z, INT32_MIN, bad) << c.shift;
+          x[4 * q + 3] |= xf_int(c, (long long)(int32_t)w[q].w, INT32_MIN, bad) << c.shift;
+        }
+      }
     }
+    // a row with any out-of-range key must be key 0 as a whole (what the generic path does)
   } else {
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
       const uint32_t rel = item_row<BLOCK, KM>(j, tid);
       x[j] = 0u;
-      if (rel < nvalid) {
-        if (KM == 0) x[j] = (uint32_t)packed_key_checked(kx.cols, kx.ncols, tile_base + rel, bad);
-        else {
-          const u64 t = xform_key(kx.cols[0], tile_base + rel);
-          const bool b = t > kx.cols[0].xmax;
-          bad |= b;
-          x[j] = b ? 0u : (uint32_t)t;
-        }
-      }
+      if (rel < nvalid) x[j] = (uint32_t)packed_key_checked(kx.cols, kx.ncols, tile_base + rel, bad);
     }
   }
 }

@@ -66,11 +66,12 @@ def _cols(cols, stypes=None, desc=None):
 class Result:
     """Device-resident result of a groupby (dthip_result)."""
 
-    def __init__(self, ctx, handle, key_stypes, naggs):
+    def __init__(self, ctx, handle, key_stypes, naggs, col_stypes=()):
         self._ctx = ctx
         self._h = handle
         self.key_stypes = list(key_stypes)
         self.naggs = naggs
+        self.col_stypes = list(col_stypes)
         lib = ctx._lib
         self.ngroups = lib.dthip_result_ngroups(handle)
         self.nrows = lib.dthip_result_nrows(handle)
@@ -113,6 +114,18 @@ class Result:
         out = np.empty(self.ngroups, ST2NP[self.agg_stype(a)])
         L.check(self._ctx._lib.dthip_result_copy_agg(self._ctx._h, self._h, a, out.ctypes.data, L.HOST))
         return out
+
+    def col(self, c):
+        """column c of a groupby_rows result, in grouped order"""
+        out = np.empty(self.nrows, ST2NP[self.col_stypes[c]])
+        L.check(self._ctx._lib.dthip_result_copy_col(self._ctx._h, self._h, c, out.ctypes.data, L.HOST))
+        return out
+
+    def col_ptr(self, c):
+        return self._ctx._lib.dthip_result_col(self._h, c)
+
+    def col_into(self, c, ptr):
+        L.check(self._ctx._lib.dthip_result_copy_col(self._ctx._h, self._h, c, C.c_void_p(ptr), L.DEVICE))
 
     # device-to-device copies into caller-owned HBM (e.g. a torch tensor's data_ptr())
     def rowindex_into(self, ptr):
@@ -216,6 +229,21 @@ class Context:
         L.check(self._lib.dthip_groupby(self._h, arr, len(keys), nrows, L.NA_LAST if na_last else L.NA_FIRST, mem,
                                         1 if want_rowindex else 0, C.byref(h)))
         return Result(self, h, [arr[i].stype for i in range(len(keys))], 0)
+
+    def groupby_rows(self, keys, cols, nrows=None, key_stypes=None, col_stypes=None, desc=None, na_last=False,
+                     want_rowindex=True):
+        """rows in grouped order: group() + the materialisation of `cols` through its RowIndex, fused"""
+        karr, kmem, kkeep = _cols(keys, key_stypes, desc)
+        carr, cmem, ckeep = _cols(cols, col_stypes)
+        if cols and kmem != cmem:
+            raise ValueError("keys and columns must live in the same memory space")
+        if nrows is None:
+            nrows = len(kkeep[0])
+        h = C.c_void_p()
+        L.check(self._lib.dthip_groupby_rows(self._h, karr, len(keys), carr, len(cols), nrows,
+                                             L.NA_LAST if na_last else L.NA_FIRST, kmem, 1 if want_rowindex else 0,
+                                             C.byref(h)))
+        return Result(self, h, [karr[i].stype for i in range(len(keys))], 0, [carr[i].stype for i in range(len(cols))])
 
     def groupby_agg(self, keys, values, aggs, nrows=None, key_stypes=None, value_stypes=None, desc=None,
                     na_last=False):

@@ -157,6 +157,18 @@ int  dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys,
                        const dthip_agg* aggs, int naggs,
                        int64_t nrows, int na_pos, int mem, dthip_result** out);
 
+/* ---- DT[:, cols, by(keys)]: rows in grouped order, materialised ------------- */
+/* group() followed by the gather of `cols` through the RowIndex
+ * (EvalContext::evaluate_select + ColumnImpl::_materialize_fw,
+ * src/core/expr/eval_context.cc:497-508, src/core/column/column_impl.cc:78-101;
+ * view.cc:140-145), fused: the columns ride through the sort, nothing is
+ * gathered at random.  The result holds offsets, the RowIndex (if wanted) and
+ * cols[c] permuted into grouped order (dthip_result_col).  Pass the key columns
+ * among `cols` to get the by-columns of the result Frame. */
+int  dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys,
+                        const dthip_col* cols, int ncols, int64_t nrows,
+                        int na_pos, int mem, int want_rowindex, dthip_result** out);
+
 /* ---- result accessors ---------------------------------------------------- */
 int64_t dthip_result_ngroups(const dthip_result* r);
 int64_t dthip_result_nrows(const dthip_result* r);
@@ -165,12 +177,14 @@ const int32_t* dthip_result_rowindex(const dthip_result* r);
 const int32_t* dthip_result_offsets(const dthip_result* r);
 const void*    dthip_result_key(const dthip_result* r, int k);
 const void*    dthip_result_agg(const dthip_result* r, int a);
+const void*    dthip_result_col(const dthip_result* r, int c);   /* dthip_groupby_rows */
 int            dthip_result_agg_stype(const dthip_result* r, int a);
 /* copy out (dst in `mem` space, sized by the caller from ngroups/nrows) */
 int  dthip_result_copy_rowindex(dthip_ctx* ctx, const dthip_result* r, int32_t* dst, int mem);
 int  dthip_result_copy_offsets(dthip_ctx* ctx, const dthip_result* r, int32_t* dst, int mem);
 int  dthip_result_copy_key(dthip_ctx* ctx, const dthip_result* r, int k, void* dst, int mem);
 int  dthip_result_copy_agg(dthip_ctx* ctx, const dthip_result* r, int a, void* dst, int mem);
+int  dthip_result_copy_col(dthip_ctx* ctx, const dthip_result* r, int c, void* dst, int mem);
 /* fill the by-column k of a groupby (not _agg) result: key[rowindex[offsets[g]]]
  * (EvalContext::update_groupby_columns, eval_context.cc:473-485) */
 int  dthip_result_group_keys(dthip_ctx* ctx, const dthip_result* r, const dthip_col* key,

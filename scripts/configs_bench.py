@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="multiply every row count")
     ap.add_argument("--configs", default="1,2,3,4,5")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--profile", action="store_true")
     args = ap.parse_args()
     import torch
     from datatable_amd import _lib as L
@@ -75,23 +76,23 @@ def main():
             x = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
             ri = torch.empty(n, dtype=torch.int32, device=dev)
             def run():
-                # V = DT[f.x > 0, :]; V[:, :, by(f.k)]: filter -> RowIndex -> view gather -> group -> rows in grouped order
+                # V = DT[f.x > 0, :]; V[:, :, by(f.k)]: filter -> RowIndex -> view gather (ascending) ->
+                # group, the key, the value and the filter's RowIndex riding through the sort
                 npass = ctx.filter_cmp_dev(devcol(x), n, ">", 0.0, ri.data_ptr())
                 kv = torch.empty(npass, dtype=torch.int64, device=dev)
+                xv = torch.empty(npass, dtype=torch.float64, device=dev)
                 ctx.gather_dev(devcol(k), ri.data_ptr(), npass, kv.data_ptr())
-                r = ctx.groupby([devcol(kv)], nrows=npass, want_rowindex=True)
+                ctx.gather_dev(devcol(x), ri.data_ptr(), npass, xv.data_ptr())
+                r = ctx.groupby_rows([devcol(kv)], [devcol(kv), devcol(xv), devcol(ri[:npass])], nrows=npass, want_rowindex=False)
                 ng = r.ngroups
-                # compose the grouped order with the filter RowIndex, then materialise both columns in that order
-                order = torch.empty(npass, dtype=torch.int32, device=dev)
-                ctx.gather_dev(devcol(ri[:npass]), r.rowindex_ptr, npass, order.data_ptr())
-                ko = torch.empty(npass, dtype=torch.int64, device=dev)
-                xo = torch.empty(npass, dtype=torch.float64, device=dev)
-                ctx.gather_dev(devcol(k), order.data_ptr(), npass, ko.data_ptr())
-                ctx.gather_dev(devcol(x), order.data_ptr(), npass, xo.data_ptr())
                 r.free()
                 return ng
             alg = int(n * 30.4)
         t, ng = timed(run)
+        if args.profile:
+            ctx.profile_reset(); ctx.profile(True); run(); torch.cuda.synchronize(); ctx.profile(False)
+            prof = sorted(((nm,) + ctx.profile_get(nm) for nm in ctx.profile_names()), key=lambda r: -r[1])
+            print("   " + " ".join("%s=%.2fx%d" % (nm.replace("_kernel", ""), ms / max(c_, 1), c_) for nm, ms, c_ in prof[:12]), flush=True)
         line = {"config": c, "rows": n, "groups": ng, "ms": t * 1e3, "rows_per_s": n / t,
                 "alg_GBps": alg / t / 1e9, "frac_of_8TBps": alg / t / 8e12}
         out.append(line)

@@ -301,6 +301,28 @@ def test_rejects_bad_arguments(ctx):
         ctx.groupby_agg([np.zeros(4, np.int32)], [np.zeros(4)], [("sum", 3)])
 
 
+@pytest.mark.parametrize("want_ri", [True, False])
+def test_groupby_rows_materialised(ctx, want_ri):
+    """dthip_groupby_rows: columns permuted into grouped order == column[RowIndex] of the oracle, bit for bit
+    (the columns ride through the sort; narrow columns and >64-bit key sets take the gather path)"""
+    rng = np.random.default_rng(91)
+    n = 300_000
+    k = rng.integers(-1000, 50_000, n).astype(np.int64)
+    k[rng.random(n) < 0.02] = -2**63
+    cols = [k, rng.standard_normal(n), rng.integers(-9, 9, n).astype(np.int32), rng.standard_normal(n).astype(np.float32),
+            rng.integers(-100, 100, n).astype(np.int8)]
+    for keys, use in (([k], cols[:4]), ([k], cols), ([cols[2], k], cols[:3]),
+                      ([rng.choice(rng.integers(-2**62, 2**62, 40), n), k], cols[:2])):
+        ri, off = o.group(keys)
+        r = ctx.groupby_rows(keys, use, want_rowindex=want_ri)
+        assert_same(r.offsets(), off, "offsets")
+        if want_ri:
+            assert_same(r.rowindex(), ri, "rowindex")
+        for c, col in enumerate(use):
+            assert_same(r.col(c), col[ri], "column %d in grouped order" % c)
+        r.free()
+
+
 def test_speculative_key_range(ctx):
     """bucketed path with the key range GUESSED from a sample (the default from 2^23 rows on):
     a guess that holds, and one that a single unsampled outlier breaks (-> retried with the exact range)"""
