@@ -309,18 +309,21 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
   DTHIP_TRY(launch_hist_scan(ctx, hist, base, npass));
   const uint32_t tile = radix_tile_items(key64, 8);
   const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
-  size_t state_words = 0;
-  for (int i = 0; i < nactive; i++) state_words += (size_t)ntiles << xa.pbits[active[i]];
-  unsigned long long* state = nullptr;
-  DTHIP_TRY(sc.get<unsigned long long>(state_words + 64, &state));
+  // per-pass run positions: per-tile digit counts of the current key order -> P, gpre
+  int maxbits = 0;
+  for (int i = 0; i < nactive; i++) maxbits = std::max(maxbits, xa.pbits[active[i]]);
+  BucketGeom hg;
+  memset(&hg, 0, sizeof(hg));
   {
-    static int debug_calls = 0;
-    const bool reuse = (radix_debug_flags() & 2) && debug_calls++ >= 1;   // experiment: keep the previous run's prefixes
-    if (reuse) DTHIP_CHECK_HIP(hipMemsetAsync(state + state_words, 0, 64 * 8, ctx->stream));
-    else DTHIP_CHECK_HIP(hipMemsetAsync(state, 0, (state_words + 64) * 8, ctx->stream));
+    const uint32_t gmax = (uint32_t)ctx->num_cus * 4;
+    hg.ntiles = ntiles;
+    hg.tpg = (ntiles + gmax - 1) / gmax; if (hg.tpg == 0) hg.tpg = 1;
+    hg.G = (ntiles + hg.tpg - 1) / hg.tpg;
   }
-  uint32_t* tickets = reinterpret_cast<uint32_t*>(state + state_words);   // [MAX_PASSES] + err flag
-  int* err = reinterpret_cast<int*>(tickets + 16);
+  uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)ntiles << maxbits, &P));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)hg.G << maxbits, &gtot));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)1 << maxbits, &tot));
   unsigned char* kB = nullptr;
   DTHIP_TRY(sc.get<unsigned char>((size_t)n * ksz, &kB));
   void* pbuf[2][MAX_PAYCOLS];
@@ -336,18 +339,16 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
     }
   }
   unsigned char* kin = kA; unsigned char* kout = kB;
-  size_t st_off = 0;
   for (int i = 0; i < nactive; i++) {
     const int p = active[i];
+    hg.F = 1u << xa.pbits[p];
+    DTHIP_TRY(launch_radix_tile_hist(ctx, kin, key64, (uint32_t)n, xa.pshift[p], xa.pbits[p], ntiles, hg.tpg, hg.G, P, gtot));
+    DTHIP_TRY(launch_bucket_gscan(ctx, hg, gtot, tot, base + (size_t)p * HIST_STRIDE, 1));
     RadixPass rp;
     memset(&rp, 0, sizeof(rp));
     rp.kin = kin; rp.kout = kout; rp.key64 = key64; rp.n = (uint32_t)n;
     rp.shift = xa.pshift[p]; rp.bits = xa.pbits[p];
-    rp.base = base + (size_t)p * HIST_STRIDE;
-    rp.state = state + st_off;
-    st_off += (size_t)ntiles << xa.pbits[p];
-    rp.ticket = tickets + i;
-    rp.err = err;
+    rp.P = P; rp.gpre = gtot; rp.tpg = hg.tpg;
     rp.iota = (i == 0 && pay.iota) ? 1 : 0;
     rp.pay.n = pay.n;
     for (int c = 0; c < pay.n; c++) {

@@ -170,15 +170,15 @@ struct PayCols {
 struct RadixPass {
   const void* kin; void* kout; int key64;
   uint32_t n; int shift; int bits;
-  const uint32_t* base;          // [1<<bits] exclusive bucket starts for this pass
-  unsigned long long* state;     // [ntiles << bits], zeroed
-  uint32_t* ticket;              // zeroed
-  int* err;
+  const uint32_t* P;             // [ntiles][1<<bits] from launch_radix_tile_hist
+  const uint32_t* gpre;          // [G][1<<bits] global run starts from launch_bucket_gscan(phase 1)
+  uint32_t tpg;
   int iota;                      // payload column 0 is the row number (not loaded)
   PayCols pay;
 };
 uint32_t radix_tile_items(int key64, int maxpaywidth);
-int radix_debug_flags();
+int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t n, int shift, int bits,
+                           uint32_t ntiles, uint32_t tpg, uint32_t G, uint32_t* P, uint32_t* gtot);
 int launch_radix_pass(dthip_ctx* ctx, const RadixPass& p);
 
 // group.hip: run heads of a sorted key sequence -> offsets, head bitmap, tile head counts
