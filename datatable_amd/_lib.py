@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libdthip.so")
 BOOL, INT8, INT16, INT32, INT64, FLOAT32, FLOAT64 = 1, 2, 3, 4, 5, 6, 7
 SUM, MEAN, MIN, MAX, COUNT, COUNT0 = 0, 1, 2, 3, 4, 5
 HOST, DEVICE = 0, 1
-NA_FIRST, NA_LAST = 0, 1
+NA_FIRST, NA_LAST, NA_REMOVE = 0, 1, 2
 FLAG_DESCENDING = 1
 GT, GE, LT, LE, EQ, NE = 0, 1, 2, 3, 4, 5
 

@@ -899,6 +899,11 @@ int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrow
                   int want_rowindex, dthip_result** out) {
   DTHIP_TRY(check_common(ctx, nrows, mem));
   if (!keys || !out) { set_error("null argument"); return DTHIP_EINVAL; }
+  const bool remove_na = na_pos == DTHIP_NA_REMOVE;
+  if (remove_na) {
+    if (nkeys != 1) { set_error("na_pos REMOVE takes one key column (as the reference's sort(na_position='remove'))"); return DTHIP_ENOTIMPL; }
+    na_pos = DTHIP_NA_FIRST;      // sorted first, then cut off the front (sort.cc:598-608)
+  }
   if (na_pos != DTHIP_NA_FIRST && na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", na_pos); return DTHIP_ENOTIMPL; }
   dthip_result* res = new dthip_result();
   res->nkeys = nkeys;
@@ -919,6 +924,24 @@ int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrow
             // the ordering may alias nothing user-owned here: it is always a scratch buffer
             result_adopt(sc, res, g.rowindex);
             res->rowindex = g.rowindex;
+          }
+          if (remove_na) {
+            // NA transforms to 0 and nothing else does: the first group is the NA group iff its key is 0
+            unsigned long long k0 = 0;
+            rc = read_back(ctx, &k0, g.sorted_keys, g.key64 ? 8 : 4);
+            int32_t first_end = 0;
+            if (rc == DTHIP_OK) rc = read_back(ctx, &first_end, g.offsets + 1, sizeof(int32_t));
+            if (rc == DTHIP_OK && k0 == 0) {
+              void* off2 = nullptr;
+              rc = result_alloc(ctx, res, sizeof(int32_t) * (size_t)g.ngroups, &off2);
+              if (rc == DTHIP_OK) rc = launch_offsets_drop_first(ctx, g.offsets, static_cast<int32_t*>(off2), g.ngroups - 1, first_end);
+              if (rc == DTHIP_OK) {
+                res->offsets = static_cast<int32_t*>(off2);
+                res->ngroups = g.ngroups - 1;
+                res->nrows = nrows - first_end;
+                if (res->rowindex) res->rowindex += first_end;
+              }
+            }
           }
         }
       }

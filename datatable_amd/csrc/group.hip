@@ -238,6 +238,18 @@ int launch_bitmap_from_offsets(dthip_ctx* ctx, const int32_t* offsets, int64_t n
   return DTHIP_OK;
 }
 
+// NaPosition::REMOVE (sort.cc:598-608): the NA group sorted first is cut off the front
+__global__ void __launch_bounds__(256) offsets_drop_first_kernel(const int32_t* in, int32_t* out, uint32_t ng_out, int32_t skip) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g <= ng_out) out[g] = in[g + 1] - skip;
+}
+
+int launch_offsets_drop_first(dthip_ctx* ctx, const int32_t* in, int32_t* out, int64_t ng_out, int32_t skip) {
+  DTHIP_LAUNCH(ctx, "offsets_drop_first_kernel", offsets_drop_first_kernel, (unsigned)((ng_out + 256) / 256), 256, 0,
+               in, out, (uint32_t)ng_out, skip);
+  return DTHIP_OK;
+}
+
 __global__ void __launch_bounds__(256) iota_kernel(int32_t* out, uint32_t n) {
   const uint32_t stride = gridDim.x * 256;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = (int32_t)i;

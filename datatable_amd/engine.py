@@ -221,12 +221,13 @@ class Context:
         return [s for s in buf.value.decode().split("\n") if s]
 
     # ---- S-grp ------------------------------------------------------------
-    def groupby(self, keys, nrows=None, stypes=None, desc=None, na_last=False, want_rowindex=True):
+    def groupby(self, keys, nrows=None, stypes=None, desc=None, na_last=False, want_rowindex=True, na_remove=False):
         arr, mem, keep = _cols(keys, stypes, desc)
         if nrows is None:
             nrows = len(keep[0])
         h = C.c_void_p()
-        L.check(self._lib.dthip_groupby(self._h, arr, len(keys), nrows, L.NA_LAST if na_last else L.NA_FIRST, mem,
+        napos = L.NA_REMOVE if na_remove else (L.NA_LAST if na_last else L.NA_FIRST)
+        L.check(self._lib.dthip_groupby(self._h, arr, len(keys), nrows, napos, mem,
                                         1 if want_rowindex else 0, C.byref(h)))
         return Result(self, h, [arr[i].stype for i in range(len(keys))], 0)
 

@@ -112,9 +112,10 @@ class sort:
             cols = tuple(cols[0])
         self.cols = [c if isinstance(c, ColRef) else ColRef(c) for c in cols]
         self.reverse = [bool(reverse)] * len(self.cols) if not isinstance(reverse, (list, tuple)) else list(reverse)
-        if na_position not in ("first", "last"):
-            raise NotImplementedError("na_position=%r is not implemented (first/last are)" % (na_position,))
+        if na_position not in ("first", "last", "remove"):
+            raise ValueError("na position value %s is not supported" % (na_position,))     # py_sort.cc's message
         self.na_last = na_position == "last"
+        self.na_remove = na_position == "remove"
 
 
 def _reducer(op):
@@ -354,7 +355,8 @@ class Frame:
         ctx = self._context()
         idx = [self._index(c) for c in s.cols]
         keys = [self._materialized(k) for k in idx]
-        r = ctx.groupby(keys, stypes=[self._stypes[k] for k in idx], desc=s.reverse, na_last=s.na_last)
+        r = ctx.groupby(keys, stypes=[self._stypes[k] for k in idx], desc=s.reverse, na_last=s.na_last,
+                        na_remove=s.na_remove)
         ri = r.rowindex()
         r.free()
         fr = Frame(self)

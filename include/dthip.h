@@ -72,8 +72,9 @@ enum dthip_op {
 
 enum dthip_mem { DTHIP_HOST = 0, DTHIP_DEVICE = 1 };
 
-/* NaPosition, src/core/sort.h:46-50 (REMOVE is not implemented) */
-enum dthip_napos { DTHIP_NA_FIRST = 0, DTHIP_NA_LAST = 1 };
+/* NaPosition, src/core/sort.h:46-50.  REMOVE: dthip_groupby with one key only (the reference's
+ * sort(na_position="remove")): rows whose key is NA are left out of the RowIndex and the groups */
+enum dthip_napos { DTHIP_NA_FIRST = 0, DTHIP_NA_LAST = 1, DTHIP_NA_REMOVE = 2 };
 
 /* SortFlag bits, src/core/sort.h:36-44 */
 #define DTHIP_FLAG_DESCENDING 1

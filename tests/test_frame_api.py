@@ -105,6 +105,31 @@ def test_sort(dt):
     assert DT[:, f.i, dt.sort(f.v)].to_list() == [[2, 4, 0, 1, 3, 5, 6, 7]]
 
 
+@pytest.mark.parametrize("rev", [True, False])
+@pytest.mark.parametrize("napos", ["first", "last", "remove"])
+@pytest.mark.parametrize("src", [[-5, -8, None, None, 11, 2, 8, None, 4] * 1000,
+                                 [-5.9, None, -8.3, 11.5576, 2.2, 8.9, None, 4.1] * 1000,
+                                 [True, None, False, None, False, True] * 1000,
+                                 [0, 1, None, 2**31 - 1, None, -(2**31 - 1), None] * 1000,
+                                 [0, 1, None, 2**63 - 1, None, -(2**63 - 1), None] * 1000])
+def test_sort_na_position(dt, rev, napos, src):
+    """tests/ijby/test-sort.py:1080-1092 of the reference, same sources and same expectation"""
+    def key_func(x):
+        return (x is None) ^ rev ^ (napos == "first")
+    if napos == "remove":
+        exp = sorted([s for s in src if s is not None], reverse=rev)
+    else:
+        exp = sorted(src, key=lambda x: (key_func(x), x if x is not None else 0), reverse=rev)
+    DT = dt.Frame(A=src)
+    RES = DT[:, :, dt.sort(0, reverse=rev, na_position=napos)]
+    assert RES.to_list() == [exp]
+
+
+def test_na_position_value_error(dt):
+    with pytest.raises(ValueError, match="na position value las is not supported"):
+        dt.sort(0, reverse=True, na_position="las")
+
+
 def test_reducers_without_by(dt):
     f = dt.f
     DT = appendix_b(dt)
