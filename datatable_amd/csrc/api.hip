@@ -1276,6 +1276,21 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
   return DTHIP_OK;
 }
 
+int dthip_ungroup(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t nrows, int mem, int32_t* out) {
+  DTHIP_TRY(check_common(ctx, nrows, mem));
+  if (ngroups < 0 || ngroups > nrows) { set_error("ngroups=%lld inconsistent with nrows=%lld", (long long)ngroups, (long long)nrows); return DTHIP_EINVAL; }
+  if (nrows == 0) return DTHIP_OK;
+  if (!offsets || !out || ngroups == 0) { set_error("null argument"); return DTHIP_EINVAL; }
+  Scratch sc(ctx);
+  const void* d_off = nullptr;
+  DTHIP_TRY(stage_in(ctx, sc, offsets, sizeof(int32_t) * (size_t)(ngroups + 1), mem, &d_off));
+  int32_t* d_out = out;
+  if (mem == DTHIP_HOST) DTHIP_TRY(sc.get<int32_t>((size_t)nrows, &d_out));
+  DTHIP_TRY(launch_ungroup(ctx, static_cast<const int32_t*>(d_off), ngroups, nrows, d_out));
+  if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, sizeof(int32_t) * (size_t)nrows, mem));
+  return DTHIP_OK;
+}
+
 static int compact_common(dthip_ctx* ctx, const PredArgs& p0, size_t elem, int64_t n, int mem, int32_t* out, int64_t* nout) {
   DTHIP_TRY(check_common(ctx, n, mem));
   if (!nout || (n > 0 && (!p0.data || !out))) { set_error("null argument"); return DTHIP_EINVAL; }

@@ -238,6 +238,29 @@ int launch_bitmap_from_offsets(dthip_ctx* ctx, const int32_t* offsets, int64_t n
   return DTHIP_OK;
 }
 
+// Groupby::ungroup_rowindex (groupby.cc:117-130): out[i] = index of the group that sorted position i
+// belongs to (the reference expands the offsets serially; here every position searches them)
+__global__ void __launch_bounds__(256) ungroup_kernel(const int32_t* __restrict__ offsets, uint32_t ngroups, uint32_t n,
+                                                      int32_t* __restrict__ out) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    uint32_t lo = 0, hi = ngroups;               // largest g with offsets[g] <= i
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((uint32_t)offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    out[i] = (int32_t)lo;
+  }
+}
+
+int launch_ungroup(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int32_t* out) {
+  if (n == 0) return DTHIP_OK;
+  long long blocks = (n + 2047) / 2048;
+  if (blocks > ctx->num_cus * 8) blocks = ctx->num_cus * 8;
+  DTHIP_LAUNCH(ctx, "ungroup_kernel", ungroup_kernel, (unsigned)blocks, 256, 0, offsets, (uint32_t)ngroups, (uint32_t)n, out);
+  return DTHIP_OK;
+}
+
 // NaPosition::REMOVE (sort.cc:598-608): the NA group sorted first is cut off the front
 __global__ void __launch_bounds__(256) offsets_drop_first_kernel(const int32_t* in, int32_t* out, uint32_t ng_out, int32_t skip) {
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;

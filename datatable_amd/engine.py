@@ -284,6 +284,16 @@ class Context:
                                        offsets.ctypes.data, ng, nrows, L.HOST, out.ctypes.data))
         return out
 
+    def ungroup(self, offsets):
+        """group index of every grouped position (Groupby::ungroup_rowindex)"""
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        ng = len(offsets) - 1
+        n = int(offsets[-1]) if ng >= 0 else 0
+        out = np.empty(n, np.int32)
+        if n:
+            L.check(self._lib.dthip_ungroup(self._h, offsets.ctypes.data, ng, n, L.HOST, out.ctypes.data))
+        return out
+
     # ---- RowIndex ---------------------------------------------------------
     def bool_to_rowindex(self, mask):
         m = np.ascontiguousarray(mask)

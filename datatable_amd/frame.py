@@ -27,7 +27,7 @@ import builtins
 import numpy as np
 
 from . import _lib as L
-from .engine import NP2ST, ST2NP, default_context
+from .engine import NP2ST, OPS as L_OPS, ST2NP, default_context
 
 __all__ = ["Frame", "f", "by", "sort", "sum", "mean", "min", "max", "count"]
 
@@ -41,10 +41,14 @@ class FExpr:
 
 
 class ColRef(FExpr):
-    """f.name / f[i]  (src/core/expr/fexpr_column.cc)"""
+    """f.name / f[i]  (src/core/expr/fexpr_column.cc).  -f.name inside by()/sort() = descending."""
 
-    def __init__(self, ref):
+    def __init__(self, ref, desc=False):
         self.ref = ref
+        self.desc = desc
+
+    def __neg__(self):
+        return ColRef(self.ref, not self.desc)
 
     def _cmp(self, op, other):
         if isinstance(other, FExpr):
@@ -61,6 +65,13 @@ class ColRef(FExpr):
 
     def __repr__(self):
         return "FExpr<f.%s>" % self.ref if isinstance(self.ref, str) else "FExpr<f[%r]>" % (self.ref,)
+
+
+class AllCols(FExpr):
+    """f[:] -- every column that is not a by() column"""
+
+    def __repr__(self):
+        return "FExpr<f[:]>"
 
 
 class Filter(FExpr):
@@ -89,6 +100,8 @@ class _Namespace:
     def __getitem__(self, item):
         if isinstance(item, (str, int, np.integer)):
             return ColRef(item)
+        if isinstance(item, slice) and item == slice(None):
+            return AllCols()
         raise NotImplementedError("f[%r]: only single-column selectors are on the accelerated path" % (item,))
 
 
@@ -102,6 +115,8 @@ class by:
         if len(cols) == 1 and isinstance(cols[0], (list, tuple)):
             cols = tuple(cols[0])
         self.cols = [c if isinstance(c, ColRef) else ColRef(c) for c in cols]
+        if not self.cols:
+            raise ValueError("by() needs at least one column")
 
 
 class sort:
@@ -126,7 +141,7 @@ def _reducer(op):
             return Reducer("count0", None)
         if isinstance(arg, str):
             arg = ColRef(arg)
-        if not isinstance(arg, ColRef):
+        if not isinstance(arg, (ColRef, AllCols)):
             raise NotImplementedError("%s() of a computed expression is outside the accelerated path" % op)
         return Reducer(op, arg)
     fn.__name__ = op
@@ -307,11 +322,18 @@ class Frame:
             raise NotImplementedError("single-selector DT[x] is outside the accelerated path")
         i = item[0]
         j = item[1] if len(item) > 1 else slice(None)
-        rest = item[2:]
-        byx = [r for r in rest if isinstance(r, by)]
-        srt = [r for r in rest if isinstance(r, sort)]
-        if len(rest) != len(byx) + len(srt) or len(byx) > 1 or len(srt) > 1:
-            raise NotImplementedError("only by() and sort() modifiers are on the accelerated path")
+        byx, srt = None, None
+        for r in item[2:]:
+            if isinstance(r, sort):
+                if srt is not None:
+                    raise TypeError("Multiple sort()'s are not allowed")
+                srt = r
+            elif isinstance(r, (by, str, ColRef, list, tuple)):
+                if byx is not None:
+                    raise TypeError("Multiple by()'s are not allowed")
+                byx = r if isinstance(r, by) else by(r)      # DT[:, j, "A"] == DT[:, j, by("A")]
+            else:
+                raise NotImplementedError("modifier %r is outside the accelerated path" % (r,))
         all_rows = i is None or i is Ellipsis or (isinstance(i, slice) and i == slice(None))
         if isinstance(i, Filter):
             if byx or srt:
@@ -320,23 +342,21 @@ class Frame:
             return self._filter(i)._select(j)
         if not all_rows:
             raise NotImplementedError("row selector %r is outside the accelerated path" % (i,))
-        if byx:
-            if srt:
-                raise NotImplementedError("by() together with sort() is outside the accelerated path")
-            return self._groupby(j, byx[0])
-        if srt:
-            return self._sorted(srt[0])._select(j)
+        if byx is not None:
+            return self._groupby(j, byx, srt)
+        if srt is not None:
+            return self._sorted(srt)._select(j)
         return self._select(j)
 
     def _select(self, j):
         if j is None or j is Ellipsis or (isinstance(j, slice) and j == slice(None)):
             return self
-        refs = j if isinstance(j, (list, tuple)) else [j]
-        if any(isinstance(r, Reducer) for r in refs):
-            return self._groupby(refs, None)
-        idx = [self._index(r) for r in refs]
-        fr = Frame._from_columns([self._cols[k] for k in idx], [self._stypes[k] for k in idx],
-                                 [self._names[k] for k in idx])
+        items = list(j.values()) if isinstance(j, dict) else (list(j) if isinstance(j, (list, tuple)) else [j])
+        if any(isinstance(r, Reducer) for r in items):
+            return self._groupby(j, None, None)
+        idx = [self._index(r) for r in items]
+        names = list(j.keys()) if isinstance(j, dict) else [self._names[k] for k in idx]
+        fr = Frame._from_columns([self._cols[k] for k in idx], [self._stypes[k] for k in idx], names)
         fr._ri = self._ri
         return fr
 
@@ -367,52 +387,129 @@ class Frame:
         """Frame.sort(cols): ascending, NA first (src/core/sort.cc:539-558)"""
         return self._sorted(sort(*cols))
 
-    def _groupby(self, j, byx):
+    def _groupby(self, j, byx, srt):
+        """DT[:, j, by(...)[, sort(...)]]  (EvalContext::evaluate, src/core/expr/eval_context.cc:144-172,
+        249-288; evaluate_select :497-508).  The result has one row per group when every j item is a
+        reducer or a by-column (GtoONE), else one row per input row in grouped order with the reducers
+        broadcast (GtoALL, workframe.cc:384-390)."""
         ctx = self._context()
         if self.nrows > 2**31 - 1:
             raise ValueError("nrows > 2**31-1: RowIndex and group offsets are int32")
-        kidx = [self._index(c) for c in byx.cols] if byx is not None else []
+        bycols = byx.cols if byx is not None else []
+        kidx = [self._index(c) for c in bycols]
+        kdesc = [bool(c.desc) for c in bycols]
         keys = [self._materialized(k) for k in kidx]
         kst = [self._stypes[k] for k in kidx]
+        nonby = [c for c in range(self.ncols) if c not in kidx]
         sel_all = j is None or j is Ellipsis or (isinstance(j, slice) and j == slice(None))
-        refs = [] if sel_all else (list(j) if isinstance(j, (list, tuple)) else [j])
-        if isinstance(j, dict):
-            raise NotImplementedError("dict selectors are outside the accelerated path")
-        reducers = [r for r in refs if isinstance(r, Reducer)]
-        if reducers and len(reducers) != len(refs):
-            raise NotImplementedError("mixing reducers and plain columns in j is outside the accelerated path")
+        # j -> flat list of (name override, item); f[:] expands to the non-by columns
+        raw = [] if sel_all else (list(j.items()) if isinstance(j, dict) else
+                                  [(None, x) for x in (j if isinstance(j, (list, tuple)) else [j])])
+        items = []
+        for nm, x in raw:
+            if isinstance(x, AllCols):
+                items += [(None, ColRef(self._names[c])) for c in nonby]
+            elif isinstance(x, Reducer) and isinstance(x.arg, AllCols):
+                items += [(None, Reducer(x.op, ColRef(self._names[c]))) for c in nonby]
+            elif isinstance(x, (Reducer, ColRef, str, int, np.integer)):
+                items.append((nm, x if isinstance(x, (Reducer, ColRef)) else ColRef(x)))
+            else:
+                raise NotImplementedError("j item %r is outside the accelerated path" % (x,))
+        if sel_all:
+            items = [(None, ColRef(self._names[c])) for c in nonby]
+        reducers = [x for _, x in items if isinstance(x, Reducer)]
+        plain = [self._index(x) for _, x in items if isinstance(x, ColRef)]
+        bynames = [self._names[k] for k in kidx]
         if not kidx:
             # DT[:, sum(f.v)] without by(): one group over all rows
-            keys, kst = [np.zeros(self.nrows, np.int8)], [L.INT8]
-        if reducers:
+            keys, kst, kdesc = [np.zeros(self.nrows, np.int8)], [L.INT8], [False]
+
+        def item_name(nm, x):
+            if nm is not None:
+                return nm
+            if isinstance(x, Reducer):
+                return "count" if x.op == "count0" else self._names[self._index(x.arg)]
+            return self._names[self._index(x)]
+
+        names = bynames + [item_name(nm, x) for nm, x in items]
+        group_level = all(isinstance(x, Reducer) or self._index(x) in kidx for _, x in items) and not sel_all
+
+        if group_level and (reducers or not items):
+            # fused groupby-aggregate: one row per group
             vidx, aggs = [], []
-            for r in reducers:
-                if r.op == "count0":
+            for x in reducers:
+                if x.op == "count0":
                     aggs.append(("count0", None)); continue
-                ci = self._index(r.arg)
+                ci = self._index(x.arg)
                 if ci not in vidx:
                     vidx.append(ci)
-                aggs.append((r.op, vidx.index(ci)))
+                aggs.append((x.op, vidx.index(ci)))
             vals = [self._materialized(c) for c in vidx]
-            res = ctx.groupby_agg(keys, vals, aggs, key_stypes=kst, value_stypes=[self._stypes[c] for c in vidx])
-            cols = [res.key(k) for k in range(len(kidx))]
-            sts = list(kst[:len(kidx)])
-            names = [self._names[k] for k in kidx]
-            for a, r in enumerate(reducers):
-                cols.append(res.agg(a)); sts.append(res.agg_stype(a))
-                names.append("count" if r.op == "count0" else self._names[self._index(r.arg)])
+            res = ctx.groupby_agg(keys, vals, aggs, key_stypes=kst, value_stypes=[self._stypes[c] for c in vidx], desc=kdesc)
+            kcols = [res.key(k) for k in range(len(kidx))]
+            cols, sts, a = list(kcols), list(kst[:len(kidx)]), 0
+            for _, x in items:
+                if isinstance(x, Reducer):
+                    cols.append(res.agg(a)); sts.append(res.agg_stype(a)); a += 1
+                else:
+                    k = kidx.index(self._index(x))
+                    cols.append(kcols[k]); sts.append(kst[k])
             res.free()
             return Frame._from_columns(cols, sts, names)
-        # rows in grouped order: by-columns first, then the selected (or all remaining) columns
-        res = ctx.groupby(keys, stypes=kst)
+
+        # the ordering: by-columns, then (inside groups) the sort() columns
+        skeys, sst, sdesc, na_last = list(keys), list(kst), list(kdesc), False
+        if srt is not None:
+            for c, rev in zip(srt.cols, srt.reverse):
+                ci = self._index(c)
+                skeys.append(self._materialized(ci)); sst.append(self._stypes[ci]); sdesc.append(bool(rev) ^ bool(c.desc))
+            na_last = srt.na_last
+        res = ctx.groupby(skeys, stypes=sst, desc=sdesc, na_last=na_last)
         ri = res.rowindex()
         res.free()
-        rest = [self._index(r) for r in refs] if refs else [c for c in range(self.ncols) if c not in kidx]
-        order = kidx + rest
-        fr = Frame._from_columns([self._cols[c] for c in order], [self._stypes[c] for c in order],
-                                 [self._names[c] for c in order])
-        fr._ri = ri if self._ri is None else ctx.gather(self._ri, ri)
-        return fr
+        full_ri = ri if self._ri is None else ctx.gather(self._ri, ri)
+
+        if group_level:
+            # only by-columns selected: their value at the first row of each group (eval_context.cc:473-485)
+            g = ctx.groupby(keys, stypes=kst, desc=kdesc)
+            first = ctx.gather(g.rowindex(), g.offsets()[:-1])
+            g.free()
+            kcols = [ctx.gather(keys[k], first, stype=kst[k]) for k in range(len(kidx))]
+            cols = list(kcols) + [kcols[kidx.index(self._index(x))] for _, x in items]
+            sts = list(kst) + [kst[kidx.index(self._index(x))] for _, x in items]
+            return Frame._from_columns(cols, sts, names)
+
+        if not reducers:
+            # rows in grouped order: by-columns first, then the selected columns (a view, like the reference)
+            order = kidx + plain
+            fr = Frame._from_columns([self._cols[c] for c in order], [self._stypes[c] for c in order], names)
+            fr._ri = full_ri
+            return fr
+
+        # reducers next to plain columns: the reducers are evaluated per group (S-red seam) and
+        # broadcast back to the rows of their group
+        g = ctx.groupby(keys, stypes=kst, desc=kdesc)
+        gri, goff = g.rowindex(), g.offsets()
+        g.free()
+        # output row i belongs to group ungroup(offsets)[i]: a sort() inside the groups permutes rows
+        # within their group only (the by-columns are the leading sort keys)
+        bcast = ctx.ungroup(goff)
+        cols = [ctx.gather(keys[k], ri, stype=kst[k]) for k in range(len(kidx))]
+        sts = list(kst[:len(kidx)])
+        for _, x in items:
+            if isinstance(x, Reducer):
+                if x.op == "count0":
+                    red = ctx.reduce("count0", None, None, goff)
+                    st = L.INT64
+                else:
+                    ci = self._index(x.arg)
+                    red = ctx.reduce(x.op, self._materialized(ci), gri, goff, stype=self._stypes[ci])
+                    st = ctx._lib.dthip_reduce_out_stype(L_OPS[x.op], self._stypes[ci])
+                cols.append(ctx.gather(red, bcast, stype=st)); sts.append(st)
+            else:
+                ci = self._index(x)
+                cols.append(ctx.gather(self._materialized(ci), ri, stype=self._stypes[ci])); sts.append(self._stypes[ci])
+        return Frame._from_columns(cols, sts, names)
 
 
 def _unused():   # keep flake-style tools quiet about the shadowed builtins being intentional

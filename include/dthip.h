@@ -203,6 +203,12 @@ int  dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value,
                   const int32_t* rowindex, const int32_t* offsets,
                   int64_t ngroups, int64_t nrows, int mem, void* out);
 
+/* Groupby::ungroup_rowindex (src/core/groupby.cc:117-130): out[i] = g for every i in
+ * [offsets[g], offsets[g+1]) -- broadcasts one-value-per-group columns back to rows (GtoALL,
+ * src/core/expr/workframe.cc:384-390) when composed with dthip_gather */
+int  dthip_ungroup(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t nrows,
+                   int mem, int32_t* out);
+
 /* ---- RowIndex construction / application ---------------------------------- */
 /* ascending ARR32 of rows whose mask is 1 and not NA; out has room for n */
 int  dthip_bool_to_rowindex(dthip_ctx* ctx, const int8_t* mask, int64_t n, int mem,
