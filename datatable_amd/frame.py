@@ -420,9 +420,6 @@ class Frame:
         reducers = [x for _, x in items if isinstance(x, Reducer)]
         plain = [self._index(x) for _, x in items if isinstance(x, ColRef)]
         bynames = [self._names[k] for k in kidx]
-        if not kidx:
-            # DT[:, sum(f.v)] without by(): one group over all rows
-            keys, kst, kdesc = [np.zeros(self.nrows, np.int8)], [L.INT8], [False]
 
         def item_name(nm, x):
             if nm is not None:
@@ -430,6 +427,22 @@ class Frame:
             if isinstance(x, Reducer):
                 return "count" if x.op == "count0" else self._names[self._index(x.arg)]
             return self._names[self._index(x)]
+
+        if not kidx:
+            # DT[:, sum(f.v)] without by(): one group over all rows
+            keys, kst, kdesc = [np.zeros(self.nrows, np.int8)], [L.INT8], [False]
+            if self.nrows == 0 and reducers and len(reducers) == len(items):
+                # a reducer over an empty frame still yields one row (reduce_unary.h): sum/count 0, else NA
+                cols, sts = [], []
+                for x in reducers:
+                    st = L.INT64 if x.op == "count0" else ctx._lib.dthip_reduce_out_stype(L_OPS[x.op], self._stypes[self._index(x.arg)])
+                    dtp = ST2NP[st]
+                    if x.op in ("sum", "count", "count0"):
+                        cols.append(np.zeros(1, dtp))
+                    else:
+                        cols.append(np.full(1, np.nan if dtp.kind == "f" else _NA_INT[dtp.itemsize], dtp))
+                    sts.append(st)
+                return Frame._from_columns(cols, sts, [item_name(nm, x) for nm, x in items])
 
         names = bynames + [item_name(nm, x) for nm, x in items]
         group_level = all(isinstance(x, Reducer) or self._index(x) in kidx for _, x in items) and not sel_all

@@ -179,3 +179,128 @@ def test_groups_large1(dt):                              # test-groups.py:318-32
     f0 = dt.Frame({"A": xs})
     f1 = f0[:, dt.count(), dt.by("A")]
     assert f1.to_list() == [list(range(251)), [4000] * 251]
+
+
+# ---- tests/test-reduce.py -------------------------------------------------------------------
+
+SRC_I = [9, 8, 2, 3, None, None, 3, 0, 5, 5, 8, None, 1]
+SRC_J = [0, 1, 0, 5, 3, 8, 1, 0, 2, 5, None, 8, 1]
+INT_STYPES = [2, 3, 4, 5]            # int8, int16, int32, int64
+REAL_STYPES = [6, 7]
+
+
+def test_count_dt_integer(dt):                           # test-reduce.py:75-81
+    f = dt.f
+    df_in = dt.Frame([SRC_I])
+    df_reduce = df_in[:, [dt.count(f.C0), dt.count()]]
+    assert df_reduce.shape == (1, 2)
+    assert df_reduce.to_list() == [[10], [13]]
+
+
+def test_count_dt_groupby_integer(dt):                   # test-reduce.py:84-92
+    f = dt.f
+    df_in = dt.Frame([SRC_I])
+    df_reduce = df_in[:, [dt.count(f.C0), dt.count()], "C0"]
+    assert df_reduce.shape == (8, 3)
+    assert df_reduce.to_list() == [[None, 0, 1, 2, 3, 5, 8, 9], [0, 1, 1, 1, 2, 2, 2, 1], [3, 1, 1, 1, 2, 2, 2, 1]]
+
+
+def test_count_2d_dt_integer(dt):                        # test-reduce.py:102-110
+    f = dt.f
+    df_in = dt.Frame([SRC_I, SRC_J])
+    df_reduce = df_in[:, [dt.count(f.C0), dt.count(f.C1), dt.count()]]
+    assert df_reduce.shape == (1, 3)
+    assert df_reduce.to_list() == [[10], [12], [13]]
+
+
+def test_count_2d_dt_groupby_integer(dt):                # test-reduce.py:113-123
+    f = dt.f
+    df_in = dt.Frame([SRC_I, SRC_J])
+    df_reduce = df_in[:, [dt.count(f.C0), dt.count(f.C1), dt.count()], "C0"]
+    assert df_reduce.shape == (8, 4)
+    assert df_reduce.to_list() == [[None, 0, 1, 2, 3, 5, 8, 9], [0, 1, 1, 1, 2, 2, 2, 1], [3, 1, 1, 1, 2, 2, 1, 1],
+                                   [3, 1, 1, 1, 2, 2, 2, 1]]
+
+
+@pytest.mark.parametrize("mm", ["min", "max"])
+@pytest.mark.parametrize("st", INT_STYPES)
+def test_minmax_integer(dt, mm, st):                     # test-reduce.py:286-291
+    src = [0, 23, 100, 99, -11, 24, -1]
+    DT = dt.Frame(A=src, stypes={"A": st})
+    assert DT[:, getattr(dt, mm)(dt.f.A)].to_list() == [[{"min": min, "max": max}[mm](src)]]
+
+
+@pytest.mark.parametrize("mm", ["min", "max"])
+@pytest.mark.parametrize("st", INT_STYPES)
+def test_minmax_integer_grouped(dt, mm, st):             # test-reduce.py:294-299
+    src = [3, 2, 2, 2, 2, 3, -100, 15, -100]
+    DT = dt.Frame(A=src, stypes={"A": st})
+    assert DT[:, getattr(dt, mm)(dt.f.A), dt.by(dt.f.A)].to_list() == [[-100, 2, 3, 15]] * 2
+
+
+@pytest.mark.parametrize("mm", ["min", "max"])
+def test_minmax_real(dt, mm):                            # test-reduce.py:302-306
+    src = [5.6, 12.99, 1e+12, -3.4e-22, math.nan, 0.0]
+    pm = {"min": min, "max": max}[mm]
+    DT = dt.Frame(A=src)
+    assert DT[:, getattr(dt, mm)(dt.f.A)].to_list() == [[pm(x for x in src if x == x)]]
+
+
+@pytest.mark.parametrize("mm", ["min", "max"])
+def test_minmax_infs(dt, mm):                            # test-reduce.py:309-314
+    src = [math.nan, 1.0, 2.5, -math.inf, 3e199, math.inf]
+    answer = -math.inf if mm == "min" else +math.inf
+    assert dt.Frame(A=src)[:, getattr(dt, mm)(dt.f.A)].to_list() == [[answer]]
+
+
+@pytest.mark.parametrize("mm", ["min", "max"])
+@pytest.mark.parametrize("src", [[math.inf], [-math.inf]])
+def test_minmax_infs_only(dt, mm, src):                  # test-reduce.py:317-321
+    assert dt.Frame(A=src)[:, getattr(dt, mm)(dt.f.A)].to_list() == [src]
+
+
+@pytest.mark.parametrize("mm", ["min", "max"])
+@pytest.mark.parametrize("st", INT_STYPES + REAL_STYPES)
+def test_minmax_empty(dt, mm, st):                       # test-reduce.py:324-328
+    DT1 = dt.Frame(A=[], stypes={"A": st})
+    assert DT1[:, getattr(dt, mm)(dt.f.A)].to_list() == [[None]]
+
+
+@pytest.mark.parametrize("mm", ["min", "max"])
+@pytest.mark.parametrize("st", INT_STYPES + REAL_STYPES)
+def test_minmax_nas(dt, mm, st):                         # test-reduce.py:331-335
+    DT2 = dt.Frame(B=[None] * 3, stypes={"B": st})
+    assert DT2[:, getattr(dt, mm)(dt.f.B)].to_list() == [[None]]
+
+
+def test_sum_void_like(dt):                              # test-reduce.py:405-423 (void column -> all-NA int32)
+    f = dt.f
+    DT = dt.Frame([[None] * 10])
+    assert_equals(DT[:, dt.sum(f.C0)], dt.Frame([[0]], stypes=[5]))
+    DT = dt.Frame([[None, None, None, None, None], [1, 2, 1, 2, 2]])
+    assert_equals(DT[:, dt.sum(f.C0), dt.by(f.C1)], dt.Frame(dict(C1=[1, 2], C0=[0, 0]), stypes={"C0": 5}))
+    R = DT[:, dt.sum(f.C0), dt.by(f.C0)]
+    assert R.to_list() == [[None], [0]] and R.stypes == (4, 5)
+
+
+def test_sum_simple(dt):                                 # test-reduce.py:426-432
+    DT = dt.Frame(A=list(range(5)))
+    assert DT[:, dt.sum(dt.f.A)].to_list() == [[10]]
+
+
+def test_sum_empty_frame(dt):                            # test-reduce.py:435-447 (void column left out)
+    f = dt.f
+    DT = dt.Frame([[], [], [], []], names=list("ABCD"), stypes=[1, 4, 6, 7])
+    assert DT.shape == (0, 4)
+    DT_sum = DT[:, dt.sum(f[:])]
+    assert DT_sum.shape == (1, 4)
+    assert DT_sum.names == ("A", "B", "C", "D")
+    assert DT_sum.stypes == (5, 5, 6, 7)
+    assert DT_sum.to_list() == [[0], [0], [0], [0]]
+
+
+def test_sum_grouped(dt):                                # test-reduce.py:450-457
+    f = dt.f
+    DT = dt.Frame(A=[True, False, True, True], B=[None, None, None, 10], C=[2, 3, 5, -5])
+    DT_sum = DT[:, dt.sum(f[:]), dt.by(f.A)]
+    assert_equals(DT_sum, dt.Frame(dict(A=[False, True], B=[0, 10], C=[3, 2]), stypes={"B": 5, "C": 5}))
