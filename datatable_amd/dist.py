@@ -34,7 +34,7 @@ class HipBackend:
 
     def groupby_agg(self, keys, values, aggs):
         from .torch_bridge import groupby_agg_tensors
-        _, gk, out = groupby_agg_tensors(self.ctx, keys, values, aggs)
+        _, gk, out = groupby_agg_tensors(self.ctx, keys, values, aggs, want_offsets=False)
         return gk, out
 
 
@@ -99,27 +99,33 @@ def sharded_groupby_agg(backend, keys, values, aggs, group=None):
             merge_ops.append(op)
         cols.append(p)
 
-    # global key range of the first key (valid keys only; NA sentinel = dtype min sorts first)
+    # global key range of the first key (valid keys only).  The local group keys are ascending with the
+    # NA group (sentinel = dtype min) first, so the range is read off three elements: one host sync.
     k0 = gk[0].to(torch.int64)
     na = torch.iinfo(gk[0].dtype).min
-    valid = k0[gk[0] != na] if k0.numel() else k0
     big = torch.iinfo(torch.int64)
-    lo = int(valid[0].item()) if valid.numel() else big.max
-    neg_hi = -int(valid[-1].item()) if valid.numel() else big.max
+    nk = k0.numel()
+    lo, neg_hi = big.max, big.max
+    if nk:
+        probe = k0[torch.tensor([0, min(1, nk - 1), nk - 1], device=dev)].tolist()
+        first_valid = probe[0] if probe[0] != na else (probe[1] if nk > 1 else None)
+        if first_valid is not None and first_valid != na:
+            lo, neg_hi = int(first_valid), -int(probe[2])
     mm = torch.tensor([lo, neg_hi], dtype=torch.int64, device=dev)
     dist.all_reduce(mm, op=dist.ReduceOp.MIN, group=group)
-    gmin, gmax = int(mm[0].item()), -int(mm[1].item())
+    gmin, neg = mm.tolist()
+    gmax = -neg
     if gmin > gmax:                       # no valid key anywhere: everything (NA groups) goes to rank 0
         gmin, gmax = 0, 0
     bounds = torch.tensor(range_boundaries(gmin, gmax, world), dtype=torch.int64, device=dev)
     # NA rows (sentinel) must land on rank 0: the sentinel is below every boundary
     cut = torch.searchsorted(k0.contiguous(), bounds) if world > 1 else bounds
     edges = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), cut.to(torch.int64),
-                       torch.tensor([k0.numel()], dtype=torch.int64, device=dev)])
+                       torch.tensor([nk], dtype=torch.int64, device=dev)])
     send_counts = (edges[1:] - edges[:-1])
     recv_counts = torch.empty_like(send_counts)
     dist.all_to_all_single(recv_counts, send_counts, group=group)
-    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    sc, rc = torch.stack([send_counts, recv_counts]).tolist()
 
     rk = [_all_to_all_v(k, sc, rc, group) for k in gk]
     rp = [_all_to_all_v(c, sc, rc, group) for c in cols]

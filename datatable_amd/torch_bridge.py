@@ -24,16 +24,22 @@ def devcol(t, desc=False):
     return DevCol(t.data_ptr(), T2ST[t.dtype], desc, keepalive=t)
 
 
-def groupby_agg_tensors(ctx, keys, values, aggs, na_last=False):
-    """keys/values: CUDA tensors.  Returns (offsets, [group key tensors], [agg tensors])."""
+def groupby_agg_tensors(ctx, keys, values, aggs, na_last=False, want_offsets=True):
+    """keys/values: CUDA tensors.  Returns (offsets or None, [group key tensors], [agg tensors])."""
     n = keys[0].numel()
     # the context may launch on its own (non-blocking) stream: order it after torch's producers ...
     torch.cuda.current_stream(keys[0].device).synchronize()
-    r = ctx.groupby_agg([devcol(k) for k in keys], [devcol(v) for v in values], aggs, nrows=n, na_last=na_last)
+    ctx.set_option("agg_offsets", 1 if want_offsets else 0)
+    try:
+        r = ctx.groupby_agg([devcol(k) for k in keys], [devcol(v) for v in values], aggs, nrows=n, na_last=na_last)
+    finally:
+        ctx.set_option("agg_offsets", 1)
     ng = r.ngroups
     dev = keys[0].device
-    off = torch.empty(ng + 1, dtype=torch.int32, device=dev)
-    r.offsets_into(off.data_ptr())
+    off = None
+    if want_offsets:
+        off = torch.empty(ng + 1, dtype=torch.int32, device=dev)
+        r.offsets_into(off.data_ptr())
     gk = []
     for i, k in enumerate(keys):
         t = torch.empty(ng, dtype=ST2T[T2ST[k.dtype]], device=dev)

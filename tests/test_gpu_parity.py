@@ -368,3 +368,58 @@ def test_full_size_properties_1e8(ctx):
     assert np.all(mn <= mx) and mn.min() == v.min() and mx.max() == v.max()
     ref = np.bincount(k, weights=v, minlength=keys.max() + 1)[keys]
     assert_close(s, ref, scale=np.bincount(k, weights=np.abs(v))[keys], rel=1e-6, what="sum vs bincount")
+
+
+def test_full_size_properties_config4_shape(ctx):
+    """5e7 rows of BASELINE config 4 (two int32 keys, count + sum) on the bucketed path: the composite
+    key packs into 24 bits; group keys ascending in (a, b), counts == bincount of the packed key,
+    sum of sums == total, and the sort path returns the very same groups."""
+    rng = np.random.default_rng(44)
+    n = 50_000_000
+    a = rng.integers(0, 3163, n, dtype=np.int32)
+    b = rng.integers(0, 3163, n, dtype=np.int32)
+    v = rng.standard_normal(n)
+    r = ctx.groupby_agg([a, b], [v], [("count0", None), ("sum", 0)])
+    ka, kb, c, s = r.key(0), r.key(1), r.agg(0), r.agg(1)
+    r.free()
+    packed = ka.astype(np.int64) * 3163 + kb
+    assert np.all(np.diff(packed) > 0)
+    ref = np.bincount(a.astype(np.int64) * 3163 + b, minlength=3163 * 3163)
+    assert c.sum() == n and np.array_equal(c, ref[packed])
+    assert abs(s.sum() - v.sum()) <= 1e-9 * np.abs(v).sum()
+    ctx.set_option("agg_path", 1)
+    try:
+        r2 = ctx.groupby_agg([a, b], [v], [("count0", None), ("sum", 0)])
+    finally:
+        ctx.set_option("agg_path", 0)
+    assert_same(r2.key(0), ka, "key a, sort path"); assert_same(r2.key(1), kb, "key b, sort path")
+    assert_same(r2.agg(0), c, "count(), sort path")
+    absum = np.bincount(a.astype(np.int64) * 3163 + b, weights=np.abs(v), minlength=3163 * 3163)[packed]
+    assert_close(r2.agg(1), s, scale=absum, rel=1e-6, what="sum, sort path vs bucketed path")
+    r2.free()
+
+
+def test_full_size_properties_config5_shape(ctx):
+    """4e7 rows of BASELINE config 5: V = DT[f.x > 0, :]; V[:, :, by(f.k)] with 4e6 groups --
+    filter RowIndex ascending and complete, rows of the result in grouped order (keys non-decreasing,
+    original row order inside a group), every passing row exactly once, values follow their rows."""
+    rng = np.random.default_rng(55)
+    n = 40_000_000
+    k = rng.integers(0, 4_000_000, n, dtype=np.int64)
+    x = rng.standard_normal(n)
+    ri_f = ctx.filter_cmp(x, ">", 0.0)
+    assert np.array_equal(ri_f, np.nonzero(x > 0)[0].astype(np.int32))
+    kv, xv = ctx.gather(k, ri_f), ctx.gather(x, ri_f)
+    assert np.array_equal(kv, k[ri_f]) and np.array_equal(xv, x[ri_f])
+    r = ctx.groupby_rows([kv], [kv, xv, ri_f])
+    ko, xo, rio, off = r.col(0), r.col(1), r.col(2), r.offsets()
+    ri = r.rowindex()
+    r.free()
+    assert np.all(np.diff(ko) >= 0)
+    assert np.array_equal(np.sort(rio), ri_f)                  # a permutation of the passing rows
+    assert np.array_equal(ko, k[rio]) and np.array_equal(xo, x[rio])
+    same = ko[1:] == ko[:-1]
+    assert np.all(rio[1:][same] > rio[:-1][same])              # stable inside a group
+    heads = np.concatenate([[0], np.nonzero(~same)[0] + 1, [len(ko)]]).astype(np.int32)
+    assert np.array_equal(off, heads)
+    assert np.array_equal(rio, ri_f[ri])
