@@ -70,6 +70,16 @@ def main():
                 r = ctx.groupby_agg([devcol(a), devcol(b)], [devcol(v)], [("count0", None), ("sum", 0)], nrows=n)
                 ng = r.ngroups; r.free(); return ng
             alg = n * 16
+        elif c == 6:
+            # hard-keys variant of C3: full-range int64 keys drawn from a pool of 1e7 values
+            n = int(1e9 * args.scale)
+            pool = torch.randint(-2**62, 2**62, (10_000_000,), dtype=torch.int64, device=dev, generator=g)
+            k = pool[torch.randint(0, 10_000_000, (n,), dtype=torch.int64, device=dev, generator=g)]
+            del pool
+            v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            def run():
+                r = ctx.groupby_agg([devcol(k)], [devcol(v)], [("sum", 0)], nrows=n); ng = r.ngroups; r.free(); return ng
+            alg = n * 16
         else:
             n = int(1e9 * args.scale)
             k = torch.randint(0, 100_000_000, (n,), dtype=torch.int64, device=dev, generator=g)

@@ -265,6 +265,37 @@ def test_descending_and_na_last(ctx):
         r.free()
 
 
+def test_fused_agg_descending_and_na_last(ctx):
+    """by(-f.k) / NA-last on every path of dthip_groupby_agg (the bucketed path inverts the same
+    transform: edge = max, NA -> range+1)"""
+    rng = np.random.default_rng(43)
+    n = 80_000
+    k = rng.integers(-1000, 1000, n).astype(np.int32)
+    k[rng.random(n) < 0.1] = -2**31
+    k2 = rng.integers(0, 40, n).astype(np.int64)
+    v = rng.standard_normal(n)
+    iv = rng.integers(-50, 50, n).astype(np.int64)
+    for keys, desc, na_last in (([k], [True], False), ([k], [False], True), ([k], [True], True),
+                                ([k2, k], [True, False], False), ([k, k2], [False, True], True)):
+        ri, off = o.group(keys, desc=desc, na_last=na_last)
+        aggs = [("sum", 0), ("min", 0), ("max", 1), ("count", 1), ("count0", None)]
+        exp = [o.reduce(op, (v, iv)[c], ri, off) for op, c in aggs[:-1]]
+        for path in AGG_PATHS:
+            ctx.set_option("agg_path", path)
+            try:
+                r = ctx.groupby_agg(keys, [v, iv], aggs, desc=desc, na_last=na_last)
+            finally:
+                ctx.set_option("agg_path", 0)
+            tag = " desc=%s na_last=%s path=%d" % (desc, na_last, path)
+            assert_same(r.offsets(), off, "offsets" + tag)
+            for i, kk in enumerate(keys):
+                assert_same(r.key(i), kk[ri[off[:-1]]], "key %d%s" % (i, tag))
+            for a, (op, c) in enumerate(aggs[:-1]):
+                check_agg(r.agg(a), exp[a], op, (v, iv)[c], ri, off, "%s%s" % (op, tag))
+            assert_same(r.agg(4), np.diff(off).astype(np.int64), "count()" + tag)
+            r.free()
+
+
 def test_bool_mask_to_rowindex(ctx):
     rng = np.random.default_rng(51)
     for n in (0, 1, 100, 5000, 300_001):
