@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libdthip.so")
 
 # stype codes == the reference's SType values (src/core/stype.h:41-62)
 BOOL, INT8, INT16, INT32, INT64, FLOAT32, FLOAT64 = 1, 2, 3, 4, 5, 6, 7
-SUM, MEAN, MIN, MAX, COUNT, COUNT0 = 0, 1, 2, 3, 4, 5
+SUM, MEAN, MIN, MAX, COUNT, COUNT0, FIRST, LAST = 0, 1, 2, 3, 4, 5, 6, 7
 HOST, DEVICE = 0, 1
 NA_FIRST, NA_LAST, NA_REMOVE = 0, 1, 2
 FLAG_DESCENDING = 1

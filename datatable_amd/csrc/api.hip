@@ -1037,7 +1037,7 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
   if (!keys || !out || (naggs > 0 && !aggs) || (nvalues > 0 && !values)) { set_error("null argument"); return DTHIP_EINVAL; }
   if (na_pos != DTHIP_NA_FIRST && na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", na_pos); return DTHIP_ENOTIMPL; }
   for (int a = 0; a < naggs; a++) {
-    if (aggs[a].op < DTHIP_SUM || aggs[a].op > DTHIP_COUNT0) { set_error("bad reducer op %d", aggs[a].op); return DTHIP_EINVAL; }
+    if (aggs[a].op < DTHIP_SUM || aggs[a].op > DTHIP_LAST) { set_error("bad reducer op %d", aggs[a].op); return DTHIP_EINVAL; }
     if (aggs[a].op != DTHIP_COUNT0 && (aggs[a].col < 0 || aggs[a].col >= nvalues)) {
       set_error("agg %d refers to value column %d of %d", a, aggs[a].col, nvalues); return DTHIP_EINVAL;
     }
@@ -1061,6 +1061,7 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
       if (aggs[a].op != DTHIP_COUNT0 && std::find(used.begin(), used.end(), aggs[a].col) == used.end()) used.push_back(aggs[a].col);
     bool fused = (int)used.size() <= MAX_PAYCOLS;
     for (int c : used) if (stype_size(vd[c].stype) < 4) fused = false;
+    for (int a = 0; a < naggs; a++) if (aggs[a].op == DTHIP_FIRST || aggs[a].op == DTHIP_LAST) fused = false;   // need the row order
     KeyPlan plan; Grouping g;
     std::vector<const void*> sorted_val(nvalues, nullptr);
     const int32_t* gather_ri = nullptr;
@@ -1125,16 +1126,24 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
     for (int c : used) {
       ReduceOuts ro;
       std::vector<std::pair<int, int>> dups;   // (agg index, first agg index with same op)
-      int first_of_op[6] = {-1, -1, -1, -1, -1, -1};
+      int first_of_op[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+      bool any_seg = false;
       for (int a = 0; a < naggs; a++) {
         if (aggs[a].op == DTHIP_COUNT0 || aggs[a].col != c) continue;
+        if (aggs[a].op == DTHIP_FIRST || aggs[a].op == DTHIP_LAST) {
+          if ((rc = launch_firstlast(ctx, sorted_val[c], vd[c].stype, gather_ri, g.offsets, ng, aggs[a].op == DTHIP_LAST,
+                                     res->agg[a])) != DTHIP_OK) break;
+          continue;
+        }
         if (first_of_op[aggs[a].op] >= 0) { dups.push_back({a, first_of_op[aggs[a].op]}); continue; }
         first_of_op[aggs[a].op] = a;
+        any_seg = true;
         if ((rc = reduce_outs_for(aggs[a].op, res->agg[a], &ro)) != DTHIP_OK) break;
       }
       if (rc != DTHIP_OK) break;
-      rc = launch_reduce(ctx, sorted_val[c], vd[c].stype, gather_ri, reinterpret_cast<const uint8_t*>(g.bitmap),
-                         g.tile_first, nrows, ro);
+      if (any_seg)
+        rc = launch_reduce(ctx, sorted_val[c], vd[c].stype, gather_ri, reinterpret_cast<const uint8_t*>(g.bitmap),
+                           g.tile_first, nrows, ro);
       if (rc != DTHIP_OK) break;
       for (auto& d : dups) {
         if (hipMemcpyAsync(res->agg[d.first], res->agg[d.second], (size_t)ng * stype_size(res->agg_stype[d.first]),
@@ -1221,7 +1230,7 @@ int dthip_reduce_out_stype(int op, int st) {
   switch (op) {
     case DTHIP_SUM: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : st == DTHIP_FLOAT64 ? DTHIP_FLOAT64 : DTHIP_INT64;
     case DTHIP_MEAN: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : DTHIP_FLOAT64;
-    case DTHIP_MIN: case DTHIP_MAX: return st;
+    case DTHIP_MIN: case DTHIP_MAX: case DTHIP_FIRST: case DTHIP_LAST: return st;
     default: return DTHIP_INT64;
   }
 }
@@ -1232,7 +1241,7 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
   if (ngroups < 0 || ngroups > nrows) { set_error("ngroups=%lld inconsistent with nrows=%lld", (long long)ngroups, (long long)nrows); return DTHIP_EINVAL; }
   if (ngroups == 0) return DTHIP_OK;
   if (!offsets || !out) { set_error("null argument"); return DTHIP_EINVAL; }
-  if (op < DTHIP_SUM || op > DTHIP_COUNT0) { set_error("bad reducer op %d", op); return DTHIP_EINVAL; }
+  if (op < DTHIP_SUM || op > DTHIP_LAST) { set_error("bad reducer op %d", op); return DTHIP_EINVAL; }
   if (op != DTHIP_COUNT0 && (!value || !value->data)) { set_error("reducer needs a value column"); return DTHIP_EINVAL; }
   Scratch sc(ctx);
   const void* d_off = nullptr;
@@ -1259,6 +1268,12 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
       int64_t vrows = nrows;
       if (rowindex) { vrows = 0; for (int64_t i = 0; i < nrows; i++) if (rowindex[i] >= vrows) vrows = (int64_t)rowindex[i] + 1; }
       DTHIP_TRY(stage_in(ctx, sc, value->data, (size_t)vrows * sz, mem, &d_val));
+    }
+    if (op == DTHIP_FIRST || op == DTHIP_LAST) {
+      DTHIP_TRY(launch_firstlast(ctx, d_val, value->stype, static_cast<const int32_t*>(d_ri), static_cast<const int32_t*>(d_off),
+                                 ngroups, op == DTHIP_LAST, d_out));
+      if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, obytes, mem));
+      return DTHIP_OK;
     }
     unsigned long long* bitmap = nullptr;
     DTHIP_TRY(sc.get<unsigned long long>((size_t)((nrows + 63) / 64) + 1, &bitmap));

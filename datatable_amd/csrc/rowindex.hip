@@ -120,6 +120,47 @@ __global__ void __launch_bounds__(256) gather_kernel(const T* __restrict__ data,
   }
 }
 
+// first(A) / last(A): the element at the first / last grouped position of every group, NA included
+// (FirstLast_ColumnImpl::_get, src/core/expr/head_reduce_unary.cc:116-160)
+template <typename T>
+__global__ void __launch_bounds__(256) firstlast_kernel(const T* __restrict__ data, const int32_t* __restrict__ ri,
+                                                        const int32_t* __restrict__ offsets, uint32_t ngroups, int last,
+                                                        T* __restrict__ out, T na) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const int32_t p = last ? offsets[g + 1] - 1 : offsets[g];
+  const int32_t r = ri ? ri[p] : p;
+  out[g] = r >= 0 ? data[r] : na;
+}
+
+int launch_firstlast(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, const int32_t* offsets,
+                     int64_t ngroups, int last, void* out) {
+  if (ngroups == 0) return DTHIP_OK;
+  const unsigned g = (unsigned)((ngroups + 255) / 256);
+  const uint32_t ng = (uint32_t)ngroups;
+  switch (stype_size(stype)) {
+    case 1:
+      DTHIP_LAUNCH(ctx, "firstlast_kernel", firstlast_kernel<uint8_t>, g, 256, 0, static_cast<const uint8_t*>(data), ri, offsets,
+                   ng, last, static_cast<uint8_t*>(out), (uint8_t)0x80);
+      break;
+    case 2:
+      DTHIP_LAUNCH(ctx, "firstlast_kernel", firstlast_kernel<uint16_t>, g, 256, 0, static_cast<const uint16_t*>(data), ri, offsets,
+                   ng, last, static_cast<uint16_t*>(out), (uint16_t)0x8000);
+      break;
+    case 4:
+      DTHIP_LAUNCH(ctx, "firstlast_kernel", firstlast_kernel<uint32_t>, g, 256, 0, static_cast<const uint32_t*>(data), ri, offsets,
+                   ng, last, static_cast<uint32_t*>(out), stype == DTHIP_FLOAT32 ? 0x7FC00000u : 0x80000000u);
+      break;
+    case 8:
+      DTHIP_LAUNCH(ctx, "firstlast_kernel", firstlast_kernel<unsigned long long>, g, 256, 0,
+                   static_cast<const unsigned long long*>(data), ri, offsets, ng, last, static_cast<unsigned long long*>(out),
+                   stype == DTHIP_FLOAT64 ? 0x7FF8000000000000ULL : 0x8000000000000000ULL);
+      break;
+    default: set_error("first/last: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
+  }
+  return DTHIP_OK;
+}
+
 int launch_gather(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, int64_t nout, void* out) {
   if (nout == 0) return DTHIP_OK;
   long long blocks = (nout + 1023) / 1024;

@@ -16,7 +16,8 @@ NP2ST = {np.dtype(np.bool_): L.BOOL, np.dtype(np.int8): L.INT8, np.dtype(np.int1
 ST2NP = {L.BOOL: np.dtype(np.int8), L.INT8: np.dtype(np.int8), L.INT16: np.dtype(np.int16),
          L.INT32: np.dtype(np.int32), L.INT64: np.dtype(np.int64),
          L.FLOAT32: np.dtype(np.float32), L.FLOAT64: np.dtype(np.float64)}
-OPS = {"sum": L.SUM, "mean": L.MEAN, "min": L.MIN, "max": L.MAX, "count": L.COUNT, "count0": L.COUNT0}
+OPS = {"sum": L.SUM, "mean": L.MEAN, "min": L.MIN, "max": L.MAX, "count": L.COUNT, "count0": L.COUNT0,
+       "first": L.FIRST, "last": L.LAST}
 CMP = {">": L.GT, ">=": L.GE, "<": L.LT, "<=": L.LE, "==": L.EQ, "!=": L.NE}
 
 

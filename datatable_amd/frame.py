@@ -29,7 +29,7 @@ import numpy as np
 from . import _lib as L
 from .engine import NP2ST, OPS as L_OPS, ST2NP, default_context
 
-__all__ = ["Frame", "f", "by", "sort", "sum", "mean", "min", "max", "count"]
+__all__ = ["Frame", "f", "by", "sort", "sum", "mean", "min", "max", "count", "first", "last"]
 
 _NA_INT = {1: np.iinfo(np.int8).min, 2: np.iinfo(np.int16).min, 4: np.iinfo(np.int32).min, 8: np.iinfo(np.int64).min}
 
@@ -153,6 +153,8 @@ mean = _reducer("mean")
 min = _reducer("min")        # noqa: A001
 max = _reducer("max")        # noqa: A001
 count = _reducer("count")
+first = _reducer("first")    # src/core/expr/head_reduce_unary.cc:116-190
+last = _reducer("last")
 
 
 # ---- Frame ---------------------------------------------------------------------------------
@@ -437,7 +439,7 @@ class Frame:
                 for x in reducers:
                     st = L.INT64 if x.op == "count0" else ctx._lib.dthip_reduce_out_stype(L_OPS[x.op], self._stypes[self._index(x.arg)])
                     dtp = ST2NP[st]
-                    if x.op in ("sum", "count", "count0"):
+                    if x.op in ("sum", "count", "count0"):       # first/last/min/max/mean of nothing: NA
                         cols.append(np.zeros(1, dtp))
                     else:
                         cols.append(np.full(1, np.nan if dtp.kind == "f" else _NA_INT[dtp.itemsize], dtp))

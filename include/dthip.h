@@ -67,7 +67,10 @@ enum dthip_stype {
 enum dthip_op {
   DTHIP_SUM = 0, DTHIP_MEAN = 1, DTHIP_MIN = 2, DTHIP_MAX = 3,
   DTHIP_COUNT = 4,   /* count(col): non-NA rows per group   (count.h:35-58) */
-  DTHIP_COUNT0 = 5   /* count():    rows per group          (count.h:61-88) */
+  DTHIP_COUNT0 = 5,  /* count():    rows per group          (count.h:61-88) */
+  DTHIP_FIRST = 6,   /* first(col): element of the group's first row, NA included */
+  DTHIP_LAST = 7     /* last(col)   (FirstLast_ColumnImpl, src/core/expr/head_reduce_unary.cc:116-160);
+                        both need the row order, so dthip_groupby_agg takes the sort path for them */
 };
 
 enum dthip_mem { DTHIP_HOST = 0, DTHIP_DEVICE = 1 };

@@ -265,6 +265,28 @@ def test_descending_and_na_last(ctx):
         r.free()
 
 
+def test_first_last(ctx):
+    """first(col) / last(col): the element at the group's first / last row in original row order, NA
+    included (head_reduce_unary.cc:116-160) -- through dthip_groupby_agg and through the S-red seam"""
+    rng = np.random.default_rng(47)
+    n = 120_000
+    k = rng.integers(0, 700, n).astype(np.int32)
+    k[rng.random(n) < 0.05] = -2**31
+    vals = [rng.standard_normal(n), rng.integers(-9, 9, n).astype(np.int8), rng.integers(-9, 9, n).astype(np.int64),
+            rng.standard_normal(n).astype(np.float32)]
+    vals[0][rng.random(n) < 0.2] = np.nan
+    ri, off = o.group([k])
+    aggs = [(op, c) for c in range(len(vals)) for op in ("first", "last")] + [("sum", 0), ("count0", None)]
+    r = ctx.groupby_agg([k], vals, aggs)
+    assert_same(r.offsets(), off, "offsets")
+    for a, (op, c) in enumerate(aggs[:-2]):
+        exp = vals[c][ri[off[:-1]]] if op == "first" else vals[c][ri[off[1:] - 1]]
+        assert_same(r.agg(a), exp, "%s(v%d)" % (op, c))
+        assert_same(ctx.reduce(op, vals[c], ri, off), exp, "dthip_reduce %s(v%d)" % (op, c))
+    check_agg(r.agg(len(aggs) - 2), o.reduce("sum", vals[0], ri, off), "sum", vals[0], ri, off, "sum next to first/last")
+    r.free()
+
+
 def test_fused_agg_descending_and_na_last(ctx):
     """by(-f.k) / NA-last on every path of dthip_groupby_agg (the bucketed path inverts the same
     transform: edge = max, NA -> range+1)"""

@@ -304,3 +304,13 @@ def test_sum_grouped(dt):                                # test-reduce.py:450-45
     DT = dt.Frame(A=[True, False, True, True], B=[None, None, None, 10], C=[2, 3, 5, -5])
     DT_sum = DT[:, dt.sum(f[:]), dt.by(f.A)]
     assert_equals(DT_sum, dt.Frame(dict(A=[False, True], B=[0, 10], C=[3, 2]), stypes={"B": 5, "C": 5}))
+
+
+def test_first_last_frame(dt):                           # tests/test-reduce.py first/last semantics (head_reduce_unary.cc:116-190)
+    f = dt.f
+    DT = dt.Frame(A=[1, 2, 1, 2, 1, 3], B=[None, 5, 7, None, 9, 11])
+    R = DT[:, [dt.first(f.B), dt.last(f.B)], dt.by(f.A)]
+    assert R.names == ("A", "B", "B.0")
+    assert R.to_list() == [[1, 2, 3], [None, 5, 11], [9, None, 11]]
+    assert DT[:, [dt.first(f.B), dt.last(f.B)]].to_list() == [[None], [11]]
+    assert dt.Frame(A=[], stypes={"A": 4})[:, dt.first(f.A)].to_list() == [[None]]
