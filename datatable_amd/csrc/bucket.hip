@@ -163,16 +163,24 @@ __global__ void __launch_bounds__(BLOCK) bucket_hist_kernel(HistArgs a) {
   constexpr uint32_t TILE = BLOCK * ITEMS;
   constexpr int NB = 2048 / BLOCK;          // bins per thread (F <= 2048)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);
+  // two counter arrays used alternately: the tile after next re-uses an array only after the
+  // barrier of the tile in between, so ONE barrier per tile separates counting from reading
+  uint32_t* cnt2 = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t Fp = (a.F + 3u) & ~3u;
   const int tid = threadIdx.x;
   uint32_t run[NB];
   bool bad = false;
 #pragma unroll
-  for (int k = 0; k < NB; k++) { run[k] = 0; const uint32_t b = (uint32_t)k * BLOCK + tid; if (b < a.F) cnt[b] = 0; }
+  for (int k = 0; k < NB; k++) {
+    run[k] = 0;
+    const uint32_t b = (uint32_t)k * BLOCK + tid;
+    if (b < a.F) { cnt2[b] = 0; cnt2[Fp + b] = 0; }
+  }
   __syncthreads();
   const uint32_t t0 = blockIdx.x * a.tpg;
   const uint32_t t1 = (t0 + a.tpg < a.ntiles) ? t0 + a.tpg : a.ntiles;
   for (uint32_t t = t0; t < t1; t++) {
+    uint32_t* cnt = cnt2 + ((t - t0) & 1u) * Fp;
     const uint32_t tile_base = t * TILE;
     const uint32_t nvalid = (a.n - tile_base < TILE) ? (a.n - tile_base) : TILE;
     const bool full = nvalid == TILE;
@@ -192,7 +200,6 @@ __global__ void __launch_bounds__(BLOCK) bucket_hist_kernel(HistArgs a) {
         run[k] += c;
       }
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int k = 0; k < NB; k++) {
@@ -437,7 +444,7 @@ void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom
 
 template <int BLOCK, int ITEMS, int KM>
 static int hist_t(dthip_ctx* ctx, const HistArgs& a, uint32_t G) {
-  DTHIP_LAUNCH(ctx, "bucket_hist_kernel", (bucket_hist_kernel<BLOCK, ITEMS, KM>), G, BLOCK, (size_t)a.F * 4 + 16, a);
+  DTHIP_LAUNCH(ctx, "bucket_hist_kernel", (bucket_hist_kernel<BLOCK, ITEMS, KM>), G, BLOCK, (size_t)((a.F + 3u) & ~3u) * 8 + 16, a);
   return DTHIP_OK;
 }
 
