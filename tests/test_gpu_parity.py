@@ -476,3 +476,47 @@ def test_full_size_properties_config5_shape(ctx):
     heads = np.concatenate([[0], np.nonzero(~same)[0] + 1, [len(ko)]]).astype(np.int32)
     assert np.array_equal(off, heads)
     assert np.array_equal(rio, ri_f[ri])
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_fused_agg_all_paths(ctx, seed):
+    """seeded random shapes: row count, key stypes / ranges / skew / NA rate, 1-3 keys, value stypes,
+    reducer subsets -- every path of dthip_groupby_agg against the oracle.  Skewed cases put > 65536
+    rows into one bucket, so split buckets (global-atomic table flush) are exercised as well."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 7, 4095, 4096, 4097, 12288, 12289, 50_000, 200_000, 700_000]))
+    nkeys = int(rng.integers(1, 4))
+    keys = []
+    for _ in range(nkeys):
+        dt_ = rng.choice([np.int8, np.int16, np.int32, np.int64])
+        span = int(rng.choice([2, 50, 3000, 200_000]))
+        span = min(span, np.iinfo(dt_).max // 2)
+        lo = int(rng.integers(-span, span))
+        if rng.random() < 0.3:       # skew: most rows share one key
+            kk = np.where(rng.random(n) < 0.9, lo, rng.integers(lo, lo + span, n))
+        else:
+            kk = rng.integers(lo, lo + span, n)
+        kk = kk.astype(dt_)
+        if rng.random() < 0.5:
+            kk[rng.random(n) < rng.choice([0.01, 0.3])] = np.iinfo(dt_).min
+        keys.append(kk)
+    vals = []
+    for _ in range(int(rng.integers(1, 4))):
+        vt = rng.choice(["f64", "f32", "i32", "i64"])
+        if vt == "f64":
+            v = rng.standard_normal(n)
+        elif vt == "f32":
+            v = rng.standard_normal(n).astype(np.float32)
+        elif vt == "i32":
+            v = rng.integers(-10**6, 10**6, n).astype(np.int32)
+        else:
+            v = rng.integers(-10**12, 10**12, n).astype(np.int64)
+        if rng.random() < 0.5:
+            m = rng.random(n) < 0.1
+            if v.dtype.kind == "f":
+                v[m] = np.nan
+            else:
+                v[m] = np.iinfo(v.dtype).min
+        vals.append(v)
+    ops = [op for op in OPS if rng.random() < 0.6] or ["sum"]
+    _vs_oracle(ctx, keys, vals, aggs=tuple(ops), check_ri=(seed % 4 == 0))
