@@ -73,6 +73,7 @@ SIGNATURES = {
     "dthip_reduce_out_stype": (C.c_int, [C.c_int, C.c_int]),
     "dthip_reduce": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Col), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                C.c_int, C.c_void_p]),
+    "dthip_range_bucket": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dthip_ungroup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "dthip_bool_to_rowindex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                          C.POINTER(C.c_int64)]),

@@ -1291,6 +1291,25 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
   return DTHIP_OK;
 }
 
+int dthip_range_bucket(dthip_ctx* ctx, const dthip_col* key, int64_t nrows, const int64_t* bounds, int nbounds, int mem,
+                       int8_t* out) {
+  DTHIP_TRY(check_common(ctx, nrows, mem));
+  if (nrows == 0) return DTHIP_OK;
+  if (!key || !key->data || !out || (nbounds > 0 && !bounds)) { set_error("null argument"); return DTHIP_EINVAL; }
+  const int sz = stype_size(key->stype);
+  if (!sz) { set_error("unsupported stype %d", key->stype); return DTHIP_ENOTIMPL; }
+  Scratch sc(ctx);
+  const void* d_key = nullptr;
+  DTHIP_TRY(stage_in(ctx, sc, key->data, (size_t)nrows * sz, mem, &d_key));
+  int8_t* d_out = out;
+  if (mem == DTHIP_HOST) DTHIP_TRY(sc.get<int8_t>((size_t)nrows, &d_out));
+  long long b[15];
+  for (int j = 0; j < nbounds && j < 15; j++) b[j] = (long long)bounds[j];
+  DTHIP_TRY(launch_range_bucket(ctx, d_key, key->stype, nrows, b, nbounds, d_out));
+  if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, (size_t)nrows, mem));
+  return DTHIP_OK;
+}
+
 int dthip_ungroup(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t nrows, int mem, int32_t* out) {
   DTHIP_TRY(check_common(ctx, nrows, mem));
   if (ngroups < 0 || ngroups > nrows) { set_error("ngroups=%lld inconsistent with nrows=%lld", (long long)ngroups, (long long)nrows); return DTHIP_EINVAL; }

@@ -275,6 +275,8 @@ struct PredArgs {
 };
 int launch_compact(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out, int64_t* nout_host);
 int launch_gather(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, int64_t nout, void* out);
+int launch_range_bucket(dthip_ctx* ctx, const void* keys, int stype, int64_t n, const long long* bounds, int nbounds,
+                        int8_t* out);
 int launch_firstlast(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, const int32_t* offsets,
                      int64_t ngroups, int last, void* out);
 

@@ -120,6 +120,49 @@ __global__ void __launch_bounds__(256) gather_kernel(const T* __restrict__ data,
   }
 }
 
+// destination of every row in a key-range partition (multi-GPU exchange of rows): out[i] = number of
+// boundaries <= key[i] (NA keys -> 0: the NA group lives on rank 0, like the smallest keys)
+struct BoundsArg { long long b[15]; int n; };
+template <typename T>
+__global__ void __launch_bounds__(256) range_bucket_kernel(const T* __restrict__ keys, uint32_t n, T na, BoundsArg bd,
+                                                           int8_t* __restrict__ out) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const T k = keys[i];
+    int d = 0;
+    if (k != na) {
+#pragma unroll
+      for (int j = 0; j < 15; j++) d += (j < bd.n && (long long)k >= bd.b[j]) ? 1 : 0;
+    }
+    out[i] = (int8_t)d;
+  }
+}
+
+int launch_range_bucket(dthip_ctx* ctx, const void* keys, int stype, int64_t n, const long long* bounds, int nbounds,
+                        int8_t* out) {
+  if (n == 0) return DTHIP_OK;
+  if (nbounds < 0 || nbounds > 15) { set_error("range_bucket: at most 15 boundaries (16 destinations)"); return DTHIP_EINVAL; }
+  BoundsArg bd;
+  memset(&bd, 0, sizeof(bd));
+  bd.n = nbounds;
+  for (int j = 0; j < nbounds; j++) bd.b[j] = bounds[j];
+  long long blocks = (n + 2047) / 2048;
+  if (blocks > ctx->num_cus * 8) blocks = ctx->num_cus * 8;
+  const unsigned g = (unsigned)blocks;
+  switch (stype) {
+    case DTHIP_INT8:
+      DTHIP_LAUNCH(ctx, "range_bucket_kernel", range_bucket_kernel<int8_t>, g, 256, 0, static_cast<const int8_t*>(keys), (uint32_t)n, (int8_t)INT8_MIN, bd, out); break;
+    case DTHIP_INT16:
+      DTHIP_LAUNCH(ctx, "range_bucket_kernel", range_bucket_kernel<int16_t>, g, 256, 0, static_cast<const int16_t*>(keys), (uint32_t)n, (int16_t)INT16_MIN, bd, out); break;
+    case DTHIP_INT32:
+      DTHIP_LAUNCH(ctx, "range_bucket_kernel", range_bucket_kernel<int32_t>, g, 256, 0, static_cast<const int32_t*>(keys), (uint32_t)n, (int32_t)INT32_MIN, bd, out); break;
+    case DTHIP_INT64:
+      DTHIP_LAUNCH(ctx, "range_bucket_kernel", range_bucket_kernel<long long>, g, 256, 0, static_cast<const long long*>(keys), (uint32_t)n, (long long)INT64_MIN, bd, out); break;
+    default: set_error("range_bucket: integer key columns only (stype %d)", stype); return DTHIP_ENOTIMPL;
+  }
+  return DTHIP_OK;
+}
+
 // first(A) / last(A): the element at the first / last grouped position of every group, NA included
 // (FirstLast_ColumnImpl::_get, src/core/expr/head_reduce_unary.cc:116-160)
 template <typename T>

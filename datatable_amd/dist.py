@@ -37,6 +37,16 @@ class HipBackend:
         _, gk, out = groupby_agg_tensors(self.ctx, keys, values, aggs, want_offsets=False)
         return gk, out
 
+    def groupby_rows(self, keys, cols):
+        """-> (offsets int32[ng+1], [cols in grouped order]); stable, NA group first"""
+        from .torch_bridge import groupby_rows_tensors
+        off, _, out = groupby_rows_tensors(self.ctx, keys, cols)
+        return off, out
+
+    def range_bucket(self, key, bounds):
+        from .torch_bridge import range_bucket_tensor
+        return range_bucket_tensor(self.ctx, key, bounds)
+
 
 def _partials_for(aggs):
     """requested aggs -> deduplicated list of local partial aggs + recipe per requested agg"""
@@ -144,3 +154,59 @@ def sharded_groupby_agg(backend, keys, values, aggs, group=None):
         else:
             out.append(merged[r[1]])
     return mk, out
+
+
+def sharded_groupby_rows(backend, keys, cols, row_offset=0, group=None):
+    """Rows in grouped order across ranks: `DT[:, cols, by(keys)]` (configuration 5's second step).
+
+    keys / cols: this rank's row shard.  Every rank ends up owning a contiguous range of the first
+    key; the concatenation of the ranks' outputs in rank order is what a single process returns
+    (groups ascending, NA group first, original row order inside a group).
+    Returns (offsets int32[ng_local+1], global row ids int64[n_local_out], [cols in grouped order]).
+
+    One exchange step: rows are grouped by destination rank on the sender (a stable
+    groupby_rows on the int8 destination, so every slab keeps the sender's row order), slabs travel
+    with one all-to-all-v per column, and because a receiver concatenates slabs in source-rank order
+    -- and shards are row blocks in rank order -- arrival order IS global row order: one stable
+    local groupby_rows reproduces the reference's permutation exactly."""
+    world = dist.get_world_size(group)
+    if keys[0].dtype not in INT_KEY_DTYPES:
+        raise NotImplementedError("distributed groupby partitions on an integer first key column")
+    if world > 16:
+        raise NotImplementedError("range partition into at most 16 destinations")
+    dev = keys[0].device
+    n = keys[0].numel()
+    k0 = keys[0]
+    na = torch.iinfo(k0.dtype).min
+    big = torch.iinfo(torch.int64)
+    # global range of the first key over its valid rows (two scalars through one all-reduce)
+    if n:
+        valid = k0 != na
+        lo = int(torch.where(valid, k0, torch.full_like(k0, torch.iinfo(k0.dtype).max)).min().item())
+        hi = int(torch.where(valid, k0, torch.full_like(k0, na)).max().item())
+        if hi == na:            # no valid key on this rank
+            lo, hi = big.max, -big.max
+    else:
+        lo, hi = big.max, -big.max
+    mm = torch.tensor([lo, -hi], dtype=torch.int64, device=dev)
+    dist.all_reduce(mm, op=dist.ReduceOp.MIN, group=group)
+    gmin, neg = mm.tolist()
+    gmax = -neg
+    if gmin > gmax:
+        gmin, gmax = 0, 0
+    bounds = range_boundaries(gmin, gmax, world)
+    rowid = torch.arange(row_offset, row_offset + n, dtype=torch.int64, device=dev)
+    payload = list(keys) + list(cols) + [rowid]
+    if world > 1:
+        dest = backend.range_bucket(k0, bounds)
+        _, slabs = backend.groupby_rows([dest], payload)             # rows grouped by destination, order kept
+        send_counts = torch.bincount(dest.to(torch.int64), minlength=world)[:world]
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+        sc, rc = torch.stack([send_counts, recv_counts]).tolist()
+        recv = [_all_to_all_v(t, sc, rc, group) for t in slabs]
+    else:
+        recv = payload
+    rkeys, rcols, rrow = recv[:len(keys)], recv[len(keys):-1], recv[-1]
+    off, out = backend.groupby_rows(rkeys, rcols + [rrow])
+    return off, out[-1], out[:-1]

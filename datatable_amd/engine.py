@@ -285,6 +285,14 @@ class Context:
                                        offsets.ctypes.data, ng, nrows, L.HOST, out.ctypes.data))
         return out
 
+    def range_bucket(self, values, bounds, stype=None):
+        """int8 destination of every row in the range partition given by ascending `bounds` (host arrays)"""
+        a, col = _host_col(values, stype)
+        out = np.empty(len(a), np.int8)
+        b = (C.c_int64 * max(len(bounds), 1))(*[int(x) for x in bounds])
+        L.check(self._lib.dthip_range_bucket(self._h, C.byref(col), len(a), b, len(bounds), L.HOST, out.ctypes.data))
+        return out
+
     def ungroup(self, offsets):
         """group index of every grouped position (Groupby::ungroup_rowindex)"""
         offsets = np.ascontiguousarray(offsets, np.int32)
@@ -323,6 +331,12 @@ class Context:
         L.check(self._lib.dthip_filter_cmp(self._h, C.byref(c), nrows, CMP[cmp], float(scalar), 0 if isf else int(scalar),
                                            L.DEVICE, C.c_void_p(out_ptr), C.byref(k)))
         return k.value
+
+    def range_bucket_dev(self, col, nrows, bounds, out_ptr):
+        """int8 destination (number of boundaries <= key) of every row of DevCol `col` at out_ptr"""
+        c = L.Col(col.ptr, col.stype, 0)
+        b = (C.c_int64 * max(len(bounds), 1))(*[int(x) for x in bounds])
+        L.check(self._lib.dthip_range_bucket(self._h, C.byref(c), nrows, b, len(bounds), L.DEVICE, C.c_void_p(out_ptr)))
 
     def gather_dev(self, col, rowindex_ptr, nout, out_ptr):
         c = L.Col(col.ptr, col.stype, 0)

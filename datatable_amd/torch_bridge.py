@@ -55,3 +55,39 @@ def groupby_agg_tensors(ctx, keys, values, aggs, na_last=False, want_offsets=Tru
     ctx.sync()          # ... and torch's consumers after the copies out of the result
     r.free()
     return off, gk, out
+
+
+def groupby_rows_tensors(ctx, keys, cols, want_rowindex=False):
+    """keys/cols: CUDA tensors.  Returns (offsets, rowindex or None, [cols in grouped order])."""
+    n = keys[0].numel()
+    dev = keys[0].device
+    torch.cuda.current_stream(dev).synchronize()
+    r = ctx.groupby_rows([devcol(k) for k in keys], [devcol(c) for c in cols], nrows=n, want_rowindex=want_rowindex)
+    ng = r.ngroups
+    off = torch.empty(ng + 1, dtype=torch.int32, device=dev)
+    r.offsets_into(off.data_ptr())
+    ri = None
+    if want_rowindex:
+        ri = torch.empty(n, dtype=torch.int32, device=dev)
+        if n:
+            r.rowindex_into(ri.data_ptr())
+    out = []
+    for c, col in enumerate(cols):
+        t = torch.empty(n, dtype=col.dtype, device=dev)
+        if n:
+            r.col_into(c, t.data_ptr())
+        out.append(t)
+    ctx.sync()
+    r.free()
+    return off, ri, out
+
+
+def range_bucket_tensor(ctx, key, bounds):
+    """int8 destination of every row of the CUDA tensor `key` in the range partition given by `bounds`"""
+    n = key.numel()
+    out = torch.empty(n, dtype=torch.int8, device=key.device)
+    torch.cuda.current_stream(key.device).synchronize()
+    if n:
+        ctx.range_bucket_dev(devcol(key), n, bounds, out.data_ptr())
+    ctx.sync()
+    return out

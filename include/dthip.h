@@ -212,6 +212,13 @@ int  dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value,
 int  dthip_ungroup(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t nrows,
                    int mem, int32_t* out);
 
+/* Multi-GPU exchange of ROWS (row-returning queries; no counterpart in the single-process
+ * reference): destination of every row in a range partition of an integer key column,
+ * out[i] = number of boundaries <= key[i] (NA -> 0); at most 15 ascending boundaries.
+ * dthip_groupby_rows on `out` then groups the rows by destination in their original order. */
+int  dthip_range_bucket(dthip_ctx* ctx, const dthip_col* key, int64_t nrows,
+                        const int64_t* bounds, int nbounds, int mem, int8_t* out);
+
 /* ---- RowIndex construction / application ---------------------------------- */
 /* ascending ARR32 of rows whose mask is 1 and not NA; out has room for n */
 int  dthip_bool_to_rowindex(dthip_ctx* ctx, const int8_t* mask, int64_t n, int mem,

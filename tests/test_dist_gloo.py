@@ -33,6 +33,23 @@ class OracleBackend:
         return gk, out
 
 
+    def groupby_rows(self, keys, cols):
+        from oracle import oracle as o
+        kn = [k.numpy() for k in keys]
+        if len(kn[0]) == 0:
+            return torch.zeros(1, dtype=torch.int32), [c.clone() for c in cols]
+        ri, off = o.group(kn)
+        return torch.from_numpy(off.copy()), [torch.from_numpy(c.numpy()[ri].copy()) for c in cols]
+
+    def range_bucket(self, key, bounds):
+        k = key.numpy()
+        valid = k != np.iinfo(k.dtype).min
+        d = np.zeros(len(k), np.int8)
+        for b in bounds:
+            d += (valid & (k.astype(np.int64) >= b)).astype(np.int8)
+        return torch.from_numpy(d)
+
+
 def make_data(seed, n, nkeys):
     rng = np.random.default_rng(seed)
     keys = [rng.integers(-40, 40, n).astype(np.int64 if i == 0 else np.int32) for i in range(nkeys)]
@@ -62,6 +79,47 @@ def worker(rank, world, port, nkeys, outdir):
     np.savez(os.path.join(outdir, "r%d.npz" % rank), *[t.numpy() for t in gk + out])
     dist.barrier()
     dist.destroy_process_group()
+
+
+def rows_worker(rank, world, port, nkeys, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from datatable_amd.dist import sharded_groupby_rows
+    keys, vals = make_data(78, 20_000, nkeys)
+    n = len(keys[0])
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    k = [torch.from_numpy(a[lo:hi].copy()) for a in keys]
+    v = [torch.from_numpy(a[lo:hi].copy()) for a in vals]
+    off, rowid, cols = sharded_groupby_rows(OracleBackend(), k, v, row_offset=lo)
+    np.savez(os.path.join(outdir, "rows%d.npz" % rank), off.numpy(), rowid.numpy(), *[t.numpy() for t in cols])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nkeys", [1, 2])
+def test_sharded_groupby_rows_world2(tmp_path, nkeys):
+    """rows in grouped order across 2 ranks == one process: global RowIndex, group offsets, columns"""
+    from oracle import oracle as o
+    world = 2
+    mp.spawn(rows_worker, args=(world, free_port(), nkeys, str(tmp_path)), nprocs=world, join=True)
+    keys, vals = make_data(78, 20_000, nkeys)
+    ri, off = o.group(keys)
+    parts = [np.load(os.path.join(str(tmp_path), "rows%d.npz" % r)) for r in range(world)]
+    rowid = np.concatenate([p["arr_1"] for p in parts])
+    assert np.array_equal(rowid, ri.astype(np.int64)), "global RowIndex differs"
+    offs, base = [np.zeros(1, np.int64)], 0
+    for p in parts:
+        o_ = p["arr_0"].astype(np.int64)
+        offs.append(o_[1:] + base)
+        base += int(o_[-1])
+    assert np.array_equal(np.concatenate(offs), off.astype(np.int64)), "group offsets differ"
+    for c, v in enumerate(vals):
+        got = np.concatenate([p["arr_%d" % (2 + c)] for p in parts])
+        assert np.array_equal(got, v[ri], equal_nan=(v.dtype.kind == "f")), "column %d differs" % c
+    assert all(len(p["arr_1"]) > 0 for p in parts)
 
 
 def free_port():

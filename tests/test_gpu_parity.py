@@ -265,6 +265,22 @@ def test_descending_and_na_last(ctx):
         r.free()
 
 
+def test_range_bucket_and_ungroup(ctx):
+    """the two small helpers of the multi-GPU row exchange / GtoALL broadcast"""
+    rng = np.random.default_rng(49)
+    for dt_ in (np.int8, np.int16, np.int32, np.int64):
+        hi = min(np.iinfo(dt_).max, 10**12)
+        k = rng.integers(-hi, hi, 100_003).astype(dt_)
+        k[rng.random(len(k)) < 0.05] = np.iinfo(dt_).min
+        bounds = sorted(int(x) for x in rng.integers(-hi, hi, 7))
+        exp = np.zeros(len(k), np.int8)
+        for b in bounds:
+            exp += ((k != np.iinfo(dt_).min) & (k.astype(np.int64) >= b)).astype(np.int8)
+        assert_same(ctx.range_bucket(k, bounds), exp, "range_bucket %s" % dt_.__name__)
+    off = np.concatenate([[0], np.cumsum(rng.integers(1, 50, 10_000))]).astype(np.int32)
+    assert_same(ctx.ungroup(off), np.repeat(np.arange(len(off) - 1, dtype=np.int32), np.diff(off)), "ungroup")
+
+
 def test_first_last(ctx):
     """first(col) / last(col): the element at the group's first / last row in original row order, NA
     included (head_reduce_unary.cc:116-160) -- through dthip_groupby_agg and through the S-red seam"""
