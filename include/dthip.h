@@ -14,6 +14,10 @@
  *   dthip_groupby_agg    <- EvalContext::evaluate() for DT[:, {reducers}, by(keys)]
  *                           src/core/expr/eval_context.cc:144-172,249-288,473-516
  *                           (group + reducers fused; no RowIndex materialised)
+ *   dthip_groupby_rows   <- DT[:, cols, by(keys)]: group() + ColumnImpl::_materialize_fw of the
+ *                           selected columns, src/core/expr/eval_context.cc:497-508,
+ *                           src/core/column/column_impl.cc:78-101
+ *   dthip_ungroup        <- Groupby::ungroup_rowindex, src/core/groupby.cc:117-130
  *   dthip_bool_to_rowindex <- ArrayRowIndexImpl::init_from_boolean_column
  *                           src/core/rowindex_array.cc:130-170
  *   dthip_filter_cmp     <- DT[f.x <cmp> c, :] : comparison FExpr + the above
