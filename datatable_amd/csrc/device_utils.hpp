@@ -67,13 +67,4 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// agent-scope relaxed accesses to a 64-bit {flag,value} word: the word is its
-// own flag, so no fence is needed (decoupled look-back state).
-__device__ __forceinline__ void st_agent_u64(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long ld_agent_u64(unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 }  // namespace dthip

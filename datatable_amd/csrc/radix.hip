@@ -1,5 +1,5 @@
 // radix.hip -- key transform + digit histograms, and the stable one-sweep
-// LSD radix pass (decoupled look-back) for gfx950.
+// LSD radix pass (run positions precomputed per tile, no inter-workgroup communication) for gfx950.
 //
 // Reference behaviour being reproduced (not its algorithm): the ordering of
 // SortContext -- stable, ascending in the transformed unsigned key, NA first
@@ -173,7 +173,7 @@ int launch_hist_scan(dthip_ctx* ctx, const uint32_t* hist, uint32_t* base, int n
 // the pass starts -- radix_tile_hist_kernel counts the digits of every tile of the CURRENT key
 // order (one extra 4/8-byte read per row and pass) and bucket_gscan_kernel turns the counts into
 // positions -- so the pass needs no inter-workgroup communication: no decoupled look-back, no
-// tickets, no spinning (the look-back cost a third of the pass: 7.2 -> 4.8 ms at 1e9 rows).
+// tickets, no spinning (measured at 1e9 rows: 7.2 ms per pass with look-back, 5.6 + 0.8 ms without).
 constexpr int RP_BLOCK = 512, RP_ITEMS = 16, RP_TILE = RP_BLOCK * RP_ITEMS;
 
 template <typename KeyT>
