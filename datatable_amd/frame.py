@@ -377,7 +377,8 @@ class Frame:
         ctx = self._context()
         idx = [self._index(c) for c in s.cols]
         keys = [self._materialized(k) for k in idx]
-        r = ctx.groupby(keys, stypes=[self._stypes[k] for k in idx], desc=s.reverse, na_last=s.na_last,
+        desc = [bool(rev) ^ bool(c.desc) for c, rev in zip(s.cols, s.reverse)]       # sort(-f.k) == reverse
+        r = ctx.groupby(keys, stypes=[self._stypes[k] for k in idx], desc=desc, na_last=s.na_last,
                         na_remove=s.na_remove)
         ri = r.rowindex()
         r.free()

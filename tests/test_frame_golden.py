@@ -1,0 +1,48 @@
+"""Frame-level golden answers: tests/golden/frame_queries.json holds 49 `DT[i, j, by/sort]` queries
+together with what the UNMODIFIED reference returned for them (tests/golden/make_frame_golden.py,
+run in the dev container).  The same query strings are evaluated here against
+datatable_amd.frame on the GPU: names, stypes and every value must agree (float sums/means to 1e-6
+relative, everything else exactly)."""
+import json
+import math
+import os
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_queries.json")))
+
+
+def _dec(x):
+    if x == "inf":
+        return math.inf
+    if x == "-inf":
+        return -math.inf
+    return x
+
+
+@pytest.mark.parametrize("qi", range(len(GOLD["queries"])), ids=[q["query"][:70] for q in GOLD["queries"]])
+def test_frame_query_matches_reference(qi):
+    from datatable_amd import frame as dt
+    from datatable_amd.frame import f, by, sort, sum, mean, min, max, count, first, last   # noqa: F401,A004
+    q = GOLD["queries"][qi]
+    spec = GOLD["frames"][q["frame"]]
+    DT = dt.Frame({nm: [_dec(x) for x in c["values"]] for nm, c in spec.items()},
+                  stypes={nm: c["stype"] for nm, c in spec.items()})
+    R = eval(q["query"])
+    assert list(R.names) == q["names"]
+    assert list(R.stypes) == q["stypes"]
+    got = R.to_list()
+    assert len(got) == len(q["columns"])
+    is_float_red = any(k in q["query"] for k in ("sum(", "mean("))
+    for ci, (g, e) in enumerate(zip(got, q["columns"])):
+        e = [_dec(x) for x in e]
+        assert len(g) == len(e), "column %d: %d rows, expected %d" % (ci, len(g), len(e))
+        for x, y in zip(g, e):
+            if isinstance(y, float) and isinstance(x, float) and is_float_red and math.isfinite(y):
+                assert abs(x - y) <= 1e-6 * abs(y) + 1e-9, (q["names"][ci], x, y)
+            else:
+                assert x == y and type(x) is type(y), (q["names"][ci], g[:12], e[:12])
