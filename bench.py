@@ -35,22 +35,40 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_ROW = 16         # key 8 B + value 8 B read once (+ ng*(8+8) written)
 
 
-def cpu_baseline(sample_rows, groups, seed):
-    """Oracle (oracle/dt_oracle.c: restatement of group() + sum reducer) on host cores."""
+def cpu_baseline(sample_rows, groups, seed, threads):
+    """Oracle (oracle/dt_oracle.c: restatement of group() + sum reducer) on the host cores: the rate on
+    `threads` OpenMP threads (chunked radix passes and per-group reducers, as the reference parallelises
+    them) over `sample_rows` rows, plus the single-thread rate on a fifth of that sample."""
     import numpy as np
     from oracle import oracle as o
     o.lib()
     rng = np.random.default_rng(seed)
     k = rng.integers(0, groups, sample_rows, dtype=np.int64)
     v = rng.standard_normal(sample_rows)
-    t0 = time.perf_counter()
-    ri, off = o.group([k])
-    s = o.reduce("sum", v, ri, off)
-    dt = time.perf_counter() - t0
-    assert len(s) == len(off) - 1
-    return {"value": sample_rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": "%d rows (%.0f%% of the workload), int64 key uniform in [0,%d), float64 N(0,1): "
-                      "oracle group()+sum on 1 host thread, %.2f s" % (sample_rows, 100.0 * sample_rows / 1e9, groups, dt),
+
+    def run(kk, vv, t):
+        o.set_threads(t)
+        t0 = time.perf_counter()
+        ri, off = o.group([kk])
+        s = o.reduce("sum", vv, ri, off)
+        dt = time.perf_counter() - t0
+        assert len(s) == len(off) - 1
+        return dt
+
+    n1 = max(sample_rows // 5, 1)
+    try:
+        dt1 = run(k[:n1], v[:n1], 1)
+        dtn = run(k, v, threads) if threads > 1 else None
+    finally:
+        o.set_threads(1)
+    if dtn is None:
+        value, cores, rows_used, dt = n1 / dt1, 1, n1, dt1
+    else:
+        value, cores, rows_used, dt = sample_rows / dtn, threads, sample_rows, dtn
+    return {"value": value, "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": "%d rows (%.0f%% of the workload), int64 key uniform in [0,%d), float64 N(0,1): oracle group()+sum "
+                      "on %d host thread(s), %.2f s" % (rows_used, 100.0 * rows_used / 1e9, groups, cores, dt),
+            "single_thread_value": n1 / dt1, "single_thread_sample_rows": n1,
             "host_cores_available": os.cpu_count()}
 
 
@@ -61,8 +79,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--groups", type=int, default=10_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=250_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=500_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(host cores, 64))")
     ap.add_argument("--no-check", action="store_true", help="skip the result sanity check (kernel timing experiments)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--agg-path", type=int, default=0, help="dthip option agg_path: 0 auto, 1 sort, 2 bucketed")
@@ -222,7 +241,8 @@ def main():
             "kernels": per_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n_total), args.groups, 1234 + 3)
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+            line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n_total), args.groups, 1234 + 3, threads)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

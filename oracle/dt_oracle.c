@@ -38,6 +38,29 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Threads used by the sort, the group-boundary scan and the reducers (bench.py's cpu_baseline; the
+ * tests run with 1).  The reference parallelises the same loops over its own thread pool
+ * (per-chunk histograms + chunked reorder, sort.cc:950-1074; reducers over groups,
+ * column_impl.cc:92-99).  Results do not depend on the thread count: the chunked radix pass is
+ * stable and every group is still reduced left to right by one thread. */
+static int g_threads = 1;
+void dto_set_threads(int n) {
+  g_threads = n < 1 ? 1 : n;
+#ifdef _OPENMP
+  omp_set_num_threads(g_threads);
+#endif
+}
+int dto_get_threads(void) {
+#ifdef _OPENMP
+  return g_threads;
+#else
+  return 1;
+#endif
+}
 
 /* reference SType codes, stype.h:41-62 */
 enum { ST_BOOL = 1, ST_INT8 = 2, ST_INT16 = 3, ST_INT32 = 4, ST_INT64 = 5,
@@ -118,6 +141,7 @@ static int transform_key(const dto_col* col, int64_t n, const int32_t* order,
          NA ? 0 : max - key + 1   (DESC, NA first)
      NA last: NA -> max-min+1 and no +1 increment. */
   int64_t mn = INT64_MAX, mx = INT64_MIN; int any = 0;
+#pragma omp parallel for reduction(min:mn) reduction(max:mx) reduction(|:any) schedule(static) if (n > 100000)
   for (int64_t j = 0; j < n; j++) {
     int na; int64_t v = load_int(col->data, st, j, &na);
     if (na) continue;
@@ -127,6 +151,7 @@ static int transform_key(const dto_col* col, int64_t n, const int32_t* order,
   const uint64_t range1 = (uint64_t)mx - (uint64_t)mn + 1;    /* max-min+1, may wrap to 0 */
   const uint64_t rna = (na_pos == NA_LAST) ? range1 : 0;
   const uint64_t inc = (na_pos == NA_LAST) ? 0 : 1;
+#pragma omp parallel for schedule(static) if (n > 100000)
   for (int64_t j = 0; j < n; j++) {
     int na; int64_t v = load_int(col->data, st, order ? order[j] : j, &na);
     x[j] = na ? rna : asc ? ((uint64_t)v - (uint64_t)mn + inc)
@@ -136,29 +161,50 @@ static int transform_key(const dto_col* col, int64_t n, const int32_t* order,
   return nb ? nb : 64;
 }
 
-/* Stable LSD byte-radix sort of (x, o) by x, skipping constant bytes. */
+/* Stable LSD byte-radix sort of (x, o) by x, skipping constant bytes.  With T threads the rows are
+ * cut into T contiguous chunks: per-chunk digit counts, exclusive scan in (digit, chunk) order, every
+ * chunk scatters its own rows -- the reference's scheme (sort.cc:950-1074), stable for any T. */
 static void stable_sort_pairs(uint64_t* x, int32_t* o, int64_t n, int nsigbits)
 {
   if (n < 2) return;
   uint64_t* x2 = (uint64_t*)malloc((size_t)n * 8);
   int32_t*  o2 = (int32_t*)malloc((size_t)n * 4);
+  uint64_t* xa = x; int32_t* oa = o; uint64_t* xb = x2; int32_t* ob = o2;
+  int T = (n > 100000) ? dto_get_threads() : 1;
+  int64_t* cnt = (int64_t*)malloc((size_t)T * 256 * sizeof(int64_t));
   int nbytes = (nsigbits + 7) / 8;
   for (int b = 0; b < nbytes; b++) {
-    int64_t cnt[256]; memset(cnt, 0, sizeof(cnt));
     const int sh = b * 8;
-    for (int64_t i = 0; i < n; i++) cnt[(x[i] >> sh) & 255]++;
+    memset(cnt, 0, (size_t)T * 256 * sizeof(int64_t));
+#pragma omp parallel for schedule(static, 1) num_threads(T) if (T > 1)
+    for (int t = 0; t < T; t++) {
+      const int64_t i0 = n * t / T, i1 = n * (t + 1) / T;
+      int64_t* c = cnt + (size_t)t * 256;
+      for (int64_t i = i0; i < i1; i++) c[(xa[i] >> sh) & 255]++;
+    }
     int constant = 0;
-    for (int d = 0; d < 256; d++) if (cnt[d] == n) constant = 1;
+    for (int d = 0; d < 256; d++) {
+      int64_t tot = 0;
+      for (int t = 0; t < T; t++) tot += cnt[(size_t)t * 256 + d];
+      if (tot == n) constant = 1;
+    }
     if (constant) continue;
     int64_t s = 0;
-    for (int d = 0; d < 256; d++) { int64_t c = cnt[d]; cnt[d] = s; s += c; }
-    for (int64_t i = 0; i < n; i++) {
-      int64_t k = cnt[(x[i] >> sh) & 255]++;
-      x2[k] = x[i]; o2[k] = o[i];
+    for (int d = 0; d < 256; d++)
+      for (int t = 0; t < T; t++) { int64_t c = cnt[(size_t)t * 256 + d]; cnt[(size_t)t * 256 + d] = s; s += c; }
+#pragma omp parallel for schedule(static, 1) num_threads(T) if (T > 1)
+    for (int t = 0; t < T; t++) {
+      const int64_t i0 = n * t / T, i1 = n * (t + 1) / T;
+      int64_t* c = cnt + (size_t)t * 256;
+      for (int64_t i = i0; i < i1; i++) {
+        int64_t k = c[(xa[i] >> sh) & 255]++;
+        xb[k] = xa[i]; ob[k] = oa[i];
+      }
     }
-    memcpy(x, x2, (size_t)n * 8); memcpy(o, o2, (size_t)n * 4);
+    { uint64_t* tx = xa; xa = xb; xb = tx; int32_t* to = oa; oa = ob; ob = to; }
   }
-  free(x2); free(o2);
+  if (xa != x) { memcpy(x, xa, (size_t)n * 8); memcpy(o, oa, (size_t)n * 4); }
+  free(x2); free(o2); free(cnt);
 }
 
 /*
@@ -175,6 +221,7 @@ int dto_group(const dto_col* keys, int nkeys, int64_t n, int na_pos,
 {
   if (n > INT32_MAX) return -1;
   if (n == 0) { *ngroups = 0; offsets[0] = 0; return 0; }   /* Groupby::zero_groups */
+#pragma omp parallel for schedule(static) if (n > 100000)
   for (int64_t i = 0; i < n; i++) rowindex[i] = (int32_t)i;
   uint64_t* x = (uint64_t*)malloc((size_t)n * 8);
   for (int k = nkeys - 1; k >= 0; k--) {
@@ -187,6 +234,7 @@ int dto_group(const dto_col* keys, int nkeys, int64_t n, int na_pos,
   head[0] = 1;
   for (int k = 0; k < nkeys; k++) {
     transform_key(&keys[k], n, rowindex, na_pos, x);
+#pragma omp parallel for schedule(static) if (n > 100000)
     for (int64_t i = 1; i < n; i++) if (x[i] != x[i - 1]) head[i] = 1;
   }
   int64_t ng = 0;
@@ -282,6 +330,7 @@ int dto_reduce(int op, const dto_col* col, const int32_t* ri, const int32_t* off
 {
   const int st = col ? col->stype : 0;
   const int isf = (st == ST_FLOAT32 || st == ST_FLOAT64);
+#pragma omp parallel for schedule(static) if (ng > 10000)
   for (int64_t g = 0; g < ng; g++) {
     const int64_t i0 = offsets[g], i1 = offsets[g + 1];
     if (op == OP_COUNT0) { ((int64_t*)out)[g] = i1 - i0; continue; }     /* count.h:77-88 */

@@ -48,6 +48,15 @@ def lib():
     return _L
 
 
+def set_threads(n):
+    """threads for the sort / group scan / reducers (default 1); results do not depend on it"""
+    lib().dto_set_threads(int(n))
+
+
+def get_threads():
+    return lib().dto_get_threads()
+
+
 def stype_of(a, stype=None):
     if stype is not None:
         return stype

@@ -41,3 +41,29 @@ def test_oracle_filter_and_gather():
     assert s.tolist() == [10.0, 16.0, np.inf]
     assert o.gather(v, np.array([0, -2**31, 6], np.int32)).tolist()[0::2] == [1.5, 16.0]
     assert np.isnan(o.gather(v, np.array([-2**31], np.int32))[0])
+
+
+def test_oracle_threads_do_not_change_results():
+    """the multi-threaded oracle (bench.py's cpu_baseline) returns exactly what the single-threaded one
+    does: same RowIndex, offsets and bit-identical float sums"""
+    import numpy as np
+    from oracle import oracle as o
+    rng = np.random.default_rng(5)
+    n = 400_000
+    keys = [rng.integers(-500, 500, n).astype(np.int32), rng.integers(0, 70_000, n).astype(np.int64)]
+    keys[1][rng.random(n) < 0.01] = np.iinfo(np.int64).min
+    v = rng.standard_normal(n)
+    ref = {}
+    try:
+        for t in (1, 3, 8):
+            o.set_threads(t)
+            ri, off = o.group(keys)
+            red = [o.reduce(op, v, ri, off) for op in ("sum", "mean", "min", "max", "count")]
+            if t == 1:
+                ref = dict(ri=ri, off=off, red=red)
+            else:
+                assert np.array_equal(ri, ref["ri"]) and np.array_equal(off, ref["off"])
+                for a, b in zip(red, ref["red"]):
+                    assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f")
+    finally:
+        o.set_threads(1)
