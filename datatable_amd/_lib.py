@@ -35,6 +35,7 @@ SIGNATURES = {
     "dthip_last_error": (C.c_char_p, []),
     "dthip_device_count": (C.c_int, []),
     "dthip_init": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dthip_use_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dthip_destroy": (C.c_int, [C.c_void_p]),
     "dthip_sync": (C.c_int, [C.c_void_p]),
     "dthip_trim": (C.c_int, [C.c_void_p]),

@@ -611,9 +611,10 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   std::vector<const void*> vsrc(vd.size(), nullptr);
   for (int c : used) vsrc[c] = vd[c].data;
   uint32_t* bbase = nullptr; WorkItem* items = nullptr; uint32_t* nitems = nullptr;
-  DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 3, &bbase));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 5, &bbase));
   nitems = bbase + g.F + 1;
   uint32_t* d_bad = bbase + g.F + 2;
+  uint32_t* d_clustered = bbase + g.F + 3;        // [2]
   DTHIP_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
   uint32_t M;
   {
@@ -625,13 +626,16 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   }
   const uint32_t max_items = g.F + (uint32_t)((uint64_t)n / M) + 1;
   DTHIP_TRY(sc.get<WorkItem>(max_items, &items));
+  // sorted / clustered / constant keys? (decides which kernel variants run; one tiny read-back)
+  bool clustered = ctx->cluster_mode == 2;
+  if (ctx->cluster_mode == 0 && n >= (1 << 20)) DTHIP_TRY(launch_bucket_cluster_sample(ctx, kx, n, g.r, d_clustered, &clustered));
   int src = 1;
   if (g.d > 0) {
     uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.ntiles * g.F, &P));
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.G * g.F, &gtot));
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.F, &tot));
-    DTHIP_TRY(launch_bucket_hist(ctx, kx, n, g, P, gtot, d_bad));
+    DTHIP_TRY(launch_bucket_hist(ctx, kx, n, g, P, gtot, d_bad, clustered));
     DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, nullptr, 0));
     DTHIP_TRY(launch_bucket_plan(ctx, tot, g.F, 0, M, bbase, items, nitems));
     DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, bbase, 1));
@@ -646,7 +650,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
       vsrc[c] = vb;
     }
     src = 0;
-    DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, P, gtot, kpart, pc));
+    DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, P, gtot, kpart, pc, clustered));
   } else {
     DTHIP_TRY(launch_bucket_plan(ctx, nullptr, 1, (uint32_t)n, M, bbase, items, nitems));
   }
@@ -672,7 +676,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     TableAggArgs ta;
     memset(&ta, 0, sizeof(ta));
     ta.items = items; ta.nitems = nitems; ta.max_items = max_items; ta.src = src;
-    ta.kpart = kpart; ta.kx = kx; ta.val = vsrc[c]; ta.vstype = vd[c].stype; ta.S = g.S; ta.flags = f; ta.tab = t; ta.bad = d_bad;
+    ta.kpart = kpart; ta.kx = kx; ta.val = vsrc[c]; ta.vstype = vd[c].stype; ta.S = g.S; ta.flags = f; ta.tab = t; ta.bad = d_bad; ta.clustered = clustered;
     DTHIP_TRY(launch_table_agg(ctx, ta));
     first = false;
   }
@@ -682,7 +686,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     ta.items = items; ta.nitems = nitems; ta.max_items = max_items; ta.src = src;
     ta.kpart = kpart; ta.kx = kx; ta.val = nullptr; ta.vstype = DTHIP_INT32; ta.S = g.S; ta.flags = first_flag;
     if (need_cnt) ta.tab.cnt = d_cnt; else ta.tab.pres = d_cnt;
-    ta.bad = d_bad;
+    ta.bad = d_bad; ta.clustered = clustered;
     DTHIP_TRY(launch_table_agg(ctx, ta));
   }
 
@@ -807,6 +811,18 @@ int dthip_destroy(dthip_ctx* ctx) {
   return DTHIP_OK;
 }
 
+int dthip_use_stream(dthip_ctx* ctx, void* stream) {
+  if (!ctx) { set_error("null context"); return DTHIP_EINVAL; }
+  DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  prof_flush(ctx);
+  dev_trim(ctx);                    // cached blocks are only safe to recycle in the stream they were used on
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  ctx->stream = static_cast<hipStream_t>(stream);     // NULL = the device's default (legacy) stream
+  ctx->own_stream = false;
+  return DTHIP_OK;
+}
+
 int dthip_sync(dthip_ctx* ctx) {
   if (!ctx) { set_error("null context"); return DTHIP_EINVAL; }
   DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -825,6 +841,11 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "bucket_variant")) { ctx->bucket_variant = (int)value; return DTHIP_OK; }
   if (!strcmp(name, "spec_min_rows")) { ctx->spec_min_rows = value; return DTHIP_OK; }
   if (!strcmp(name, "agg_offsets")) { ctx->agg_offsets = value != 0; return DTHIP_OK; }
+  if (!strcmp(name, "cluster_mode")) {
+    if (value < 0 || value > 2) { set_error("cluster_mode must be 0 (sample), 1 (never) or 2 (always)"); return DTHIP_EINVAL; }
+    ctx->cluster_mode = (int)value;
+    return DTHIP_OK;
+  }
   set_error("unknown option '%s'", name);
   return DTHIP_EINVAL;
 }

@@ -36,6 +36,21 @@ typedef uint32_t bu32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t bu32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
+// LDS counter increment that returns the arrival rank.  Sorted or constant key columns put a whole
+// wave into one bucket: 64 same-address DS atomics would serialise, so a wave-uniform bucket is
+// counted by one lane (one ds_add of the wave's population) and ranked with v_mbcnt.
+__device__ __forceinline__ uint32_t lds_count_rank(uint32_t* cnt, uint32_t d) {
+  const unsigned long long act = __ballot(1);
+  const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+  if (__ballot(d == d0) == act) {
+    const uint32_t r = mbcnt64(act);
+    uint32_t base = 0;
+    if (r == 0) base = atomicAdd(&cnt[d0], (uint32_t)__popcll(act));
+    return __builtin_amdgcn_readfirstlane(base) + r;
+  }
+  return atomicAdd(&cnt[d], 1u);
+}
+
 // ---------------------------------------------------------------------------------------
 // tile loaders.  KM = 1: 16-B aligned int64 key column(s), 2 consecutive rows per lane per
 // load; KM = 2: aligned int32 key column(s), 4 consecutive rows; KM = 0: anything, 1 row.
@@ -148,6 +163,32 @@ __device__ __forceinline__ void load_tile_vals(const PT* __restrict__ src, uint3
   }
 }
 
+// Do neighbouring rows tend to fall into the same bucket (sorted / clustered / constant keys)?
+// 65536 evenly spaced row pairs decide; the histogram and partition kernels then count a
+// wave-uniform bucket with one DS atomic per wave instead of 64 serialised ones.  For random keys
+// the per-row uniformity test would cost ~8 % of those kernels, hence the switch.
+__global__ void __launch_bounds__(256) bucket_cluster_sample_kernel(KeyXform kx, uint32_t n, int r, uint32_t nsamp, uint32_t* acc) {
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+  bool same = false;
+  if (gid < nsamp && n > 1) {
+    const uint32_t p = (uint32_t)(((unsigned long long)gid * (n - 1)) / nsamp);
+    const unsigned long long x0 = packed_key(kx.cols, kx.ncols, p), x1 = packed_key(kx.cols, kx.ncols, p + 1);
+    same = (x0 >> r) == (x1 >> r);
+  }
+  const unsigned long long b = __ballot(same);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&acc[1], (uint32_t)__popcll(b));
+}
+
+int launch_bucket_cluster_sample(dthip_ctx* ctx, const KeyXform& kx, int64_t n, int r, uint32_t* flag2, bool* clustered) {
+  const uint32_t nsamp = 65536;
+  DTHIP_CHECK_HIP(hipMemsetAsync(flag2, 0, 2 * sizeof(uint32_t), ctx->stream));
+  DTHIP_LAUNCH(ctx, "bucket_cluster_sample_kernel", bucket_cluster_sample_kernel, nsamp / 256, 256, 0, kx, (uint32_t)n, r, nsamp, flag2);
+  uint32_t same = 0;
+  DTHIP_TRY(read_back(ctx, &same, flag2 + 1, sizeof(same)));
+  *clustered = same * 4u > nsamp;
+  return DTHIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // hist: per-tile bucket counts -> P[tile][b] = rows of bucket b in the earlier tiles of the
 // same group; gtot[group][b] = rows of bucket b in the group.  One workgroup per group.
@@ -158,7 +199,7 @@ struct HistArgs {
   uint32_t* P; uint32_t* gtot; uint32_t* bad;
 };
 
-template <int BLOCK, int ITEMS, int KM>
+template <int BLOCK, int ITEMS, int KM, bool CL>
 __global__ void __launch_bounds__(BLOCK) bucket_hist_kernel(HistArgs a) {
   constexpr uint32_t TILE = BLOCK * ITEMS;
   constexpr int NB = 2048 / BLOCK;          // bins per thread (F <= 2048)
@@ -188,7 +229,10 @@ __global__ void __launch_bounds__(BLOCK) bucket_hist_kernel(HistArgs a) {
     load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x, bad);
 #pragma unroll
     for (int j = 0; j < ITEMS; j++)
-      if (full || item_row<BLOCK, KM>(j, tid) < nvalid) atomicAdd(&cnt[x[j] >> a.r], 1u);
+      if (full || item_row<BLOCK, KM>(j, tid) < nvalid) {
+        if (CL) (void)lds_count_rank(cnt, x[j] >> a.r);
+        else atomicAdd(&cnt[x[j] >> a.r], 1u);
+      }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NB; k++) {
@@ -306,7 +350,7 @@ __device__ __forceinline__ void move_payload(const PT* __restrict__ pin, PT* __r
   }
 }
 
-template <int BLOCK, int ITEMS, int KM>
+template <int BLOCK, int ITEMS, int KM, bool CL>
 __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
   constexpr uint32_t TILE = BLOCK * ITEMS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -336,7 +380,8 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
     lpos[j] = 0;
-    if (full || item_row<BLOCK, KM>(j, tid) < nvalid) lpos[j] = atomicAdd(&cnt[x[j] >> a.r], 1u);
+    if (full || item_row<BLOCK, KM>(j, tid) < nvalid)
+      lpos[j] = CL ? lds_count_rank(cnt, x[j] >> a.r) : atomicAdd(&cnt[x[j] >> a.r], 1u);
   }
   __syncthreads();
 
@@ -402,7 +447,7 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
 // geometry + launchers
 // ---------------------------------------------------------------------------------------
 struct BkGeomV { uint32_t block, items; };
-static const BkGeomV BK_GEOMS[] = {{1024, 12}, {512, 12}, {1024, 8}, {512, 16}};
+static const BkGeomV BK_GEOMS[] = {{1024, 12}, {512, 12}};
 
 void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom* g) {
   int v = ctx->bucket_variant;
@@ -420,39 +465,33 @@ void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom
   g->km = km;
 }
 
-#define BK_DISPATCH(FN, g, ...)                                                                   \
+#define BK_DISPATCH_KM(FN, B_, I_, CL_, g, ...)                                                  \
   do {                                                                                            \
-    const int _km = (g).km;                                                                       \
-    if ((g).block == 1024 && (g).items == 12) {                                                   \
-      if (_km == 1) return FN<1024, 12, 1>(__VA_ARGS__);                                          \
-      if (_km == 2) return FN<1024, 12, 2>(__VA_ARGS__);                                          \
-      return FN<1024, 12, 0>(__VA_ARGS__);                                                        \
-    } else if ((g).block == 512 && (g).items == 12) {                                             \
-      if (_km == 1) return FN<512, 12, 1>(__VA_ARGS__);                                           \
-      if (_km == 2) return FN<512, 12, 2>(__VA_ARGS__);                                           \
-      return FN<512, 12, 0>(__VA_ARGS__);                                                         \
-    } else if ((g).block == 1024 && (g).items == 8) {                                             \
-      if (_km == 1) return FN<1024, 8, 1>(__VA_ARGS__);                                           \
-      if (_km == 2) return FN<1024, 8, 2>(__VA_ARGS__);                                           \
-      return FN<1024, 8, 0>(__VA_ARGS__);                                                         \
-    } else {                                                                                      \
-      if (_km == 1) return FN<512, 16, 1>(__VA_ARGS__);                                           \
-      if (_km == 2) return FN<512, 16, 2>(__VA_ARGS__);                                           \
-      return FN<512, 16, 0>(__VA_ARGS__);                                                         \
+    if ((g).km == 1) return FN<B_, I_, 1, CL_>(__VA_ARGS__);                                      \
+    if ((g).km == 2) return FN<B_, I_, 2, CL_>(__VA_ARGS__);                                      \
+    return FN<B_, I_, 0, CL_>(__VA_ARGS__);                                                       \
+  } while (0)
+#define BK_DISPATCH(FN, g, cl, ...)                                                               \
+  do {                                                                                            \
+    if ((g).block == 1024) {                                                                      \
+      if (cl) BK_DISPATCH_KM(FN, 1024, 12, true, g, __VA_ARGS__);                                 \
+      BK_DISPATCH_KM(FN, 1024, 12, false, g, __VA_ARGS__);                                        \
     }                                                                                             \
+    if (cl) BK_DISPATCH_KM(FN, 512, 12, true, g, __VA_ARGS__);                                    \
+    BK_DISPATCH_KM(FN, 512, 12, false, g, __VA_ARGS__);                                           \
   } while (0)
 
-template <int BLOCK, int ITEMS, int KM>
+template <int BLOCK, int ITEMS, int KM, bool CL>
 static int hist_t(dthip_ctx* ctx, const HistArgs& a, uint32_t G) {
-  DTHIP_LAUNCH(ctx, "bucket_hist_kernel", (bucket_hist_kernel<BLOCK, ITEMS, KM>), G, BLOCK, (size_t)((a.F + 3u) & ~3u) * 8 + 16, a);
+  DTHIP_LAUNCH(ctx, "bucket_hist_kernel", (bucket_hist_kernel<BLOCK, ITEMS, KM, CL>), G, BLOCK, (size_t)((a.F + 3u) & ~3u) * 8 + 16, a);
   return DTHIP_OK;
 }
 
 int launch_bucket_hist(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, uint32_t* P, uint32_t* gtot,
-                       uint32_t* bad) {
+                       uint32_t* bad, bool clustered) {
   HistArgs a;
   a.kx = kx; a.n = (uint32_t)n; a.r = g.r; a.F = g.F; a.ntiles = g.ntiles; a.tpg = g.tpg; a.P = P; a.gtot = gtot; a.bad = bad;
-  BK_DISPATCH(hist_t, g, ctx, a, g.G);
+  BK_DISPATCH(hist_t, g, clustered, ctx, a, g.G);
 }
 
 int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uint32_t* tot, const uint32_t* bbase, int phase) {
@@ -467,9 +506,9 @@ int launch_bucket_plan(dthip_ctx* ctx, const uint32_t* tot, uint32_t F, uint32_t
   return DTHIP_OK;
 }
 
-template <int BLOCK, int ITEMS, int KM>
+template <int BLOCK, int ITEMS, int KM, bool CL>
 static int part_t(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds) {
-  auto kfn = bucket_partition_kernel<BLOCK, ITEMS, KM>;
+  auto kfn = bucket_partition_kernel<BLOCK, ITEMS, KM, CL>;
   static bool attr_set = false;
   if (!attr_set) {
     DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -481,7 +520,7 @@ static int part_t(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds
 }
 
 int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
-                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay) {
+                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay, bool clustered) {
   PartArgs a;
   a.kx = kx; a.n = (uint32_t)n; a.r = g.r; a.F = g.F; a.tpg = g.tpg; a.P = P; a.gpre = gpre;
   a.kout = kout; a.pay = pay;
@@ -489,7 +528,7 @@ int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const
   for (int c = 0; c < pay.n; c++) maxw = pay.width[c] > maxw ? pay.width[c] : maxw;
   const uint32_t Fp = (g.F + 3u) & ~3u;
   const size_t lds = (size_t)(2 * Fp + 32) * 4 + (size_t)g.tile * maxw;
-  BK_DISPATCH(part_t, g, ctx, a, g.ntiles, lds);
+  BK_DISPATCH(part_t, g, clustered, ctx, a, g.ntiles, lds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -563,8 +602,56 @@ __device__ __forceinline__ void lds_fadd(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+__device__ __forceinline__ u64 wave_reduce_u64(u64 v, int op) {     // op 0 add, 1 min, 2 max; all 64 lanes active
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 w = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+    v = op == 0 ? v + w : op == 1 ? (w < v ? w : v) : (w > v ? w : v);
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_reduce_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 b = (u64)__double_as_longlong(v);
+    const u64 w = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(b >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)b, o, 64);
+    v += __longlong_as_double((long long)w);
+  }
+  return v;
+}
+
+// the whole (fully active) wave addresses ONE slot -- sorted / constant / heavily skewed keys: reduce in
+// registers, one lane updates the table (64 same-address DS atomics would serialise)
 template <typename VT>
+__device__ __forceinline__ void acc_wave_uniform(const LdsTab& t, int flags, uint32_t slot, VT v) {
+  const bool lead = (threadIdx.x & 63) == 0;
+  if (lead && (flags & ACC_CNT)) atomicAdd(&t.cnt[slot], 64u);
+  if (lead && (flags & ACC_PRES)) atomicOr(&t.pres[slot >> 5], 1u << (slot & 31));
+  if (!(flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM))) return;
+  const bool ok = !ValTraits<VT>::isna(v);
+  const uint32_t nok = (uint32_t)__popcll(__ballot(ok));
+  if (nok == 0) return;
+  if (lead && (flags & ACC_VCNT)) atomicAdd(&t.vcnt[slot], nok);
+  if (ValTraits<VT>::is_float) {
+    const double d = (double)v;
+    if (flags & ACC_SUM) { const double r = wave_reduce_f64(ok ? d : 0.0); if (lead) lds_fadd(reinterpret_cast<double*>(&t.sum[slot]), r); }
+    if (flags & ACC_MIN) { const u64 r = wave_reduce_u64(ok ? sortable_f64(d) : ~0ULL, 1); if (lead) atomicMin(&t.mn[slot], r); }
+    if (flags & ACC_MAX) { const u64 r = wave_reduce_u64(ok ? sortable_f64(d) : 0ULL, 2); if (lead) atomicMax(&t.mx[slot], r); }
+  } else {
+    const long long iv = (long long)v;
+    if (flags & ACC_SUM) { const u64 r = wave_reduce_u64(ok ? (u64)iv : 0ULL, 0); if (lead) atomicAdd(&t.sum[slot], r); }
+    if (flags & ACC_FSUM) { const double r = wave_reduce_f64(ok ? (double)iv : 0.0); if (lead) lds_fadd(&t.fsum[slot], r); }
+    if (flags & ACC_MIN) { const u64 r = wave_reduce_u64(ok ? sortable_i64(iv) : ~0ULL, 1); if (lead) atomicMin(&t.mn[slot], r); }
+    if (flags & ACC_MAX) { const u64 r = wave_reduce_u64(ok ? sortable_i64(iv) : 0ULL, 2); if (lead) atomicMax(&t.mx[slot], r); }
+  }
+}
+
+template <typename VT, bool UNI>
 __device__ __forceinline__ void acc_row(const LdsTab& t, int flags, uint32_t slot, VT v) {
+  if (UNI && __ballot(1) == ~0ULL && __ballot(slot == (uint32_t)__builtin_amdgcn_readfirstlane(slot)) == ~0ULL) {
+    acc_wave_uniform<VT>(t, flags, (uint32_t)__builtin_amdgcn_readfirstlane(slot), v);
+    return;
+  }
   if (flags & ACC_CNT) atomicAdd(&t.cnt[slot], 1u);
   if (flags & ACC_PRES) atomicOr(&t.pres[slot >> 5], 1u << (slot & 31));
   if (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) {
@@ -603,7 +690,7 @@ struct TableAggDev {
 
 // SRC: 0 = slot keys (uint16) + value column of the partitioned rows, 1 = raw rows (keys transformed
 // on the fly; one table holds the whole key range)
-template <typename VT, int SRC>
+template <typename VT, int SRC, bool UNI>
 __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
   constexpr bool RAW = SRC == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -630,7 +717,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
     for (uint32_t row = it.begin + tid; row < it.end; row += TA_BLOCK) {
       const uint32_t slot = (uint32_t)packed_key_checked(a.kx.cols, a.kx.ncols, row, bad);
       const VT v = hasval ? val[row] : VT(0);
-      acc_row<VT>(t, flags, slot, v);
+      acc_row<VT, UNI>(t, flags, slot, v);
     }
     if (__ballot(bad) && (tid & 63) == 0) atomicOr(a.bad, 1u);
   } else {
@@ -642,10 +729,10 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
       const uint32_t nh = a0 - it.begin, ntl = it.end - a1;
       if ((uint32_t)tid < nh) {
         const uint32_t row = it.begin + tid;
-        acc_row<VT>(t, flags, kp[row], hasval ? val[row] : VT(0));
+        acc_row<VT, UNI>(t, flags, kp[row], hasval ? val[row] : VT(0));
       } else if ((uint32_t)tid >= 64u && (uint32_t)tid - 64u < ntl) {
         const uint32_t row = a1 + ((uint32_t)tid - 64u);
-        acc_row<VT>(t, flags, kp[row], hasval ? val[row] : VT(0));
+        acc_row<VT, UNI>(t, flags, kp[row], hasval ? val[row] : VT(0));
       }
     }
     const uint32_t ngr = (a1 - a0) >> 3;
@@ -670,7 +757,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
         for (int j = 0; j < 8; j++) v[j] = VT(0);
       }
 #pragma unroll
-      for (int j = 0; j < 8; j++) acc_row<VT>(t, flags, slot[j], v[j]);
+      for (int j = 0; j < 8; j++) acc_row<VT, UNI>(t, flags, slot[j], v[j]);
     }
   }
   __syncthreads();
@@ -706,9 +793,9 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
   }
 }
 
-template <typename VT, int SRC>
+template <typename VT, int SRC, bool UNI>
 static int table_agg_t(dthip_ctx* ctx, const TableAggDev& d, uint32_t grid, size_t lds) {
-  auto kfn = table_agg_kernel<VT, SRC>;
+  auto kfn = table_agg_kernel<VT, SRC, UNI>;
   static bool attr_set = false;
   if (!attr_set) {
     DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -730,8 +817,10 @@ int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a) {
   const int st = a.val ? a.vstype : DTHIP_INT32;
 #define TA_GO(VT)                                                                 \
   do {                                                                            \
-    if (a.src == 1) return table_agg_t<VT, 1>(ctx, d, a.max_items, lds);          \
-    return table_agg_t<VT, 0>(ctx, d, a.max_items, lds);                          \
+    if (a.src == 1) { if (a.clustered) return table_agg_t<VT, 1, true>(ctx, d, a.max_items, lds);   \
+                      return table_agg_t<VT, 1, false>(ctx, d, a.max_items, lds); }                 \
+    if (a.clustered) return table_agg_t<VT, 0, true>(ctx, d, a.max_items, lds);   \
+    return table_agg_t<VT, 0, false>(ctx, d, a.max_items, lds);                   \
   } while (0)
   switch (st) {
     case DTHIP_INT32: TA_GO(int32_t);

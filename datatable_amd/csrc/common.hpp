@@ -70,6 +70,7 @@ struct dthip_ctx {
   int agg_path = 0;          // 0 auto, 1 sort path, 2 bucket path whenever eligible
   int bucket_variant = 0;    // partition tile geometry (experiments)
   int64_t spec_min_rows = 1 << 23;   // key ranges are guessed from a sample only at or above this many rows
+  int cluster_mode = 0;      // clustered-key kernel variants: 0 decide from a sample, 1 never, 2 always
   int agg_offsets = 1;       // dthip_groupby_agg results carry group offsets (= sizes) even when no count() asks for them
 };
 
@@ -229,14 +230,16 @@ struct AggTable {
 void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom* g);
 // *bad is set when a row's transformed key exceeds its column's xmax (such rows are counted as key 0)
 int launch_bucket_hist(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, uint32_t* P, uint32_t* gtot,
-                       uint32_t* bad);
+                       uint32_t* bad, bool clustered);
+// *clustered <- neighbouring rows mostly share a bucket (65536 sampled row pairs; synchronises); flag2: 2 words of scratch
+int launch_bucket_cluster_sample(dthip_ctx* ctx, const KeyXform& kx, int64_t n, int r, uint32_t* flag2, bool* clustered);
 // phase 0: tot[F] <- bucket sizes; phase 1: gtot <- bbase + exclusive prefix over groups (in place)
 int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uint32_t* tot, const uint32_t* bbase, int phase);
 // tot (nullable: one bucket of n_raw rows) -> bbase[F+1], work items of <= M rows, *nitems
 int launch_bucket_plan(dthip_ctx* ctx, const uint32_t* tot, uint32_t F, uint32_t n_raw, uint32_t M,
                        uint32_t* bbase, WorkItem* items, uint32_t* nitems);
 int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
-                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay);
+                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay, bool clustered);
 struct TableAggArgs {
   const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
   int src;                    // 0: kpart + val of the partitioned rows, 1: raw rows (kx + val)
@@ -246,6 +249,7 @@ struct TableAggArgs {
   uint32_t S; int flags;
   AggTable tab;
   uint32_t* bad;              // raw mode: set when a key exceeds its column's xmax
+  bool clustered;             // waves mostly address one slot: reduce in registers first
 };
 int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a);
 size_t table_agg_slot_bytes(int flags);

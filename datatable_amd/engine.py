@@ -186,6 +186,10 @@ class Context:
         except Exception:
             pass
 
+    def use_stream(self, handle):
+        """launch on the caller's HIP stream (0 / None = the device's default stream) from now on"""
+        L.check(self._lib.dthip_use_stream(self._h, C.c_void_p(handle) if handle else None))
+
     def sync(self):
         L.check(self._lib.dthip_sync(self._h))
 

@@ -12,11 +12,14 @@ ST2T = {L.BOOL: torch.int8, L.INT8: torch.int8, L.INT16: torch.int16, L.INT32: t
 
 
 def context_for_current_stream(device_index):
-    """A Context that launches on torch's current stream of that device, so torch ops and
-    libdthip kernels are ordered without extra synchronisation."""
+    """A Context that launches on torch's current stream of that device -- also when that is the
+    default stream (handle 0) -- so torch ops and libdthip kernels are ordered without extra
+    synchronisation."""
     with torch.cuda.device(device_index):
         stream = torch.cuda.current_stream().cuda_stream
-    return Context(device_index, stream)
+    ctx = Context(device_index)
+    ctx.use_stream(stream)
+    return ctx
 
 
 def devcol(t, desc=False):

@@ -113,6 +113,9 @@ int         dthip_device_count(void);
 /* stream: a hipStream_t to launch on (e.g. the caller's current stream), or NULL
  * to let the context create its own non-blocking stream. */
 int  dthip_init(int device, void* stream, dthip_ctx** out);
+/* launch on the caller's stream from now on; NULL = the device's default (legacy) stream, which
+ * dthip_init cannot express because NULL there means "create one".  The context never owns it. */
+int  dthip_use_stream(dthip_ctx* ctx, void* stream);
 int  dthip_destroy(dthip_ctx* ctx);
 int  dthip_sync(dthip_ctx* ctx);
 /* release cached workspace back to the driver */
@@ -125,6 +128,9 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    0: only when a count() aggregate asks for group sizes -- the reference's result
  *                    Frame of DT[:, sum(f.v), by(f.k)] holds keys and sums only, and not counting rows
  *                    lets the bucketed aggregation use twice as many table slots per bucket
+ *   "cluster_mode"   0 (default): a sample of neighbouring rows decides whether the bucketed aggregation
+ *                    runs its variants for sorted / clustered / constant keys (a wave that addresses one
+ *                    bucket or slot is counted / reduced in registers first); 1 = never, 2 = always
  *   "spec_min_rows"  from this many rows on, integer key ranges are first guessed from a sample
  *                    and verified by the bucketed aggregation (default 2^23) */
 int  dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value);

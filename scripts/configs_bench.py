@@ -70,6 +70,28 @@ def main():
                 r = ctx.groupby_agg([devcol(a), devcol(b)], [devcol(v)], [("count0", None), ("sum", 0)], nrows=n)
                 ng = r.ngroups; r.free(); return ng
             alg = n * 16
+        elif c in (7, 8, 9):
+            # robustness variants of C3: 7 = heavy skew (key = 1e7 * u^6: a few keys hold most rows),
+            # 8 = keys already sorted, 9 = one single key
+            n = int(1e9 * args.scale)
+            if c == 7:
+                k = (torch.rand(n, dtype=torch.float64, device=dev, generator=g) ** 6 * 1e7).to(torch.int64)
+            elif c == 8:
+                k = (torch.arange(n, dtype=torch.int64, device=dev) // 100)
+            else:
+                k = torch.full((n,), 12345, dtype=torch.int64, device=dev)
+            v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            def run():
+                r = ctx.groupby_agg([devcol(k)], [devcol(v)], [("sum", 0), ("count0", None)], nrows=n)
+                ng = r.ngroups
+                tot = torch.empty(ng, dtype=torch.float64, device=dev); cnt = torch.empty(ng, dtype=torch.int64, device=dev)
+                r.agg_into(0, tot.data_ptr()); r.agg_into(1, cnt.data_ptr()); r.free()
+                torch.cuda.synchronize()
+                assert int(cnt.sum().item()) == n, (int(cnt.sum().item()), n)
+                d = abs(float(tot.sum().item()) - float(v.sum().item()))
+                assert d <= 1e-9 * float(v.abs().sum().item()), (d, float(tot.sum().item()), float(v.sum().item()), ng)
+                return ng
+            alg = n * 16
         elif c == 6:
             # hard-keys variant of C3: full-range int64 keys drawn from a pool of 1e7 values
             n = int(1e9 * args.scale)

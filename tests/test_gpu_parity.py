@@ -265,6 +265,27 @@ def test_descending_and_na_last(ctx):
         r.free()
 
 
+def test_clustered_key_variants(ctx):
+    """the kernel variants for sorted / clustered / constant keys (wave-uniform bucket or slot: one DS
+    atomic per wave after a register reduction), forced on and off, on sorted, constant, skewed and
+    random keys -- same results as the oracle either way"""
+    rng = np.random.default_rng(53)
+    n = 400_000
+    cases = [np.sort(rng.integers(0, 30_000, n)).astype(np.int64), np.full(n, 7, np.int32),
+             np.where(rng.random(n) < 0.95, 5, rng.integers(0, 100_000, n)).astype(np.int64),
+             rng.integers(0, 200_000, n).astype(np.int32), (np.arange(n) // 3).astype(np.int64)]
+    v = rng.standard_normal(n)
+    v[rng.random(n) < 0.1] = np.nan
+    iv = rng.integers(-1000, 1000, n).astype(np.int64)
+    for k in cases:
+        for mode in (1, 2):
+            ctx.set_option("cluster_mode", mode)
+            try:
+                _vs_oracle(ctx, [k], [v, iv], check_ri=False)
+            finally:
+                ctx.set_option("cluster_mode", 0)
+
+
 def test_range_bucket_and_ungroup(ctx):
     """the two small helpers of the multi-GPU row exchange / GtoALL broadcast"""
     rng = np.random.default_rng(49)
