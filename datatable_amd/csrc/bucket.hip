@@ -36,21 +36,6 @@ typedef uint32_t bu32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t bu32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 
-// LDS counter increment that returns the arrival rank.  Sorted or constant key columns put a whole
-// wave into one bucket: 64 same-address DS atomics would serialise, so a wave-uniform bucket is
-// counted by one lane (one ds_add of the wave's population) and ranked with v_mbcnt.
-__device__ __forceinline__ uint32_t lds_count_rank(uint32_t* cnt, uint32_t d) {
-  const unsigned long long act = __ballot(1);
-  const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
-  if (__ballot(d == d0) == act) {
-    const uint32_t r = mbcnt64(act);
-    uint32_t base = 0;
-    if (r == 0) base = atomicAdd(&cnt[d0], (uint32_t)__popcll(act));
-    return __builtin_amdgcn_readfirstlane(base) + r;
-  }
-  return atomicAdd(&cnt[d], 1u);
-}
-
 // ---------------------------------------------------------------------------------------
 // tile loaders.  KM = 1: 16-B aligned int64 key column(s), 2 consecutive rows per lane per
 // load; KM = 2: aligned int32 key column(s), 4 consecutive rows; KM = 0: anything, 1 row.

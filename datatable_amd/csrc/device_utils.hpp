@@ -67,4 +67,47 @@ __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// LDS counter increment that returns the arrival rank; a wave whose lanes all address one bin (sorted /
+// constant keys: 64 same-address DS atomics would serialise) is counted by one lane and ranked with v_mbcnt
+__device__ __forceinline__ uint32_t lds_count_rank(uint32_t* cnt, uint32_t d) {
+  const uint64_t act = __ballot(1);
+  const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+  if (__ballot(d == d0) == act) {
+    const uint32_t r = mbcnt64(act);
+    uint32_t base = 0;
+    if (r == 0) base = atomicAdd(&cnt[d0], (uint32_t)__popcll(act));
+    return __builtin_amdgcn_readfirstlane(base) + r;
+  }
+  return atomicAdd(&cnt[d], 1u);
+}
+
+// LDS counter increment for keys that arrive in runs (sorted / clustered / constant columns), where
+// plain DS atomics would pile 64 lanes onto one address and serialise.  The wave's lanes are peeled
+// cluster by cluster: all lanes that share the first remaining lane's bin are counted by ONE ds_add of
+// the cluster's population and ranked with a masked v_mbcnt.  A first cluster smaller than 8 lanes means
+// the bins are scattered (random keys): everybody falls back to an individual atomic at once, so the
+// test costs one ballot.  Returns the arrival rank inside the bin (unordered between clusters).
+__device__ __forceinline__ uint32_t lds_count_peel_rank(uint32_t* cnt, uint32_t d) {
+  const int lane = lane_id();
+  const uint64_t lt = (1ULL << lane) - 1ULL;
+  uint64_t rem = __ballot(1);
+  uint32_t rank = 0;
+  bool done = false;
+#pragma unroll 1
+  for (int it = 0; it < 4 && rem; it++) {
+    const int leader = __ffsll((long long)rem) - 1;
+    const uint32_t d0 = (uint32_t)__shfl((int)d, leader, 64);
+    const uint64_t m = __ballot(!done && d == d0) & rem;
+    const uint32_t pop = (uint32_t)__popcll(m);
+    if (it == 0 && pop < 8) break;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&cnt[d0], pop);
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (!done && d == d0) { rank = base + (uint32_t)__popcll(m & lt); done = true; }
+    rem &= ~m;
+  }
+  if (!done) rank = atomicAdd(&cnt[d], 1u);
+  return rank;
+}
+
 }  // namespace dthip

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(XH_BLOCK) xform_hist_int_kernel(XformArgs a) {
       const uint32_t msk = (1u << a.pbits[p]) - 1u;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        if ((uint32_t)j < nv) atomicAdd(&lhist[p * HIST_STRIDE + ((uint32_t)(k[j] >> sh) & msk)], 1u);
+        if ((uint32_t)j < nv) (void)lds_count_peel_rank(&lhist[p * HIST_STRIDE], (uint32_t)(k[j] >> sh) & msk);
       }
     }
   }
@@ -212,9 +212,9 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_tile_hist_kernel(const KeyT* _
       for (int j = 0; j < NV; j++) w[j] = src[j * RP_BLOCK + tid];
       const KeyT* k = reinterpret_cast<const KeyT*>(w);
 #pragma unroll
-      for (int j = 0; j < RP_ITEMS; j++) atomicAdd(&cnt[(uint32_t)(k[j] >> shift) & dmask], 1u);
+      for (int j = 0; j < RP_ITEMS; j++) (void)lds_count_rank(cnt, (uint32_t)(k[j] >> shift) & dmask);
     } else {
-      for (uint32_t i = tid; i < nvalid; i += RP_BLOCK) atomicAdd(&cnt[(uint32_t)(keys[tile_base + i] >> shift) & dmask], 1u);
+      for (uint32_t i = tid; i < nvalid; i += RP_BLOCK) (void)lds_count_rank(cnt, (uint32_t)(keys[tile_base + i] >> shift) & dmask);
     }
     __syncthreads();
     if ((uint32_t)tid < bins) {

@@ -17,12 +17,14 @@ def main():
     ap.add_argument("--configs", default="1,2,3,4,5")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--agg-path", type=int, default=0)
     args = ap.parse_args()
     import torch
     from datatable_amd import _lib as L
     from datatable_amd.torch_bridge import context_for_current_stream, devcol
     dev = torch.device("cuda", 0)
     ctx = context_for_current_stream(0)
+    ctx.set_option("agg_path", args.agg_path)
     g = torch.Generator(device=dev)
 
     def timed(fn):
