@@ -752,6 +752,223 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   return DTHIP_OK;
 }
 
+
+// ---- hash combiner for sparse keys (bucket.hip): partial groups + merge ------------------------
+constexpr int DTHIP_NOT_APPLICABLE = 2;     // internal: this path does not fit, take the next one
+constexpr int HASH_PK_BITS = 24, HASH_R = 13;          // pseudo key: 2048 buckets by hash
+
+// distinct-key estimate from a strided sample of m rows: group the sample with the ordinary path,
+// invert  u = N (1 - exp(-m / N))  (u distinct keys among m draws from N equally likely keys)
+static int estimate_distinct(dthip_ctx* ctx, const std::vector<dthip_col>& kd, int nkeys, int64_t n, int na_pos, double* est) {
+  const int64_t m = std::min<int64_t>(n, 1 << 21);
+  Scratch sc(ctx);
+  int32_t* ri = nullptr;
+  DTHIP_TRY(sc.get<int32_t>((size_t)m, &ri));
+  DTHIP_TRY(launch_sample_rows(ctx, ri, m, n));
+  std::vector<dthip_col> sk(nkeys);
+  for (int k = 0; k < nkeys; k++) {
+    unsigned char* b = nullptr;
+    DTHIP_TRY(sc.get<unsigned char>((size_t)m * stype_size(kd[k].stype), &b));
+    DTHIP_TRY(launch_gather(ctx, kd[k].data, kd[k].stype, ri, m, b));
+    sk[k] = kd[k];
+    sk[k].data = b;
+  }
+  dthip_result* r = nullptr;
+  DTHIP_TRY(dthip_groupby(ctx, sk.data(), nkeys, m, na_pos, DTHIP_DEVICE, 0, &r));
+  const double u = (double)dthip_result_ngroups(r);
+  dthip_result_free(ctx, r);
+  if (m == n) { *est = u; return DTHIP_OK; }
+  if (u > 0.97 * (double)m) { *est = 1e300; return DTHIP_OK; }     // (nearly) all distinct in the sample
+  double lo = u, hi = 1e15;
+  for (int it = 0; it < 200; it++) {
+    const double mid = 0.5 * (lo + hi);
+    const double f = mid * (1.0 - exp(-(double)m / mid));
+    if (f < u) lo = mid; else hi = mid;
+  }
+  *est = hi;
+  return DTHIP_OK;
+}
+
+static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const KeyPlan& plan,
+                            const std::vector<dthip_col>& kd, const std::vector<dthip_col>& vd,
+                            const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int na_pos) {
+  const int nkeys = plan.nkeys;
+  if (ctx->hash_mode == 1 || ctx->in_merge || ctx->agg_path == 1) return DTHIP_NOT_APPLICABLE;
+  if (plan.nstages != 1 || used.size() > 1) return DTHIP_NOT_APPLICABLE;
+  if (ctx->hash_mode != 2 && n < (1 << 22)) return DTHIP_NOT_APPLICABLE;
+  const int c0 = used.empty() ? -1 : used[0];
+  if (c0 >= 0 && stype_size(vd[c0].stype) != 4 && stype_size(vd[c0].stype) != 8) return DTHIP_NOT_APPLICABLE;
+  const bool need_cnt = bucket_need_counts(ctx, aggs, naggs);
+  const int vst = c0 >= 0 ? vd[c0].stype : DTHIP_INT32;
+  const int flags = (c0 >= 0 ? acc_flags_for(aggs, naggs, c0, vst) : 0) | (need_cnt ? ACC_CNT : 0);
+  const size_t entry = hash_agg_entry_bytes(flags);
+  uint32_t C = (uint32_t)((158 * 1024) / entry) - 1;                // the whole LDS of a CU for one table ...
+  for (;; C--) {                                                     // ... with a prime number of entries (double hashing)
+    bool prime = C % 2 != 0;
+    for (uint32_t q = 3; prime && q * q <= C; q += 2) prime = C % q != 0;
+    if (prime) break;
+  }
+  const uint32_t F = 1u << (HASH_PK_BITS - HASH_R);
+  double est = 0;
+  DTHIP_TRY(estimate_distinct(ctx, kd, nkeys, n, na_pos, &est));
+  if (est * 1.05 > 0.75 * (double)F * (double)C) return DTHIP_NOT_APPLICABLE;      // expected load factor <= 0.75
+
+  KeyXform kx;
+  memset(&kx, 0, sizeof(kx));
+  kx.ncols = nkeys;
+  for (int k = 0; k < nkeys; k++) kx.cols[k] = plan.col[k];
+  unsigned long long* xs = nullptr; int32_t* pk = nullptr;
+  DTHIP_TRY(sc.get<unsigned long long>((size_t)n + 2, &xs));
+  DTHIP_TRY(sc.get<int32_t>((size_t)n + 4, &pk));
+  DTHIP_TRY(launch_hash_xform(ctx, kx, n, xs, pk));
+  // the bucket machinery, driven by the pseudo key pk in [0, 2^24)
+  KeyXform pkx;
+  memset(&pkx, 0, sizeof(pkx));
+  pkx.ncols = 1;
+  pkx.cols[0].data = pk; pkx.cols[0].stype = DTHIP_INT32; pkx.cols[0].desc = 0; pkx.cols[0].edge = 0;
+  pkx.cols[0].na_repl = 0; pkx.cols[0].inc = 0; pkx.cols[0].xmax = ~0ULL; pkx.cols[0].shift = 0;
+  int km = 2;
+  if (c0 >= 0 && (reinterpret_cast<uintptr_t>(vd[c0].data) & 15)) km = 0;
+  BucketGeom g;
+  bucket_geometry(ctx, n, HASH_PK_BITS, HASH_R, km, &g);
+  uint32_t* bbase = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 8, &bbase));
+  uint32_t* nitems = bbase + g.F + 1;
+  uint32_t* d_bad = bbase + g.F + 2;
+  uint32_t* d_outn = bbase + g.F + 3;
+  uint32_t* d_ovf = bbase + g.F + 4;
+  DTHIP_CHECK_HIP(hipMemsetAsync(bbase + g.F + 1, 0, 7 * sizeof(uint32_t), ctx->stream));
+  uint32_t M;
+  {
+    const uint64_t denom = std::max<uint64_t>(g.F, (uint64_t)ctx->num_cus * 4);
+    uint64_t m = (2 * (uint64_t)n + denom - 1) / denom;
+    if (m < 65536) m = 65536;
+    m = (m + 7) & ~7ULL;
+    M = (uint32_t)std::min<uint64_t>(m, 0x7FFFFFF8ULL);
+  }
+  const uint32_t max_items = g.F + (uint32_t)((uint64_t)n / M) + 1;
+  WorkItem* items = nullptr;
+  DTHIP_TRY(sc.get<WorkItem>(max_items, &items));
+  uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)g.ntiles * g.F, &P));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)g.G * g.F, &gtot));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)g.F, &tot));
+  DTHIP_TRY(launch_bucket_hist(ctx, pkx, n, g, P, gtot, d_bad, false));
+  DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, nullptr, 0));
+  DTHIP_TRY(launch_bucket_plan(ctx, tot, g.F, 0, M, bbase, items, nitems));
+  DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, bbase, 1));
+  uint16_t* kslot = nullptr;         // not written: the packed key itself travels as payload 0
+  unsigned long long* xs_part = nullptr;
+  DTHIP_TRY(sc.get<unsigned long long>((size_t)n + 8, &xs_part));
+  PayCols pc;
+  memset(&pc, 0, sizeof(pc));
+  pc.in[0] = xs; pc.out[0] = xs_part; pc.width[0] = 8; pc.n = 1;
+  unsigned char* v_part = nullptr;
+  if (c0 >= 0) {
+    const int w = stype_size(vst);
+    DTHIP_TRY(sc.get<unsigned char>((size_t)n * w + 64, &v_part));
+    pc.in[1] = vd[c0].data; pc.out[1] = v_part; pc.width[1] = w; pc.n = 2;
+  }
+  DTHIP_TRY(launch_bucket_partition(ctx, pkx, n, g, P, gtot, kslot, pc, false));
+
+  // partial groups
+  const size_t out_cap = std::min<size_t>((size_t)n, (size_t)max_items * (C + 1));
+  HashAggArgs ha;
+  memset(&ha, 0, sizeof(ha));
+  ha.items = items; ha.nitems = nitems; ha.max_items = max_items; ha.xs = xs_part; ha.val = v_part; ha.vstype = vst;
+  ha.C = C; ha.flags = flags; ha.out_n = d_outn; ha.out_cap = (uint32_t)out_cap; ha.overflow = d_ovf;
+  DTHIP_TRY(sc.get<unsigned long long>(out_cap, &ha.o_key));
+  if (flags & ACC_CNT) DTHIP_TRY(sc.get<uint32_t>(out_cap, &ha.o_tab.cnt));
+  if (flags & ACC_VCNT) DTHIP_TRY(sc.get<uint32_t>(out_cap, &ha.o_tab.vcnt));
+  if (flags & ACC_SUM) DTHIP_TRY(sc.get<unsigned long long>(out_cap, &ha.o_tab.sum));
+  if (flags & ACC_MIN) DTHIP_TRY(sc.get<unsigned long long>(out_cap, &ha.o_tab.mn));
+  if (flags & ACC_MAX) DTHIP_TRY(sc.get<unsigned long long>(out_cap, &ha.o_tab.mx));
+  if (flags & ACC_FSUM) DTHIP_TRY(sc.get<double>(out_cap, &ha.o_tab.fsum));
+  DTHIP_TRY(launch_hash_agg(ctx, ha));
+  uint32_t hn[2] = {0, 0};
+  DTHIP_TRY(read_back(ctx, hn, d_outn, sizeof(hn)));       // {number of partial groups, overflow bits}
+  if (hn[1]) return DTHIP_NOT_APPLICABLE;                    // a table filled up: the sort path takes over
+  const int64_t np = hn[0];
+
+  // typed columns of the partial groups
+  std::vector<dthip_col> k2(nkeys);
+  for (int k = 0; k < nkeys; k++) {
+    unsigned char* b = nullptr;
+    DTHIP_TRY(sc.get<unsigned char>((size_t)np * stype_size(kd[k].stype) + 16, &b));
+    DTHIP_TRY(launch_untransform_keys(ctx, ha.o_key, 1, nullptr, np, plan.col[k], plan.nsig[k], b));
+    k2[k] = kd[k];
+    k2[k].data = b;
+  }
+  const bool isf = stype_is_float(vst);
+  PartialColsArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.tab = ha.o_tab; pa.n = (uint32_t)np; pa.vstype = vst;
+  std::vector<dthip_col> v2;
+  std::vector<dthip_agg> a2;
+  int iSUM = -1, iFSUM = -1, iMIN = -1, iMAX = -1, iVCNT = -1, iCNT = -1;
+  auto add_col = [&](void* data, int st, int op) { v2.push_back(dthip_col{data, st, 0}); a2.push_back(dthip_agg{op, (int32_t)v2.size() - 1}); return (int)a2.size() - 1; };
+  if (flags & ACC_SUM) { DTHIP_TRY(sc.get<unsigned long long>((size_t)np + 2, &pa.o_sum)); iSUM = add_col(pa.o_sum, isf ? DTHIP_FLOAT64 : DTHIP_INT64, DTHIP_SUM); }
+  if (flags & ACC_FSUM) { DTHIP_TRY(sc.get<double>((size_t)np + 2, &pa.o_fsum)); iFSUM = add_col(pa.o_fsum, DTHIP_FLOAT64, DTHIP_SUM); }
+  if (flags & ACC_MIN) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)np * 8 + 16, &b)); pa.o_min = b; iMIN = add_col(b, vst, DTHIP_MIN); }
+  if (flags & ACC_MAX) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)np * 8 + 16, &b)); pa.o_max = b; iMAX = add_col(b, vst, DTHIP_MAX); }
+  if (flags & ACC_VCNT) { DTHIP_TRY(sc.get<int64_t>((size_t)np + 2, &pa.o_vcnt)); iVCNT = add_col(pa.o_vcnt, DTHIP_INT64, DTHIP_SUM); }
+  if (flags & ACC_CNT) { DTHIP_TRY(sc.get<int64_t>((size_t)np + 2, &pa.o_cnt)); iCNT = add_col(pa.o_cnt, DTHIP_INT64, DTHIP_SUM); }
+  DTHIP_TRY(launch_partial_columns(ctx, pa));
+
+  // merge: the ordinary path on the partial groups (few rows), keys in their own stypes and flags
+  dthip_result* r2 = nullptr;
+  const int saved_off = ctx->agg_offsets;
+  ctx->in_merge = true; ctx->agg_offsets = 0;
+  int rc = dthip_groupby_agg(ctx, k2.data(), nkeys, v2.empty() ? nullptr : v2.data(), (int)v2.size(),
+                             a2.empty() ? nullptr : a2.data(), (int)a2.size(), np, na_pos, DTHIP_DEVICE, &r2);
+  ctx->in_merge = false; ctx->agg_offsets = saved_off;
+  if (rc != DTHIP_OK) return rc;
+  const int64_t ng = dthip_result_ngroups(r2);
+  res->nrows = n; res->ngroups = ng;
+  do {
+    for (int k = 0; k < nkeys && rc == DTHIP_OK; k++) {
+      void* kp = nullptr;
+      const size_t bytes = (size_t)ng * stype_size(kd[k].stype);
+      if ((rc = result_alloc(ctx, res, bytes, &kp)) != DTHIP_OK) break;
+      res->key[k] = kp;
+      if (bytes && hipMemcpyAsync(kp, dthip_result_key(r2, k), bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { set_error("D2D copy failed"); rc = DTHIP_EDEVICE; }
+    }
+    if (rc != DTHIP_OK) break;
+    if (need_cnt) {
+      void* off = nullptr;
+      if ((rc = result_alloc(ctx, res, sizeof(int32_t) * ((size_t)ng + 2 + (size_t)ng / 8192 + 1), &off)) != DTHIP_OK) break;
+      if ((rc = launch_narrow_i64_u32(ctx, static_cast<const long long*>(dthip_result_agg(r2, iCNT)), ng, static_cast<uint32_t*>(off))) != DTHIP_OK) break;
+      if ((rc = launch_scan_tiles(ctx, static_cast<uint32_t*>(off), (uint32_t)ng, static_cast<uint32_t*>(off) + ng)) != DTHIP_OK) break;
+      res->offsets = static_cast<int32_t*>(off);
+    }
+    for (int a = 0; a < naggs && rc == DTHIP_OK; a++) {
+      void* ap = nullptr;
+      const size_t bytes = (size_t)ng * stype_size(res->agg_stype[a]);
+      if ((rc = result_alloc(ctx, res, bytes, &ap)) != DTHIP_OK) break;
+      res->agg[a] = ap;
+      if (ng == 0) continue;
+      const void* src = nullptr;
+      switch (aggs[a].op) {
+        case DTHIP_SUM:
+          if (vst == DTHIP_FLOAT32) rc = launch_cast_f64_f32(ctx, static_cast<const double*>(dthip_result_agg(r2, iSUM)), ng, static_cast<float*>(ap));
+          else src = dthip_result_agg(r2, iSUM);
+          break;
+        case DTHIP_MEAN:
+          rc = launch_mean_div(ctx, static_cast<const double*>(dthip_result_agg(r2, isf ? iSUM : iFSUM)),
+                               static_cast<const long long*>(dthip_result_agg(r2, iVCNT)), ng, ap, vst == DTHIP_FLOAT32);
+          break;
+        case DTHIP_MIN: src = dthip_result_agg(r2, iMIN); break;
+        case DTHIP_MAX: src = dthip_result_agg(r2, iMAX); break;
+        case DTHIP_COUNT: src = dthip_result_agg(r2, iVCNT); break;
+        default: src = dthip_result_agg(r2, iCNT); break;      // COUNT0
+      }
+      if (rc == DTHIP_OK && src && hipMemcpyAsync(ap, src, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { set_error("D2D copy failed"); rc = DTHIP_EDEVICE; }
+    }
+  } while (0);
+  dthip_result_free(ctx, r2);
+  return rc;
+}
+
 }  // namespace dthip
 
 extern "C" {
@@ -841,6 +1058,11 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "bucket_variant")) { ctx->bucket_variant = (int)value; return DTHIP_OK; }
   if (!strcmp(name, "spec_min_rows")) { ctx->spec_min_rows = value; return DTHIP_OK; }
   if (!strcmp(name, "agg_offsets")) { ctx->agg_offsets = value != 0; return DTHIP_OK; }
+  if (!strcmp(name, "hash_mode")) {
+    if (value < 0 || value > 2) { set_error("hash_mode must be 0 (estimate), 1 (never) or 2 (whenever it fits)"); return DTHIP_EINVAL; }
+    ctx->hash_mode = (int)value;
+    return DTHIP_OK;
+  }
   if (!strcmp(name, "cluster_mode")) {
     if (value < 0 || value > 2) { set_error("cluster_mode must be 0 (sample), 1 (never) or 2 (always)"); return DTHIP_EINVAL; }
     ctx->cluster_mode = (int)value;
@@ -1105,6 +1327,13 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
         }
       }
       if (rc != DTHIP_OK || done) break;
+      // sparse keys (exact plan at this point): hash combiner + merge, when its tables are large enough
+      rc = hash_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, na_pos);
+      if (rc == DTHIP_OK) break;
+      if (rc != DTHIP_NOT_APPLICABLE) break;
+      rc = DTHIP_OK;
+      for (void* p : res->owned) dev_release(ctx, p);      // nothing of a half-built attempt survives
+      res->owned.clear();
       if (plan.nstages != 1) fused = false;
     }
     if (fused) {

@@ -70,6 +70,8 @@ struct dthip_ctx {
   int agg_path = 0;          // 0 auto, 1 sort path, 2 bucket path whenever eligible
   int bucket_variant = 0;    // partition tile geometry (experiments)
   int64_t spec_min_rows = 1 << 23;   // key ranges are guessed from a sample only at or above this many rows
+  int hash_mode = 0;         // hash combiner for sparse keys: 0 decide from a distinct-count estimate, 1 never, 2 whenever it fits
+  bool in_merge = false;     // internal: the merge of partial groups must not take the hash path again
   int cluster_mode = 0;      // clustered-key kernel variants: 0 decide from a sample, 1 never, 2 always
   int agg_offsets = 1;       // dthip_groupby_agg results carry group offsets (= sizes) even when no count() asks for them
 };
@@ -259,6 +261,27 @@ struct TableFinArgs {
   void* o_sum; void* o_mean; void* o_min; void* o_max; int64_t* o_count;
 };
 int launch_table_finalize(dthip_ctx* ctx, const TableFinArgs& a);
+
+// hash combiner (bucket.hip): partial groups of sparse keys
+int launch_hash_xform(dthip_ctx* ctx, const KeyXform& kx, int64_t n, unsigned long long* xs, int32_t* pk);
+struct HashAggArgs {
+  const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
+  const unsigned long long* xs;      // packed transformed keys of the partitioned rows
+  const void* val; int vstype;       // value column of the partitioned rows (null: counts only)
+  uint32_t C; int flags;             // table entries per workgroup, accumulators
+  unsigned long long* o_key; AggTable o_tab; uint32_t* out_n; uint32_t out_cap; uint32_t* overflow;
+};
+size_t hash_agg_entry_bytes(int flags);
+int launch_hash_agg(dthip_ctx* ctx, const HashAggArgs& a);
+struct PartialColsArgs {
+  AggTable tab; uint32_t n; int vstype;
+  unsigned long long* o_sum; double* o_fsum; void* o_min; void* o_max; int64_t* o_vcnt; int64_t* o_cnt;
+};
+int launch_partial_columns(dthip_ctx* ctx, const PartialColsArgs& a);
+int launch_mean_div(dthip_ctx* ctx, const double* sum, const long long* cnt, int64_t n, void* out, int out_f32);
+int launch_cast_f64_f32(dthip_ctx* ctx, const double* in, int64_t n, float* out);
+int launch_sample_rows(dthip_ctx* ctx, int32_t* out, int64_t m, int64_t n);
+int launch_narrow_i64_u32(dthip_ctx* ctx, const long long* in, int64_t n, uint32_t* out);
 
 // reduce.hip
 struct ReduceOuts {

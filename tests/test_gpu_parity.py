@@ -113,6 +113,20 @@ def _vs_oracle(ctx, keys, vals, aggs=OPS, key_stypes=None, check_ri=True):
             check_agg(r.agg(a), expected[a], opn, vals[vi], ri, off, "%s(v%d)%s" % (opn, vi, tag))
         assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count()" + tag)
         r.free()
+    # sparse key ranges: the hash combiner (LDS hash tables -> partial groups -> merge), forced on
+    # (takes effect where the bucketed path does not apply and there is at most one value column)
+    ctx.set_option("hash_mode", 2)
+    try:
+        r = ctx.groupby_agg(keys, vals, alist, key_stypes=key_stypes)
+    finally:
+        ctx.set_option("hash_mode", 0)
+    assert_same(r.offsets(), off, "fused offsets [hash_mode=2]")
+    for i in range(len(keys)):
+        assert_same(r.key(i), gkeys[i], "fused group key %d [hash_mode=2]" % i)
+    for a, (opn, vi) in enumerate(alist[:-1]):
+        check_agg(r.agg(a), expected[a], opn, vals[vi], ri, off, "%s(v%d) [hash_mode=2]" % (opn, vi))
+    assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count() [hash_mode=2]")
+    r.free()
     # the same without group sizes in the result (option agg_offsets=0, no count()): the bucketed
     # path then tracks key presence only and uses larger tables / fewer buckets
     ctx.set_option("agg_path", 2)
@@ -263,6 +277,36 @@ def test_descending_and_na_last(ctx):
         assert_same(r.offsets(), off, "offsets desc=%s na_last=%s" % (desc, na_last))
         assert_same(r.rowindex(), ri, "rowindex desc=%s na_last=%s" % (desc, na_last))
         r.free()
+
+
+def test_hash_combiner_sparse_keys(ctx):
+    """keys whose range is far too wide for slot tables (pooled 62-bit ints, float64, a > 32-bit composite):
+    LDS hash tables per hash bucket -> partial groups -> merge by the sort path.  Single value column or
+    none; NA keys and values; a skewed case whose big bucket is split into parts (duplicated partial groups)."""
+    rng = np.random.default_rng(57)
+    n = 300_000
+    pool = rng.integers(-2**62, 2**62, 20_000)
+    k_int = rng.choice(pool, n).astype(np.int64)
+    k_int[rng.random(n) < 0.02] = np.iinfo(np.int64).min
+    k_f = rng.choice(rng.standard_normal(5_000), n)
+    k_f[rng.random(n) < 0.02] = np.nan
+    k_skew = np.where(rng.random(n) < 0.85, pool[7], rng.choice(pool, n)).astype(np.int64)
+    k_a = rng.integers(0, 2**31 - 1, n).astype(np.int32) // 50_000 * 50_000
+    k_b = rng.choice(pool[:300], n).astype(np.int64)
+    v = rng.standard_normal(n)
+    v[rng.random(n) < 0.1] = np.nan
+    iv = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    fv = rng.standard_normal(n).astype(np.float32)
+    i32 = rng.integers(-1000, 1000, n).astype(np.int32)
+    i32[rng.random(n) < 0.1] = -2**31
+    ctx.set_option("hash_mode", 2)
+    try:
+        for keys in ([k_int], [k_f], [k_skew], [k_a, k_b]):
+            for val in (v, iv, fv, i32):
+                _vs_oracle(ctx, keys, [val], check_ri=False)
+            _vs_oracle(ctx, keys, [], aggs=(), check_ri=False)
+    finally:
+        ctx.set_option("hash_mode", 0)
 
 
 def test_clustered_key_variants(ctx):
