@@ -909,13 +909,15 @@ struct HashAggDev {
   uint32_t* overflow;      // set when a table fills up or the output capacity is exceeded
 };
 
-template <typename VT>
+// CFLAGS >= 0: the accumulator set is a compile-time constant (the common sum / sum+count shapes: the
+// eight unrolled inserts then carry no per-row flag tests); -1: taken from the arguments
+template <typename VT, int CFLAGS>
 __global__ void __launch_bounds__(TA_BLOCK) hash_agg_kernel(HashAggDev a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (blockIdx.x >= *a.nitems) return;
   const WorkItem it = a.items[blockIdx.x];
   const int tid = threadIdx.x;
-  const int flags = a.flags;
+  const int flags = CFLAGS >= 0 ? CFLAGS : a.flags;
   const uint32_t C = a.C, S = C + 1;                 // entry C is reserved for the key that equals HASH_EMPTY
   u64* hk = reinterpret_cast<u64*>(smem);            // [S] keys
   const LdsTab t = carve_tab(smem + (size_t)S * 8, S, flags);
@@ -988,9 +990,51 @@ __global__ void __launch_bounds__(TA_BLOCK) hash_agg_kernel(HashAggDev a) {
 #pragma unroll
         for (int j = 0; j < 8; j++) v[j] = VT(0);
       }
-      const u64* kx8 = reinterpret_cast<const u64*>(kw);
+      // Every lane walks through ITS eight rows at its own pace: one probe step per loop iteration on the
+      // lane's current row, and a lane that resolved its row accumulates and moves on to its next one.
+      // Row-by-row in lock-step, each row costs the wave the probe count of its slowest lane (~9 at load
+      // 0.6); this way a wave runs about max-over-lanes of the SUM of a lane's probes (~18 for 8 rows, not 72).
+      u64 qx[8]; VT qv[8];
+      {
+        const u64* kx8 = reinterpret_cast<const u64*>(kw);
 #pragma unroll
-      for (int j = 0; j < 8; j++) insert(kx8[j], v[j]);
+        for (int j = 0; j < 8; j++) { qx[j] = kx8[j]; qv[j] = v[j]; }
+      }
+      int left = 8;
+      uint32_t p = 0, step = 0, probes = 0;
+      bool fresh = true;
+      while (__any(left > 0)) {
+        if (left > 0) {
+          const u64 x = qx[0];
+          bool resolved = false;
+          if (fresh) {
+            fresh = false; probes = 0;
+            if (x == HASH_EMPTY) { p = C; s_misc[16] = 1; resolved = true; }
+            else {
+              const u64 h2 = mix64(x ^ 0x9E3779B97F4A7C15ULL);
+              p = (uint32_t)(((h2 & 0xFFFFFFFFULL) * (u64)C) >> 32);
+              step = 1u + (uint32_t)(((h2 >> 32) * (u64)(C - 1)) >> 32);
+            }
+          }
+          if (!resolved) {
+            u64 cur = __hip_atomic_load(&hk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (cur == HASH_EMPTY) cur = atomicCAS(&hk[p], HASH_EMPTY, x);
+            if (cur == HASH_EMPTY || cur == x) resolved = true;
+            else {
+              p += step; if (p >= C) p -= C;
+              if (++probes >= C) { full = true; left = 0; }
+            }
+          }
+          if (resolved) {
+            // (acc_row's wave-uniform fast path is off here: lanes are on different rows)
+            acc_row<VT, false>(t, flags, p, qv[0]);
+#pragma unroll
+            for (int j = 0; j < 7; j++) { qx[j] = qx[j + 1]; qv[j] = qv[j + 1]; }
+            left--;
+            fresh = true;
+          }
+        }
+      }
     }
   }
   if (__ballot(full) && (tid & 63) == 0) atomicOr(a.overflow, 1u);
@@ -1027,9 +1071,9 @@ __global__ void __launch_bounds__(TA_BLOCK) hash_agg_kernel(HashAggDev a) {
 
 size_t hash_agg_entry_bytes(int flags) { return 8 + table_agg_slot_bytes(flags); }
 
-template <typename VT>
+template <typename VT, int CFLAGS>
 static int hash_agg_t(dthip_ctx* ctx, const HashAggDev& d, uint32_t grid, size_t lds) {
-  auto kfn = hash_agg_kernel<VT>;
+  auto kfn = hash_agg_kernel<VT, CFLAGS>;
   static bool attr_set = false;
   if (!attr_set) {
     DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -1048,11 +1092,13 @@ int launch_hash_agg(dthip_ctx* ctx, const HashAggArgs& a) {
   const size_t lds = (size_t)(a.C + 1) * hash_agg_entry_bytes(a.flags) + 32;
   if (lds > 160 * 1024 - 512) { set_error("hash_agg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
   const int st = a.val ? a.vstype : DTHIP_INT32;
+  if (st == DTHIP_FLOAT64 && a.flags == ACC_SUM) return hash_agg_t<double, ACC_SUM>(ctx, d, a.max_items, lds);
+  if (st == DTHIP_FLOAT64 && a.flags == (ACC_SUM | ACC_CNT)) return hash_agg_t<double, ACC_SUM | ACC_CNT>(ctx, d, a.max_items, lds);
   switch (st) {
-    case DTHIP_INT32: return hash_agg_t<int32_t>(ctx, d, a.max_items, lds);
-    case DTHIP_INT64: return hash_agg_t<long long>(ctx, d, a.max_items, lds);
-    case DTHIP_FLOAT32: return hash_agg_t<float>(ctx, d, a.max_items, lds);
-    case DTHIP_FLOAT64: return hash_agg_t<double>(ctx, d, a.max_items, lds);
+    case DTHIP_INT32: return hash_agg_t<int32_t, -1>(ctx, d, a.max_items, lds);
+    case DTHIP_INT64: return hash_agg_t<long long, -1>(ctx, d, a.max_items, lds);
+    case DTHIP_FLOAT32: return hash_agg_t<float, -1>(ctx, d, a.max_items, lds);
+    case DTHIP_FLOAT64: return hash_agg_t<double, -1>(ctx, d, a.max_items, lds);
     default: set_error("hash_agg: unsupported value stype %d", a.vstype); return DTHIP_ENOTIMPL;
   }
 }
