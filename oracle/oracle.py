@@ -28,7 +28,8 @@ def build():
 
 
 def _lib():
-    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "dt_oracle.c")):
+    srcs = [os.path.join(_HERE, n) for n in ("dt_oracle.c", "dt_oracle_groupwise.c")]
+    if not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(s) for s in srcs):
         build()
     lib = C.CDLL(_SO)
     lib.dto_group.restype = C.c_int
@@ -139,4 +140,69 @@ def gather(values, ri, stype=None):
     ri = np.ascontiguousarray(ri, np.int32)
     out = np.empty(len(ri), a.dtype)
     lib().dto_gather(C.byref(c), C.c_void_p(ri.ctypes.data), C.c_int64(len(ri)), C.c_void_p(out.ctypes.data))
+    return out
+
+
+# ---- group-wise operators sharing the Groupby (dt_oracle_groupwise.c) --------------------------
+SD, MEDIAN, NUNIQUE = 8, 9, 10
+COV, CORR = 0, 1
+CUMSUM, CUMPROD, CUMMIN, CUMMAX, CUMCOUNT, NGROUP = 0, 1, 2, 3, 4, 5
+OPSX = {"sd": SD, "median": MEDIAN, "nunique": NUNIQUE}
+OPS2 = {"cov": COV, "corr": CORR}
+CUMOPS = {"cumsum": CUMSUM, "cumprod": CUMPROD, "cummin": CUMMIN, "cummax": CUMMAX, "cumcount": CUMCOUNT,
+          "ngroup": NGROUP}
+
+
+def _ri_off(ri, offsets):
+    offsets = np.ascontiguousarray(offsets, np.int32)
+    rip = None
+    if ri is not None:
+        ri = np.ascontiguousarray(ri, np.int32)
+        rip = C.c_void_p(ri.ctypes.data)
+    return ri, rip, offsets
+
+
+def reducex(op, values, ri, offsets, stype=None):
+    """sd / median / nunique per group (NA = the output stype's sentinel)."""
+    opc = OPSX[op] if isinstance(op, str) else op
+    ri, rip, offsets = _ri_off(ri, offsets)
+    ng = len(offsets) - 1
+    a, c = _col(values, stype)
+    ost = lib().dto_reducex_out_stype(C.c_int(opc), C.c_int(c.stype))
+    out = np.empty(ng, _ST2NP[ost])
+    lib().dto_reducex(C.c_int(opc), C.byref(c), rip, C.c_void_p(offsets.ctypes.data), C.c_int64(ng),
+                      C.c_void_p(out.ctypes.data))
+    return out
+
+
+def reduce2(op, va, vb, ri, offsets, stypes=(None, None)):
+    """cov / corr per group."""
+    opc = OPS2[op] if isinstance(op, str) else op
+    ri, rip, offsets = _ri_off(ri, offsets)
+    ng = len(offsets) - 1
+    a, ca = _col(va, stypes[0])
+    b, cb = _col(vb, stypes[1])
+    ost = lib().dto_reduce2_out_stype(C.c_int(ca.stype), C.c_int(cb.stype))
+    out = np.empty(ng, _ST2NP[ost])
+    lib().dto_reduce2(C.c_int(opc), C.byref(ca), C.byref(cb), rip, C.c_void_p(offsets.ctypes.data), C.c_int64(ng),
+                      C.c_void_p(out.ctypes.data))
+    return out
+
+
+def cumulate(op, values, ri, offsets, reverse=False, stype=None):
+    """cumsum / cumprod / cummin / cummax / cumcount / ngroup inside groups; output in grouped order."""
+    opc = CUMOPS[op] if isinstance(op, str) else op
+    ri, rip, offsets = _ri_off(ri, offsets)
+    ng = len(offsets) - 1
+    n = int(offsets[-1]) if ng >= 0 and len(offsets) else 0
+    if opc in (CUMCOUNT, NGROUP):
+        out = np.empty(n, np.int64)
+        lib().dto_cumulate(C.c_int(opc), None, rip, C.c_void_p(offsets.ctypes.data), C.c_int64(ng),
+                           C.c_int(1 if reverse else 0), C.c_void_p(out.ctypes.data))
+        return out
+    a, c = _col(values, stype)
+    ost = lib().dto_cumulate_out_stype(C.c_int(opc), C.c_int(c.stype))
+    out = np.empty(n, _ST2NP[ost])
+    lib().dto_cumulate(C.c_int(opc), C.byref(c), rip, C.c_void_p(offsets.ctypes.data), C.c_int64(ng),
+                       C.c_int(1 if reverse else 0), C.c_void_p(out.ctypes.data))
     return out
