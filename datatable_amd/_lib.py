@@ -13,6 +13,9 @@ LIB_PATH = os.path.join(_HERE, "libdthip.so")
 # stype codes == the reference's SType values (src/core/stype.h:41-62)
 BOOL, INT8, INT16, INT32, INT64, FLOAT32, FLOAT64 = 1, 2, 3, 4, 5, 6, 7
 SUM, MEAN, MIN, MAX, COUNT, COUNT0, FIRST, LAST = 0, 1, 2, 3, 4, 5, 6, 7
+SD, MEDIAN, NUNIQUE = 8, 9, 10                      # dthip_reduce only
+COV, CORR = 0, 1                                    # enum dthip_op2
+CUMSUM, CUMPROD, CUMMIN, CUMMAX, CUMCOUNT, NGROUP = 0, 1, 2, 3, 4, 5   # enum dthip_cumop
 HOST, DEVICE = 0, 1
 NA_FIRST, NA_LAST, NA_REMOVE = 0, 1, 2
 FLAG_DESCENDING = 1
@@ -74,6 +77,12 @@ SIGNATURES = {
     "dthip_reduce_out_stype": (C.c_int, [C.c_int, C.c_int]),
     "dthip_reduce": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Col), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                C.c_int, C.c_void_p]),
+    "dthip_reduce2_out_stype": (C.c_int, [C.c_int, C.c_int]),
+    "dthip_reduce2": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Col), C.POINTER(Col), C.c_void_p, C.c_void_p, C.c_int64,
+                                C.c_int64, C.c_int, C.c_void_p]),
+    "dthip_cumulate_out_stype": (C.c_int, [C.c_int, C.c_int]),
+    "dthip_cumulate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Col), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                 C.c_int, C.c_int, C.c_void_p]),
     "dthip_range_bucket": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dthip_ungroup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "dthip_bool_to_rowindex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,

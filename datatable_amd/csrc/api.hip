@@ -1484,9 +1484,74 @@ int dthip_reduce_out_stype(int op, int st) {
     case DTHIP_SUM: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : st == DTHIP_FLOAT64 ? DTHIP_FLOAT64 : DTHIP_INT64;
     case DTHIP_MEAN: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : DTHIP_FLOAT64;
     case DTHIP_MIN: case DTHIP_MAX: case DTHIP_FIRST: case DTHIP_LAST: return st;
+    case DTHIP_SD: case DTHIP_MEDIAN: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : DTHIP_FLOAT64;   // head_reduce_unary.cc:221-229,484-491
     default: return DTHIP_INT64;
   }
 }
+
+namespace dthip {
+
+// value column of a reducer on the device: it may be longer than nrows when read through a
+// RowIndex (the caller guarantees the indices fit); host staging copies max(index)+1 rows
+static int stage_value_col(dthip_ctx* ctx, Scratch& sc, const dthip_col* value, const int32_t* rowindex, int64_t nrows,
+                           int mem, const void** d_val) {
+  const int sz = stype_size(value->stype);
+  if (!sz) { set_error("unsupported stype %d", value->stype); return DTHIP_ENOTIMPL; }
+  *d_val = value->data;
+  if (mem == DTHIP_HOST) {
+    int64_t vrows = nrows;
+    if (rowindex) { vrows = 0; for (int64_t i = 0; i < nrows; i++) if (rowindex[i] >= vrows) vrows = (int64_t)rowindex[i] + 1; }
+    DTHIP_TRY(stage_in(ctx, sc, value->data, (size_t)vrows * sz, mem, d_val));
+  }
+  return DTHIP_OK;
+}
+
+// head bitmap (1 bit per grouped position) + per-tile "heads before this tile" from the offsets
+static int heads_from_offsets(dthip_ctx* ctx, Scratch& sc, const int32_t* d_off, int64_t ngroups, int64_t nrows,
+                              unsigned long long** bitmap, uint32_t** tile_counts) {
+  DTHIP_TRY(sc.get<unsigned long long>((size_t)((nrows + 63) / 64) + 1, bitmap));
+  const uint32_t nt = (uint32_t)((nrows + SEG_TILE - 1) / SEG_TILE);
+  DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, tile_counts));
+  return launch_bitmap_from_offsets(ctx, d_off, ngroups, nrows, *bitmap, *tile_counts, *tile_counts + nt);
+}
+
+// column as float64 in grouped order (NA -> NaN); a float64 column already in order is used as is
+static int grouped_f64(dthip_ctx* ctx, Scratch& sc, const void* d_val, int stype, const int32_t* d_ri, int64_t nrows,
+                       const double** out) {
+  if (stype == DTHIP_FLOAT64 && !d_ri) { *out = static_cast<const double*>(d_val); return DTHIP_OK; }
+  double* t = nullptr;
+  DTHIP_TRY(sc.get<double>((size_t)nrows, &t));
+  DTHIP_TRY(launch_gather_f64(ctx, d_val, stype, d_ri, nrows, t));
+  *out = t;
+  return DTHIP_OK;
+}
+
+// median / nunique: order the rows by (group, value) with the library's own radix path -- the
+// reference sorts every group separately (Column::sort_grouped, head_reduce_unary.cc:442-444) or
+// fills a std::set per group (:379-385)
+static int median_nunique(dthip_ctx* ctx, Scratch& sc, int op, const void* d_val, int stype, const int32_t* d_ri,
+                          const int32_t* d_off, int64_t ngroups, int64_t nrows, void* d_out) {
+  int32_t* gid = nullptr;
+  DTHIP_TRY(sc.get<int32_t>((size_t)nrows, &gid));
+  DTHIP_TRY(launch_ungroup(ctx, d_off, ngroups, nrows, gid));
+  const void* vg = d_val;
+  if (d_ri) {
+    unsigned char* t = nullptr;
+    DTHIP_TRY(sc.get<unsigned char>((size_t)nrows * stype_size(stype), &t));
+    DTHIP_TRY(launch_gather(ctx, d_val, stype, d_ri, nrows, t));
+    vg = t;
+  }
+  dthip_col keys[2] = {{gid, DTHIP_INT32, 0}, {vg, stype, 0}};
+  dthip_result* r2 = nullptr;
+  DTHIP_TRY(dthip_groupby(ctx, keys, 2, nrows, DTHIP_NA_FIRST, DTHIP_DEVICE, 1, &r2));
+  int rc;
+  if (op == DTHIP_MEDIAN) rc = launch_median(ctx, vg, stype, r2->rowindex, d_off, ngroups, d_out);
+  else rc = launch_nunique(ctx, vg, stype, gid, r2->rowindex, r2->offsets, r2->ngroups, ngroups, static_cast<int64_t*>(d_out));
+  result_destroy(ctx, r2);
+  return rc;
+}
+
+}  // namespace dthip
 
 int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* rowindex, const int32_t* offsets,
                  int64_t ngroups, int64_t nrows, int mem, void* out) {
@@ -1494,11 +1559,12 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
   if (ngroups < 0 || ngroups > nrows) { set_error("ngroups=%lld inconsistent with nrows=%lld", (long long)ngroups, (long long)nrows); return DTHIP_EINVAL; }
   if (ngroups == 0) return DTHIP_OK;
   if (!offsets || !out) { set_error("null argument"); return DTHIP_EINVAL; }
-  if (op < DTHIP_SUM || op > DTHIP_LAST) { set_error("bad reducer op %d", op); return DTHIP_EINVAL; }
+  if (op < DTHIP_SUM || op > DTHIP_NUNIQUE) { set_error("bad reducer op %d", op); return DTHIP_EINVAL; }
   if (op != DTHIP_COUNT0 && (!value || !value->data)) { set_error("reducer needs a value column"); return DTHIP_EINVAL; }
   Scratch sc(ctx);
   const void* d_off = nullptr;
   DTHIP_TRY(stage_in(ctx, sc, offsets, sizeof(int32_t) * (size_t)(ngroups + 1), mem, &d_off));
+  const int32_t* off32 = static_cast<const int32_t*>(d_off);
   const int ost = dthip_reduce_out_stype(op, op == DTHIP_COUNT0 ? DTHIP_INT64 : value->stype);
   const size_t obytes = (size_t)ngroups * stype_size(ost);
   void* d_out = out;
@@ -1508,37 +1574,114 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
     d_out = t;
   }
   if (op == DTHIP_COUNT0) {
-    DTHIP_TRY(launch_count0(ctx, static_cast<const int32_t*>(d_off), ngroups, static_cast<int64_t*>(d_out)));
+    DTHIP_TRY(launch_count0(ctx, off32, ngroups, static_cast<int64_t*>(d_out)));
   } else {
-    const int sz = stype_size(value->stype);
-    if (!sz) { set_error("unsupported stype %d", value->stype); return DTHIP_ENOTIMPL; }
     const void* d_ri = nullptr;
     DTHIP_TRY(stage_in(ctx, sc, rowindex, sizeof(int32_t) * (size_t)nrows, mem, &d_ri));
-    // the value column may be longer than nrows when read through a RowIndex; the caller
-    // guarantees rowindex values index into it.  Host staging copies max(index)+1 rows.
-    const void* d_val = value->data;
-    if (mem == DTHIP_HOST) {
-      int64_t vrows = nrows;
-      if (rowindex) { vrows = 0; for (int64_t i = 0; i < nrows; i++) if (rowindex[i] >= vrows) vrows = (int64_t)rowindex[i] + 1; }
-      DTHIP_TRY(stage_in(ctx, sc, value->data, (size_t)vrows * sz, mem, &d_val));
-    }
+    const int32_t* ri32 = static_cast<const int32_t*>(d_ri);
+    const void* d_val = nullptr;
+    DTHIP_TRY(stage_value_col(ctx, sc, value, rowindex, nrows, mem, &d_val));
     if (op == DTHIP_FIRST || op == DTHIP_LAST) {
-      DTHIP_TRY(launch_firstlast(ctx, d_val, value->stype, static_cast<const int32_t*>(d_ri), static_cast<const int32_t*>(d_off),
-                                 ngroups, op == DTHIP_LAST, d_out));
-      if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, obytes, mem));
-      return DTHIP_OK;
+      DTHIP_TRY(launch_firstlast(ctx, d_val, value->stype, ri32, off32, ngroups, op == DTHIP_LAST, d_out));
+    } else if (op == DTHIP_MEDIAN || op == DTHIP_NUNIQUE) {
+      DTHIP_TRY(median_nunique(ctx, sc, op, d_val, value->stype, ri32, off32, ngroups, nrows, d_out));
+    } else {
+      unsigned long long* bitmap = nullptr;
+      uint32_t* tile_counts = nullptr;
+      DTHIP_TRY(heads_from_offsets(ctx, sc, off32, ngroups, nrows, &bitmap, &tile_counts));
+      if (op == DTHIP_SD) {
+        const double* xg = nullptr;
+        DTHIP_TRY(grouped_f64(ctx, sc, d_val, value->stype, ri32, nrows, &xg));
+        DTHIP_TRY(launch_moments(ctx, xg, nullptr, reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, 0, d_out,
+                                 ost == DTHIP_FLOAT32));
+      } else {
+        ReduceOuts ro;
+        DTHIP_TRY(reduce_outs_for(op, d_out, &ro));
+        DTHIP_TRY(launch_reduce(ctx, d_val, value->stype, ri32, reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, ro));
+      }
     }
+  }
+  if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, obytes, mem));
+  return DTHIP_OK;
+}
+
+int dthip_reduce2_out_stype(int stype_a, int stype_b) {
+  return (stype_a == DTHIP_FLOAT32 && stype_b == DTHIP_FLOAT32) ? DTHIP_FLOAT32 : DTHIP_FLOAT64;
+}
+
+int dthip_reduce2(dthip_ctx* ctx, int op, const dthip_col* a, const dthip_col* b, const int32_t* rowindex,
+                  const int32_t* offsets, int64_t ngroups, int64_t nrows, int mem, void* out) {
+  DTHIP_TRY(check_common(ctx, nrows, mem));
+  if (ngroups < 0 || ngroups > nrows) { set_error("ngroups=%lld inconsistent with nrows=%lld", (long long)ngroups, (long long)nrows); return DTHIP_EINVAL; }
+  if (ngroups == 0) return DTHIP_OK;
+  if (!offsets || !out || !a || !b || !a->data || !b->data) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (op != DTHIP_COV && op != DTHIP_CORR) { set_error("bad binary reducer op %d", op); return DTHIP_EINVAL; }
+  Scratch sc(ctx);
+  const void *d_off = nullptr, *d_ri = nullptr, *d_a = nullptr, *d_b = nullptr;
+  DTHIP_TRY(stage_in(ctx, sc, offsets, sizeof(int32_t) * (size_t)(ngroups + 1), mem, &d_off));
+  DTHIP_TRY(stage_in(ctx, sc, rowindex, sizeof(int32_t) * (size_t)nrows, mem, &d_ri));
+  DTHIP_TRY(stage_value_col(ctx, sc, a, rowindex, nrows, mem, &d_a));
+  DTHIP_TRY(stage_value_col(ctx, sc, b, rowindex, nrows, mem, &d_b));
+  const int ost = dthip_reduce2_out_stype(a->stype, b->stype);
+  const size_t obytes = (size_t)ngroups * stype_size(ost);
+  void* d_out = out;
+  if (mem == DTHIP_HOST) {
+    unsigned char* t = nullptr;
+    DTHIP_TRY(sc.get<unsigned char>(obytes, &t));
+    d_out = t;
+  }
+  unsigned long long* bitmap = nullptr;
+  uint32_t* tile_counts = nullptr;
+  DTHIP_TRY(heads_from_offsets(ctx, sc, static_cast<const int32_t*>(d_off), ngroups, nrows, &bitmap, &tile_counts));
+  const double *xg = nullptr, *yg = nullptr;
+  DTHIP_TRY(grouped_f64(ctx, sc, d_a, a->stype, static_cast<const int32_t*>(d_ri), nrows, &xg));
+  if (d_b == d_a && b->stype == a->stype) yg = xg;
+  else DTHIP_TRY(grouped_f64(ctx, sc, d_b, b->stype, static_cast<const int32_t*>(d_ri), nrows, &yg));
+  DTHIP_TRY(launch_moments(ctx, xg, yg, reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, op == DTHIP_COV ? 1 : 2,
+                           d_out, ost == DTHIP_FLOAT32));
+  if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, obytes, mem));
+  return DTHIP_OK;
+}
+
+int dthip_cumulate_out_stype(int op, int st) {
+  if (op == DTHIP_CUMCOUNT || op == DTHIP_NGROUP) return DTHIP_INT64;
+  if (op == DTHIP_CUMSUM || op == DTHIP_CUMPROD) return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : st == DTHIP_FLOAT64 ? DTHIP_FLOAT64 : DTHIP_INT64;
+  return st;
+}
+
+int dthip_cumulate(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* rowindex, const int32_t* offsets,
+                   int64_t ngroups, int64_t nrows, int reverse, int mem, void* out) {
+  DTHIP_TRY(check_common(ctx, nrows, mem));
+  if (ngroups < 0 || ngroups > nrows) { set_error("ngroups=%lld inconsistent with nrows=%lld", (long long)ngroups, (long long)nrows); return DTHIP_EINVAL; }
+  if (nrows == 0) return DTHIP_OK;
+  if (!offsets || !out || ngroups == 0) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (op < DTHIP_CUMSUM || op > DTHIP_NGROUP) { set_error("bad cumulative op %d", op); return DTHIP_EINVAL; }
+  const bool counting = op == DTHIP_CUMCOUNT || op == DTHIP_NGROUP;
+  if (!counting && (!value || !value->data)) { set_error("cumulative op needs a value column"); return DTHIP_EINVAL; }
+  Scratch sc(ctx);
+  const void* d_off = nullptr;
+  DTHIP_TRY(stage_in(ctx, sc, offsets, sizeof(int32_t) * (size_t)(ngroups + 1), mem, &d_off));
+  const int32_t* off32 = static_cast<const int32_t*>(d_off);
+  const int ost = dthip_cumulate_out_stype(op, counting ? DTHIP_INT64 : value->stype);
+  const size_t obytes = (size_t)nrows * stype_size(ost);
+  if (!obytes) { set_error("unsupported stype"); return DTHIP_ENOTIMPL; }
+  void* d_out = out;
+  if (mem == DTHIP_HOST) {
+    unsigned char* t = nullptr;
+    DTHIP_TRY(sc.get<unsigned char>(obytes, &t));
+    d_out = t;
+  }
+  if (counting) {
+    DTHIP_TRY(launch_cumcount(ctx, off32, ngroups, nrows, op == DTHIP_NGROUP, reverse, static_cast<int64_t*>(d_out)));
+  } else {
+    const void *d_ri = nullptr, *d_val = nullptr;
+    DTHIP_TRY(stage_in(ctx, sc, rowindex, sizeof(int32_t) * (size_t)nrows, mem, &d_ri));
+    DTHIP_TRY(stage_value_col(ctx, sc, value, rowindex, nrows, mem, &d_val));
     unsigned long long* bitmap = nullptr;
-    DTHIP_TRY(sc.get<unsigned long long>((size_t)((nrows + 63) / 64) + 1, &bitmap));
-    const uint32_t nt = (uint32_t)((nrows + SEG_TILE - 1) / SEG_TILE);
     uint32_t* tile_counts = nullptr;
-    DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, &tile_counts));
-    DTHIP_TRY(launch_bitmap_from_offsets(ctx, static_cast<const int32_t*>(d_off), ngroups, nrows, bitmap, tile_counts,
-                                         tile_counts + nt));
-    ReduceOuts ro;
-    DTHIP_TRY(reduce_outs_for(op, d_out, &ro));
-    DTHIP_TRY(launch_reduce(ctx, d_val, value->stype, static_cast<const int32_t*>(d_ri),
-                            reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, ro));
+    DTHIP_TRY(heads_from_offsets(ctx, sc, off32, ngroups, nrows, &bitmap, &tile_counts));
+    DTHIP_TRY(launch_cumulate(ctx, d_val, value->stype, static_cast<const int32_t*>(d_ri), reinterpret_cast<const uint8_t*>(bitmap),
+                              nrows, op, reverse, d_out, ost));
   }
   if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, obytes, mem));
   return DTHIP_OK;

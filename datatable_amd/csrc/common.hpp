@@ -296,6 +296,18 @@ int launch_reduce(dthip_ctx* ctx, const void* values, int stype, const int32_t* 
                   const ReduceOuts& outs);
 int launch_count0(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t* out);
 
+// groupwise.hip: sd / cov / corr, cumulative operators, median / nunique
+int launch_gather_f64(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, int64_t n, double* out);
+int launch_moments(dthip_ctx* ctx, const double* x, const double* y, const uint8_t* bitmap, const uint32_t* tile_first_head,
+                   int64_t n, int op /*0 sd, 1 cov, 2 corr*/, void* out, int out_f32);
+int launch_cumulate(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, const uint8_t* bitmap, int64_t n,
+                    int op, int reverse, void* out, int ostype);
+int launch_cumcount(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int ngroup, int reverse, int64_t* out);
+int launch_median(dthip_ctx* ctx, const void* vg, int stype, const int32_t* order, const int32_t* offsets, int64_t ngroups,
+                  void* out);
+int launch_nunique(dthip_ctx* ctx, const void* vg, int stype, const int32_t* gid, const int32_t* order, const int32_t* run_offsets,
+                   int64_t nruns, int64_t ngroups, int64_t* out);
+
 // rowindex.hip
 struct PredArgs {
   const void* data; int stype; int cmp; double cf; long long ci; int is_mask;   // is_mask 2: data is a bitmap (uint32 words)

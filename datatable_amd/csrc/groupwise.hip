@@ -1,0 +1,547 @@
+// groupwise.hip -- operators that share the Groupby of the hot path:
+//   sd, cov, corr            expr/head_reduce_unary.cc:194-216, head_reduce_binary.cc:113-198
+//   median, nunique          expr/head_reduce_unary.cc:377-387,424-470
+//   cumsum/cumprod/cummin/cummax (+reverse)   column/cumsumprod.h:52-92, column/cumminmax.h:48-98
+//   cumcount/ngroup          column/cumcountngroup.h:55-72
+//
+// The reference runs one sequential loop per group (parallel over groups, so one huge group is
+// serial).  Here every operator that is an associative fold is one *segmented scan* over the
+// grouped row order, independent of the group-size distribution:
+//
+//   gw_summary_kernel   tile of 2048 positions -> state of the tile's trailing open segment
+//   gw_carry_kernel     segmented exclusive scan over the tile states (single workgroup)
+//   gw_apply_kernel     re-scan the tile with its carry; SCAN writes every position's running
+//                       value, REDUCE emits the state at each group's last row
+//
+// and a policy P supplies the state and the fold:
+//   MomP<1>/MomP<2>  (count, mean, M2[, mean2, M2', C12]) merged with Chan's pairwise update --
+//                    the parallel form of the reference's Welford loops; inputs pre-cast to f64
+//   CumP<A,OP>       running sum / product / min / max in A = int64 or double
+// Segment heads come from the same 1-bit-per-position bitmap the reducers use; `reverse` mirrors
+// the position order.  Float results are re-associated (tests: 1e-6 relative; float32 5e-5),
+// integer results are exact (sums/products wrap like the reference's int64 arithmetic).
+//
+// median / nunique need the group's values in order: the caller sorts (group id, value) with the
+// library's own radix path and the two small kernels below read the sorted run of each group.
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace dthip {
+
+constexpr int GW_BLOCK = 256;
+constexpr int GW_ITEMS = 8;
+constexpr int GW_TILE = GW_BLOCK * GW_ITEMS;   // 2048 == SEG_TILE (tile_first_head granularity)
+static_assert(GW_TILE == SEG_TILE, "tile size shared with group.hip");
+
+template <typename T> __device__ __forceinline__ T shfl_up_any(const T& v, int o) {
+  static_assert(sizeof(T) % 4 == 0, "state must be a multiple of 4 bytes");
+  constexpr int W = sizeof(T) / 4;
+  uint32_t w[W];
+  __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+  for (int i = 0; i < W; i++) w[i] = (uint32_t)__shfl_up((int)w[i], o, 64);
+  T r;
+  __builtin_memcpy(&r, w, sizeof(T));
+  return r;
+}
+
+__device__ __forceinline__ bool head_bit(const uint32_t* __restrict__ bm, uint32_t p) { return (bm[p >> 5] >> (p & 31)) & 1u; }
+// logical position q of the scan order -> physical grouped position
+__device__ __forceinline__ uint32_t phys_pos(uint32_t q, uint32_t n, int rev) { return rev ? n - 1 - q : q; }
+// does a segment start at logical position q?
+__device__ __forceinline__ bool seg_head(const uint32_t* __restrict__ bm, uint32_t q, uint32_t n, int rev) {
+  const uint32_t p = phys_pos(q, n, rev);
+  if (!rev) return head_bit(bm, p);
+  return p == n - 1 || head_bit(bm, p + 1);
+}
+
+template <class St> struct TileSum { St s; uint32_t has_head; uint32_t pad; };
+
+// ---- kernel 1: per-tile trailing-segment state --------------------------------------------------
+template <class P>
+__global__ void __launch_bounds__(GW_BLOCK) gw_summary_kernel(typename P::Args a, const uint32_t* __restrict__ bm, uint32_t n,
+                                                              int rev, TileSum<typename P::St>* __restrict__ sums) {
+  typedef typename P::St St;
+  __shared__ St w_val[GW_BLOCK / 64];
+  __shared__ uint32_t w_flag[GW_BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t q0 = blockIdx.x * GW_TILE + tid * GW_ITEMS;
+  St cur = P::ident();
+  uint32_t flag = 0;
+#pragma unroll
+  for (int j = 0; j < GW_ITEMS; j++) {
+    const uint32_t q = q0 + j;
+    if (q < n) {
+      if (seg_head(bm, q, n, rev)) { cur = P::ident(); flag = 1; }
+      cur = P::comb(cur, P::load(a, phys_pos(q, n, rev)));
+    }
+  }
+  St sv = cur; uint32_t sf = flag;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const St pv = shfl_up_any(sv, o);
+    const uint32_t pf = (uint32_t)__shfl_up((int)sf, o, 64);
+    if (lane >= o) { if (!sf) sv = P::comb(pv, sv); sf |= pf; }
+  }
+  if (lane == 63) { w_val[wave] = sv; w_flag[wave] = sf; }
+  __syncthreads();
+  if (tid == 0) {
+    St acc = w_val[0]; uint32_t f = w_flag[0];
+    for (int w = 1; w < GW_BLOCK / 64; w++) {
+      if (w_flag[w]) { acc = w_val[w]; f = 1; } else { acc = P::comb(acc, w_val[w]); }
+    }
+    sums[blockIdx.x].s = acc;
+    sums[blockIdx.x].has_head = f;
+  }
+}
+
+// ---- kernel 2: exclusive segmented scan over the tile states (one workgroup) -------------------
+constexpr int GC_BLOCK = 1024;
+constexpr int GC_ITEMS = 4;
+template <class P>
+__global__ void __launch_bounds__(GC_BLOCK) gw_carry_kernel(const TileSum<typename P::St>* __restrict__ sums, uint32_t nt,
+                                                            typename P::St* __restrict__ carry) {
+  typedef typename P::St St;
+  __shared__ St w_val[GC_BLOCK / 64];
+  __shared__ uint32_t w_flag[GC_BLOCK / 64];
+  __shared__ St run_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) run_s = P::ident();
+  __syncthreads();
+  for (uint32_t base = 0; base < nt; base += GC_BLOCK * GC_ITEMS) {
+    const uint32_t t0 = base + tid * GC_ITEMS;
+    St s[GC_ITEMS]; uint32_t f[GC_ITEMS];
+    St cur = P::ident(); uint32_t flag = 0;
+#pragma unroll
+    for (int j = 0; j < GC_ITEMS; j++) {
+      s[j] = P::ident(); f[j] = 0;
+      if (t0 + j < nt) { s[j] = sums[t0 + j].s; f[j] = sums[t0 + j].has_head; }
+      if (f[j]) { cur = s[j]; flag = 1; } else { cur = P::comb(cur, s[j]); }
+    }
+    St sv = cur; uint32_t sf = flag;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const St pv = shfl_up_any(sv, o);
+      const uint32_t pf = (uint32_t)__shfl_up((int)sf, o, 64);
+      if (lane >= o) { if (!sf) sv = P::comb(pv, sv); sf |= pf; }
+    }
+    if (lane == 63) { w_val[wave] = sv; w_flag[wave] = sf; }
+    __syncthreads();
+    St acc = run_s;
+    for (int w = 0; w < wave; w++) { if (w_flag[w]) acc = w_val[w]; else acc = P::comb(acc, w_val[w]); }
+    {
+      St ev = shfl_up_any(sv, 1);
+      uint32_t ef = (uint32_t)__shfl_up((int)sf, 1, 64);
+      if (lane == 0) { ev = P::ident(); ef = 0; }
+      if (ef) acc = ev; else acc = P::comb(acc, ev);
+    }
+#pragma unroll
+    for (int j = 0; j < GC_ITEMS; j++) {
+      if (t0 + j < nt) carry[t0 + j] = acc;
+      if (f[j]) acc = s[j]; else acc = P::comb(acc, s[j]);
+    }
+    __syncthreads();
+    if (tid == GC_BLOCK - 1) run_s = acc;
+    __syncthreads();
+  }
+}
+
+// ---- kernel 3: tile scan with carry; SCAN stores every position, REDUCE emits at group ends -----
+template <class P, int REDUCE>
+__global__ void __launch_bounds__(GW_BLOCK) gw_apply_kernel(typename P::Args a, const uint32_t* __restrict__ bm,
+                                                            const uint32_t* __restrict__ tile_first_head, uint32_t n, int rev,
+                                                            const typename P::St* __restrict__ carry, typename P::Out out) {
+  typedef typename P::St St;
+  __shared__ St w_val[GW_BLOCK / 64];
+  __shared__ uint32_t w_flag[GW_BLOCK / 64];
+  __shared__ uint32_t w_nh[GW_BLOCK / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t q0 = tile * GW_TILE + tid * GW_ITEMS;
+  St x[GW_ITEMS];
+  uint32_t hb = 0;
+  St cur = P::ident();
+#pragma unroll
+  for (int j = 0; j < GW_ITEMS; j++) {
+    const uint32_t q = q0 + j;
+    x[j] = P::ident();
+    if (q < n) {
+      if (seg_head(bm, q, n, rev)) { hb |= 1u << j; cur = P::ident(); }
+      x[j] = P::load(a, phys_pos(q, n, rev));
+      cur = P::comb(cur, x[j]);
+    }
+  }
+  const uint32_t nh = (uint32_t)__popc(hb);
+  St sv = cur; uint32_t sf = nh ? 1u : 0u; uint32_t sn = nh;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const St pv = shfl_up_any(sv, o);
+    const uint32_t pf = (uint32_t)__shfl_up((int)sf, o, 64);
+    const uint32_t pn = (uint32_t)__shfl_up((int)sn, o, 64);
+    if (lane >= o) { if (!sf) sv = P::comb(pv, sv); sf |= pf; sn += pn; }
+  }
+  if (lane == 63) { w_val[wave] = sv; w_flag[wave] = sf; w_nh[wave] = sn; }
+  __syncthreads();
+  St acc = carry[tile];
+  uint32_t k = 0;
+  for (int w = 0; w < wave; w++) {
+    if (w_flag[w]) acc = w_val[w]; else acc = P::comb(acc, w_val[w]);
+    k += w_nh[w];
+  }
+  {
+    St ev = shfl_up_any(sv, 1);
+    uint32_t ef = (uint32_t)__shfl_up((int)sf, 1, 64), en = (uint32_t)__shfl_up((int)sn, 1, 64);
+    if (lane == 0) { ev = P::ident(); ef = 0; en = 0; }
+    if (ef) acc = ev; else acc = P::comb(acc, ev);
+    k += en;
+  }
+  const uint32_t G = REDUCE ? tile_first_head[tile] : 0u;    // heads in earlier tiles
+#pragma unroll
+  for (int j = 0; j < GW_ITEMS; j++) {
+    const uint32_t q = q0 + j;
+    if (q < n) {
+      if ((hb >> j) & 1u) { acc = P::ident(); k++; }
+      acc = P::comb(acc, x[j]);
+      if (REDUCE) {
+        if (q == n - 1 || seg_head(bm, q + 1, n, rev)) P::emit(out, G + k - 1, acc);
+      } else {
+        P::store(out, phys_pos(q, n, rev), acc);
+      }
+    }
+  }
+}
+
+template <class P, int REDUCE>
+static int run_segscan(dthip_ctx* ctx, const typename P::Args& a, const uint32_t* bm, const uint32_t* tile_first_head,
+                       int64_t n, int rev, const typename P::Out& out, const char* name) {
+  typedef typename P::St St;
+  const uint32_t nt = (uint32_t)((n + GW_TILE - 1) / GW_TILE);
+  if (nt == 0) return DTHIP_OK;
+  Scratch sc(ctx);
+  TileSum<St>* sums = nullptr; St* carry = nullptr;
+  DTHIP_TRY(sc.get<TileSum<St>>(nt, &sums));
+  DTHIP_TRY(sc.get<St>(nt, &carry));
+  DTHIP_LAUNCH(ctx, "gw_summary_kernel", gw_summary_kernel<P>, nt, GW_BLOCK, 0, a, bm, (uint32_t)n, rev, sums);
+  DTHIP_LAUNCH(ctx, "gw_carry_kernel", gw_carry_kernel<P>, 1, GC_BLOCK, 0, sums, nt, carry);
+  DTHIP_LAUNCH(ctx, name, (gw_apply_kernel<P, REDUCE>), nt, GW_BLOCK, 0, a, bm, tile_first_head, (uint32_t)n, rev, carry, out);
+  return DTHIP_OK;
+}
+
+// ---- policy: running moments (sd / cov / corr) ---------------------------------------------------
+struct MomArgs { const double* x; const double* y; };
+struct MomOut { void* out; int op; int f32; };   // op: 0 sd, 1 cov, 2 corr
+template <int NC> struct MomSt;
+template <> struct MomSt<1> { double n, mx, cxx; };
+template <> struct MomSt<2> { double n, mx, my, cxx, cyy, cxy; };
+
+template <int NC> struct MomP;
+template <> struct MomP<1> {
+  typedef MomSt<1> St; typedef MomArgs Args; typedef MomOut Out;
+  static __device__ __forceinline__ St ident() { return St{0.0, 0.0, 0.0}; }
+  static __device__ __forceinline__ St comb(const St& a, const St& b) {
+    if (b.n == 0.0) return a;
+    if (a.n == 0.0) return b;
+    St r;
+    r.n = a.n + b.n;
+    const double d = b.mx - a.mx, f = b.n / r.n;
+    r.mx = a.mx + d * f;
+    r.cxx = a.cxx + b.cxx + d * d * a.n * f;
+    return r;
+  }
+  static __device__ __forceinline__ St load(const Args& a, uint32_t p) {
+    const double x = a.x[p];
+    if (x != x) return ident();
+    return St{1.0, x, x - x};             // x - x: 0, or NaN for +-inf (the reference's m2 turns NaN too)
+  }
+  static __device__ __forceinline__ void emit(const Out& o, uint32_t g, const St& s) {
+    double r = __builtin_nan("");
+    if (s.n > 1.0 && !(s.cxx != s.cxx)) r = s.cxx >= 0.0 ? sqrt(s.cxx / (s.n - 1.0)) : 0.0;
+    if (o.f32) static_cast<float*>(o.out)[g] = (float)r; else static_cast<double*>(o.out)[g] = r;
+  }
+  static __device__ __forceinline__ void store(const Out&, uint32_t, const St&) {}
+};
+template <> struct MomP<2> {
+  typedef MomSt<2> St; typedef MomArgs Args; typedef MomOut Out;
+  static __device__ __forceinline__ St ident() { return St{0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; }
+  static __device__ __forceinline__ St comb(const St& a, const St& b) {
+    if (b.n == 0.0) return a;
+    if (a.n == 0.0) return b;
+    St r;
+    r.n = a.n + b.n;
+    const double dx = b.mx - a.mx, dy = b.my - a.my, f = b.n / r.n, w = a.n * f;
+    r.mx = a.mx + dx * f;
+    r.my = a.my + dy * f;
+    r.cxx = a.cxx + b.cxx + dx * dx * w;
+    r.cyy = a.cyy + b.cyy + dy * dy * w;
+    r.cxy = a.cxy + b.cxy + dx * dy * w;
+    return r;
+  }
+  static __device__ __forceinline__ St load(const Args& a, uint32_t p) {
+    const double x = a.x[p], y = a.y[p];
+    if (x != x || y != y) return ident();           // a row counts only when both values are valid
+    return St{1.0, x, y, x - x, y - y, (x - x) * (y - y)};
+  }
+  static __device__ __forceinline__ void emit(const Out& o, uint32_t g, const St& s) {
+    double r = __builtin_nan("");
+    if (o.op == 1) { if (s.n > 1.0) r = s.cxy / (s.n - 1.0); }
+    else { const double vv = s.cxx * s.cyy; if (s.n > 1.0 && vv > 0.0) r = s.cxy / sqrt(vv); }
+    if (o.f32) static_cast<float*>(o.out)[g] = (float)r; else static_cast<double*>(o.out)[g] = r;
+  }
+  static __device__ __forceinline__ void store(const Out&, uint32_t, const St&) {}
+};
+
+// value of a column element as double, NA -> NaN (SentinelFw get_element + cast_inplace(FLOAT64))
+__device__ __forceinline__ double load_as_f64(const void* data, int stype, int64_t j) {
+  switch (stype) {
+    case DTHIP_BOOL: case DTHIP_INT8: { const int8_t v = static_cast<const int8_t*>(data)[j]; return v == INT8_MIN ? __builtin_nan("") : (double)v; }
+    case DTHIP_INT16: { const int16_t v = static_cast<const int16_t*>(data)[j]; return v == INT16_MIN ? __builtin_nan("") : (double)v; }
+    case DTHIP_INT32: { const int32_t v = static_cast<const int32_t*>(data)[j]; return v == INT32_MIN ? __builtin_nan("") : (double)v; }
+    case DTHIP_INT64: { const long long v = static_cast<const long long*>(data)[j]; return v == INT64_MIN ? __builtin_nan("") : (double)v; }
+    case DTHIP_FLOAT32: return (double)static_cast<const float*>(data)[j];
+    default: return static_cast<const double*>(data)[j];
+  }
+}
+
+__global__ void __launch_bounds__(256) gather_f64_kernel(const void* __restrict__ data, int stype, const int32_t* __restrict__ ri,
+                                                         uint32_t n, double* __restrict__ out) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < n; p += stride) {
+    const int32_t j = ri ? ri[p] : (int32_t)p;
+    out[p] = j < 0 ? __builtin_nan("") : load_as_f64(data, stype, j);
+  }
+}
+
+int launch_gather_f64(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, int64_t n, double* out) {
+  if (n == 0) return DTHIP_OK;
+  long long blocks = (n + 1023) / 1024;
+  if (blocks > (long long)ctx->num_cus * 16) blocks = (long long)ctx->num_cus * 16;
+  DTHIP_LAUNCH(ctx, "gather_f64_kernel", gather_f64_kernel, (unsigned)blocks, 256, 0, data, stype, ri, (uint32_t)n, out);
+  return DTHIP_OK;
+}
+
+int launch_moments(dthip_ctx* ctx, const double* x, const double* y, const uint8_t* bitmap, const uint32_t* tile_first_head,
+                   int64_t n, int op, void* out, int out_f32) {
+  MomArgs a{x, y};
+  MomOut o{out, op, out_f32};
+  const uint32_t* bm = reinterpret_cast<const uint32_t*>(bitmap);
+  if (op == 0) return run_segscan<MomP<1>, 1>(ctx, a, bm, tile_first_head, n, 0, o, "gw_apply_kernel<sd>");
+  return run_segscan<MomP<2>, 1>(ctx, a, bm, tile_first_head, n, 0, o, "gw_apply_kernel<cov>");
+}
+
+// ---- policy: cumulative sum / product / min / max -------------------------------------------------
+struct CumArgs { const void* data; int stype; const int32_t* ri; };
+struct CumOut { void* out; int ostype; };
+template <typename A> struct CumSt { A v; uint32_t has; uint32_t pad; };
+
+template <typename A> __device__ __forceinline__ bool load_as(const void* data, int stype, int64_t j, A* out);
+template <> __device__ __forceinline__ bool load_as<long long>(const void* data, int stype, int64_t j, long long* out) {
+  switch (stype) {
+    case DTHIP_BOOL: case DTHIP_INT8: { const int8_t v = static_cast<const int8_t*>(data)[j]; *out = v; return v != INT8_MIN; }
+    case DTHIP_INT16: { const int16_t v = static_cast<const int16_t*>(data)[j]; *out = v; return v != INT16_MIN; }
+    case DTHIP_INT32: { const int32_t v = static_cast<const int32_t*>(data)[j]; *out = v; return v != INT32_MIN; }
+    default: { const long long v = static_cast<const long long*>(data)[j]; *out = v; return v != INT64_MIN; }
+  }
+}
+template <> __device__ __forceinline__ bool load_as<double>(const void* data, int stype, int64_t j, double* out) {
+  const double v = stype == DTHIP_FLOAT32 ? (double)static_cast<const float*>(data)[j] : static_cast<const double*>(data)[j];
+  *out = v;
+  return !(v != v);
+}
+
+enum { CUM_SUM = 0, CUM_PROD = 1, CUM_MIN = 2, CUM_MAX = 3 };
+
+template <typename A, int OP> struct CumP {
+  typedef CumSt<A> St; typedef CumArgs Args; typedef CumOut Out;
+  static __device__ __forceinline__ St ident() { return St{OP == CUM_PROD ? A(1) : A(0), 0u, 0u}; }
+  static __device__ __forceinline__ A add(A a, A b) { return a + b; }
+  static __device__ __forceinline__ A mul(A a, A b) { return a * b; }
+  static __device__ __forceinline__ St comb(const St& a, const St& b) {   // a = earlier rows, b = later rows
+    St r; r.pad = 0;
+    r.has = a.has | b.has;
+    if (OP == CUM_SUM) r.v = add(a.v, b.v);
+    else if (OP == CUM_PROD) r.v = mul(a.v, b.v);
+    else if (!b.has) r.v = a.v;
+    else if (!a.has) r.v = b.v;
+    else if (OP == CUM_MIN) r.v = (a.v < b.v) ? a.v : b.v;               // ties keep the later row's value
+    else r.v = (a.v > b.v) ? a.v : b.v;                                  // (cumminmax.h:83-87)
+    return r;
+  }
+  static __device__ __forceinline__ St load(const Args& a, uint32_t p) {
+    const int32_t j = a.ri ? a.ri[p] : (int32_t)p;
+    A v;
+    if (j < 0 || !load_as<A>(a.data, a.stype, j, &v)) return ident();     // NA: 0 / 1 / "nothing yet"
+    return St{v, 1u, 0u};
+  }
+  static __device__ __forceinline__ void store(const Out& o, uint32_t p, const St& s) {
+    const bool valid = (OP == CUM_SUM || OP == CUM_PROD) ? true : (s.has != 0);
+    switch (o.ostype) {
+      case DTHIP_BOOL: case DTHIP_INT8: static_cast<int8_t*>(o.out)[p] = valid ? (int8_t)s.v : INT8_MIN; break;
+      case DTHIP_INT16: static_cast<int16_t*>(o.out)[p] = valid ? (int16_t)s.v : INT16_MIN; break;
+      case DTHIP_INT32: static_cast<int32_t*>(o.out)[p] = valid ? (int32_t)s.v : INT32_MIN; break;
+      case DTHIP_INT64: static_cast<long long*>(o.out)[p] = valid ? (long long)s.v : INT64_MIN; break;
+      case DTHIP_FLOAT32: static_cast<float*>(o.out)[p] = valid ? (float)s.v : __builtin_nanf(""); break;
+      default: static_cast<double*>(o.out)[p] = valid ? (double)s.v : __builtin_nan(""); break;
+    }
+  }
+  static __device__ __forceinline__ void emit(const Out&, uint32_t, const St&) {}
+};
+// int64 sums and products wrap (two's complement), as the reference's do in practice
+template <> __device__ __forceinline__ long long CumP<long long, CUM_SUM>::add(long long a, long long b) {
+  return (long long)((unsigned long long)a + (unsigned long long)b);
+}
+template <> __device__ __forceinline__ long long CumP<long long, CUM_PROD>::mul(long long a, long long b) {
+  return (long long)((unsigned long long)a * (unsigned long long)b);
+}
+
+int launch_cumulate(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, const uint8_t* bitmap, int64_t n,
+                    int op, int reverse, void* out, int ostype) {
+  CumArgs a{data, stype, ri};
+  CumOut o{out, ostype};
+  const uint32_t* bm = reinterpret_cast<const uint32_t*>(bitmap);
+  const bool isf = stype == DTHIP_FLOAT32 || stype == DTHIP_FLOAT64;
+  const int rev = reverse ? 1 : 0;
+#define DTHIP_CUM_CASE(OPC)                                                                                         \
+  case OPC:                                                                                                         \
+    return isf ? run_segscan<CumP<double, OPC>, 0>(ctx, a, bm, nullptr, n, rev, o, "gw_apply_kernel<cum>")          \
+               : run_segscan<CumP<long long, OPC>, 0>(ctx, a, bm, nullptr, n, rev, o, "gw_apply_kernel<cum>");
+  switch (op) {
+    DTHIP_CUM_CASE(CUM_SUM)
+    DTHIP_CUM_CASE(CUM_PROD)
+    DTHIP_CUM_CASE(CUM_MIN)
+    DTHIP_CUM_CASE(CUM_MAX)
+    default: set_error("bad cumulative op %d", op); return DTHIP_EINVAL;
+  }
+#undef DTHIP_CUM_CASE
+}
+
+// cumcount(): row number inside the group; ngroup(): group number (cumcountngroup.h:55-72)
+__global__ void __launch_bounds__(256) cumcount_kernel(const int32_t* __restrict__ offsets, uint32_t ngroups, uint32_t n, int ngroup,
+                                                       int rev, long long* __restrict__ out) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    uint32_t lo = 0, hi = ngroups;               // largest g with offsets[g] <= i
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((uint32_t)offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    long long r;
+    if (ngroup) r = rev ? (long long)(ngroups - 1 - lo) : (long long)lo;
+    else r = rev ? (long long)offsets[lo + 1] - 1 - (long long)i : (long long)i - (long long)offsets[lo];
+    out[i] = r;
+  }
+}
+
+int launch_cumcount(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int ngroup, int reverse, int64_t* out) {
+  if (n == 0) return DTHIP_OK;
+  long long blocks = (n + 2047) / 2048;
+  if (blocks > (long long)ctx->num_cus * 8) blocks = (long long)ctx->num_cus * 8;
+  DTHIP_LAUNCH(ctx, "cumcount_kernel", cumcount_kernel, (unsigned)blocks, 256, 0, offsets, (uint32_t)ngroups, (uint32_t)n, ngroup,
+               reverse ? 1 : 0, reinterpret_cast<long long*>(out));
+  return DTHIP_OK;
+}
+
+// ---- median / nunique over rows sorted by (group, value), NA first ---------------------------------
+template <typename T> struct NaOf;
+template <> struct NaOf<int8_t> { static __device__ __forceinline__ bool isna(int8_t v) { return v == INT8_MIN; } };
+template <> struct NaOf<int16_t> { static __device__ __forceinline__ bool isna(int16_t v) { return v == INT16_MIN; } };
+template <> struct NaOf<int32_t> { static __device__ __forceinline__ bool isna(int32_t v) { return v == INT32_MIN; } };
+template <> struct NaOf<long long> { static __device__ __forceinline__ bool isna(long long v) { return v == INT64_MIN; } };
+template <> struct NaOf<float> { static __device__ __forceinline__ bool isna(float v) { return v != v; } };
+template <> struct NaOf<double> { static __device__ __forceinline__ bool isna(double v) { return v != v; } };
+
+// Median_ColumnImpl::get_element (head_reduce_unary.cc:446-466): skip the leading NAs of the sorted
+// group, then the middle element, or the mean of the two middle ones computed in U
+template <typename T, typename U>
+__global__ void __launch_bounds__(256) median_kernel(const T* __restrict__ vg, const int32_t* __restrict__ order,
+                                                     const int32_t* __restrict__ offsets, uint32_t ngroups, U* __restrict__ out) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const uint32_t i0 = (uint32_t)offsets[g], i1 = (uint32_t)offsets[g + 1];
+  uint32_t lo = i0, hi = i1;                     // first valid position
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (NaOf<T>::isna(vg[order[mid]])) lo = mid + 1; else hi = mid;
+  }
+  if (lo == i1) { out[g] = (U)__builtin_nan(""); return; }
+  const uint32_t j = (lo + i1) >> 1;
+  const T v1 = vg[order[j]];
+  if ((i1 - lo) & 1u) out[g] = (U)v1;
+  else out[g] = ((U)v1 + (U)vg[order[j - 1]]) / (U)2;
+}
+
+// op_nunique (head_reduce_unary.cc:377-387): distinct valid values per group.  One thread per
+// (group, value) run of the sorted order; a run counts when its value is valid and differs -- as a
+// VALUE, so -0.0 == 0.0 like std::set's ordering -- from the previous run of the same group.
+// Lanes of a wave that fall into the same group add once.
+template <typename T>
+__global__ void __launch_bounds__(256) nunique_kernel(const T* __restrict__ vg, const int32_t* __restrict__ gid,
+                                                      const int32_t* __restrict__ order, const int32_t* __restrict__ run_offsets,
+                                                      uint32_t nruns, unsigned long long* __restrict__ out) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int32_t g = -1;
+  bool distinct = false;
+  if (s < nruns) {
+    const int32_t r = order[run_offsets[s]];
+    g = gid[r];
+    const T v = vg[r];
+    distinct = !NaOf<T>::isna(v);
+    if (distinct && s > 0) {
+      const int32_t rp = order[run_offsets[s - 1]];
+      if (gid[rp] == g && vg[rp] == v) distinct = false;
+    }
+  }
+  const int32_t gp = __shfl_up(g, 1, 64);
+  const bool leader = lane == 0 || g != gp;
+  const unsigned long long leaders = __ballot(leader);
+  const unsigned long long dmask = __ballot(distinct);
+  if (leader && g >= 0) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long higher = leaders & ~(below | (1ull << lane));
+    const int end = higher ? (__ffsll((long long)higher) - 1) : 64;
+    const unsigned long long upto = end == 64 ? ~0ull : ((1ull << end) - 1ull);
+    const int c = __popcll(dmask & upto & ~below);
+    if (c) atomicAdd(&out[g], (unsigned long long)c);
+  }
+}
+
+int launch_median(dthip_ctx* ctx, const void* vg, int stype, const int32_t* order, const int32_t* offsets, int64_t ngroups,
+                  void* out) {
+  if (ngroups == 0) return DTHIP_OK;
+  const unsigned grid = (unsigned)((ngroups + 255) / 256);
+#define DTHIP_MED(T, U) DTHIP_LAUNCH(ctx, "median_kernel", (median_kernel<T, U>), grid, 256, 0, static_cast<const T*>(vg), order, offsets, \
+                                     (uint32_t)ngroups, static_cast<U*>(out)); break
+  switch (stype) {
+    case DTHIP_BOOL: case DTHIP_INT8: DTHIP_MED(int8_t, double);
+    case DTHIP_INT16: DTHIP_MED(int16_t, double);
+    case DTHIP_INT32: DTHIP_MED(int32_t, double);
+    case DTHIP_INT64: DTHIP_MED(long long, double);
+    case DTHIP_FLOAT32: DTHIP_MED(float, float);
+    case DTHIP_FLOAT64: DTHIP_MED(double, double);
+    default: set_error("median: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
+  }
+#undef DTHIP_MED
+  return DTHIP_OK;
+}
+
+int launch_nunique(dthip_ctx* ctx, const void* vg, int stype, const int32_t* gid, const int32_t* order, const int32_t* run_offsets,
+                   int64_t nruns, int64_t ngroups, int64_t* out) {
+  DTHIP_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int64_t) * (size_t)ngroups, ctx->stream));
+  if (nruns == 0) return DTHIP_OK;
+  const unsigned grid = (unsigned)((nruns + 255) / 256);
+#define DTHIP_NU(T) DTHIP_LAUNCH(ctx, "nunique_kernel", nunique_kernel<T>, grid, 256, 0, static_cast<const T*>(vg), gid, order, run_offsets, \
+                                 (uint32_t)nruns, reinterpret_cast<unsigned long long*>(out)); break
+  switch (stype) {
+    case DTHIP_BOOL: case DTHIP_INT8: DTHIP_NU(int8_t);
+    case DTHIP_INT16: DTHIP_NU(int16_t);
+    case DTHIP_INT32: DTHIP_NU(int32_t);
+    case DTHIP_INT64: DTHIP_NU(long long);
+    case DTHIP_FLOAT32: DTHIP_NU(float);
+    case DTHIP_FLOAT64: DTHIP_NU(double);
+    default: set_error("nunique: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
+  }
+#undef DTHIP_NU
+  return DTHIP_OK;
+}
+
+}  // namespace dthip

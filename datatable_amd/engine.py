@@ -17,7 +17,10 @@ ST2NP = {L.BOOL: np.dtype(np.int8), L.INT8: np.dtype(np.int8), L.INT16: np.dtype
          L.INT32: np.dtype(np.int32), L.INT64: np.dtype(np.int64),
          L.FLOAT32: np.dtype(np.float32), L.FLOAT64: np.dtype(np.float64)}
 OPS = {"sum": L.SUM, "mean": L.MEAN, "min": L.MIN, "max": L.MAX, "count": L.COUNT, "count0": L.COUNT0,
-       "first": L.FIRST, "last": L.LAST}
+       "first": L.FIRST, "last": L.LAST, "sd": L.SD, "median": L.MEDIAN, "nunique": L.NUNIQUE}
+OPS2 = {"cov": L.COV, "corr": L.CORR}
+CUMOPS = {"cumsum": L.CUMSUM, "cumprod": L.CUMPROD, "cummin": L.CUMMIN, "cummax": L.CUMMAX,
+          "cumcount": L.CUMCOUNT, "ngroup": L.NGROUP}
 CMP = {">": L.GT, ">=": L.GE, "<": L.LT, "<=": L.LE, "==": L.EQ, "!=": L.NE}
 
 
@@ -287,6 +290,40 @@ class Context:
         out = np.empty(ng, ST2NP[ost])
         L.check(self._lib.dthip_reduce(self._h, opc, C.byref(col), ri.ctypes.data if ri is not None else None,
                                        offsets.ctypes.data, ng, nrows, L.HOST, out.ctypes.data))
+        return out
+
+    def reduce2(self, op, va, vb, rowindex, offsets, stypes=(None, None)):
+        """cov / corr of two columns per group (head_reduce_binary.cc:113-198); host arrays"""
+        opc = OPS2[op] if isinstance(op, str) else int(op)
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        ng = len(offsets) - 1
+        nrows = int(offsets[-1]) if ng >= 0 and len(offsets) else 0
+        ri = np.ascontiguousarray(rowindex, np.int32) if rowindex is not None else None
+        a, ca = _host_col(va, stypes[0])
+        b, cb = _host_col(vb, stypes[1])
+        out = np.empty(ng, ST2NP[self._lib.dthip_reduce2_out_stype(ca.stype, cb.stype)])
+        L.check(self._lib.dthip_reduce2(self._h, opc, C.byref(ca), C.byref(cb), ri.ctypes.data if ri is not None else None,
+                                        offsets.ctypes.data, ng, nrows, L.HOST, out.ctypes.data))
+        return out
+
+    def cumulate(self, op, values, rowindex, offsets, reverse=False, stype=None):
+        """cumsum / cumprod / cummin / cummax inside groups, cumcount / ngroup; output in grouped row order"""
+        opc = CUMOPS[op] if isinstance(op, str) else int(op)
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        ng = len(offsets) - 1
+        nrows = int(offsets[-1]) if ng >= 0 and len(offsets) else 0
+        ri = np.ascontiguousarray(rowindex, np.int32) if rowindex is not None else None
+        if opc in (L.CUMCOUNT, L.NGROUP):
+            out = np.empty(nrows, np.int64)
+            if nrows:
+                L.check(self._lib.dthip_cumulate(self._h, opc, None, None, offsets.ctypes.data, ng, nrows,
+                                                 1 if reverse else 0, L.HOST, out.ctypes.data))
+            return out
+        a, col = _host_col(values, stype)
+        out = np.empty(nrows, ST2NP[self._lib.dthip_cumulate_out_stype(opc, col.stype)])
+        if nrows:
+            L.check(self._lib.dthip_cumulate(self._h, opc, C.byref(col), ri.ctypes.data if ri is not None else None,
+                                             offsets.ctypes.data, ng, nrows, 1 if reverse else 0, L.HOST, out.ctypes.data))
         return out
 
     def range_bucket(self, values, bounds, stype=None):

@@ -73,8 +73,24 @@ enum dthip_op {
   DTHIP_COUNT = 4,   /* count(col): non-NA rows per group   (count.h:35-58) */
   DTHIP_COUNT0 = 5,  /* count():    rows per group          (count.h:61-88) */
   DTHIP_FIRST = 6,   /* first(col): element of the group's first row, NA included */
-  DTHIP_LAST = 7     /* last(col)   (FirstLast_ColumnImpl, src/core/expr/head_reduce_unary.cc:116-160);
+  DTHIP_LAST = 7,    /* last(col)   (FirstLast_ColumnImpl, src/core/expr/head_reduce_unary.cc:116-160);
                         both need the row order, so dthip_groupby_agg takes the sort path for them */
+  /* dthip_reduce only: */
+  DTHIP_SD = 8,      /* sd(col): sample standard deviation, NA if < 2 valid rows or a non-finite value
+                        (sd_reducer, src/core/expr/head_reduce_unary.cc:194-216) */
+  DTHIP_MEDIAN = 9,  /* median(col) of the valid values (Median_ColumnImpl, head_reduce_unary.cc:424-470) */
+  DTHIP_NUNIQUE = 10 /* nunique(col): distinct valid values, int64 (op_nunique, head_reduce_unary.cc:377-387) */
+};
+
+/* binary group reducers, dthip_reduce2 (src/core/expr/head_reduce_binary.cc:113-198) */
+enum dthip_op2 { DTHIP_COV = 0, DTHIP_CORR = 1 };
+
+/* group-wise cumulative operators, dthip_cumulate (src/core/column/cumsumprod.h:52-92,
+ * cumminmax.h:48-98, cumcountngroup.h:55-72) */
+enum dthip_cumop {
+  DTHIP_CUMSUM = 0, DTHIP_CUMPROD = 1, DTHIP_CUMMIN = 2, DTHIP_CUMMAX = 3,
+  DTHIP_CUMCOUNT = 4,  /* cumcount(): row number inside the group, int64 (no value column) */
+  DTHIP_NGROUP = 5     /* ngroup():   group number, int64 (no value column) */
 };
 
 enum dthip_mem { DTHIP_HOST = 0, DTHIP_DEVICE = 1 };
@@ -218,6 +234,26 @@ int  dthip_reduce_out_stype(int op, int stype);
 int  dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value,
                   const int32_t* rowindex, const int32_t* offsets,
                   int64_t ngroups, int64_t nrows, int mem, void* out);
+
+/* cov / corr of two columns per group, over the rows where BOTH values are valid
+ * (cov_reducer / corr_reducer, src/core/expr/head_reduce_binary.cc:113-135,167-198).
+ * Output stype: float32 when both inputs are float32, else float64 (:47-51,150-155);
+ * cov: NA for < 2 valid pairs; corr: NA unless var(a)*var(b) > 0.  out: T_out[ngroups]. */
+int  dthip_reduce2_out_stype(int stype_a, int stype_b);
+int  dthip_reduce2(dthip_ctx* ctx, int op /* enum dthip_op2 */, const dthip_col* a, const dthip_col* b,
+                   const int32_t* rowindex, const int32_t* offsets,
+                   int64_t ngroups, int64_t nrows, int mem, void* out);
+
+/* cumsum / cumprod / cummin / cummax inside every group, in grouped row order (or from the
+ * group's last row backwards when reverse != 0), and cumcount() / ngroup()
+ * (FExpr_CumSumProd::evaluate1, src/core/expr/fexpr_cumsumprod.cc:72-99: integers -> int64,
+ * float32 stays float32; NA counts as 0 / 1.  FExpr_CumMinMax::evaluate1,
+ * fexpr_cumminmax.cc:87-101: output stype = input stype, NA until the first valid row).
+ * out: T_out[nrows], row i of the result is grouped position i (value[rowindex[i]]). */
+int  dthip_cumulate_out_stype(int op /* enum dthip_cumop */, int stype);
+int  dthip_cumulate(dthip_ctx* ctx, int op, const dthip_col* value,
+                    const int32_t* rowindex, const int32_t* offsets,
+                    int64_t ngroups, int64_t nrows, int reverse, int mem, void* out);
 
 /* Groupby::ungroup_rowindex (src/core/groupby.cc:117-130): out[i] = g for every i in
  * [offsets[g], offsets[g+1]) -- broadcasts one-value-per-group columns back to rows (GtoALL,
