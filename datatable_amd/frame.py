@@ -27,9 +27,10 @@ import builtins
 import numpy as np
 
 from . import _lib as L
-from .engine import NP2ST, OPS as L_OPS, ST2NP, default_context
+from .engine import CUMOPS as L_CUMOPS, NP2ST, OPS as L_OPS, ST2NP, default_context
 
-__all__ = ["Frame", "f", "by", "sort", "sum", "mean", "min", "max", "count", "first", "last"]
+__all__ = ["Frame", "f", "by", "sort", "sum", "mean", "min", "max", "count", "first", "last",
+           "sd", "median", "nunique", "cov", "corr", "cumsum", "cumprod", "cummin", "cummax", "cumcount", "ngroup"]
 
 _NA_INT = {1: np.iinfo(np.int8).min, 2: np.iinfo(np.int16).min, 4: np.iinfo(np.int32).min, 8: np.iinfo(np.int64).min}
 
@@ -89,6 +90,28 @@ class Reducer(FExpr):
 
     def __repr__(self):
         return "FExpr<%s(%s)>" % (self.op, "" if self.arg is None else repr(self.arg)[6:-1])
+
+
+class Reducer2(FExpr):
+    """cov(f.a, f.b) / corr(f.a, f.b)  (src/core/expr/head_reduce_binary.cc:226-270); unnamed in the result"""
+
+    def __init__(self, op, a, b):
+        self.op, self.a, self.b = op, a, b
+
+    def __repr__(self):
+        return "FExpr<%s(%s, %s)>" % (self.op, repr(self.a)[6:-1], repr(self.b)[6:-1])
+
+
+class Cumulative(FExpr):
+    """cumsum / cumprod / cummin / cummax(f.col, reverse=False), cumcount(reverse) / ngroup(reverse)
+    (src/core/expr/fexpr_cumsumprod.cc, fexpr_cumminmax.cc, fexpr_cumcountngroup.cc): one value per row,
+    rows in grouped order"""
+
+    def __init__(self, op, arg, reverse=False):
+        self.op, self.arg, self.reverse = op, arg, bool(reverse)
+
+    def __repr__(self):
+        return "FExpr<%s(%sreverse=%s)>" % (self.op, "" if self.arg is None else repr(self.arg)[6:-1] + ", ", self.reverse)
 
 
 class _Namespace:
@@ -155,6 +178,48 @@ max = _reducer("max")        # noqa: A001
 count = _reducer("count")
 first = _reducer("first")    # src/core/expr/head_reduce_unary.cc:116-190
 last = _reducer("last")
+sd = _reducer("sd")          # src/core/expr/head_reduce_unary.cc:194-243
+median = _reducer("median")  # :424-510
+nunique = _reducer("nunique")  # :377-417
+
+
+def _colarg(arg, what):
+    if isinstance(arg, str):
+        arg = ColRef(arg)
+    if not isinstance(arg, (ColRef, AllCols)):
+        raise NotImplementedError("%s of a computed expression is outside the accelerated path" % what)
+    return arg
+
+
+def cov(a, b):
+    return Reducer2("cov", _colarg(a, "cov()"), _colarg(b, "cov()"))
+
+
+def corr(a, b):
+    return Reducer2("corr", _colarg(a, "corr()"), _colarg(b, "corr()"))
+
+
+def _cumulative(op):
+    def fn(arg=None, reverse=False):
+        if arg is None:
+            raise TypeError("Function `datatable.%s()` requires exactly 1 positional argument, but none were given" % op)
+        return Cumulative(op, _colarg(arg, op + "()"), reverse)
+    fn.__name__ = op
+    return fn
+
+
+cumsum = _cumulative("cumsum")
+cumprod = _cumulative("cumprod")
+cummin = _cumulative("cummin")
+cummax = _cumulative("cummax")
+
+
+def cumcount(reverse=False):
+    return Cumulative("cumcount", None, reverse)
+
+
+def ngroup(reverse=False):
+    return Cumulative("ngroup", None, reverse)
 
 
 # ---- Frame ---------------------------------------------------------------------------------
@@ -181,7 +246,20 @@ def _to_column(x):
 
 
 def _mangle(names):
-    """duplicate-name mangling of result frames: v, v -> v, v.0 (src/core/frame/names.cc:232-266)"""
+    """duplicate-name mangling of result frames: v, v -> v, v.0 (src/core/frame/names.cc:455-510); unnamed
+    columns ("") become C<k>, counting on from the largest C<num> already present (names.cc:572-607)"""
+    if "" in names:
+        nxt = 0
+        for nm in names:
+            if len(nm) > 1 and nm[0] == "C" and nm[1:].isdigit():
+                nxt = builtins.max(nxt, int(nm[1:]) + 1)
+        filled = []
+        for nm in names:
+            if nm == "":
+                nm = "C%d" % nxt
+                nxt += 1
+            filled.append(nm)
+        names = filled
     seen, out = set(), []
     for nm in names:
         if nm not in seen:
@@ -354,7 +432,7 @@ class Frame:
         if j is None or j is Ellipsis or (isinstance(j, slice) and j == slice(None)):
             return self
         items = list(j.values()) if isinstance(j, dict) else (list(j) if isinstance(j, (list, tuple)) else [j])
-        if any(isinstance(r, Reducer) for r in items):
+        if any(isinstance(r, (Reducer, Reducer2, Cumulative)) for r in items):
             return self._groupby(j, None, None)
         idx = [self._index(r) for r in items]
         names = list(j.keys()) if isinstance(j, dict) else [self._names[k] for k in idx]
@@ -408,49 +486,85 @@ class Frame:
         # j -> flat list of (name override, item); f[:] expands to the non-by columns
         raw = [] if sel_all else (list(j.items()) if isinstance(j, dict) else
                                   [(None, x) for x in (j if isinstance(j, (list, tuple)) else [j])])
+
+        def expand(arg):
+            return [ColRef(self._names[c]) for c in nonby] if isinstance(arg, AllCols) else [arg]
+
         items = []
         for nm, x in raw:
             if isinstance(x, AllCols):
-                items += [(None, ColRef(self._names[c])) for c in nonby]
+                items += [(None, c) for c in expand(x)]
             elif isinstance(x, Reducer) and isinstance(x.arg, AllCols):
-                items += [(None, Reducer(x.op, ColRef(self._names[c]))) for c in nonby]
-            elif isinstance(x, (Reducer, ColRef, str, int, np.integer)):
-                items.append((nm, x if isinstance(x, (Reducer, ColRef)) else ColRef(x)))
+                items += [(None, Reducer(x.op, c)) for c in expand(x.arg)]
+            elif isinstance(x, Cumulative) and isinstance(x.arg, AllCols):
+                items += [(None, Cumulative(x.op, c, x.reverse)) for c in expand(x.arg)]
+            elif isinstance(x, Reducer2):
+                la, lb = expand(x.a), expand(x.b)
+                if not (len(la) == len(lb) or len(la) == 1 or len(lb) == 1):
+                    raise ValueError("Cannot apply reducer function %s: argument 1 has %d columns, while argument 2 "
+                                     "has %d columns" % (x.op, len(la), len(lb)))    # head_reduce_binary.cc:248-252
+                m = builtins.max(len(la), len(lb))
+                items += [(nm, Reducer2(x.op, la[i if len(la) > 1 else 0], lb[i if len(lb) > 1 else 0])) for i in range(m)]
+            elif isinstance(x, (Reducer, Cumulative, ColRef, str, int, np.integer)):
+                items.append((nm, x if isinstance(x, FExpr) else ColRef(x)))
             else:
                 raise NotImplementedError("j item %r is outside the accelerated path" % (x,))
         if sel_all:
             items = [(None, ColRef(self._names[c])) for c in nonby]
-        reducers = [x for _, x in items if isinstance(x, Reducer)]
+        reducers = [x for _, x in items if isinstance(x, (Reducer, Reducer2))]
+        cums = [x for _, x in items if isinstance(x, Cumulative)]
         plain = [self._index(x) for _, x in items if isinstance(x, ColRef)]
         bynames = [self._names[k] for k in kidx]
 
         def item_name(nm, x):
             if nm is not None:
                 return nm
+            if isinstance(x, Reducer2):
+                return ""                                   # auto-named C<k>
             if isinstance(x, Reducer):
                 return "count" if x.op == "count0" else self._names[self._index(x.arg)]
+            if isinstance(x, Cumulative):
+                return "" if x.arg is None else self._names[self._index(x.arg)]
             return self._names[self._index(x)]
+
+        def out_stype(x):
+            if isinstance(x, Reducer2):
+                return ctx._lib.dthip_reduce2_out_stype(self._stypes[self._index(x.a)], self._stypes[self._index(x.b)])
+            if isinstance(x, Reducer):
+                return L.INT64 if x.op == "count0" else ctx._lib.dthip_reduce_out_stype(L_OPS[x.op], self._stypes[self._index(x.arg)])
+            if isinstance(x, Cumulative):
+                return ctx._lib.dthip_cumulate_out_stype(L_CUMOPS[x.op], L.INT64 if x.arg is None else self._stypes[self._index(x.arg)])
+            return self._stypes[self._index(x)]
+
+        names = bynames + [item_name(nm, x) for nm, x in items]
+        group_level = not sel_all and all(isinstance(x, (Reducer, Reducer2)) or (isinstance(x, ColRef) and self._index(x) in kidx)
+                                          for _, x in items)
+
+        if self.nrows == 0 and (reducers or cums):
+            # a reducer over an empty frame without by() still yields one row (reduce_unary.h):
+            # sum / count / nunique 0, everything else NA; with by(), and for row-level items, no rows
+            one = not kidx and group_level
+            cols, sts = [], []
+            for k in range(len(kidx)):
+                cols.append(np.zeros(0, ST2NP[kst[k]])); sts.append(kst[k])
+            for _, x in items:
+                st = out_stype(x)
+                dtp = ST2NP[st]
+                if not one:
+                    cols.append(np.zeros(0, dtp))
+                elif isinstance(x, Reducer) and x.op in ("sum", "count", "count0", "nunique"):
+                    cols.append(np.zeros(1, dtp))
+                else:
+                    cols.append(np.full(1, np.nan if dtp.kind == "f" else _NA_INT[dtp.itemsize], dtp))
+                sts.append(st)
+            return Frame._from_columns(cols, sts, names)
 
         if not kidx:
             # DT[:, sum(f.v)] without by(): one group over all rows
             keys, kst, kdesc = [np.zeros(self.nrows, np.int8)], [L.INT8], [False]
-            if self.nrows == 0 and reducers and len(reducers) == len(items):
-                # a reducer over an empty frame still yields one row (reduce_unary.h): sum/count 0, else NA
-                cols, sts = [], []
-                for x in reducers:
-                    st = L.INT64 if x.op == "count0" else ctx._lib.dthip_reduce_out_stype(L_OPS[x.op], self._stypes[self._index(x.arg)])
-                    dtp = ST2NP[st]
-                    if x.op in ("sum", "count", "count0"):       # first/last/min/max/mean of nothing: NA
-                        cols.append(np.zeros(1, dtp))
-                    else:
-                        cols.append(np.full(1, np.nan if dtp.kind == "f" else _NA_INT[dtp.itemsize], dtp))
-                    sts.append(st)
-                return Frame._from_columns(cols, sts, [item_name(nm, x) for nm, x in items])
 
-        names = bynames + [item_name(nm, x) for nm, x in items]
-        group_level = all(isinstance(x, Reducer) or self._index(x) in kidx for _, x in items) and not sel_all
-
-        if group_level and (reducers or not items):
+        fusable = all(isinstance(x, Reducer) and x.op in _FUSED_OPS for x in reducers)
+        if group_level and fusable and (reducers or not items):
             # fused groupby-aggregate: one row per group
             vidx, aggs = [], []
             for x in reducers:
@@ -473,6 +587,35 @@ class Frame:
             res.free()
             return Frame._from_columns(cols, sts, names)
 
+        def reduce_item(x, order, goff):
+            """one value per group through the S-red seam (dthip_reduce / dthip_reduce2)"""
+            if isinstance(x, Reducer2):
+                ia, ib = self._index(x.a), self._index(x.b)
+                return ctx.reduce2(x.op, self._materialized(ia), self._materialized(ib), order, goff,
+                                   stypes=(self._stypes[ia], self._stypes[ib]))
+            if x.op == "count0":
+                return ctx.reduce("count0", None, None, goff)
+            ci = self._index(x.arg)
+            return ctx.reduce(x.op, self._materialized(ci), order, goff, stype=self._stypes[ci])
+
+        if group_level:
+            # one row per group, with reducers the fused aggregation does not carry (sd, median, nunique,
+            # cov, corr), or only by-columns: group once, reduce per item; the by-columns take their value
+            # at the first row of each group (eval_context.cc:473-485)
+            g = ctx.groupby(keys, stypes=kst, desc=kdesc)
+            gri, goff = g.rowindex(), g.offsets()
+            g.free()
+            first = ctx.gather(gri, goff[:-1])
+            kcols = [ctx.gather(keys[k], first, stype=kst[k]) for k in range(len(kidx))]
+            cols, sts = list(kcols), list(kst[:len(kidx)])
+            for _, x in items:
+                if isinstance(x, (Reducer, Reducer2)):
+                    cols.append(reduce_item(x, gri, goff)); sts.append(out_stype(x))
+                else:
+                    k = kidx.index(self._index(x))
+                    cols.append(kcols[k]); sts.append(kst[k])
+            return Frame._from_columns(cols, sts, names)
+
         # the ordering: by-columns, then (inside groups) the sort() columns
         skeys, sst, sdesc, na_last = list(keys), list(kst), list(kdesc), False
         if srt is not None:
@@ -482,50 +625,47 @@ class Frame:
             na_last = srt.na_last
         res = ctx.groupby(skeys, stypes=sst, desc=sdesc, na_last=na_last)
         ri = res.rowindex()
+        goff = res.offsets() if srt is None else None
         res.free()
         full_ri = ri if self._ri is None else ctx.gather(self._ri, ri)
 
-        if group_level:
-            # only by-columns selected: their value at the first row of each group (eval_context.cc:473-485)
-            g = ctx.groupby(keys, stypes=kst, desc=kdesc)
-            first = ctx.gather(g.rowindex(), g.offsets()[:-1])
-            g.free()
-            kcols = [ctx.gather(keys[k], first, stype=kst[k]) for k in range(len(kidx))]
-            cols = list(kcols) + [kcols[kidx.index(self._index(x))] for _, x in items]
-            sts = list(kst) + [kst[kidx.index(self._index(x))] for _, x in items]
-            return Frame._from_columns(cols, sts, names)
-
-        if not reducers:
+        if not reducers and not cums:
             # rows in grouped order: by-columns first, then the selected columns (a view, like the reference)
             order = kidx + plain
             fr = Frame._from_columns([self._cols[c] for c in order], [self._stypes[c] for c in order], names)
             fr._ri = full_ri
             return fr
 
-        # reducers next to plain columns: the reducers are evaluated per group (S-red seam) and
-        # broadcast back to the rows of their group
-        g = ctx.groupby(keys, stypes=kst, desc=kdesc)
-        gri, goff = g.rowindex(), g.offsets()
-        g.free()
-        # output row i belongs to group ungroup(offsets)[i]: a sort() inside the groups permutes rows
-        # within their group only (the by-columns are the leading sort keys)
-        bcast = ctx.ungroup(goff)
+        # reducers / cumulative operators next to plain columns: one row per input row in grouped order.
+        # Reducers are evaluated per group (S-red seam) and broadcast back to the rows of their group;
+        # cumulative operators run along the grouped order.  A sort() inside the groups permutes rows
+        # within their group only (the by-columns are the leading sort keys), so the by-only offsets
+        # delimit the same groups in `ri`.
+        if goff is None:
+            g = ctx.groupby(keys, stypes=kst, desc=kdesc, want_rowindex=False)
+            goff = g.offsets()
+            g.free()
+        bcast = ctx.ungroup(goff) if reducers else None
         cols = [ctx.gather(keys[k], ri, stype=kst[k]) for k in range(len(kidx))]
         sts = list(kst[:len(kidx)])
         for _, x in items:
-            if isinstance(x, Reducer):
-                if x.op == "count0":
-                    red = ctx.reduce("count0", None, None, goff)
-                    st = L.INT64
+            st = out_stype(x)
+            if isinstance(x, (Reducer, Reducer2)):
+                cols.append(ctx.gather(reduce_item(x, ri, goff), bcast, stype=st))
+            elif isinstance(x, Cumulative):
+                if x.arg is None:
+                    cols.append(ctx.cumulate(x.op, None, None, goff, reverse=x.reverse))
                 else:
                     ci = self._index(x.arg)
-                    red = ctx.reduce(x.op, self._materialized(ci), gri, goff, stype=self._stypes[ci])
-                    st = ctx._lib.dthip_reduce_out_stype(L_OPS[x.op], self._stypes[ci])
-                cols.append(ctx.gather(red, bcast, stype=st)); sts.append(st)
+                    cols.append(ctx.cumulate(x.op, self._materialized(ci), ri, goff, reverse=x.reverse, stype=self._stypes[ci]))
             else:
                 ci = self._index(x)
-                cols.append(ctx.gather(self._materialized(ci), ri, stype=self._stypes[ci])); sts.append(self._stypes[ci])
+                cols.append(ctx.gather(self._materialized(ci), ri, stype=self._stypes[ci]))
+            sts.append(st)
         return Frame._from_columns(cols, sts, names)
+
+
+_FUSED_OPS = ("sum", "mean", "min", "max", "count", "count0", "first", "last")   # what dthip_groupby_agg carries
 
 
 def _unused():   # keep flake-style tools quiet about the shadowed builtins being intentional

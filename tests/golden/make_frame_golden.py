@@ -16,6 +16,7 @@ SRC = os.environ.get("DT_REFERENCE_SRC", "/tmp/dt_oracle/src")
 sys.path.insert(0, SRC)
 import datatable as dt  # noqa: E402
 from datatable import f, by, sort, sum, mean, min, max, count, first, last  # noqa: E402,A004
+from datatable import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup  # noqa: E402
 
 dt.options.progress.enabled = False
 inf = math.inf
@@ -83,6 +84,38 @@ QUERIES = [
     ("big", "DT[:, f.n, by(f.k)]"),
     ("big", "DT[:, :, sort(f.n, f.k)]"),
     ("big", "DT[:, [first(f.n), last(f.v)], by(f.k)]"),
+    # the other group reducers and the cumulative operators
+    ("appendixB", "DT[:, [sd(f.v), median(f.v), nunique(f.v)], by(f.k)]"),
+    ("appendixB", "DT[:, [sd(f.i), median(f.i), nunique(f.i), sum(f.i)], by(f.k)]"),
+    ("appendixB", "DT[:, [cov(f.v, f.i), corr(f.v, f.i)], by(f.k)]"),
+    ("appendixB", "DT[:, [cumsum(f.v), cumsum(f.i), cummax(f.v), cumcount(), ngroup()], by(f.k)]"),
+    ("appendixB", "DT[:, [cumsum(f.v, reverse=True), cummin(f.i, reverse=True), cumcount(reverse=True), ngroup(reverse=True)], by(f.k)]"),
+    ("appendixB", "DT[:, [cumsum(f.i), cumprod(f.i), cummin(f.v), cummax(f.i)]]"),
+    ("appendixB", "DT[:, [sd(f.v), median(f.i), nunique(f.k), cov(f.i, f.i), corr(f.i, f.v)]]"),
+    ("appendixB", "DT[:, [f.i, cumsum(f.i), mean(f.i)], by(f.k)]"),
+    ("appendixB", "DT[:, cumsum(f[:]), by(f.k)]"),
+    ("appendixB", "DT[:, cumsum(f.k), by(f.k)]"),
+    ("appendixB", "DT[:, {'s': sd(f.v), 'm': median(f.v)}, by(f.k)]"),
+    ("appendixB", "DT[:, cumsum(f.i), by(f.k), sort(-f.i)]"),
+    ("appendixB", "DT[f.v > 1.6, :][:, [median(f.v), cumsum(f.i)], by(f.k)]"),
+    ("two_keys", "DT[:, [sd(f.w), median(f.v), nunique(f.w)], by(f.a, f.b)]"),
+    ("two_keys", "DT[:, [cumsum(f.v), cumprod(f.v), cummin(f.w), cummax(f.w)], by(f.a)]"),
+    ("two_keys", "DT[:, corr(f.v, f[:]), by(f.a)]"),
+    ("two_keys", "DT[:, [cumcount(), ngroup()], by(f.a, f.b)]"),
+    ("types", "DT[:, sd(f[:]), by(f.g)]"),
+    ("types", "DT[:, median(f[:]), by(f.g)]"),
+    ("types", "DT[:, nunique(f[:]), by(f.g)]"),
+    ("types", "DT[:, cumsum(f[:]), by(f.g)]"),
+    ("types", "DT[:, cumprod(f[:]), by(f.g)]"),
+    ("types", "DT[:, cummin(f[:]), by(f.g)]"),
+    ("types", "DT[:, cummax(f[:], reverse=True), by(f.g)]"),
+    ("types", "DT[:, [cov(f.i8, f.i16), cov(f.f32, f.f32), corr(f.i64, f.f32)], by(f.g)]"),
+    ("floatkey", "DT[:, [nunique(f.k), median(f.v)], by(f.k)]"),
+    ("floatkey", "DT[:, [nunique(f.k), median(f.k), sd(f.k)]]"),
+    ("big", "DT[:, [sd(f.v), median(f.v), nunique(f.v), median(f.n), nunique(f.n)], by(f.k)]"),
+    ("big", "DT[:, [cov(f.v, f.n), corr(f.v, f.n)], by(f.k)]"),
+    ("big", "DT[:, [cumsum(f.n), cummax(f.v), cummin(f.n, reverse=True), cumcount()], by(f.k)]"),
+    ("big", "DT[:, [cumsum(f.v), cumsum(f.n), ngroup()]]"),
 ]
 
 ST = {1: dt.bool8, 2: dt.int8, 3: dt.int16, 4: dt.int32, 5: dt.int64, 6: dt.float32, 7: dt.float64}

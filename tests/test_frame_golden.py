@@ -1,4 +1,4 @@
-"""Frame-level golden answers: tests/golden/frame_queries.json holds 49 `DT[i, j, by/sort]` queries
+"""Frame-level golden answers: tests/golden/frame_queries.json holds 80 `DT[i, j, by/sort]` queries
 together with what the UNMODIFIED reference returned for them (tests/golden/make_frame_golden.py,
 run in the dev container).  The same query strings are evaluated here against
 datatable_amd.frame on the GPU: names, stypes and every value must agree (float sums/means to 1e-6
@@ -28,6 +28,7 @@ def _dec(x):
 def test_frame_query_matches_reference(qi):
     from datatable_amd import frame as dt
     from datatable_amd.frame import f, by, sort, sum, mean, min, max, count, first, last   # noqa: F401,A004
+    from datatable_amd.frame import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup  # noqa: F401
     q = GOLD["queries"][qi]
     spec = GOLD["frames"][q["frame"]]
     DT = dt.Frame({nm: [_dec(x) for x in c["values"]] for nm, c in spec.items()},
@@ -37,7 +38,7 @@ def test_frame_query_matches_reference(qi):
     assert list(R.stypes) == q["stypes"]
     got = R.to_list()
     assert len(got) == len(q["columns"])
-    is_float_red = any(k in q["query"] for k in ("sum(", "mean("))
+    is_float_red = any(k in q["query"] for k in ("sum(", "mean(", "sd(", "cov(", "corr(", "cumprod("))
     for ci, (g, e) in enumerate(zip(got, q["columns"])):
         e = [_dec(x) for x in e]
         assert len(g) == len(e), "column %d: %d rows, expected %d" % (ci, len(g), len(e))

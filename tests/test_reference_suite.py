@@ -314,3 +314,183 @@ def test_first_last_frame(dt):                           # tests/test-reduce.py 
     assert R.to_list() == [[1, 2, 3], [None, 5, 11], [9, None, 11]]
     assert DT[:, [dt.first(f.B), dt.last(f.B)]].to_list() == [[None], [11]]
     assert dt.Frame(A=[], stypes={"A": 4})[:, dt.first(f.A)].to_list() == [[None]]
+
+
+# ---- tests/test-reduce.py: median / cov / corr / sd; tests/dt/test-cum*.py, test-nunique.py ---------
+#   `[..]/dt.int64` of the originals is spelled stypes=[...] here.
+
+I64, F32, F64, I32, I8, I16, B8 = 5, 6, 7, 4, 2, 3, 1
+
+
+def test_median_bool_even_nrows(dt):                    # test-reduce.py:592-597
+    RES = dt.Frame(A=[True, False, True, False])[:, dt.median(dt.f.A)]
+    assert RES.shape == (1, 1) and RES.stypes == (F64,) and RES.to_list() == [[0.5]]
+
+
+def test_median_bool_odd_nrows(dt):                     # test-reduce.py:600-605
+    RES = dt.Frame(B=[True, False, True])[:, dt.median(dt.f.B)]
+    assert RES.stypes == (F64,) and RES.to_list() == [[1.0]]
+
+
+def test_median_bygroup(dt):                            # test-reduce.py:608-613
+    DT = dt.Frame(A=[0.1, 0.2, 0.5, 0.4, 0.3, 0], B=[1, 2, 1, 1, 2, 2])
+    assert DT[:, dt.median(dt.f.A), dt.by(dt.f.B)].to_list() == [[1, 2], [0.4, 0.2]]
+
+
+@pytest.mark.parametrize("st", [I8, I16, I32, I64])
+def test_median_int(dt, st):                            # test-reduce.py:616-633
+    DT = dt.Frame(A=[7, 11, -2, 3, 0, 12, 12, 3, 5, 91], stypes=[st])
+    RES = DT[:, dt.median(dt.f.A)]
+    assert RES.shape == (1, 1) and RES.stypes == (F64,) and RES.to_list() == [[6.0]]
+    DT = dt.Frame(A=[4, -5, 12, 11, 4, 7, 0, 23, 45, 8, 10], stypes=[st])
+    assert DT[:, dt.median(dt.f.A)].to_list() == [[8.0]]
+
+
+def test_median_int_no_overflow(dt):                    # test-reduce.py:636-641
+    assert dt.Frame(A=[111, 112], stypes=[I8])[:, dt.median(dt.f.A)].to_list() == [[111.5]]
+
+
+@pytest.mark.parametrize("st", [F32, F64])
+def test_median_float(dt, st):                          # test-reduce.py:644-650
+    RES = dt.Frame(W=[0.0, 5.5, 7.9, math.inf, -math.inf], stypes=[st])[:, dt.median(dt.f.W)]
+    assert RES.stypes == (st,) and RES.to_list() == [[5.5]]
+
+
+def test_median_all_and_some_nas(dt):                   # test-reduce.py:653-666
+    RES = dt.Frame(N=[math.nan] * 8)[:, dt.median(dt.f.N)]
+    assert RES.stypes == (F64,) and RES.to_list() == [[None]]
+    RES = dt.Frame(S=[None, 5, None, 12, None, -3, None, None, None, 4])[:, dt.median(dt.f.S)]
+    assert RES.stypes == (F64,) and RES.to_list() == [[4.5]]
+
+
+def test_median_grouped(dt):                            # test-reduce.py:669-676
+    DT = dt.Frame(A=[0, 0, 0, 0, 1, 1, 1, 1, 1], B=[2, 6, 1, 0, -3, 4, None, None, -1], stypes={"A": I16, "B": I32})
+    RES = DT[:, dt.median(dt.f.B), dt.by(dt.f.A)]
+    assert RES.shape == (2, 2) and RES.stypes == (I16, F64) and RES.to_list() == [[0, 1], [1.5, -1.0]]
+
+
+def test_cov_simple_small_float32(dt):                  # test-reduce.py:710-733
+    DT = dt.Frame(A=list(range(5)), B=list(range(5)))
+    assert_equals(DT[:, dt.cov(dt.f.A, dt.f.B)], dt.Frame([2.5]))
+    assert_equals(dt.Frame(A=[1], B=[2])[:, dt.cov(dt.f.A, dt.f.B)], dt.Frame([None], stypes=[F64]))
+    DT = dt.Frame(A=[1.0, 2.0, 3.0], B=[7.5, 7.0, 6.5], stypes=[F32, F32])
+    assert_equals(DT[:, dt.cov(dt.f.A, dt.f.B)], dt.Frame([-0.5], stypes=[F32]))
+
+
+def test_cov_bygroup(dt):                               # test-reduce.py:736-739
+    DT = dt.Frame(ID=[1, 2, 1, 2, 1, 2], A=[0, 5, 10, 20, 2, 8])
+    assert_equals(DT[:, dt.cov(dt.f.A, dt.f.A), dt.by(dt.f.ID)], dt.Frame(ID=[1, 2], C0=[28.0, 63.0]))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_cov_corr_random(dt, seed):                     # test-reduce.py:742-752,785-794
+    rng = np.random.default_rng(seed)
+    arr1, arr2 = rng.random(100), rng.random(100)
+    DT = dt.Frame([arr1, arr2])
+    assert np.isclose(np.cov(arr1, arr2)[0, 1], DT[:, dt.cov(dt.f[0], dt.f[1])].to_list()[0][0], atol=1e-12, rtol=1e-12)
+    assert np.isclose(np.corrcoef(arr1, arr2)[0, 1], DT[:, dt.corr(dt.f[0], dt.f[1])].to_list()[0][0], atol=1e-12, rtol=1e-12)
+
+
+def test_corr_simple_and_constant(dt):                  # test-reduce.py:760-782
+    DT = dt.Frame(A=list(range(5)), B=list(range(5)))
+    assert_equals(DT[:, dt.corr(dt.f.A, dt.f.B)], dt.Frame([1.0]))
+    DT = dt.Frame(A=list(range(5)), B=list(range(5, 0, -1)))
+    assert_equals(DT[:, dt.corr(dt.f.A, dt.f.B)], dt.Frame([-1.0]))
+    assert_equals(dt.Frame(A=[1], B=[2])[:, dt.corr(dt.f.A, dt.f.B)], dt.Frame([None], stypes=[F64]))
+    DT = dt.Frame(A=list(range(23)), B=[2.5] * 23)
+    assert_equals(DT[:, dt.corr(dt.f.A, dt.f.B)], dt.Frame([None], stypes=[F64]))
+
+
+def test_corr_multiple(dt):                             # test-reduce.py:797-806
+    DT = dt.Frame(A=[3, 5, 9, 1], B=[4, 7, 0, 0], C=[3, 2, 1, 0], D=list(range(4)))
+    a, b, c = -0.07168504827326534, 0.07559289460184544, 0.7207110797203374
+    assert_equals(DT[:, dt.corr(dt.f.A, dt.f[:])], dt.Frame([[1.0], [a], [b], [-b]]))
+    assert_equals(DT[:, dt.corr(dt.f[:], dt.f.D)], dt.Frame([[-b], [-c], [-1.0], [1.0]]))
+    assert_equals(DT[:, dt.corr(dt.f[:], dt.f[:])], dt.Frame([[1.0], [1.0], [1.0], [1.0]]))
+
+
+def test_sd(dt):                                        # test-reduce.py:920-941
+    DT = dt.Frame([[3], [None], [1], [5], [None]])
+    assert_equals(DT[:, dt.sd(dt.f[:])], dt.Frame([[None]] * 5, stypes=[F64] * 5))
+    DT = dt.Frame([[1] * 10, [-1.1] * 10, [0] * 10, [4.3] * 10, [300] * 10])
+    assert_equals(DT[:, dt.sd(dt.f[:])], dt.Frame([[0.0]] * 5))
+    DT = dt.Frame([[1.5, 6.4, 0.0, None, 7.22], [2.0, -1.1, math.inf, 4.0, 3.2], [1.5, 9.9, None, None, math.nan],
+                   [math.inf, -math.inf, None, 0.0, math.nan]])
+    assert_equals(DT[:, dt.sd(dt.f[:])],
+                  dt.Frame([[3.5676696409094086], [None], [5.939696961966999], [None]], stypes=[F64] * 4))
+
+
+def test_sd_per_group(dt):                              # test-reduce.py:907-911 (void column -> all-NA int column)
+    DT = dt.Frame([[None, None, None, None, None], [1, 2, 1, 2, 2]], stypes=[I32, I32])
+    assert_equals(DT[:, dt.sd(dt.f.C0), dt.by(dt.f.C1)], dt.Frame(C1=[1, 2], C0=[None, None], stypes={"C0": F64}))
+
+
+def test_cumsum(dt):                                    # tests/dt/test-cumsum.py:78-112
+    DT = dt.Frame([0], stypes=[I64])
+    assert_equals(DT[:, dt.cumsum(dt.f[:])], DT)
+    DT = dt.Frame([list(range(5)), [-1, 1, None, 2, 5.5]])
+    assert_equals(DT[:, dt.cumsum(dt.f[:])], dt.Frame([[0, 1, 3, 6, 10], [-1, 0, 0, 2, 7.5]], stypes=[I64, F64]))
+    assert_equals(DT[:, dt.cumsum(dt.f[:], reverse=True)], dt.Frame([[10, 10, 9, 7, 4], [7.5, 8.5, 7.5, 7.5, 5.5]], stypes=[I64, F64]))
+    DT = dt.Frame([[2, 1, 1, 1, 2], [1.5, -1.5, math.inf, 2, 3]])
+    assert_equals(DT[:, dt.cumsum(dt.f[:]), dt.by(dt.f[0])], dt.Frame([[1, 1, 1, 2, 2], [-1.5, math.inf, math.inf, 1.5, 4.5]]))
+    assert_equals(DT[:, dt.cumsum(dt.f[:], reverse=True), dt.by(dt.f[0])],
+                  dt.Frame([[1, 1, 1, 2, 2], [math.inf, math.inf, 2.0, 4.5, 3.0]]))
+
+
+def test_cumsum_grouped_column(dt):                     # tests/dt/test-cumsum.py:120-124
+    DT = dt.Frame([2, 1, None, 1, 2])
+    assert_equals(DT[:, dt.cumsum(dt.f[0]), dt.by(dt.f[0])],
+                  dt.Frame([[None, 1, 1, 2, 2], [0, 1, 2, 2, 4]], names=["C0", "C0.0"], stypes=[I32, I64]))
+
+
+def test_cumprod(dt):                                   # tests/dt/test-cumprod.py:87-112
+    DT = dt.Frame([list(range(5)), [-1, 1, None, 2, 5.5]])
+    assert_equals(DT[:, dt.cumprod(dt.f[:])], dt.Frame([[0, 0, 0, 0, 0], [-1, -1, -1, -2, -11]], stypes=[I64, F64]))
+    DT = dt.Frame([[2, 1, 1, 1, 2], [1.5, -1.5, math.inf, 2, 3]])
+    assert_equals(DT[:, dt.cumprod(dt.f[:]), dt.by(dt.f[0])], dt.Frame([[1, 1, 1, 2, 2], [-1.5, -math.inf, -math.inf, 1.5, 4.5]]))
+    assert_equals(DT[:, dt.cumprod(dt.f[:], reverse=True), dt.by(dt.f[0])],
+                  dt.Frame([[1, 1, 1, 2, 2], [-math.inf, math.inf, 2.0, 4.5, 3.0]]))
+
+
+def test_cumminmax(dt):                                 # tests/dt/test-cumminmax.py:97-159
+    DT = dt.Frame([None, False, None, True, False, True])
+    assert_equals(DT[:, [dt.cummin(dt.f[:]), dt.cummax(dt.f[:])]],
+                  dt.Frame([[None, False, False, False, False, False], [None, False, False, True, True, True]], names=["C0", "C0.0"]))
+    DT = dt.Frame([list(range(5)), [None, -1, None, 5.5, 3]])
+    assert_equals(DT[:, [dt.cummin(dt.f[:]), dt.cummax(dt.f[:])]],
+                  dt.Frame([[0, 0, 0, 0, 0], [None, -1, -1, -1, -1], [0, 1, 2, 3, 4], [None, -1, -1, 5.5, 5.5]],
+                           names=["C0", "C1", "C0.0", "C1.0"], stypes=[I32, F64, I32, F64]))
+    DT = dt.Frame([[2, 1, 1, 1, 2], [1.5, -1.5, math.inf, None, 3]])
+    assert_equals(DT[:, [dt.cummin(dt.f[:]), dt.cummax(dt.f[:])], dt.by(dt.f[0])],
+                  dt.Frame([[1, 1, 1, 2, 2], [-1.5, -1.5, -1.5, 1.5, 1.5], [-1.5, math.inf, math.inf, 1.5, 3]],
+                           names=["C0", "C1", "C1.0"]))
+
+
+def test_cumminmax_grouped_column_and_reverse(dt):      # tests/dt/test-cumminmax.py:162-170,194-203
+    DT = dt.Frame([2, 1, None, 1, 2])
+    assert_equals(DT[:, [dt.cummin(dt.f[0]), dt.cummax(dt.f[0])], dt.by(dt.f[0])],
+                  dt.Frame([[None, 1, 1, 2, 2]] * 3, names=["C0", "C0.0", "C0.1"]))
+    DT = dt.Frame([[3, 14, 15, 92, 6], [0, 1, 0, 2, 1]])           # string key of the original -> its rank
+    assert_equals(DT[:, [dt.cummin(dt.f[0], reverse=True), dt.cummax(dt.f[0], True)], dt.by(dt.f[1])],
+                  dt.Frame([[0, 0, 1, 1, 2], [3, 15, 6, 6, 92], [15, 15, 14, 6, 92]], names=["C1", "C0", "C0.0"]))
+
+
+def test_cumcount_ngroup(dt):                           # tests/dt/test-cumcountngroup.py:76-100
+    DT = dt.Frame([0], stypes=[I64])
+    assert_equals(DT[:, [dt.cumcount(True), dt.cumcount(False), dt.ngroup(True), dt.ngroup(False)]],
+                  dt.Frame([[0]] * 4, stypes=[I64] * 4))
+    DT = dt.Frame([0, 0, 0, 1, 1, 0])                                # 'a'/'b' of the original -> 0/1
+    assert_equals(DT[:, [dt.cumcount(False), dt.cumcount(True), dt.ngroup(True), dt.ngroup(False)]],
+                  dt.Frame([list(range(6)), list(range(5, -1, -1)), [0] * 6, [0] * 6], stypes=[I64] * 4))
+    assert_equals(DT[:, [dt.cumcount(False), dt.ngroup(True)], dt.by(dt.f[0])],
+                  dt.Frame([[0, 0, 0, 0, 1, 1], [0, 1, 2, 3, 0, 1], [1, 1, 1, 1, 0, 0]], names=["C0", "C1", "C2"],
+                           stypes=[I32, I64, I64]))
+
+
+def test_nunique_with_by(dt):                           # tests/dt/test-nunique.py:69-93
+    DT = dt.Frame(G=[1, 1, 1, 2, 2, 2], V=[None, None, None, None, 3, 5], N=[None] * 6, stypes={"N": I32})
+    RES = DT[:, {"V1": dt.nunique(dt.f.V), "V3": dt.nunique(dt.f.N)}, dt.by(dt.f.G)]
+    assert_equals(RES, dt.Frame(G=[1, 2], V1=[0, 2], V3=[0, 0], stypes={"V1": I64, "V3": I64}))
+    DT = dt.Frame([1, None, 1, 2, None, None])
+    assert_equals(DT[:, {"nunique": dt.nunique(dt.f[0])}, dt.by(dt.f[0])],
+                  dt.Frame(C0=[None, 1, 2], nunique=[0, 1, 1], stypes={"nunique": I64}))
