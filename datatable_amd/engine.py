@@ -379,6 +379,28 @@ class Context:
         b = (C.c_int64 * max(len(bounds), 1))(*[int(x) for x in bounds])
         L.check(self._lib.dthip_range_bucket(self._h, C.byref(c), nrows, b, len(bounds), L.DEVICE, C.c_void_p(out_ptr)))
 
+    # device-resident forms of the S-red seam: every pointer is a device address, nothing is copied
+    def reduce_dev(self, op, col, rowindex_ptr, offsets_ptr, ngroups, nrows, out_ptr):
+        opc = OPS[op] if isinstance(op, str) else int(op)
+        c = L.Col(col.ptr, col.stype, 0) if col is not None else None
+        L.check(self._lib.dthip_reduce(self._h, opc, C.byref(c) if c is not None else None,
+                                       C.c_void_p(rowindex_ptr) if rowindex_ptr else None, C.c_void_p(offsets_ptr),
+                                       ngroups, nrows, L.DEVICE, C.c_void_p(out_ptr)))
+
+    def reduce2_dev(self, op, cola, colb, rowindex_ptr, offsets_ptr, ngroups, nrows, out_ptr):
+        opc = OPS2[op] if isinstance(op, str) else int(op)
+        ca, cb = L.Col(cola.ptr, cola.stype, 0), L.Col(colb.ptr, colb.stype, 0)
+        L.check(self._lib.dthip_reduce2(self._h, opc, C.byref(ca), C.byref(cb),
+                                        C.c_void_p(rowindex_ptr) if rowindex_ptr else None, C.c_void_p(offsets_ptr),
+                                        ngroups, nrows, L.DEVICE, C.c_void_p(out_ptr)))
+
+    def cumulate_dev(self, op, col, rowindex_ptr, offsets_ptr, ngroups, nrows, out_ptr, reverse=False):
+        opc = CUMOPS[op] if isinstance(op, str) else int(op)
+        c = L.Col(col.ptr, col.stype, 0) if col is not None else None
+        L.check(self._lib.dthip_cumulate(self._h, opc, C.byref(c) if c is not None else None,
+                                         C.c_void_p(rowindex_ptr) if rowindex_ptr else None, C.c_void_p(offsets_ptr),
+                                         ngroups, nrows, 1 if reverse else 0, L.DEVICE, C.c_void_p(out_ptr)))
+
     def gather_dev(self, col, rowindex_ptr, nout, out_ptr):
         c = L.Col(col.ptr, col.stype, 0)
         L.check(self._lib.dthip_gather(self._h, C.byref(c), C.c_void_p(rowindex_ptr), nout, L.DEVICE, C.c_void_p(out_ptr)))

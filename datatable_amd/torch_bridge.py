@@ -94,3 +94,44 @@ def range_bucket_tensor(ctx, key, bounds):
         ctx.range_bucket_dev(devcol(key), n, bounds, out.data_ptr())
     ctx.sync()
     return out
+
+
+def group_reduce_tensor(ctx, op, value, rowindex, offsets, value2=None):
+    """one value per group of a CUDA tensor: op in sum..last, sd, median, nunique; cov / corr with value2.
+    rowindex (int32 CUDA tensor or None) and offsets (int32 CUDA tensor, ngroups+1) describe the grouping."""
+    dev = offsets.device
+    ng = offsets.numel() - 1
+    n = rowindex.numel() if rowindex is not None else value.numel()
+    torch.cuda.current_stream(dev).synchronize()
+    if value2 is not None:
+        st = ctx._lib.dthip_reduce2_out_stype(T2ST[value.dtype], T2ST[value2.dtype])
+        out = torch.empty(ng, dtype=ST2T[st], device=dev)
+        if ng:
+            ctx.reduce2_dev(op, devcol(value), devcol(value2), rowindex.data_ptr() if rowindex is not None else 0,
+                            offsets.data_ptr(), ng, n, out.data_ptr())
+    else:
+        from .engine import OPS
+        st = ctx._lib.dthip_reduce_out_stype(OPS[op], T2ST[value.dtype])
+        out = torch.empty(ng, dtype=ST2T[st], device=dev)
+        if ng:
+            ctx.reduce_dev(op, devcol(value), rowindex.data_ptr() if rowindex is not None else 0, offsets.data_ptr(), ng, n,
+                           out.data_ptr())
+    ctx.sync()
+    return out
+
+
+def group_cumulate_tensor(ctx, op, value, rowindex, offsets, reverse=False):
+    """cumsum / cumprod / cummin / cummax of a CUDA tensor inside groups (value=None: cumcount / ngroup),
+    one value per row in grouped order"""
+    from .engine import CUMOPS
+    dev = offsets.device
+    ng = offsets.numel() - 1
+    n = rowindex.numel() if rowindex is not None else (value.numel() if value is not None else int(offsets[-1].item()))
+    torch.cuda.current_stream(dev).synchronize()
+    st = ctx._lib.dthip_cumulate_out_stype(CUMOPS[op], T2ST[value.dtype] if value is not None else L.INT64)
+    out = torch.empty(n, dtype=ST2T[st], device=dev)
+    if n:
+        ctx.cumulate_dev(op, devcol(value) if value is not None else None, rowindex.data_ptr() if rowindex is not None else 0,
+                         offsets.data_ptr(), ng, n, out.data_ptr(), reverse=reverse)
+    ctx.sync()
+    return out
