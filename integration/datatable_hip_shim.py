@@ -1,5 +1,7 @@
 """Reference-side binding (seam S-py): what a datatable maintainer adds to route
-the `DT[:, {sum|mean|min|max|count}(f.col) ..., by(cols)]` hot path to libdthip.so.
+the `DT[:, {sum|mean|min|max|count}(f.col) ..., by(cols)]` hot path to libdthip.so -- and, through
+the S-red entry points, the other reducers and group-wise operators that share its Groupby
+(first/last/sd/median/nunique, cov/corr, cumsum/cumprod/cummin/cummax/cumcount/ngroup).
 
 It runs INSIDE the reference's Python process (needs `import datatable`), touches no reference
 source, and forwards every other form of `DT[...]` to the reference unchanged:
@@ -41,6 +43,14 @@ from datatable_amd.engine import ST2NP, default_context
 # min()/max() print their argument as a one-element list: FExpr<min([f.v])>
 _REDUCER = re.compile(r"^FExpr<(sum|mean|min|max|count)\(\[?(?:f\.(\w+)|f\['([^']+)'\]|f\[(\d+)\])?\]?\)>$")
 _COLUMN = re.compile(r"^FExpr<(?:f\.(\w+)|f\['([^']+)'\]|f\[(\d+)\])>$")
+_CREF = r"(?:f\.\w+|f\['[^']+'\]|f\[\d+\])"
+# old-style expression nodes print as  Expr:stdev(FExpr<f.v>; )
+_REDUCER_OLD = re.compile(r"^Expr:(stdev|median|nunique|first|last)\((FExpr<%s>); \)$" % _CREF)
+_REDUCER2 = re.compile(r"^Expr:(cov|corr)\((FExpr<%s>), (FExpr<%s>); \)$" % (_CREF, _CREF))
+_CUMULATIVE = re.compile(r"^FExpr<(cumsum|cumprod|cummin|cummax)\((%s), reverse=(True|False)\)>$" % _CREF)
+_CUMCOUNT = re.compile(r"^FExpr<(cumcount|ngroup)\(reverse=(True|False)\)>$")
+_OLD2OP = {"stdev": "sd"}
+_FUSED = ("sum", "mean", "min", "max", "count", "count0")
 _ACCEL_STYPES = {1, 2, 3, 4, 5, 6, 7}
 
 
@@ -82,28 +92,147 @@ def match(frame, item):
         return None
     aggs = []
     for expr in (j if isinstance(j, (list, tuple)) else [j]):
-        m = _REDUCER.match(repr(expr))
-        if not m:
-            return None
-        op, ref = m.group(1), (m.group(2) or m.group(3) or m.group(4))
-        if ref is None:
-            if op != "count":
+        r = repr(expr)
+        m = _REDUCER.match(r)
+        if m:
+            op, ref = m.group(1), (m.group(2) or m.group(3) or m.group(4))
+            if ref is None:
+                if op != "count":
+                    return None
+                aggs.append(("count0", None))
+                continue
+            ci = _colindex(frame, int(ref) if m.group(4) is not None else ref)
+            if ci is None:
                 return None
-            aggs.append(("count0", None))
+            aggs.append((op, ci))
             continue
-        ci = _colindex(frame, int(ref) if m.group(4) is not None else ref)
-        if ci is None:
-            return None
-        aggs.append((op, ci))
-    used = keys + [c for _, c in aggs if c is not None]
+        m = _REDUCER_OLD.match(r)
+        if m:
+            ci = _colspec(frame, m.group(2))
+            if ci is None:
+                return None
+            aggs.append((_OLD2OP.get(m.group(1), m.group(1)), ci))
+            continue
+        m = _REDUCER2.match(r)
+        if m:
+            ca, cb = _colspec(frame, m.group(2)), _colspec(frame, m.group(3))
+            if ca is None or cb is None:
+                return None
+            aggs.append((m.group(1), (ca, cb)))
+            continue
+        m = _CUMULATIVE.match(r)
+        if m:
+            ci = _colspec(frame, "FExpr<%s>" % m.group(2))
+            if ci is None:
+                return None
+            aggs.append((m.group(1), ci, m.group(3) == "True"))
+            continue
+        m = _CUMCOUNT.match(r)
+        if m:
+            aggs.append((m.group(1), None, m.group(2) == "True"))
+            continue
+        return None
+    rowwise = [len(a) == 3 for a in aggs]
+    if any(rowwise) and not all(rowwise):
+        return None           # reducers broadcast next to row-level columns: left to the reference
+    used = list(keys)
+    for a in aggs:
+        c = a[1]
+        used += list(c) if isinstance(c, tuple) else ([] if c is None else [c])
     if any(frame.stypes[c].value not in _ACCEL_STYPES for c in used):
         return None           # strings, dates, ...: the reference handles them
     return keys, aggs
 
 
+def _colspec(frame, text):
+    """'FExpr<f.v>' (as printed inside an old-style Expr) -> column index"""
+    m = _COLUMN.match(text)
+    if not m:
+        return None
+    if m.group(3) is not None:
+        return _colindex(frame, int(m.group(3)))
+    return _colindex(frame, m.group(1) or m.group(2))
+
+
+def _col(frame, c):
+    return L.Col(dt.internal.frame_column_data_r(frame, c).value, frame.stypes[c].value, 0)
+
+
+def _finish(frame, keys, cols, names):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", dt.exceptions.DatatableWarning)     # duplicate names are mangled, as in the reference
+        res = dt.Frame(cols, names=names)                                   # "" -> auto-named C<k> by the reference
+    for i, k in enumerate(keys):                                            # bool8 keys travel as int8
+        if frame.stypes[k] == dt.stype.bool8:
+            res[:, i] = dt.Frame(res[:, i].to_numpy().astype(np.bool_))
+    return res
+
+
+def run_sred(frame, keys, aggs, ctx=None):
+    """the S-red route: dthip_groupby once, then dthip_reduce / dthip_reduce2 (one row per group) or
+    dthip_cumulate (one row per input row, grouped order) per j item -- host pointers throughout"""
+    import ctypes as C
+    from datatable_amd.engine import OPS, OPS2, CUMOPS
+    ctx = ctx or default_context()
+    lib = ctx._lib
+    n = frame.nrows
+    karr = (L.Col * len(keys))(*[_col(frame, k) for k in keys])
+    h = C.c_void_p()
+    L.check(lib.dthip_groupby(ctx._h, karr, len(keys), n, L.NA_FIRST, L.HOST, 1, C.byref(h)))
+    try:
+        ng = lib.dthip_result_ngroups(h)
+        ri, off = np.empty(n, np.int32), np.empty(ng + 1, np.int32)
+        L.check(lib.dthip_result_copy_rowindex(ctx._h, h, ri.ctypes.data, L.HOST))
+        L.check(lib.dthip_result_copy_offsets(ctx._h, h, off.ctypes.data, L.HOST))
+    finally:
+        lib.dthip_result_free(ctx._h, h)
+    rowwise = bool(aggs) and len(aggs[0]) == 3
+    cols, names = [], []
+    sel = ri if rowwise else ri[off[:-1]]              # the by-columns: every row / first row of each group
+    for k in keys:
+        out = np.empty(len(sel), ST2NP[frame.stypes[k].value])
+        kc = _col(frame, k)
+        L.check(lib.dthip_gather(ctx._h, C.byref(kc), sel.ctypes.data, len(sel), L.HOST, out.ctypes.data))
+        cols.append(out); names.append(frame.names[k])
+    for a in aggs:
+        op, c = a[0], a[1]
+        if rowwise:
+            st = lib.dthip_cumulate_out_stype(CUMOPS[op], L.INT64 if c is None else frame.stypes[c].value)
+            out = np.empty(n, ST2NP[st])
+            vc = _col(frame, c) if c is not None else None
+            if n:
+                L.check(lib.dthip_cumulate(ctx._h, CUMOPS[op], C.byref(vc) if vc is not None else None,
+                                           ri.ctypes.data if c is not None else None, off.ctypes.data, ng, n,
+                                           1 if a[2] else 0, L.HOST, out.ctypes.data))
+            names.append("" if c is None else frame.names[c])
+        elif isinstance(c, tuple):
+            ca, cb = _col(frame, c[0]), _col(frame, c[1])
+            out = np.empty(ng, ST2NP[lib.dthip_reduce2_out_stype(ca.stype, cb.stype)])
+            if ng:
+                L.check(lib.dthip_reduce2(ctx._h, OPS2[op], C.byref(ca), C.byref(cb), ri.ctypes.data, off.ctypes.data, ng, n,
+                                          L.HOST, out.ctypes.data))
+            names.append("")
+        elif c is None:
+            out = np.empty(ng, np.int64)
+            if ng:
+                L.check(lib.dthip_reduce(ctx._h, L.COUNT0, None, None, off.ctypes.data, ng, n, L.HOST, out.ctypes.data))
+            names.append("count")
+        else:
+            vc = _col(frame, c)
+            out = np.empty(ng, ST2NP[lib.dthip_reduce_out_stype(OPS[op], vc.stype)])
+            if ng:
+                L.check(lib.dthip_reduce(ctx._h, OPS[op], C.byref(vc), ri.ctypes.data, off.ctypes.data, ng, n, L.HOST,
+                                         out.ctypes.data))
+            names.append(frame.names[c])
+        cols.append(out)
+    return _finish(frame, keys, cols, names)
+
+
 def run(frame, keys, aggs, ctx=None):
     """evaluate the matched query through the C ABI (dthip_groupby_agg, host pointers)"""
     import ctypes as C
+    if not all(len(a) == 2 and a[0] in _FUSED for a in aggs):
+        return run_sred(frame, keys, aggs, ctx)
     ctx = ctx or default_context()
     lib = ctx._lib
     vcols = sorted({c for _, c in aggs if c is not None})
@@ -127,13 +256,7 @@ def run(frame, keys, aggs, ctx=None):
             cols.append(out); names.append("count" if c is None else frame.names[c])
     finally:
         lib.dthip_result_free(ctx._h, h)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", dt.exceptions.DatatableWarning)     # duplicate names are mangled, as in the reference
-        res = dt.Frame(cols, names=names)
-    for i, k in enumerate(keys):                                            # bool8 keys travel as int8
-        if frame.stypes[k] == dt.stype.bool8:
-            res[:, i] = dt.Frame(res[:, i].to_numpy().astype(np.bool_))
-    return res
+    return _finish(frame, keys, cols, names)
 
 
 class Frame(dt.Frame):

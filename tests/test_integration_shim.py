@@ -37,3 +37,24 @@ def test_borrowed_pointers_are_the_numpy_buffers():
     DT = shim.Frame(k=a)
     assert dt.internal.frame_column_data_r(DT, 0).value == a.ctypes.data
     assert DT.stypes[0].value == 5          # == DTHIP_INT64
+
+
+def test_match_groupwise_operators():
+    """sd / median / nunique / first / last, cov / corr and the cumulative operators are recognised from
+    the reference's own reprs (old-style `Expr:stdev(FExpr<f.v>; )` nodes included)"""
+    import datatable
+    from datatable import f
+    from integration import datatable_hip_shim as shim
+    DT = shim.Frame(k=np.array([3, 1, 3], np.int64), v=np.array([1.0, 2.0, 4.0]), w=np.array([1, 2, 3], np.int32),
+                    s=["a", "b", "c"])
+    j = [datatable.sd(f.v), datatable.median(f["w"]), datatable.nunique(f[1]), datatable.first(f.v), datatable.cov(f.v, f.w),
+         datatable.corr(f.w, f.v), datatable.count()]
+    assert shim.match(DT, (slice(None), j, shim.by(f.k))) == \
+        ([0], [("sd", 1), ("median", 2), ("nunique", 1), ("first", 1), ("cov", (1, 2)), ("corr", (2, 1)), ("count0", None)])
+    j = [datatable.cumsum(f.v), datatable.cummax(f.w, reverse=True), datatable.cumcount(), datatable.ngroup(reverse=True)]
+    assert shim.match(DT, (slice(None), j, shim.by(f.k))) == \
+        ([0], [("cumsum", 1, False), ("cummax", 2, True), ("cumcount", None, False), ("ngroup", None, True)])
+    # a reducer next to a row-level operator, or a string argument: the reference evaluates it
+    assert shim.match(DT, (slice(None), [datatable.sd(f.v), datatable.cumsum(f.v)], shim.by(f.k))) is None
+    assert shim.match(DT, (slice(None), datatable.nunique(f.s), shim.by(f.k))) is None
+    assert shim.match(DT, (slice(None), datatable.sd(f.v + 1), shim.by(f.k))) is None
