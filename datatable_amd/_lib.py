@@ -16,6 +16,7 @@ SUM, MEAN, MIN, MAX, COUNT, COUNT0, FIRST, LAST = 0, 1, 2, 3, 4, 5, 6, 7
 SD, MEDIAN, NUNIQUE = 8, 9, 10                      # dthip_reduce only
 COV, CORR = 0, 1                                    # enum dthip_op2
 CUMSUM, CUMPROD, CUMMIN, CUMMAX, CUMCOUNT, NGROUP = 0, 1, 2, 3, 4, 5   # enum dthip_cumop
+UNION, INTERSECT, SETDIFF, SYMDIFF = 0, 1, 2, 3     # enum dthip_setfn
 HOST, DEVICE = 0, 1
 NA_FIRST, NA_LAST, NA_REMOVE = 0, 1, 2
 FLAG_DESCENDING = 1
@@ -83,6 +84,10 @@ SIGNATURES = {
     "dthip_cumulate_out_stype": (C.c_int, [C.c_int, C.c_int]),
     "dthip_cumulate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Col), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                  C.c_int, C.c_int, C.c_void_p]),
+    "dthip_setop": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Col), C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                              C.POINTER(C.c_int64)]),
+    "dthip_join_index": (C.c_int, [C.c_void_p, C.POINTER(Col), C.POINTER(Col), C.c_int, C.c_int64, C.c_int64, C.c_int,
+                                   C.c_void_p]),
     "dthip_range_bucket": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dthip_ungroup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "dthip_bool_to_rowindex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,

@@ -1687,6 +1687,64 @@ int dthip_cumulate(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t
   return DTHIP_OK;
 }
 
+int dthip_setop(dthip_ctx* ctx, int op, const dthip_col* stacked, const int64_t* cumsizes, int nsources, int64_t nrows,
+                int mem, int32_t* out_indices, int64_t* nout) {
+  DTHIP_TRY(check_common(ctx, nrows, mem));
+  if (!nout) { set_error("null argument"); return DTHIP_EINVAL; }
+  *nout = 0;
+  if (nrows == 0) return DTHIP_OK;
+  if (!stacked || !stacked->data || !cumsizes || !out_indices || nsources < 1) { set_error("null argument"); return DTHIP_EINVAL; }
+  if (op < DTHIP_UNION || op > DTHIP_SYMDIFF) { set_error("bad set function %d", op); return DTHIP_EINVAL; }
+  if (cumsizes[nsources - 1] != nrows) { set_error("cumsizes[last]=%lld != nrows=%lld", (long long)cumsizes[nsources - 1], (long long)nrows); return DTHIP_EINVAL; }
+  // group the stacked column: stable, so row ids ascend inside every group
+  dthip_result* g = nullptr;
+  DTHIP_TRY(dthip_groupby(ctx, stacked, 1, nrows, DTHIP_NA_FIRST, mem, 1, &g));
+  int rc = DTHIP_OK;
+  {
+    Scratch sc(ctx);
+    const int64_t ng = g->ngroups;
+    std::vector<int32_t> cum32((size_t)nsources);
+    for (int k = 0; k < nsources; k++) cum32[(size_t)k] = (int32_t)cumsizes[k];
+    const void* d_cum = nullptr;
+    int8_t* mask = nullptr; int32_t *gidx = nullptr, *first = nullptr;
+    int32_t* d_out = out_indices;
+    int64_t cnt = 0;
+    rc = stage_in(ctx, sc, cum32.data(), sizeof(int32_t) * (size_t)nsources, DTHIP_HOST, &d_cum);
+    if (rc == DTHIP_OK) rc = sc.get<int8_t>((size_t)ng, &mask);
+    if (rc == DTHIP_OK) rc = sc.get<int32_t>((size_t)ng, &gidx);
+    if (rc == DTHIP_OK) rc = sc.get<int32_t>((size_t)ng, &first);
+    if (rc == DTHIP_OK && mem == DTHIP_HOST) rc = sc.get<int32_t>((size_t)ng, &d_out);
+    if (rc == DTHIP_OK) rc = launch_setop_flags(ctx, g->rowindex, g->offsets, ng, op, static_cast<const int32_t*>(d_cum), nsources, mask);
+    if (rc == DTHIP_OK) { PredArgs p{mask, DTHIP_BOOL, 0, 0.0, 0, 1}; rc = launch_compact(ctx, p, ng, gidx, &cnt); }
+    if (rc == DTHIP_OK && cnt) rc = launch_gather(ctx, g->offsets, DTHIP_INT32, gidx, cnt, first);
+    if (rc == DTHIP_OK && cnt) rc = launch_gather(ctx, g->rowindex, DTHIP_INT32, first, cnt, d_out);
+    if (rc == DTHIP_OK && cnt && mem == DTHIP_HOST) rc = copy_out(ctx, out_indices, d_out, sizeof(int32_t) * (size_t)cnt, mem);
+    if (rc == DTHIP_OK) *nout = cnt;
+  }
+  result_destroy(ctx, g);
+  return rc;
+}
+
+int dthip_join_index(dthip_ctx* ctx, const dthip_col* xkeys, const dthip_col* jkeys, int nkeys, int64_t xrows, int64_t jrows,
+                     int mem, int32_t* out) {
+  DTHIP_TRY(check_common(ctx, xrows, mem));
+  DTHIP_TRY(check_common(ctx, jrows, mem));
+  if (xrows == 0) return DTHIP_OK;
+  if (!xkeys || !jkeys || !out || nkeys < 1 || nkeys > MAX_KEYCOLS) { set_error("bad join arguments (nkeys=%d)", nkeys); return DTHIP_EINVAL; }
+  for (int k = 0; k < nkeys; k++) {
+    if (!stype_size(xkeys[k].stype) || !stype_size(jkeys[k].stype)) { set_error("join: unsupported key stype"); return DTHIP_ENOTIMPL; }
+  }
+  Scratch sc(ctx);
+  std::vector<dthip_col> xd, jd;
+  DTHIP_TRY(stage_cols(ctx, sc, xkeys, nkeys, xrows, mem, &xd));
+  DTHIP_TRY(stage_cols(ctx, sc, jkeys, nkeys, jrows, mem, &jd));
+  int32_t* d_out = out;
+  if (mem == DTHIP_HOST) DTHIP_TRY(sc.get<int32_t>((size_t)xrows, &d_out));
+  DTHIP_TRY(launch_join_index(ctx, xd.data(), jd.data(), nkeys, xrows, jrows, d_out));
+  if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, sizeof(int32_t) * (size_t)xrows, mem));
+  return DTHIP_OK;
+}
+
 int dthip_range_bucket(dthip_ctx* ctx, const dthip_col* key, int64_t nrows, const int64_t* bounds, int nbounds, int mem,
                        int8_t* out) {
   DTHIP_TRY(check_common(ctx, nrows, mem));

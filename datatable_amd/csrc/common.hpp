@@ -308,6 +308,12 @@ int launch_median(dthip_ctx* ctx, const void* vg, int stype, const int32_t* orde
 int launch_nunique(dthip_ctx* ctx, const void* vg, int stype, const int32_t* gid, const int32_t* order, const int32_t* run_offsets,
                    int64_t nruns, int64_t ngroups, int64_t* out);
 
+// setjoin.hip: set functions over a stacked column, natural-join index
+int launch_setop_flags(dthip_ctx* ctx, const int32_t* ri, const int32_t* off, int64_t ngroups, int op, const int32_t* cum,
+                       int nsrc, int8_t* mask);
+int launch_join_index(dthip_ctx* ctx, const dthip_col* xkeys, const dthip_col* jkeys, int nkeys, int64_t xrows, int64_t jrows,
+                      int32_t* out);
+
 // rowindex.hip
 struct PredArgs {
   const void* data; int stype; int cmp; double cf; long long ci; int is_mask;   // is_mask 2: data is a bitmap (uint32 words)

@@ -1,0 +1,180 @@
+// setjoin.hip -- the callers of group() next to the hot path:
+//   union / unique / intersect / setdiff / symdiff   src/core/set_funcs.cc:134-431
+//   natural join                                     src/core/frame/join.cc:368-446
+//
+// Set functions: the sources are stacked into one column, grouped by the library's own radix path
+// (stable, so inside a group the row ids ascend = sources in order), and one thread per group
+// decides from the group's row ids which sources it touches -- the reference walks the groups
+// serially on one thread (set_funcs.cc:244-272).  Selected groups are compacted and their first
+// row id is the result element.
+//
+// Natural join: J is keyed (sorted ascending, unique).  One thread per X row converts its key to
+// J's types the way FwCmp<TX,TJ>::set_xrow does (frame/join.cc:171-200: an X value J's type cannot
+// represent never matches; NA matches NA) and binary-searches J (join.cc:368-380).  The reference
+// does the same search per row through two virtual calls per probe.
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace dthip {
+
+// ---- set functions ---------------------------------------------------------------------------------
+enum { SET_UNION = 0, SET_INTERSECT = 1, SET_SETDIFF = 2, SET_SYMDIFF = 3 };
+
+__global__ void __launch_bounds__(256) setop_flag_kernel(const int32_t* __restrict__ ri, const int32_t* __restrict__ off,
+                                                         uint32_t ngroups, int op, const int32_t* __restrict__ cum, int nsrc,
+                                                         int8_t* __restrict__ mask) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const int32_t off0 = off[g], off1 = off[g + 1];
+  const int32_t x = ri[off0], y = ri[off1 - 1];
+  const int32_t n1 = cum[0];
+  bool take;
+  if (op == SET_UNION || nsrc <= 1) take = true;
+  else if (op == SET_SETDIFF) take = x < n1 && y < n1;
+  else if (nsrc == 2) take = (op == SET_INTERSECT) ? (x < n1 && y >= n1) : ((x < n1) == (y < n1));
+  else {
+    // number of sources with a row in this group: row ids ascend inside the group, so source k is
+    // present iff the first id not below cum[k-1] is below cum[k]
+    int32_t ii = off0; int kk = 0; bool all = true;
+    for (int k = 0; k < nsrc; k++) {
+      const int32_t nk = cum[k];
+      if (ii >= off1 || ri[ii] >= nk) { all = false; continue; }
+      kk++;
+      int32_t lo = ii, hi = off1;                 // first position with ri >= nk
+      while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (ri[mid] < nk) lo = mid + 1; else hi = mid; }
+      ii = lo;
+    }
+    take = (op == SET_INTERSECT) ? all : ((kk & 1) != 0);
+  }
+  mask[g] = take ? 1 : 0;
+}
+
+int launch_setop_flags(dthip_ctx* ctx, const int32_t* ri, const int32_t* off, int64_t ngroups, int op, const int32_t* cum,
+                       int nsrc, int8_t* mask) {
+  if (ngroups == 0) return DTHIP_OK;
+  DTHIP_LAUNCH(ctx, "setop_flag_kernel", setop_flag_kernel, (unsigned)((ngroups + 255) / 256), 256, 0, ri, off,
+               (uint32_t)ngroups, op, cum, nsrc, mask);
+  return DTHIP_OK;
+}
+
+// ---- natural join ----------------------------------------------------------------------------------
+struct XVal { int valid; int nomatch; long long i; double d; float f; };
+
+__device__ __forceinline__ bool jn_is_float(int st) { return st == DTHIP_FLOAT32 || st == DTHIP_FLOAT64; }
+
+__device__ __forceinline__ bool jn_get_i64(const void* data, int st, uint32_t r, long long* out) {
+  switch (st) {
+    case DTHIP_BOOL: case DTHIP_INT8: { const int8_t v = static_cast<const int8_t*>(data)[r]; *out = v; return v != INT8_MIN; }
+    case DTHIP_INT16: { const int16_t v = static_cast<const int16_t*>(data)[r]; *out = v; return v != INT16_MIN; }
+    case DTHIP_INT32: { const int32_t v = static_cast<const int32_t*>(data)[r]; *out = v; return v != INT32_MIN; }
+    default: { const long long v = static_cast<const long long*>(data)[r]; *out = v; return v != INT64_MIN; }
+  }
+}
+__device__ __forceinline__ bool jn_get_f64(const void* data, int st, uint32_t r, double* out) {
+  const double v = st == DTHIP_FLOAT64 ? static_cast<const double*>(data)[r] : (double)static_cast<const float*>(data)[r];
+  *out = v;
+  return !(v != v);
+}
+__device__ __forceinline__ void jn_limits(int st, long long* lo, long long* hi) {
+  switch (st) {
+    case DTHIP_BOOL: case DTHIP_INT8: *lo = INT8_MIN; *hi = INT8_MAX; break;
+    case DTHIP_INT16: *lo = INT16_MIN; *hi = INT16_MAX; break;
+    case DTHIP_INT32: *lo = INT32_MIN; *hi = INT32_MAX; break;
+    default: *lo = INT64_MIN; *hi = INT64_MAX; break;
+  }
+}
+
+// FwCmp<TX,TJ>::set_xrow: the X value in J's domain
+__device__ __forceinline__ XVal jn_set_xrow(const void* xdata, int xst, int jst, uint32_t row) {
+  XVal v{0, 0, 0, 0.0, 0.0f};
+  if (jn_is_float(xst)) {
+    double x;
+    v.valid = jn_get_f64(xdata, xst, row, &x);
+    if (!v.valid) return v;
+    if (jn_is_float(jst)) { v.d = x; v.f = (float)x; }
+    else {
+      long long lo, hi; jn_limits(jst, &lo, &hi);
+      if (!(x >= (double)lo && x <= (double)hi && x < 9223372036854775808.0)) { v.nomatch = 1; return v; }
+      v.i = (long long)x;
+      if ((double)v.i != x || v.i < lo || v.i > hi) v.nomatch = 1;
+    }
+  } else {
+    long long x;
+    v.valid = jn_get_i64(xdata, xst, row, &x);
+    if (!v.valid) return v;
+    if (jn_is_float(jst)) { v.d = (double)x; v.f = (float)x; }
+    else {
+      long long lo, hi; jn_limits(jst, &lo, &hi);
+      if (x < lo || x > hi) { v.nomatch = 1; return v; }
+      v.i = x;
+    }
+  }
+  return v;
+}
+
+// FwCmp<TX,TJ>::cmp_jrow: sign of (J value - X value); NA sorts first and equals NA
+__device__ __forceinline__ int jn_cmp_jrow(const void* jdata, int jst, uint32_t row, const XVal& x) {
+  int jvalid, r;
+  if (jst == DTHIP_FLOAT64) { double jv; jvalid = jn_get_f64(jdata, jst, row, &jv); r = (jv > x.d) - (jv < x.d); }
+  else if (jst == DTHIP_FLOAT32) { const float jv = static_cast<const float*>(jdata)[row]; jvalid = !(jv != jv); r = (jv > x.f) - (jv < x.f); }
+  else { long long jv; jvalid = jn_get_i64(jdata, jst, row, &jv); r = (jv > x.i) - (jv < x.i); }
+  if (jvalid && x.valid) return r;
+  return jvalid - x.valid;
+}
+
+struct JoinCols {
+  const void* x[MAX_KEYCOLS];
+  const void* j[MAX_KEYCOLS];
+  int xst[MAX_KEYCOLS];
+  int jst[MAX_KEYCOLS];
+};
+
+template <int NK>
+__global__ void __launch_bounds__(256) join_index_kernel(JoinCols c, uint32_t xrows, uint32_t jrows, int32_t* __restrict__ out) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < xrows; i += stride) {
+    XVal xv[NK];
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < NK; k++) { xv[k] = jn_set_xrow(c.x[k], c.xst[k], c.jst[k], i); bad |= xv[k].nomatch; }
+    int32_t res = INT32_MIN;
+    if (!bad && jrows) {
+      uint32_t start = 0, end = jrows - 1;
+      bool found = false;
+      while (start < end) {
+        const uint32_t mid = (start + end) >> 1;
+        int r = 0;
+#pragma unroll
+        for (int k = 0; k < NK; k++) if (!r) r = jn_cmp_jrow(c.j[k], c.jst[k], mid, xv[k]);
+        if (r > 0) end = mid; else if (r < 0) start = mid + 1; else { start = mid; found = true; break; }
+      }
+      if (!found) {
+        int r = 0;
+#pragma unroll
+        for (int k = 0; k < NK; k++) if (!r) r = jn_cmp_jrow(c.j[k], c.jst[k], start, xv[k]);
+        found = r == 0;
+      }
+      if (found) res = (int32_t)start;
+    }
+    out[i] = res;
+  }
+}
+
+int launch_join_index(dthip_ctx* ctx, const dthip_col* xkeys, const dthip_col* jkeys, int nkeys, int64_t xrows, int64_t jrows,
+                      int32_t* out) {
+  if (xrows == 0) return DTHIP_OK;
+  JoinCols c{};
+  for (int k = 0; k < nkeys; k++) { c.x[k] = xkeys[k].data; c.j[k] = jkeys[k].data; c.xst[k] = xkeys[k].stype; c.jst[k] = jkeys[k].stype; }
+  long long blocks = (xrows + 1023) / 1024;
+  if (blocks > (long long)ctx->num_cus * 16) blocks = (long long)ctx->num_cus * 16;
+#define DTHIP_JOIN(NK) case NK: DTHIP_LAUNCH(ctx, "join_index_kernel", join_index_kernel<NK>, (unsigned)blocks, 256, 0, c, \
+                                             (uint32_t)xrows, (uint32_t)jrows, out); break
+  switch (nkeys) {
+    DTHIP_JOIN(1); DTHIP_JOIN(2); DTHIP_JOIN(3); DTHIP_JOIN(4); DTHIP_JOIN(5); DTHIP_JOIN(6); DTHIP_JOIN(7); DTHIP_JOIN(8);
+    default: set_error("join: %d key columns (max %d)", nkeys, MAX_KEYCOLS); return DTHIP_EINVAL;
+  }
+#undef DTHIP_JOIN
+  return DTHIP_OK;
+}
+
+}  // namespace dthip

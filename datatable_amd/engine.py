@@ -19,6 +19,7 @@ ST2NP = {L.BOOL: np.dtype(np.int8), L.INT8: np.dtype(np.int8), L.INT16: np.dtype
 OPS = {"sum": L.SUM, "mean": L.MEAN, "min": L.MIN, "max": L.MAX, "count": L.COUNT, "count0": L.COUNT0,
        "first": L.FIRST, "last": L.LAST, "sd": L.SD, "median": L.MEDIAN, "nunique": L.NUNIQUE}
 OPS2 = {"cov": L.COV, "corr": L.CORR}
+SETOPS = {"union": L.UNION, "intersect": L.INTERSECT, "setdiff": L.SETDIFF, "symdiff": L.SYMDIFF}
 CUMOPS = {"cumsum": L.CUMSUM, "cumprod": L.CUMPROD, "cummin": L.CUMMIN, "cummax": L.CUMMAX,
           "cumcount": L.CUMCOUNT, "ngroup": L.NGROUP}
 CMP = {">": L.GT, ">=": L.GE, "<": L.LT, "<=": L.LE, "==": L.EQ, "!=": L.NE}
@@ -325,6 +326,44 @@ class Context:
             L.check(self._lib.dthip_cumulate(self._h, opc, C.byref(col), ri.ctypes.data if ri is not None else None,
                                              offsets.ctypes.data, ng, nrows, 1 if reverse else 0, L.HOST, out.ctypes.data))
         return out
+
+    # ---- set functions / natural join (the other callers of group()) -------
+    def setop(self, op, columns, stype=None):
+        """columns: list of host arrays of ONE stype (the sources).  Returns the row ids into their
+        concatenation of the result elements of union / intersect / setdiff / symdiff, ascending by value."""
+        opc = SETOPS[op] if isinstance(op, str) else int(op)
+        stacked = np.concatenate([np.ascontiguousarray(c) for c in columns]) if columns else np.zeros(0, np.int32)
+        a, col = _host_col(stacked, stype)
+        cum = np.cumsum([len(x) for x in columns]).astype(np.int64)
+        out = np.empty(len(a), np.int32)
+        k = C.c_int64(0)
+        L.check(self._lib.dthip_setop(self._h, opc, C.byref(col), cum.ctypes.data, len(columns), len(a), L.HOST,
+                                      out.ctypes.data, C.byref(k)))
+        return out[:k.value].copy()
+
+    def join_index(self, xkeys, jkeys, xstypes=None, jstypes=None):
+        """per row of X the row of the keyed frame J (key columns sorted ascending, unique) it joins to, or INT32_MIN"""
+        xarr, xmem, xkeep = _cols(xkeys, xstypes)
+        jarr, jmem, jkeep = _cols(jkeys, jstypes)
+        if xmem != L.HOST or jmem != L.HOST:
+            raise ValueError("join_index takes host arrays; device columns: join_index_dev")
+        out = np.empty(len(xkeep[0]), np.int32)
+        L.check(self._lib.dthip_join_index(self._h, xarr, jarr, len(xkeys), len(xkeep[0]), len(jkeep[0]), L.HOST,
+                                           out.ctypes.data))
+        return out
+
+    def join_index_dev(self, xcols, jcols, xrows, jrows, out_ptr):
+        xarr = (L.Col * len(xcols))(*[L.Col(c.ptr, c.stype, 0) for c in xcols])
+        jarr = (L.Col * len(jcols))(*[L.Col(c.ptr, c.stype, 0) for c in jcols])
+        L.check(self._lib.dthip_join_index(self._h, xarr, jarr, len(xcols), xrows, jrows, L.DEVICE, C.c_void_p(out_ptr)))
+
+    def setop_dev(self, op, col, cumsizes, nrows, out_ptr):
+        opc = SETOPS[op] if isinstance(op, str) else int(op)
+        c = L.Col(col.ptr, col.stype, 0)
+        cum = (C.c_int64 * len(cumsizes))(*[int(x) for x in cumsizes])
+        k = C.c_int64(0)
+        L.check(self._lib.dthip_setop(self._h, opc, C.byref(c), cum, len(cumsizes), nrows, L.DEVICE, C.c_void_p(out_ptr), C.byref(k)))
+        return k.value
 
     def range_bucket(self, values, bounds, stype=None):
         """int8 destination of every row in the range partition given by ascending `bounds` (host arrays)"""

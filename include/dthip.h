@@ -255,6 +255,22 @@ int  dthip_cumulate(dthip_ctx* ctx, int op, const dthip_col* value,
                     const int32_t* rowindex, const int32_t* offsets,
                     int64_t ngroups, int64_t nrows, int reverse, int mem, void* out);
 
+/* ---- set functions and natural join: the other callers of group() ------- */
+/* dt.union / unique / intersect / setdiff / symdiff (src/core/set_funcs.cc:134-431).  `stacked` is the
+ * sources' single columns concatenated (rbind, set_funcs.cc:118-124; one stype), cumsizes[k] = rows of
+ * sources 0..k (host array).  out_indices (room for nrows): row ids into `stacked` of the result
+ * elements, ascending by value, NA first -- the values are stacked[out_indices[i]]; *nout = their count. */
+enum dthip_setfn { DTHIP_UNION = 0, DTHIP_INTERSECT = 1, DTHIP_SETDIFF = 2, DTHIP_SYMDIFF = 3 };
+int  dthip_setop(dthip_ctx* ctx, int op, const dthip_col* stacked, const int64_t* cumsizes, int nsources,
+                 int64_t nrows, int mem, int32_t* out_indices, int64_t* nout);
+
+/* RowIndex natural_join(xdt, jdt) (src/core/frame/join.cc:386-446): jkeys are the key columns of a KEYED
+ * frame (sorted ascending, unique: DataTable::set_key, src/core/frame/key.cc:74-133 = dthip_groupby_rows
+ * + ngroups == nrows), xkeys the same-named columns of X, possibly of other stypes (comparators
+ * FwCmp<TX,TJ>, join.cc:146-200,268-331).  out[i] = row of J matching X row i, or INT32_MIN. */
+int  dthip_join_index(dthip_ctx* ctx, const dthip_col* xkeys, const dthip_col* jkeys, int nkeys,
+                      int64_t xrows, int64_t jrows, int mem, int32_t* out);
+
 /* Groupby::ungroup_rowindex (src/core/groupby.cc:117-130): out[i] = g for every i in
  * [offsets[g], offsets[g+1]) -- broadcasts one-value-per-group columns back to rows (GtoALL,
  * src/core/expr/workframe.cc:384-390) when composed with dthip_gather */

@@ -28,7 +28,7 @@ def build():
 
 
 def _lib():
-    srcs = [os.path.join(_HERE, n) for n in ("dt_oracle.c", "dt_oracle_groupwise.c")]
+    srcs = [os.path.join(_HERE, n) for n in ("dt_oracle.c", "dt_oracle_groupwise.c", "dt_oracle_sets.c")]
     if not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(s) for s in srcs):
         build()
     lib = C.CDLL(_SO)
@@ -205,4 +205,40 @@ def cumulate(op, values, ri, offsets, reverse=False, stype=None):
     out = np.empty(n, _ST2NP[ost])
     lib().dto_cumulate(C.c_int(opc), C.byref(c), rip, C.c_void_p(offsets.ctypes.data), C.c_int64(ng),
                        C.c_int(1 if reverse else 0), C.c_void_p(out.ctypes.data))
+    return out
+
+
+# ---- set functions and natural join (dt_oracle_sets.c) --------------------------------------------
+SETOPS = {"union": 0, "intersect": 1, "setdiff": 2, "symdiff": 3}
+
+
+def setop(op, columns, stype=None):
+    """columns: list of numpy arrays of ONE stype (the sources).  Returns the row indices into their
+    concatenation of the result elements, ascending by value (NA first)."""
+    opc = SETOPS[op] if isinstance(op, str) else op
+    stacked = np.concatenate([np.ascontiguousarray(c) for c in columns]) if columns else np.zeros(0, np.int32)
+    a, c = _col(stacked, stype)
+    cum = np.cumsum([len(x) for x in columns]).astype(np.int64)
+    out = np.empty(len(a), np.int32)
+    lib().dto_setop.restype = C.c_int64
+    k = lib().dto_setop(C.c_int(opc), C.byref(c), C.c_void_p(cum.ctypes.data), C.c_int(len(columns)), C.c_int64(len(a)),
+                        C.c_void_p(out.ctypes.data))
+    return out[:k].copy()
+
+
+def join_index(xkeys, jkeys, xstypes=None, jstypes=None):
+    """per row of X the row of the keyed frame J (key columns sorted ascending, unique) with equal key
+    values, or INT32_MIN"""
+    nk = len(xkeys)
+    xs, js = (_Col * nk)(), (_Col * nk)()
+    keep = []
+    for i in range(nk):
+        a, c = _col(xkeys[i], xstypes[i] if xstypes else None)
+        b, d = _col(jkeys[i], jstypes[i] if jstypes else None)
+        keep += [a, b]
+        xs[i], js[i] = c, d
+    out = np.empty(len(keep[0]), np.int32)
+    rc = lib().dto_join_index(xs, js, C.c_int(nk), C.c_int64(len(keep[0])), C.c_int64(len(keep[1])), C.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise ValueError("dto_join_index failed")
     return out
