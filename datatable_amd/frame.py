@@ -30,7 +30,8 @@ from . import _lib as L
 from .engine import CUMOPS as L_CUMOPS, NP2ST, OPS as L_OPS, ST2NP, default_context
 
 __all__ = ["Frame", "f", "by", "sort", "sum", "mean", "min", "max", "count", "first", "last",
-           "sd", "median", "nunique", "cov", "corr", "cumsum", "cumprod", "cummin", "cummax", "cumcount", "ngroup"]
+           "sd", "median", "nunique", "cov", "corr", "cumsum", "cumprod", "cummin", "cummax", "cumcount", "ngroup",
+           "unique", "union", "intersect", "setdiff", "symdiff", "join"]
 
 _NA_INT = {1: np.iinfo(np.int8).min, 2: np.iinfo(np.int16).min, 4: np.iinfo(np.int32).min, 8: np.iinfo(np.int64).min}
 
@@ -154,6 +155,17 @@ class sort:
             raise ValueError("na position value %s is not supported" % (na_position,))     # py_sort.cc's message
         self.na_last = na_position == "last"
         self.na_remove = na_position == "remove"
+
+
+class join:
+    """join(J): natural left join on J's key columns (src/core/expr/py_join.cc:40-70)"""
+
+    def __init__(self, frame):
+        if not isinstance(frame, Frame):
+            raise TypeError("The argument to join() must be a Frame")
+        if not frame.key:
+            raise ValueError("The join frame is not keyed")          # py_join.cc:60-62
+        self.frame = frame
 
 
 def _reducer(op):
@@ -396,15 +408,84 @@ class Frame:
         fr._cols, fr._stypes, fr._names = list(cols), list(stypes), _mangle(list(names))
         return fr
 
+    # -- keys and joins (src/core/frame/key.cc:74-133, frame/join.cc:386-446) ---------------
+    @property
+    def key(self):
+        return tuple(self._names[:getattr(self, "_nkeys", 0)])
+
+    @key.setter
+    def key(self, cols):
+        if cols is None or (isinstance(cols, (list, tuple)) and not cols):
+            self._nkeys = 0
+            return
+        if isinstance(cols, str):
+            cols = [cols]
+        if not isinstance(cols, (list, tuple)):
+            raise TypeError("Key should be a column name, or a list/tuple of column names")
+        for i, c in enumerate(cols):
+            if not isinstance(c, str):
+                raise TypeError("Key should be a list/tuple of column names, instead element %d was a %s" % (i, type(c)))
+        kidx = [self._index(c) for c in cols]
+        for a in range(len(kidx)):
+            if kidx[a] in kidx[a + 1:]:
+                raise ValueError("Column %s is specified multiple times within the key" % self._names[kidx[a]])
+        ctx = self._context()
+        order = kidx + [c for c in range(self.ncols) if c not in kidx]
+        if self.nrows:
+            # group(key columns): the key is valid when every group is a single row (key.cc:92-96); the
+            # columns then ride through the sort into key order (apply_rowindex + materialize, :113-126)
+            mats = [self._materialized(c) for c in order]
+            sts = [self._stypes[c] for c in order]
+            r = ctx.groupby_rows(mats[:len(kidx)], mats, key_stypes=sts[:len(kidx)], col_stypes=sts, want_rowindex=False)
+            try:
+                if r.ngroups < self.nrows:
+                    raise ValueError("Cannot set a key: the values are not unique")
+                newcols = [r.col(c) for c in range(len(order))]
+            finally:
+                r.free()
+        else:
+            newcols = [self._cols[c] for c in order]
+        self._cols, self._stypes, self._names = newcols, [self._stypes[c] for c in order], [self._names[c] for c in order]
+        self._ri = None
+        self._nkeys = len(kidx)
+
+    def _joined(self, J):
+        """X[:, :, join(J)]: X's columns, then J's non-key columns read through the join index"""
+        ctx = self._context()
+        nk = len(J.key)
+        xidx = []
+        for nm in J.key:
+            if nm not in self._names:
+                raise ValueError("Key column `%s` does not exist in the left Frame" % nm)     # join.cc:394-397
+            xidx.append(self._names.index(nm))
+        xk = [self._materialized(c) for c in xidx]
+        jk = [J._cols[c] for c in range(nk)]
+        if self.nrows:
+            idx = ctx.join_index(xk, jk, xstypes=[self._stypes[c] for c in xidx], jstypes=J._stypes[:nk])
+        else:
+            idx = np.zeros(0, np.int32)
+        cols = [self._materialized(c) for c in range(self.ncols)]
+        sts, names = list(self._stypes), list(self._names)
+        for c in range(nk, J.ncols):
+            cols.append(ctx.gather(J._cols[c], idx, stype=J._stypes[c]) if J.nrows else
+                        np.full(len(idx), np.nan if ST2NP[J._stypes[c]].kind == "f" else _NA_INT[ST2NP[J._stypes[c]].itemsize],
+                                ST2NP[J._stypes[c]]))
+            sts.append(J._stypes[c]); names.append(J._names[c])
+        return Frame._from_columns(cols, sts, names)
+
     # -- DT[i, j, by] -------------------------------------------------------------------
     def __getitem__(self, item):
         if not isinstance(item, tuple):
             raise NotImplementedError("single-selector DT[x] is outside the accelerated path")
         i = item[0]
         j = item[1] if len(item) > 1 else slice(None)
-        byx, srt = None, None
+        byx, srt, jn = None, None, None
         for r in item[2:]:
-            if isinstance(r, sort):
+            if isinstance(r, join):
+                if jn is not None:
+                    raise NotImplementedError("multiple joins are outside the accelerated path")
+                jn = r
+            elif isinstance(r, sort):
                 if srt is not None:
                     raise TypeError("Multiple sort()'s are not allowed")
                 srt = r
@@ -415,6 +496,10 @@ class Frame:
             else:
                 raise NotImplementedError("modifier %r is outside the accelerated path" % (r,))
         all_rows = i is None or i is Ellipsis or (isinstance(i, slice) and i == slice(None))
+        if jn is not None:
+            if byx or srt or not all_rows:
+                raise NotImplementedError("join() combined with i / by() / sort() is outside the accelerated path")
+            return self._joined(jn.frame)._select(j)
         if isinstance(i, Filter):
             if byx or srt:
                 # the reference cannot do this either: src/core/expr/fexpr_func.cc:61-73
@@ -666,6 +751,75 @@ class Frame:
 
 
 _FUSED_OPS = ("sum", "mean", "min", "max", "count", "count0", "first", "last")   # what dthip_groupby_agg carries
+
+
+# ---- set functions (src/core/set_funcs.cc) ------------------------------------------------------
+
+_ST_RANK = [L.BOOL, L.INT8, L.INT16, L.INT32, L.INT64, L.FLOAT32, L.FLOAT64]
+
+
+def _set_columns(args, fname):
+    """the single columns of the argument frames (columns_from_args, set_funcs.cc:64-101)"""
+    cols, name = [], None
+
+    def walk(a, level):
+        nonlocal name
+        if isinstance(a, Frame):
+            if a.ncols == 0:
+                return
+            if a.ncols > 1:
+                raise ValueError("Only single-column Frames are allowed, but received a Frame with %d columns" % a.ncols)
+            cols.append((a._materialized(0), a._stypes[0]))
+            if name is None:
+                name = a._names[0]
+        elif isinstance(a, (list, tuple)) and level < 2:
+            for x in a:
+                walk(x, level + 1)
+        else:
+            raise TypeError("%s() expects a list or sequence of Frames, but got an argument of type %s" % (fname, type(a)))
+
+    for a in args:
+        walk(a, 0)
+    return cols, name
+
+
+def _setop(op, cols, name):
+    if not cols:
+        return Frame()
+    # rbind of the sources: one stype, the widest (Column::rbind up-casts)
+    st = _ST_RANK[builtins.max(_ST_RANK.index(s) for _, s in cols)]
+    srcs = [a if s == st else Frame._cast(a, s, st) for a, s in cols]
+    if len(srcs) <= 1:
+        op = "union"                                        # set_funcs.cc:281-283,338-341,437-440
+    ctx = default_context()
+    idx = ctx.setop(op, srcs, stype=st)
+    stacked = np.concatenate(srcs)                          # the rbind of the sources
+    vals = ctx.gather(stacked, idx, stype=st) if len(idx) else stacked[:0]
+    return Frame._from_columns([vals], [st], [name if name is not None else ""])
+
+
+def unique(frame):
+    """dt.unique(frame): the distinct values of ALL columns of the frame, as one sorted column (set_funcs.cc:180-193)"""
+    if not isinstance(frame, Frame):
+        raise ValueError("Function `unique()` expects a Frame as a parameter")
+    cols = [(frame._materialized(c), frame._stypes[c]) for c in range(frame.ncols)]
+    return _setop("union", cols, frame._names[0] if frame.ncols == 1 else None)
+
+
+def union(*frames):
+    return _setop("union", *_set_columns(frames, "union"))
+
+
+def intersect(*frames):
+    return _setop("intersect", *_set_columns(frames, "intersect"))
+
+
+def setdiff(*frames):
+    return _setop("setdiff", *_set_columns(frames, "setdiff"))
+
+
+def symdiff(*frames):
+    return _setop("symdiff", *_set_columns(frames, "symdiff"))
 
 
 def _unused():   # keep flake-style tools quiet about the shadowed builtins being intentional

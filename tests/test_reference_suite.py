@@ -494,3 +494,161 @@ def test_nunique_with_by(dt):                           # tests/dt/test-nunique.
     DT = dt.Frame([1, None, 1, 2, None, None])
     assert_equals(DT[:, {"nunique": dt.nunique(dt.f[0])}, dt.by(dt.f[0])],
                   dt.Frame(C0=[None, 1, 2], nunique=[0, 1, 1], stypes={"nunique": I64}))
+
+
+# ---- tests/test-sets.py, tests/test-keys.py, tests/test-join.py ----------------
+# string columns of the originals are replaced by integer codes that sort the same way
+
+def _set_fns(dt):
+    return [dt.union, dt.intersect, dt.setdiff, dt.symdiff]
+
+
+def test_setfns_basic(dt):                              # test-sets.py:38-100
+    for fn in _set_fns(dt):
+        assert fn().shape == (0, 0)
+        res = fn(dt.Frame([1, 2, 3, 1]))
+        assert res.shape == (3, 1) and res.to_list() == [[1, 2, 3]]
+        dt0, dt1, dt2 = dt.Frame([1, 2, 3, 4, 5]), dt.Frame([3, 5, 7, 9]), dt.Frame([2, 7, 11])
+        r1, r2 = fn(dt0, dt1, dt2), fn([dt0, dt1, dt2])
+        assert r1.names == r2.names and r1.stypes == r2.stypes and r1.to_list() == r2.to_list()
+        a, b = dt.Frame(A=[2, 3, 5]), dt.Frame(B=list(range(4)))
+        assert fn(a, b).names == ("A",) and fn(b, a).names == ("B",)
+        d1, d2 = dt.Frame([2, 5, 7, 2, 3]), dt.Frame([3, 4, 2, 5])
+        assert fn(d1, d2).to_list() == fn(d1, dt.Frame(), d2).to_list()
+        assert fn(dt.Frame(), dt.Frame()).shape == (0, 0)
+
+
+def test_union_intersect_setdiff_symdiff(dt):           # test-sets.py:129-207
+    dt1, dt2, dt3 = dt.Frame([2, 5, 7, 2, 3]), dt.Frame([3, 4, 2, 5]), dt.Frame([0, 3, 2, 2, 2, 2, 2, 2, 0])
+    assert dt.union(dt1, dt2).to_list() == [[2, 3, 4, 5, 7]]
+    assert dt.union(dt3, dt1, dt2).to_list() == [[0, 2, 3, 4, 5, 7]]
+    assert dt.intersect(dt1, dt2).to_list() == [[2, 3, 5]]
+    assert dt.intersect(dt3, dt1, dt2).to_list() == [[2, 3]]
+    assert dt.setdiff(dt1, dt2).to_list() == [[7]]
+    assert dt.symdiff(dt1, dt2).to_list() == [[4, 7]]
+    dt1 = dt.Frame([2, 5, 7, 2, 3, 6, 0])
+    assert dt.setdiff(dt1, dt2, dt3).to_list() == [[6, 7]]
+    assert dt.symdiff(dt1, dt2, dt3).to_list() == [[2, 3, 4, 6, 7]]
+    with pytest.raises(ValueError, match="Only single-column Frames are allowed"):
+        dt.union(dt.Frame(A=[1], B=[2]))
+    with pytest.raises(TypeError, match=r"union\(\) expects a list or sequence of Frames"):
+        dt.union("a")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_setfns_random(dt, seed):                       # test-sets.py:217-260
+    rng = random.Random(seed)
+    srcs = [[rng.randint(1, 20) for _ in range(rng.randint(1, 30))] for _ in range(rng.randint(2, 5))]
+    frames = [dt.Frame(s) for s in srcs]
+    sets = [set(s) for s in srcs]
+    assert dt.union(frames).to_list() == [sorted(set.union(*sets))]
+    assert dt.intersect(frames).to_list() == [sorted(set.intersection(*sets))]
+    assert dt.setdiff(frames).to_list() == [sorted(sets[0].difference(*sets[1:]))]
+    sym = set()
+    for x in sets:
+        sym = sym.symmetric_difference(x)
+    assert dt.symdiff(frames).to_list() == [sorted(sym)]
+
+
+def test_unique(dt):                                    # tests/test-sets.py via dt.unique; set_funcs.cc:180-193
+    assert dt.unique(dt.Frame(A=[3, None, 1, 3, None])).to_dict() == {"A": [None, 1, 3]}
+    res = dt.unique(dt.Frame(A=[1, 2, 2], B=[2.5, 1.0, None]))            # all columns, up-cast to float64
+    assert res.names == ("C0",) and res.stypes == (F64,) and res.to_list() == [[None, 1.0, 2.0, 2.5]]
+
+
+def test_keys_simple_and_multi(dt):                     # test-keys.py:31-55,78-87
+    dt0 = dt.Frame([[2, 4, 3, 0, 1], [1, 5, 15, 12, 8], [3.6, 9.78, 2.01, -4.23, 5.3819]], names=["name", "sex", "avg"])
+    assert dt0.key == tuple()
+    dt0.key = "name"
+    assert dt0.key == ("name",) and dt0.shape == (5, 3) and dt0.names == ("name", "sex", "avg")
+    assert dt0.to_list() == [[0, 1, 2, 3, 4], [12, 8, 1, 15, 5], [-4.23, 5.3819, 3.6, 2.01, 9.78]]
+    dt0.key = "sex"
+    assert dt0.key == ("sex",) and dt0.names == ("sex", "name", "avg")
+    assert dt0.to_list() == [[1, 5, 8, 12, 15], [2, 4, 1, 0, 3], [3.6, 9.78, 5.3819, -4.23, 2.01]]
+    dt0.key = None
+    assert dt0.key == tuple()
+    dt0 = dt.Frame(D=list(range(6)), A=[3, 7, 5, 2, 2, 3], B=[1, 2, 2, 3, 4, 4])
+    dt0.key = ["A", "B"]
+    assert dt0.key == ("A", "B") and dt0.names == ("A", "B", "D")
+    assert dt0.to_list() == [[2, 2, 3, 3, 5, 7], [3, 4, 1, 4, 2, 2], [3, 4, 0, 5, 2, 1]]
+
+
+def test_key_invalid(dt):                               # test-keys.py:90-133
+    dt0 = dt.Frame(A=list(range(5)), B=[3] * 5)
+    with pytest.raises(TypeError, match="Key should be a column name, or a list/tuple of column names"):
+        dt0.key = 0
+    with pytest.raises(TypeError, match="instead element 1 was a <class 'NoneType'>"):
+        dt0.key = ["A", None]
+    dt0 = dt.Frame([[3, 4, 2, 0, 1], [7, 9, 2, 2, 7], [3, 4, 5, 3, 4]], names=["name", "A", "B"])
+    with pytest.raises(ValueError, match="the values are not unique"):
+        dt0.key = "A"
+    dt0.key = ["A", "B"]
+    assert dt0.key == ("A", "B") and dt0.names == ("A", "B", "name")
+    assert dt0.to_list() == [[2, 2, 7, 7, 9], [3, 5, 3, 4, 4], [0, 2, 3, 1, 4]]
+    with pytest.raises(ValueError, match="the values are not unique"):
+        dt0.key = "B"
+    assert dt0.key == ("A", "B") and dt0.names == ("A", "B", "name")      # untouched by the failed assignment
+    with pytest.raises(ValueError, match="Column A is specified multiple times within the key"):
+        dt.Frame(A=list(range(5))).key = ("A", "A")
+
+
+def test_join_simple(dt):                               # test-join.py:33-45 (string columns -> codes)
+    d0 = dt.Frame([[1, 3, 2, 1, 1, 2, 0], [10, 11, 12, 13, 14, 15, 16]], names=("A", "B"))
+    d1 = dt.Frame([list(range(4)), [100, 101, 102, 103]], names=("A", "V"))
+    d1.key = "A"
+    res = d0[:, :, dt.join(d1)]
+    assert res.shape == (7, 3) and res.names == ("A", "B", "V")
+    assert res.to_list() == [[1, 3, 2, 1, 1, 2, 0], [10, 11, 12, 13, 14, 15, 16], [101, 103, 102, 101, 101, 102, 100]]
+
+
+def test_join_missing_levels_and_errors(dt):            # test-join.py:62-85
+    d0 = dt.Frame(A=[1, 2, 3])
+    d1 = dt.Frame(A=[1, 2], K=[True, False])
+    d1.key = "A"
+    assert d0[:, :, dt.join(d1)].to_list() == [[1, 2, 3], [True, False, None]]
+    with pytest.raises(ValueError, match="The join frame is not keyed"):
+        d0[:, :, dt.join(dt.Frame(A=[1, 2]))]
+    d2 = dt.Frame(Z=[1, 2], K=[5, 6])
+    d2.key = "Z"
+    with pytest.raises(ValueError, match="Key column `Z` does not exist in the left Frame"):
+        d0[:, :, dt.join(d2)]
+
+
+def test_join_multi(dt):                                # test-join.py:169-182
+    fr1 = dt.Frame(A=[1, 2, 1, 2], B=[3, 3, 4, 4], C=[70, 71, 72, 73])
+    fr1.key = ("A", "B")
+    fr2 = dt.Frame([[1, 2, 3, 2, 3, 1, 2, 1, 1], [3, 4, 5, 4, 3, 3, 3, 4, 3]], names=("A", "B"))
+    res = fr2[:, :, dt.join(fr1)]
+    assert res.names == ("A", "B", "C")
+    assert res.to_list() == [[1, 2, 3, 2, 3, 1, 2, 1, 1], [3, 4, 5, 4, 3, 3, 3, 4, 3], [70, 73, None, 73, None, 70, 71, 72, 70]]
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_join_random(dt, seed):                         # test-join.py:102-138
+    rng = random.Random(seed)
+    ndata, nkeys = rng.randint(1, 2000), rng.randint(1, 200)
+    keys = rng.sample(range(-500, 500), nkeys)
+    vals = [rng.random() for _ in keys]
+    J = dt.Frame(K=keys, V=vals)
+    J.key = "K"
+    data = [rng.randint(-520, 520) for _ in range(ndata)]
+    X = dt.Frame(K=data, I=list(range(ndata)))
+    R = X[:, :, dt.join(J)]
+    look = dict(zip(keys, vals))
+    assert R.names == ("K", "I", "V")
+    assert R.to_list() == [data, list(range(ndata)), [look.get(k) for k in data]]
+
+
+def test_join_view_and_issue1800(dt):                   # test-join.py:247-256,270-279
+    x = dt.Frame(A=[1, 2, 3, 1, 2, 3], B=[3, 6, 2, 4, 3, 1], C=[0, 1, 0, 0, 1, 0])
+    a = x[dt.f.A == 1, ["A", "B", "C"]]
+    r = dt.Frame(C=[0, 9], BB=[2, 1000])
+    r.key = "C"
+    res = a[:, :, dt.join(r)]
+    assert res.shape == (2, 4) and res.names == ("A", "B", "C", "BB")
+    assert res.to_list() == [[1, 1], [3, 4], [0, 0], [2, 2]]
+    X1 = dt.Frame(A=list(range(5)), B=[0.1, 0.2, 0.3, 0.4, 0.5])
+    X1.key = "A"
+    X2 = dt.Frame(A=[0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5])
+    assert X2[:, :, dt.join(X1)].to_dict() == {"A": [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5],
+                                                "B": [0.1, 0.1, 0.2, 0.2, 0.3, 0.3, 0.4, 0.4, 0.5, 0.5, None, None]}
