@@ -754,7 +754,6 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
 
 
 // ---- hash combiner for sparse keys (bucket.hip): partial groups + merge ------------------------
-constexpr int DTHIP_NOT_APPLICABLE = 2;     // internal: this path does not fit, take the next one
 constexpr int HASH_PK_BITS = 24, HASH_R = 13;          // pseudo key: 2048 buckets by hash
 
 // distinct-key estimate from a strided sample of m rows: group the sample with the ordinary path,
@@ -1058,6 +1057,7 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "bucket_variant")) { ctx->bucket_variant = (int)value; return DTHIP_OK; }
   if (!strcmp(name, "spec_min_rows")) { ctx->spec_min_rows = value; return DTHIP_OK; }
   if (!strcmp(name, "agg_offsets")) { ctx->agg_offsets = value != 0; return DTHIP_OK; }
+  if (!strcmp(name, "join_table")) { ctx->join_table = value != 0; return DTHIP_OK; }
   if (!strcmp(name, "hash_mode")) {
     if (value < 0 || value > 2) { set_error("hash_mode must be 0 (estimate), 1 (never) or 2 (whenever it fits)"); return DTHIP_EINVAL; }
     ctx->hash_mode = (int)value;

@@ -71,6 +71,7 @@ struct dthip_ctx {
   int bucket_variant = 0;    // partition tile geometry (experiments)
   int64_t spec_min_rows = 1 << 23;   // key ranges are guessed from a sample only at or above this many rows
   int hash_mode = 0;         // hash combiner for sparse keys: 0 decide from a distinct-count estimate, 1 never, 2 whenever it fits
+  int join_table = 1;        // dthip_join_index: direct key->row table for a dense single integer key (0: always search)
   bool in_merge = false;     // internal: the merge of partial groups must not take the hash path again
   int cluster_mode = 0;      // clustered-key kernel variants: 0 decide from a sample, 1 never, 2 always
   int agg_offsets = 1;       // dthip_groupby_agg results carry group offsets (= sizes) even when no count() asks for them
@@ -295,6 +296,8 @@ int launch_reduce(dthip_ctx* ctx, const void* values, int stype, const int32_t* 
                   const uint8_t* bitmap, const uint32_t* tile_first_head, int64_t nrows,
                   const ReduceOuts& outs);
 int launch_count0(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t* out);
+
+constexpr int DTHIP_NOT_APPLICABLE = 2;     // internal: this path does not fit, take the next one
 
 // groupwise.hip: sd / cov / corr, cumulative operators, median / nunique
 int launch_gather_f64(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, int64_t n, double* out);

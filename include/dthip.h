@@ -144,6 +144,8 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    0: only when a count() aggregate asks for group sizes -- the reference's result
  *                    Frame of DT[:, sum(f.v), by(f.k)] holds keys and sums only, and not counting rows
  *                    lets the bucketed aggregation use twice as many table slots per bucket
+ *   "join_table"     1 (default): dthip_join_index looks a dense single integer key up in a direct
+ *                    key -> row table instead of binary-searching J; 0 = always search
  *   "hash_mode"      0 (default): sparse key ranges (too wide for the bucketed aggregation) are combined
  *                    through LDS hash tables when a sampled distinct-count estimate says they fit, and the
  *                    partial groups are merged by the sort path; 1 = never; 2 = whenever the query shape allows

@@ -55,6 +55,25 @@ def main():
     timed("cumsum(int64) rev", lambda: tb.group_cumulate_tensor(ctx, "cumsum", vi, ri, off, reverse=True), R + n * 16)
     timed("cummax(f64)", lambda: tb.group_cumulate_tensor(ctx, "cummax", v, ri, off), R + n * 16)
     timed("cumcount", lambda: tb.group_cumulate_tensor(ctx, "cumcount", None, None, off), n * 8)
+    # set function / natural join: union of the two halves of k; join of k against its distinct values
+    import numpy as np
+    from datatable_amd.engine import DevCol
+    from datatable_amd import _lib as L
+    half = n // 2
+    oidx = torch.empty(n, dtype=torch.int32, device=dev)
+    res = {}
+    def run_set(op):
+        res["n"] = ctx.setop_dev(op, DevCol(k.data_ptr(), L.INT64), [half, n], n, oidx.data_ptr())
+    timed("union(2 x n/2)", lambda: run_set("union"), n * 8 + ngr * 4)
+    timed("symdiff(2 x n/2)", lambda: run_set("symdiff"), n * 8 + ngr * 4)
+    off2, gk, _ = tb.groupby_agg_tensors(ctx, [k], [], [("count0", None)])
+    jk = gk[0]                                   # sorted distinct keys = a keyed frame's key column
+    jidx = torch.empty(n, dtype=torch.int32, device=dev)
+    timed("join_index(n x %d keys)" % jk.numel(),
+          lambda: ctx.join_index_dev([DevCol(k.data_ptr(), L.INT64)], [DevCol(jk.data_ptr(), L.INT64)], n, jk.numel(), jidx.data_ptr()),
+          n * 12)
+    torch.cuda.synchronize()
+    assert bool((jk[jidx.long()[:1000000]] == k[:1000000]).all())
     if a.profile:
         rows = [(nm,) + ctx.profile_get(nm) for nm in ctx.profile_names()]
         for nm, ms, cnt in sorted(rows, key=lambda t: -t[1]):

@@ -66,7 +66,17 @@ def test_setops_edge_cases(ctx):
 
 @pytest.mark.parametrize("xdt,jdt", [(np.int32, np.int32), (np.int64, np.int32), (np.int32, np.int64), (np.float64, np.int64),
                                      (np.int16, np.float64), (np.float64, np.float32), (np.int64, np.int8)])
-def test_join_vs_oracle(ctx, xdt, jdt):
+@pytest.mark.parametrize("table", [1, 0])
+def test_join_vs_oracle(ctx, xdt, jdt, table):
+    """table=1: dense single integer keys go through the direct key->row table; 0: always the binary search"""
+    ctx.set_option("join_table", table)
+    try:
+        _join_vs_oracle(ctx, xdt, jdt)
+    finally:
+        ctx.set_option("join_table", 1)
+
+
+def _join_vs_oracle(ctx, xdt, jdt):
     rng = np.random.default_rng(900)
     nj, nx = 50_000, 400_000
     if np.dtype(jdt) == np.int8:
@@ -82,6 +92,10 @@ def test_join_vs_oracle(ctx, xdt, jdt):
         xv = rng.integers(-lim, lim, nx).astype(xdt)
         xv[rng.random(nx) < 0.02] = np.iinfo(xdt).min
     assert_same(ctx.join_index([xv], [jv]), o.join_index([xv], [jv]), "join %s->%s" % (xdt, jdt))
+    if np.dtype(jdt).kind == "i":
+        # a keyed frame whose first key is NA: NA rows of X join row 0
+        jn = np.concatenate([[np.iinfo(jdt).min], jv]).astype(jdt)
+        assert_same(ctx.join_index([xv], [jn]), o.join_index([xv], [jn]), "join with NA key %s->%s" % (xdt, jdt))
 
 
 def test_join_two_keys_and_na_key(ctx):
