@@ -215,6 +215,20 @@ def test_groupwise_large(ctx):
     assert np.array_equal(cs, total - base)
     ng = ctx.cumulate("ngroup", None, ri, off)
     assert np.array_equal(ng, np.repeat(np.arange(len(off) - 1), np.diff(off)))
+    # sd / cov per group at a size where the tile-carry scan runs several chunks (> 4096 tiles)
+    vf = vg.astype(np.float64)
+    cnt = np.diff(off).astype(np.float64)
+    s1 = np.add.reduceat(vf, off[:-1].astype(np.int64))
+    s2 = np.add.reduceat(vf * vf, off[:-1].astype(np.int64))
+    var = (s2 - s1 * s1 / cnt) / (cnt - 1)
+    sdg = ctx.reduce("sd", v, ri, off)
+    assert np.allclose(sdg, np.sqrt(var), rtol=1e-9)
+    w = (np.arange(n) % 1000).astype(np.int64)
+    wf = w[ri].astype(np.float64)
+    sw = np.add.reduceat(wf, off[:-1].astype(np.int64))
+    svw = np.add.reduceat(vf * wf, off[:-1].astype(np.int64))
+    covg = ctx.reduce2("cov", v, w, ri, off)
+    assert np.allclose(covg, (svw - s1 * sw / cnt) / (cnt - 1), rtol=1e-7, atol=1e-6)
     one = np.array([0, n], np.int32)
     cm = ctx.cumulate("cummax", v, None, one)
     assert np.array_equal(cm, np.maximum.accumulate(v))
