@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--agg-path", type=int, default=0)
+    ap.add_argument("--bucket-variant", type=int, default=0)
     args = ap.parse_args()
     import torch
     from datatable_amd import _lib as L
@@ -25,6 +26,7 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = context_for_current_stream(0)
     ctx.set_option("agg_path", args.agg_path)
+    ctx.set_option("bucket_variant", args.bucket_variant)
     g = torch.Generator(device=dev)
 
     def timed(fn):
