@@ -1058,6 +1058,7 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "spec_min_rows")) { ctx->spec_min_rows = value; return DTHIP_OK; }
   if (!strcmp(name, "agg_offsets")) { ctx->agg_offsets = value != 0; return DTHIP_OK; }
   if (!strcmp(name, "join_table")) { ctx->join_table = value != 0; return DTHIP_OK; }
+  if (!strcmp(name, "median_pairs")) { ctx->pairs_always = value != 0; return DTHIP_OK; }
   if (!strcmp(name, "hash_mode")) {
     if (value < 0 || value > 2) { set_error("hash_mode must be 0 (estimate), 1 (never) or 2 (whenever it fits)"); return DTHIP_EINVAL; }
     ctx->hash_mode = (int)value;
@@ -1526,9 +1527,11 @@ static int grouped_f64(dthip_ctx* ctx, Scratch& sc, const void* d_val, int stype
   return DTHIP_OK;
 }
 
-// median / nunique: order the rows by (group, value) with the library's own radix path -- the
-// reference sorts every group separately (Column::sort_grouped, head_reduce_unary.cc:442-444) or
-// fills a std::set per group (:379-385)
+// median / nunique: the distinct (group, value) pairs in (group, value) order with their row counts =
+// the fused groupby-aggregate on keys (group id, value) with count().  It takes the sort-free bucketed /
+// hash paths when the composite key is dense or has few distinct values, the sort path otherwise.  The
+// reference sorts every group separately (Column::sort_grouped, head_reduce_unary.cc:442-444) or fills
+// a std::set per group (:379-385).
 static int median_nunique(dthip_ctx* ctx, Scratch& sc, int op, const void* d_val, int stype, const int32_t* d_ri,
                           const int32_t* d_off, int64_t ngroups, int64_t nrows, void* d_out) {
   int32_t* gid = nullptr;
@@ -1542,11 +1545,25 @@ static int median_nunique(dthip_ctx* ctx, Scratch& sc, int op, const void* d_val
     vg = t;
   }
   dthip_col keys[2] = {{gid, DTHIP_INT32, 0}, {vg, stype, 0}};
+  if (stype_is_float(stype) && !ctx->pairs_always) {
+    // mostly-distinct values: order the rows by (group, value) and read them through that order
+    dthip_result* r1 = nullptr;
+    DTHIP_TRY(dthip_groupby(ctx, keys, 2, nrows, DTHIP_NA_FIRST, DTHIP_DEVICE, 1, &r1));
+    int rc1;
+    if (op == DTHIP_MEDIAN) rc1 = launch_median_sorted(ctx, vg, stype, r1->rowindex, d_off, ngroups, d_out);
+    else rc1 = launch_nunique_sorted(ctx, vg, stype, gid, r1->rowindex, r1->offsets, r1->ngroups, ngroups, static_cast<int64_t*>(d_out));
+    result_destroy(ctx, r1);
+    return rc1;
+  }
+  const dthip_agg cnt{DTHIP_COUNT0, -1};
   dthip_result* r2 = nullptr;
-  DTHIP_TRY(dthip_groupby(ctx, keys, 2, nrows, DTHIP_NA_FIRST, DTHIP_DEVICE, 1, &r2));
-  int rc;
-  if (op == DTHIP_MEDIAN) rc = launch_median(ctx, vg, stype, r2->rowindex, d_off, ngroups, d_out);
-  else rc = launch_nunique(ctx, vg, stype, gid, r2->rowindex, r2->offsets, r2->ngroups, ngroups, static_cast<int64_t*>(d_out));
+  const int saved_off = ctx->agg_offsets;
+  ctx->agg_offsets = 1;                                         // the pairs' row offsets are needed (median)
+  int rc = dthip_groupby_agg(ctx, keys, 2, nullptr, 0, &cnt, 1, nrows, DTHIP_NA_FIRST, DTHIP_DEVICE, &r2);
+  ctx->agg_offsets = saved_off;
+  if (rc != DTHIP_OK) return rc;
+  if (op == DTHIP_MEDIAN) rc = launch_median(ctx, r2->key[1], stype, r2->offsets, r2->ngroups, d_off, ngroups, d_out);
+  else rc = launch_nunique(ctx, r2->key[1], stype, static_cast<const int32_t*>(r2->key[0]), r2->ngroups, ngroups, static_cast<int64_t*>(d_out));
   result_destroy(ctx, r2);
   return rc;
 }

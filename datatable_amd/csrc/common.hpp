@@ -71,6 +71,7 @@ struct dthip_ctx {
   int bucket_variant = 0;    // partition tile geometry (experiments)
   int64_t spec_min_rows = 1 << 23;   // key ranges are guessed from a sample only at or above this many rows
   int hash_mode = 0;         // hash combiner for sparse keys: 0 decide from a distinct-count estimate, 1 never, 2 whenever it fits
+  int pairs_always = 0;      // median / nunique of float columns through the distinct (group, value) pairs too (tests)
   int join_table = 1;        // dthip_join_index: direct key->row table for a dense single integer key (0: always search)
   bool in_merge = false;     // internal: the merge of partial groups must not take the hash path again
   int cluster_mode = 0;      // clustered-key kernel variants: 0 decide from a sample, 1 never, 2 always
@@ -306,10 +307,15 @@ int launch_moments(dthip_ctx* ctx, const double* x, const double* y, const uint8
 int launch_cumulate(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, const uint8_t* bitmap, int64_t n,
                     int op, int reverse, void* out, int ostype);
 int launch_cumcount(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int ngroup, int reverse, int64_t* out);
-int launch_median(dthip_ctx* ctx, const void* vg, int stype, const int32_t* order, const int32_t* offsets, int64_t ngroups,
-                  void* out);
-int launch_nunique(dthip_ctx* ctx, const void* vg, int stype, const int32_t* gid, const int32_t* order, const int32_t* run_offsets,
-                   int64_t nruns, int64_t ngroups, int64_t* out);
+int launch_median(dthip_ctx* ctx, const void* pair_val, int stype, const int32_t* pair_off, int64_t npairs, const int32_t* offsets,
+                  int64_t ngroups, void* out);
+int launch_nunique(dthip_ctx* ctx, const void* pair_val, int stype, const int32_t* pair_gid, int64_t npairs, int64_t ngroups,
+                   int64_t* out);
+
+int launch_median_sorted(dthip_ctx* ctx, const void* vg, int stype, const int32_t* order, const int32_t* offsets, int64_t ngroups,
+                         void* out);
+int launch_nunique_sorted(dthip_ctx* ctx, const void* vg, int stype, const int32_t* gid, const int32_t* order,
+                          const int32_t* run_offsets, int64_t nruns, int64_t ngroups, int64_t* out);
 
 // setjoin.hip: set functions over a stacked column, natural-join index
 int launch_setop_flags(dthip_ctx* ctx, const int32_t* ri, const int32_t* off, int64_t ngroups, int op, const int32_t* cum,

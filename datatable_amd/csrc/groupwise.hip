@@ -21,8 +21,9 @@
 // the position order.  Float results are re-associated (tests: 1e-6 relative; float32 5e-5),
 // integer results are exact (sums/products wrap like the reference's int64 arithmetic).
 //
-// median / nunique need the group's values in order: the caller sorts (group id, value) with the
-// library's own radix path and the two small kernels below read the sorted run of each group.
+// median / nunique need the group's distinct values in order with their multiplicities: the caller
+// runs the library's own fused groupby-aggregate on (group id, value) with count() -- sort-free when
+// that composite key is dense or has few distinct values -- and two small kernels read the pairs.
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -582,10 +583,116 @@ template <> struct NaOf<long long> { static __device__ __forceinline__ bool isna
 template <> struct NaOf<float> { static __device__ __forceinline__ bool isna(float v) { return v != v; } };
 template <> struct NaOf<double> { static __device__ __forceinline__ bool isna(double v) { return v != v; } };
 
+// median / nunique read the DISTINCT (group, value) pairs of the grouped column, ordered by (group,
+// value) with NA first, and the number of rows before each pair (`pair_off`): what the fused
+// groupby-aggregate returns for keys (group id, value) and count().  Rows of group g occupy sorted
+// positions [offsets[g], offsets[g+1]); the value at sorted position p belongs to the last pair whose
+// pair_off <= p.
+
+__device__ __forceinline__ uint32_t pair_of(const int32_t* __restrict__ pair_off, uint32_t npairs, uint32_t p) {
+  uint32_t lo = 0, hi = npairs;                  // largest s with pair_off[s] <= p
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((uint32_t)pair_off[mid] <= p) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 // Median_ColumnImpl::get_element (head_reduce_unary.cc:446-466): skip the leading NAs of the sorted
 // group, then the middle element, or the mean of the two middle ones computed in U
 template <typename T, typename U>
-__global__ void __launch_bounds__(256) median_kernel(const T* __restrict__ vg, const int32_t* __restrict__ order,
+__global__ void __launch_bounds__(256) median_kernel(const T* __restrict__ pair_val, const int32_t* __restrict__ pair_off,
+                                                     uint32_t npairs, const int32_t* __restrict__ offsets, uint32_t ngroups,
+                                                     U* __restrict__ out) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const uint32_t i0 = (uint32_t)offsets[g], i1 = (uint32_t)offsets[g + 1];
+  const uint32_t s0 = pair_of(pair_off, npairs, i0);
+  uint32_t a = i0;                               // first valid position: the NA pair, if any, leads the group
+  if (NaOf<T>::isna(pair_val[s0])) a = (uint32_t)pair_off[s0 + 1];
+  if (a >= i1) { out[g] = (U)__builtin_nan(""); return; }
+  const uint32_t j = (a + i1) >> 1;
+  const T v1 = pair_val[pair_of(pair_off, npairs, j)];
+  if ((i1 - a) & 1u) out[g] = (U)v1;
+  else out[g] = ((U)v1 + (U)pair_val[pair_of(pair_off, npairs, j - 1)]) / (U)2;
+}
+
+// op_nunique (head_reduce_unary.cc:377-387): distinct valid values per group.  One thread per pair; a
+// pair counts when its value is valid and differs -- as a VALUE, so -0.0 == 0.0 like std::set's
+// ordering -- from the previous pair of the same group.  Lanes of a wave in the same group add once.
+template <typename T>
+__global__ void __launch_bounds__(256) nunique_kernel(const T* __restrict__ pair_val, const int32_t* __restrict__ pair_gid,
+                                                      uint32_t npairs, unsigned long long* __restrict__ out) {
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int32_t g = -1;
+  bool distinct = false;
+  if (s < npairs) {
+    g = pair_gid[s];
+    const T v = pair_val[s];
+    distinct = !NaOf<T>::isna(v);
+    if (distinct && s > 0 && pair_gid[s - 1] == g && pair_val[s - 1] == v) distinct = false;
+  }
+  const int32_t gp = __shfl_up(g, 1, 64);
+  const bool leader = lane == 0 || g != gp;
+  const unsigned long long leaders = __ballot(leader);
+  const unsigned long long dmask = __ballot(distinct);
+  if (leader && g >= 0) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long higher = leaders & ~(below | (1ull << lane));
+    const int end = higher ? (__ffsll((long long)higher) - 1) : 64;
+    const unsigned long long upto = end == 64 ? ~0ull : ((1ull << end) - 1ull);
+    const int c = __popcll(dmask & upto & ~below);
+    if (c) atomicAdd(&out[g], (unsigned long long)c);
+  }
+}
+
+int launch_median(dthip_ctx* ctx, const void* pair_val, int stype, const int32_t* pair_off, int64_t npairs, const int32_t* offsets,
+                  int64_t ngroups, void* out) {
+  if (ngroups == 0) return DTHIP_OK;
+  const unsigned grid = (unsigned)((ngroups + 255) / 256);
+#define DTHIP_MED(T, U) DTHIP_LAUNCH(ctx, "median_kernel", (median_kernel<T, U>), grid, 256, 0, static_cast<const T*>(pair_val), pair_off, \
+                                     (uint32_t)npairs, offsets, (uint32_t)ngroups, static_cast<U*>(out)); break
+  switch (stype) {
+    case DTHIP_BOOL: case DTHIP_INT8: DTHIP_MED(int8_t, double);
+    case DTHIP_INT16: DTHIP_MED(int16_t, double);
+    case DTHIP_INT32: DTHIP_MED(int32_t, double);
+    case DTHIP_INT64: DTHIP_MED(long long, double);
+    case DTHIP_FLOAT32: DTHIP_MED(float, float);
+    case DTHIP_FLOAT64: DTHIP_MED(double, double);
+    default: set_error("median: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
+  }
+#undef DTHIP_MED
+  return DTHIP_OK;
+}
+
+int launch_nunique(dthip_ctx* ctx, const void* pair_val, int stype, const int32_t* pair_gid, int64_t npairs, int64_t ngroups,
+                   int64_t* out) {
+  DTHIP_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int64_t) * (size_t)ngroups, ctx->stream));
+  if (npairs == 0) return DTHIP_OK;
+  const unsigned grid = (unsigned)((npairs + 255) / 256);
+#define DTHIP_NU(T) DTHIP_LAUNCH(ctx, "nunique_kernel", nunique_kernel<T>, grid, 256, 0, static_cast<const T*>(pair_val), pair_gid, \
+                                 (uint32_t)npairs, reinterpret_cast<unsigned long long*>(out)); break
+  switch (stype) {
+    case DTHIP_BOOL: case DTHIP_INT8: DTHIP_NU(int8_t);
+    case DTHIP_INT16: DTHIP_NU(int16_t);
+    case DTHIP_INT32: DTHIP_NU(int32_t);
+    case DTHIP_INT64: DTHIP_NU(long long);
+    case DTHIP_FLOAT32: DTHIP_NU(float);
+    case DTHIP_FLOAT64: DTHIP_NU(double);
+    default: set_error("nunique: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
+  }
+#undef DTHIP_NU
+  return DTHIP_OK;
+}
+
+// ---- the same two reducers over ROWS sorted by (group, value) ------------------------------------
+// Used for float columns, whose values are mostly distinct: the pairs would be as many as the rows and
+// materialising them costs more (2 ms per 1e8 rows) than reading the sorted rows through their order.
+// Median_ColumnImpl::get_element (head_reduce_unary.cc:446-466): skip the leading NAs of the sorted
+// group, then the middle element, or the mean of the two middle ones computed in U
+template <typename T, typename U>
+__global__ void __launch_bounds__(256) median_sorted_kernel(const T* __restrict__ vg, const int32_t* __restrict__ order,
                                                      const int32_t* __restrict__ offsets, uint32_t ngroups, U* __restrict__ out) {
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
   if (g >= ngroups) return;
@@ -607,7 +714,7 @@ __global__ void __launch_bounds__(256) median_kernel(const T* __restrict__ vg, c
 // VALUE, so -0.0 == 0.0 like std::set's ordering -- from the previous run of the same group.
 // Lanes of a wave that fall into the same group add once.
 template <typename T>
-__global__ void __launch_bounds__(256) nunique_kernel(const T* __restrict__ vg, const int32_t* __restrict__ gid,
+__global__ void __launch_bounds__(256) nunique_sorted_kernel(const T* __restrict__ vg, const int32_t* __restrict__ gid,
                                                       const int32_t* __restrict__ order, const int32_t* __restrict__ run_offsets,
                                                       uint32_t nruns, unsigned long long* __restrict__ out) {
   const uint32_t s = blockIdx.x * 256 + threadIdx.x;
@@ -638,43 +745,45 @@ __global__ void __launch_bounds__(256) nunique_kernel(const T* __restrict__ vg, 
   }
 }
 
-int launch_median(dthip_ctx* ctx, const void* vg, int stype, const int32_t* order, const int32_t* offsets, int64_t ngroups,
+int launch_median_sorted(dthip_ctx* ctx, const void* vg, int stype, const int32_t* order, const int32_t* offsets, int64_t ngroups,
                   void* out) {
   if (ngroups == 0) return DTHIP_OK;
   const unsigned grid = (unsigned)((ngroups + 255) / 256);
-#define DTHIP_MED(T, U) DTHIP_LAUNCH(ctx, "median_kernel", (median_kernel<T, U>), grid, 256, 0, static_cast<const T*>(vg), order, offsets, \
+#define DTHIP_MEDS(T, U) DTHIP_LAUNCH(ctx, "median_sorted_kernel", (median_sorted_kernel<T, U>), grid, 256, 0, static_cast<const T*>(vg), order, offsets, \
                                      (uint32_t)ngroups, static_cast<U*>(out)); break
   switch (stype) {
-    case DTHIP_BOOL: case DTHIP_INT8: DTHIP_MED(int8_t, double);
-    case DTHIP_INT16: DTHIP_MED(int16_t, double);
-    case DTHIP_INT32: DTHIP_MED(int32_t, double);
-    case DTHIP_INT64: DTHIP_MED(long long, double);
-    case DTHIP_FLOAT32: DTHIP_MED(float, float);
-    case DTHIP_FLOAT64: DTHIP_MED(double, double);
+    case DTHIP_BOOL: case DTHIP_INT8: DTHIP_MEDS(int8_t, double);
+    case DTHIP_INT16: DTHIP_MEDS(int16_t, double);
+    case DTHIP_INT32: DTHIP_MEDS(int32_t, double);
+    case DTHIP_INT64: DTHIP_MEDS(long long, double);
+    case DTHIP_FLOAT32: DTHIP_MEDS(float, float);
+    case DTHIP_FLOAT64: DTHIP_MEDS(double, double);
     default: set_error("median: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
   }
-#undef DTHIP_MED
+#undef DTHIP_MEDSS
   return DTHIP_OK;
 }
 
-int launch_nunique(dthip_ctx* ctx, const void* vg, int stype, const int32_t* gid, const int32_t* order, const int32_t* run_offsets,
+int launch_nunique_sorted(dthip_ctx* ctx, const void* vg, int stype, const int32_t* gid, const int32_t* order, const int32_t* run_offsets,
                    int64_t nruns, int64_t ngroups, int64_t* out) {
   DTHIP_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int64_t) * (size_t)ngroups, ctx->stream));
   if (nruns == 0) return DTHIP_OK;
   const unsigned grid = (unsigned)((nruns + 255) / 256);
-#define DTHIP_NU(T) DTHIP_LAUNCH(ctx, "nunique_kernel", nunique_kernel<T>, grid, 256, 0, static_cast<const T*>(vg), gid, order, run_offsets, \
+#define DTHIP_NUS(T) DTHIP_LAUNCH(ctx, "nunique_sorted_kernel", nunique_sorted_kernel<T>, grid, 256, 0, static_cast<const T*>(vg), gid, order, run_offsets, \
                                  (uint32_t)nruns, reinterpret_cast<unsigned long long*>(out)); break
   switch (stype) {
-    case DTHIP_BOOL: case DTHIP_INT8: DTHIP_NU(int8_t);
-    case DTHIP_INT16: DTHIP_NU(int16_t);
-    case DTHIP_INT32: DTHIP_NU(int32_t);
-    case DTHIP_INT64: DTHIP_NU(long long);
-    case DTHIP_FLOAT32: DTHIP_NU(float);
-    case DTHIP_FLOAT64: DTHIP_NU(double);
+    case DTHIP_BOOL: case DTHIP_INT8: DTHIP_NUS(int8_t);
+    case DTHIP_INT16: DTHIP_NUS(int16_t);
+    case DTHIP_INT32: DTHIP_NUS(int32_t);
+    case DTHIP_INT64: DTHIP_NUS(long long);
+    case DTHIP_FLOAT32: DTHIP_NUS(float);
+    case DTHIP_FLOAT64: DTHIP_NUS(double);
     default: set_error("nunique: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
   }
-#undef DTHIP_NU
+#undef DTHIP_NUS
   return DTHIP_OK;
 }
+
+
 
 }  // namespace dthip

@@ -144,6 +144,9 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    0: only when a count() aggregate asks for group sizes -- the reference's result
  *                    Frame of DT[:, sum(f.v), by(f.k)] holds keys and sums only, and not counting rows
  *                    lets the bucketed aggregation use twice as many table slots per bucket
+ *   "median_pairs"   0 (default): median / nunique of FLOAT columns order the rows by (group, value); integer
+ *                    columns go through the distinct (group, value) pairs of a fused count() aggregation,
+ *                    which is sort-free for categorical data; 1 = floats too
  *   "join_table"     1 (default): dthip_join_index looks a dense single integer key up in a direct
  *                    key -> row table instead of binary-searching J; 0 = always search
  *   "hash_mode"      0 (default): sparse key ranges (too wide for the bucketed aggregation) are combined

@@ -51,6 +51,9 @@ def main():
     timed("corr", lambda: tb.group_reduce_tensor(ctx, "corr", v, ri, off, value2=w), R + n * 16 + ngr * 8)
     timed("median", lambda: tb.group_reduce_tensor(ctx, "median", v, ri, off), R + n * 8 + ngr * 8)
     timed("nunique(int64)", lambda: tb.group_reduce_tensor(ctx, "nunique", vi, ri, off), R + n * 8 + ngr * 8)
+    vc = torch.randint(0, 50, (n,), device=dev, dtype=torch.int32, generator=g)       # a categorical column
+    timed("nunique(int32, 50 levels)", lambda: tb.group_reduce_tensor(ctx, "nunique", vc, ri, off), R + n * 4 + ngr * 8)
+    timed("median(int32, 50 levels)", lambda: tb.group_reduce_tensor(ctx, "median", vc, ri, off), R + n * 4 + ngr * 8)
     timed("cumsum(f64)", lambda: tb.group_cumulate_tensor(ctx, "cumsum", v, ri, off), R + n * 16)
     timed("cumsum(int64) rev", lambda: tb.group_cumulate_tensor(ctx, "cumsum", vi, ri, off, reverse=True), R + n * 16)
     timed("cummax(f64)", lambda: tb.group_cumulate_tensor(ctx, "cummax", v, ri, off), R + n * 16)

@@ -149,6 +149,13 @@ def test_groupwise_vs_oracle(ctx, shape, n, ng, vst):
             close(got, want, op, scale=vscale(v))
         else:
             assert_same(got, want, op)
+            if vst in (6, 7):
+                # float columns take the sorted-rows path by default; the distinct-pairs path must agree
+                ctx.set_option("median_pairs", 1)
+                try:
+                    assert_same(ctx.reduce(op, v, ri, off), want, op + " (pairs)")
+                finally:
+                    ctx.set_option("median_pairs", 0)
     for op in ("cov", "corr"):
         close(ctx.reduce2(op, v, w, ri, off), o.reduce2(op, v, w, ri, off), op, scale=vscale(v, w) if op == "cov" else 1.0)
     for op in ("cumsum", "cummin", "cummax"):
