@@ -114,8 +114,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dthip_abi_version() != 1:
-        raise ImportError("libdthip.so ABI version %d != 1" % lib.dthip_abi_version())
+    if lib.dthip_abi_version() != 2:
+        raise ImportError("libdthip.so ABI version %d != 2" % lib.dthip_abi_version())
     _lib = lib
     return lib
 

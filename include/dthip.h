@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define DTHIP_ABI_VERSION 1
+#define DTHIP_ABI_VERSION 2   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10 */
 
 /* error codes */
 #define DTHIP_OK        0
