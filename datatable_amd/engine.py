@@ -36,6 +36,20 @@ class DevCol:
         self.keepalive = keepalive
 
 
+class _DevBuf:
+    """owner of one dthip_malloc allocation; freed when the last DevCol referring to it goes away"""
+
+    def __init__(self, ctx, ptr):
+        self.ctx, self.ptr = ctx, ptr
+
+    def __del__(self):
+        try:
+            if self.ctx._h is not None and self.ptr:
+                self.ctx._lib.dthip_free(self.ctx._h, C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
 def _host_col(a, stype=None, desc=False):
     a = np.ascontiguousarray(a)
     st = stype if stype is not None else NP2ST[a.dtype]
@@ -203,6 +217,17 @@ class Context:
     def set_option(self, name, value):
         """tuning knobs of dthip_set_option(): 'agg_path' (0 auto / 1 sort / 2 bucketed), 'bucket_variant'"""
         L.check(self._lib.dthip_set_option(self._h, name.encode(), int(value)))
+
+    # ---- device memory ---------------------------------------------------
+    def upload(self, values, stype=None):
+        """host array -> HBM (dthip_malloc + one host->device copy).  Returns a DevCol that owns the buffer."""
+        a, col = _host_col(values, stype)
+        p = C.c_void_p()
+        L.check(self._lib.dthip_malloc(self._h, max(a.nbytes, 1), C.byref(p)))
+        buf = _DevBuf(self, p.value)
+        if a.nbytes:
+            L.check(self._lib.dthip_memcpy_h2d(self._h, p, a.ctypes.data, a.nbytes))
+        return DevCol(p.value, col.stype, keepalive=buf)
 
     # ---- timing -----------------------------------------------------------
     def timer_start(self):

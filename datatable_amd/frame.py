@@ -375,6 +375,23 @@ class Frame:
             return self._cols[i]
         return self._context().gather(self._cols[i], self._ri, stype=self._stypes[i])
 
+    def to_device(self):
+        """Keep this Frame's columns resident in HBM: they are uploaded once, and the fused
+        groupby-aggregate of later `DT[:, reducers, by(...)]` calls reads them there instead of copying
+        them over PCIe on every call (results are small and still come back as host columns).
+        An extension over the reference, whose frames live in host memory; returns self."""
+        self.materialize()
+        ctx = self._context()
+        self._dev = [ctx.upload(self._cols[i], self._stypes[i]) for i in range(self.ncols)]
+        return self
+
+    def _operand(self, i):
+        """column i as the fused aggregation takes it: the resident device copy if there is one"""
+        dev = getattr(self, "_dev", None)
+        if dev is not None and self._ri is None and len(dev) == self.ncols:
+            return dev[i]
+        return self._materialized(i)
+
     def materialize(self):
         if self._ri is not None:
             self._cols = [self._materialized(i) for i in range(self.ncols)]
@@ -659,8 +676,15 @@ class Frame:
                 if ci not in vidx:
                     vidx.append(ci)
                 aggs.append((x.op, vidx.index(ci)))
-            vals = [self._materialized(c) for c in vidx]
-            res = ctx.groupby_agg(keys, vals, aggs, key_stypes=kst, value_stypes=[self._stypes[c] for c in vidx], desc=kdesc)
+            resident = bool(kidx) and getattr(self, "_dev", None) is not None and self._ri is None
+            vals = [self._operand(c) if resident else self._materialized(c) for c in vidx]
+            fkeys = keys
+            if resident:
+                from .engine import DevCol
+                fkeys = [DevCol(self._dev[c].ptr, self._dev[c].stype, kdesc[j], keepalive=self._dev[c].keepalive)
+                         for j, c in enumerate(kidx)]
+            res = ctx.groupby_agg(fkeys, vals, aggs, nrows=self.nrows, key_stypes=kst,
+                                  value_stypes=[self._stypes[c] for c in vidx], desc=kdesc)
             kcols = [res.key(k) for k in range(len(kidx))]
             cols, sts, a = list(kcols), list(kst[:len(kidx)]), 0
             for _, x in items:
