@@ -258,7 +258,7 @@ def _to_column(x):
 
 
 def _mangle(names):
-    """duplicate-name mangling of result frames: v, v -> v, v.0 (src/core/frame/names.cc:455-510); unnamed
+    """duplicate-name mangling of result frames: v, v -> v, v.0 and v1, v1 -> v1, v2 (src/core/frame/names.cc:455-510); unnamed
     columns ("") become C<k>, counting on from the largest C<num> already present (names.cc:572-607)"""
     if "" in names:
         nxt = 0
@@ -272,15 +272,33 @@ def _mangle(names):
                 nxt += 1
             filled.append(nm)
         names = filled
-    seen, out = set(), []
+    seen, out, stems = set(), [], {}
     for nm in names:
-        if nm not in seen:
-            seen.add(nm); out.append(nm); continue
-        k = 0
-        while "%s.%d" % (nm, k) in seen:
-            k += 1
-        new = "%s.%d" % (nm, k)
-        seen.add(new); out.append(new)
+        if nm in seen:
+            # _deduplicate (names.cc:455-510): a name ending in digits continues counting from that number
+            # ("v1" -> "v2"), any other name gets ".<k>" appended ("v" -> "v.0"); counts already handed out
+            # for a stem are skipped
+            j = len(nm)
+            while j > 0 and nm[j - 1].isdigit():
+                j -= 1
+            stem = nm[:j]
+            if j < len(nm):
+                cnt = int(nm[j:]) + 1
+            else:
+                cnt = 0
+                if not nm.endswith("."):
+                    stem += "."
+            used = stems.setdefault(stem, set())
+            while True:
+                while cnt in used:
+                    cnt += 1
+                nm = "%s%d" % (stem, cnt)
+                used.add(cnt)
+                if nm not in seen:
+                    break
+                cnt += 1
+        seen.add(nm)
+        out.append(nm)
     return out
 
 

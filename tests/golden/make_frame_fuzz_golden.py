@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""Randomised Frame-level golden answers: seeded random frames (every fixed-width stype, NAs, +-inf, -0.0)
+and random `DT[i, j, by/sort]` queries over them, evaluated by THE UNMODIFIED REFERENCE in the dev container
+(DT_REFERENCE_SRC=/tmp/dt_oracle/src).  Output: tests/golden/frame_fuzz.json, same layout as
+frame_queries.json; tests/test_frame_golden.py evaluates the same strings against datatable_amd.frame."""
+import json
+import math
+import os
+import random
+import sys
+import warnings
+
+SRC = os.environ.get("DT_REFERENCE_SRC", "/tmp/dt_oracle/src")
+sys.path.insert(0, SRC)
+import datatable as dt  # noqa: E402
+from datatable import f, by, sort, sum, mean, min, max, count, first, last  # noqa: E402,A004
+from datatable import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup  # noqa: E402
+
+dt.options.progress.enabled = False
+ST = {1: dt.bool8, 2: dt.int8, 3: dt.int16, 4: dt.int32, 5: dt.int64, 6: dt.float32, 7: dt.float64}
+rnd = random.Random(20251001)
+
+
+def rand_col(st, n, role):
+    vals = []
+    for _ in range(n):
+        if rnd.random() < (0.08 if role == "key" else 0.12):
+            vals.append(None)
+        elif st == 1:
+            vals.append(rnd.random() < 0.5)
+        elif st in (6, 7):
+            if role == "key":
+                vals.append(rnd.choice([0.0, -0.0, 1.5, -2.25, 3.0, math.inf]))
+            else:
+                r = rnd.random()
+                vals.append(math.inf if r < 0.02 else -math.inf if r < 0.03 else rnd.randint(-400, 400) / 8.0)
+        else:
+            lim = {2: 5, 3: 8, 4: 12, 5: 6}[st] if role == "key" else {2: 100, 3: 3000, 4: 10**6, 5: 10**12}[st]
+            vals.append(rnd.randint(-lim, lim))
+    return vals
+
+
+def make_frame(seed):
+    rnd.seed(seed)
+    n = rnd.choice([1, 2, 7, 40, 150])
+    spec = {}
+    for i in range(rnd.randint(1, 2)):
+        spec["k%d" % i] = (rand_col(rnd.choice([1, 2, 3, 4, 5, 4, 5, 7]), n, "key"), None)
+    for i in range(rnd.randint(2, 4)):
+        spec["v%d" % i] = (rand_col(rnd.choice([1, 2, 3, 4, 5, 6, 7, 7, 4]), n, "val"), None)
+    out = {}
+    for nm, (vals, _) in spec.items():
+        st = 1 if all(isinstance(x, bool) or x is None for x in vals) and any(isinstance(x, bool) for x in vals) else None
+        out[nm] = vals
+    return out
+
+
+def stype_of(vals_hint):
+    return vals_hint
+
+
+RED = ["sum", "mean", "min", "max", "count", "first", "last", "sd", "median", "nunique"]
+CUM = ["cumsum", "cumprod", "cummin", "cummax"]
+
+
+def rand_query(names):
+    keys = [nm for nm in names if nm.startswith("k")]
+    vals = [nm for nm in names if nm.startswith("v")]
+    kk = rnd.sample(keys, rnd.randint(1, len(keys)))
+    bys = "by(%s)" % ", ".join(("-f.%s" if rnd.random() < 0.15 else "f.%s") % k for k in kk)
+    kind = rnd.random()
+    if kind < 0.45:
+        items = []
+        for _ in range(rnd.randint(1, 4)):
+            r = rnd.random()
+            if r < 0.1:
+                items.append("count()")
+            elif r < 0.2 and len(vals) >= 2:
+                a, b = rnd.sample(vals, 2)
+                items.append("%s(f.%s, f.%s)" % (rnd.choice(["cov", "corr"]), a, b))
+            else:
+                items.append("%s(f.%s)" % (rnd.choice(RED), rnd.choice(vals)))
+        j = "[%s]" % ", ".join(items)
+        return "DT[:, %s, %s]" % (j, bys) if rnd.random() < 0.85 else "DT[:, %s]" % j
+    if kind < 0.65:
+        items = []
+        for _ in range(rnd.randint(1, 3)):
+            r = rnd.random()
+            if r < 0.15:
+                items.append("%s(%s)" % (rnd.choice(["cumcount", "ngroup"]), rnd.choice(["", "reverse=True"])))
+            else:
+                items.append("%s(f.%s%s)" % (rnd.choice(CUM), rnd.choice(vals), rnd.choice(["", ", reverse=True"])))
+        j = "[%s]" % ", ".join(items)
+        return "DT[:, %s, %s]" % (j, bys) if rnd.random() < 0.8 else "DT[:, %s]" % j
+    if kind < 0.75:
+        cols = ", ".join("f.%s" % c for c in rnd.sample(names, rnd.randint(1, len(names))))
+        opt = rnd.choice(["", ", reverse=True", ", na_position='last'"])
+        return "DT[:, :, sort(%s%s)]" % (cols, opt)
+    if kind < 0.85:
+        return "DT[:, %s, %s]" % (rnd.choice([":", "f.%s" % rnd.choice(vals), "[f.%s, mean(f.%s)]" % (rnd.choice(vals), rnd.choice(vals))]), bys)
+    if kind < 0.93:
+        v = rnd.choice(vals)
+        op = rnd.choice([">", ">=", "<", "<=", "==", "!="])
+        return "DT[f.%s %s %s, :][:, [%s(f.%s), count()], %s]" % (v, op, rnd.choice(["0", "1", "-3", "2.5"]), rnd.choice(RED), rnd.choice(vals), bys)
+    return "DT[:, :, %s, sort(f.%s)]" % (bys, rnd.choice(vals))
+
+
+def clean(cols):
+    out = []
+    for c in cols:
+        cc = []
+        for x in c:
+            if isinstance(x, float):
+                if x != x:
+                    x = None
+                elif math.isinf(x):
+                    x = "inf" if x > 0 else "-inf"
+                elif x == 0 and math.copysign(1, x) < 0:
+                    x = "-0.0"
+            cc.append(x)
+        out.append(cc)
+    return out
+
+
+def main():
+    frames, queries = {}, []
+    seed = 0
+    while len(queries) < 260:
+        seed += 1
+        spec = make_frame(seed)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            DT = dt.Frame(spec)
+        # stypes as the reference inferred them (all-None columns become void: skip such frames)
+        if any(s.value not in ST for s in DT.stypes):
+            continue
+        fname = "fz%d" % seed
+        frames[fname] = {nm: {"values": clean([DT[:, nm].to_list()[0]])[0], "stype": DT.stypes[i].value} for i, nm in enumerate(DT.names)}
+        for _ in range(4):
+            q = rand_query(list(DT.names))
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    R = eval(q)
+                if any(s.value not in ST for s in R.stypes):
+                    continue
+                queries.append({"frame": fname, "query": q, "names": list(R.names), "stypes": [s.value for s in R.stypes],
+                                "columns": clean(R.to_list())})
+            except Exception as e:      # the reference refuses the query: record its exception type
+                queries.append({"frame": fname, "query": q, "error": type(e).__name__})
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "frame_fuzz.json")
+    json.dump({"frames": frames, "queries": queries}, open(path, "w"))
+    nerr = len([q for q in queries if "error" in q])
+    print("wrote %s: %d frames, %d queries (%d refused by the reference)" % (path, len(frames), len(queries), nerr))
+    from collections import Counter
+    print(Counter(q.get("error") for q in queries if "error" in q))
+
+
+if __name__ == "__main__":
+    main()

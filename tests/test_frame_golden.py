@@ -47,3 +47,41 @@ def test_frame_query_matches_reference(qi):
                 assert abs(x - y) <= 1e-6 * abs(y) + 1e-9, (q["names"][ci], x, y)
             else:
                 assert x == y and type(x) is type(y), (q["names"][ci], g[:12], e[:12])
+
+
+# ---- randomised queries (tests/golden/make_frame_fuzz_golden.py) -----------------------------------
+FUZZ = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_fuzz.json")))
+
+
+def _dec2(x):
+    if x == "-0.0":
+        return -0.0
+    return _dec(x)
+
+
+@pytest.mark.parametrize("qi", range(len(FUZZ["queries"])), ids=["%d:%s" % (i, q["query"][:60]) for i, q in enumerate(FUZZ["queries"])])
+def test_fuzz_query_matches_reference(qi):
+    """260 seeded random queries over 65 random frames (all fixed-width stypes, NAs, +-inf, -0.0 keys):
+    names, stypes and values as the unmodified reference returned them"""
+    from datatable_amd import frame as dt
+    from datatable_amd.frame import f, by, sort, sum, mean, min, max, count, first, last   # noqa: F401,A004
+    from datatable_amd.frame import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup  # noqa: F401
+    q = FUZZ["queries"][qi]
+    spec = FUZZ["frames"][q["frame"]]
+    DT = dt.Frame({nm: [_dec2(x) for x in c["values"]] for nm, c in spec.items()},
+                  stypes={nm: c["stype"] for nm, c in spec.items()})
+    assert list(DT.stypes) == [c["stype"] for c in spec.values()]
+    R = eval(q["query"])
+    assert list(R.names) == q["names"]
+    assert list(R.stypes) == q["stypes"]
+    got = R.to_list()
+    assert len(got) == len(q["columns"])
+    for ci, (g, e) in enumerate(zip(got, q["columns"])):
+        e = [_dec2(x) for x in e]
+        assert len(g) == len(e), "column %d: %d rows, expected %d" % (ci, len(g), len(e))
+        rel = 2e-5 if q["stypes"][ci] == 6 else 1e-6
+        for ri, (x, y) in enumerate(zip(g, e)):
+            if isinstance(y, float) and isinstance(x, float) and math.isfinite(y) and math.isfinite(x):
+                assert abs(x - y) <= rel * abs(y) + 1e-9, (q["names"][ci], ri, x, y)
+            else:
+                assert x == y and type(x) is type(y), (q["names"][ci], ri, g[:12], e[:12])

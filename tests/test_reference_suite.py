@@ -440,7 +440,7 @@ def test_cumsum(dt):                                    # tests/dt/test-cumsum.p
 def test_cumsum_grouped_column(dt):                     # tests/dt/test-cumsum.py:120-124
     DT = dt.Frame([2, 1, None, 1, 2])
     assert_equals(DT[:, dt.cumsum(dt.f[0]), dt.by(dt.f[0])],
-                  dt.Frame([[None, 1, 1, 2, 2], [0, 1, 2, 2, 4]], names=["C0", "C0.0"], stypes=[I32, I64]))
+                  dt.Frame([[None, 1, 1, 2, 2], [0, 1, 2, 2, 4]], stypes=[I32, I64]))
 
 
 def test_cumprod(dt):                                   # tests/dt/test-cumprod.py:87-112
@@ -455,24 +455,24 @@ def test_cumprod(dt):                                   # tests/dt/test-cumprod.
 def test_cumminmax(dt):                                 # tests/dt/test-cumminmax.py:97-159
     DT = dt.Frame([None, False, None, True, False, True])
     assert_equals(DT[:, [dt.cummin(dt.f[:]), dt.cummax(dt.f[:])]],
-                  dt.Frame([[None, False, False, False, False, False], [None, False, False, True, True, True]], names=["C0", "C0.0"]))
+                  dt.Frame([[None, False, False, False, False, False], [None, False, False, True, True, True]]))
     DT = dt.Frame([list(range(5)), [None, -1, None, 5.5, 3]])
     assert_equals(DT[:, [dt.cummin(dt.f[:]), dt.cummax(dt.f[:])]],
                   dt.Frame([[0, 0, 0, 0, 0], [None, -1, -1, -1, -1], [0, 1, 2, 3, 4], [None, -1, -1, 5.5, 5.5]],
-                           names=["C0", "C1", "C0.0", "C1.0"], stypes=[I32, F64, I32, F64]))
+                           stypes=[I32, F64, I32, F64]))
     DT = dt.Frame([[2, 1, 1, 1, 2], [1.5, -1.5, math.inf, None, 3]])
     assert_equals(DT[:, [dt.cummin(dt.f[:]), dt.cummax(dt.f[:])], dt.by(dt.f[0])],
                   dt.Frame([[1, 1, 1, 2, 2], [-1.5, -1.5, -1.5, 1.5, 1.5], [-1.5, math.inf, math.inf, 1.5, 3]],
-                           names=["C0", "C1", "C1.0"]))
+                           names=["C0", "C1", "C2"]))
 
 
 def test_cumminmax_grouped_column_and_reverse(dt):      # tests/dt/test-cumminmax.py:162-170,194-203
     DT = dt.Frame([2, 1, None, 1, 2])
     assert_equals(DT[:, [dt.cummin(dt.f[0]), dt.cummax(dt.f[0])], dt.by(dt.f[0])],
-                  dt.Frame([[None, 1, 1, 2, 2]] * 3, names=["C0", "C0.0", "C0.1"]))
+                  dt.Frame([[None, 1, 1, 2, 2]] * 3))
     DT = dt.Frame([[3, 14, 15, 92, 6], [0, 1, 0, 2, 1]])           # string key of the original -> its rank
     assert_equals(DT[:, [dt.cummin(dt.f[0], reverse=True), dt.cummax(dt.f[0], True)], dt.by(dt.f[1])],
-                  dt.Frame([[0, 0, 1, 1, 2], [3, 15, 6, 6, 92], [15, 15, 14, 6, 92]], names=["C1", "C0", "C0.0"]))
+                  dt.Frame([[0, 0, 1, 1, 2], [3, 15, 6, 6, 92], [15, 15, 14, 6, 92]], names=["C1", "C0", "C2"]))
 
 
 def test_cumcount_ngroup(dt):                           # tests/dt/test-cumcountngroup.py:76-100
