@@ -1610,7 +1610,7 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
         const double* xg = nullptr;
         DTHIP_TRY(grouped_f64(ctx, sc, d_val, value->stype, ri32, nrows, &xg));
         DTHIP_TRY(launch_moments(ctx, xg, nullptr, reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, 0, d_out,
-                                 ost == DTHIP_FLOAT32));
+                                 ost == DTHIP_FLOAT32, off32, ngroups));
       } else {
         ReduceOuts ro;
         DTHIP_TRY(reduce_outs_for(op, d_out, &ro));
@@ -1655,7 +1655,7 @@ int dthip_reduce2(dthip_ctx* ctx, int op, const dthip_col* a, const dthip_col* b
   if (d_b == d_a && b->stype == a->stype) yg = xg;
   else DTHIP_TRY(grouped_f64(ctx, sc, d_b, b->stype, static_cast<const int32_t*>(d_ri), nrows, &yg));
   DTHIP_TRY(launch_moments(ctx, xg, yg, reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, op == DTHIP_COV ? 1 : 2,
-                           d_out, ost == DTHIP_FLOAT32));
+                           d_out, ost == DTHIP_FLOAT32, static_cast<const int32_t*>(d_off), ngroups));
   if (mem == DTHIP_HOST) DTHIP_TRY(copy_out(ctx, out, d_out, obytes, mem));
   return DTHIP_OK;
 }

@@ -303,7 +303,7 @@ constexpr int DTHIP_NOT_APPLICABLE = 2;     // internal: this path does not fit,
 // groupwise.hip: sd / cov / corr, cumulative operators, median / nunique
 int launch_gather_f64(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, int64_t n, double* out);
 int launch_moments(dthip_ctx* ctx, const double* x, const double* y, const uint8_t* bitmap, const uint32_t* tile_first_head,
-                   int64_t n, int op /*0 sd, 1 cov, 2 corr*/, void* out, int out_f32);
+                   int64_t n, int op /*0 sd, 1 cov, 2 corr*/, void* out, int out_f32, const int32_t* offsets, int64_t ngroups);
 int launch_cumulate(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, const uint8_t* bitmap, int64_t n,
                     int op, int reverse, void* out, int ostype);
 int launch_cumcount(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int ngroup, int reverse, int64_t* out);

@@ -281,7 +281,7 @@ static int run_segscan(dthip_ctx* ctx, const typename P::Args& a, const uint32_t
 
 // ---- policy: running moments (sd / cov / corr) ---------------------------------------------------
 struct MomArgs { const double* x; const double* y; };
-struct MomOut { void* out; int op; int f32; };   // op: 0 sd, 1 cov, 2 corr
+struct MomOut { void* out; int op; int f32; uint8_t* nonfinite; };   // op: 0 sd, 1 cov, 2 corr; nonfinite[g]: see cov_seq_kernel
 template <int NC> struct MomSt;
 template <> struct MomSt<1> { double n, mx, cxx; };
 template <> struct MomSt<2> { double n, mx, my, cxx, cyy, cxy; };
@@ -364,6 +364,7 @@ template <> struct MomP<2> {
   static __device__ __forceinline__ void store_block(const Out&, uint32_t, const St*) {}
   static __device__ __forceinline__ void emit(const Out& o, uint32_t g, const St& s) {
     double r = __builtin_nan("");
+    if (s.cxx != s.cxx || s.cyy != s.cyy) { o.nonfinite[g] = 1; return; }     // +-inf among the pairs: redone sequentially
     if (o.op == 1) { if (s.n > 1.0) r = s.cxy / (s.n - 1.0); }
     else { const double vv = s.cxx * s.cyy; if (s.n > 1.0 && vv > 0.0) r = s.cxy / sqrt(vv); }
     if (o.f32) static_cast<float*>(o.out)[g] = (float)r; else static_cast<double*>(o.out)[g] = r;
@@ -400,13 +401,54 @@ int launch_gather_f64(dthip_ctx* ctx, const void* data, int stype, const int32_t
   return DTHIP_OK;
 }
 
+// cov / corr of a group that holds +-inf among its valid pairs: what the reference's sequential update
+// yields then (+-inf or NaN) depends on the row order -- e.g. an infinity in the last row leaves cov at
+// +-inf, one earlier usually turns it into NaN -- so those (rare) groups are re-evaluated exactly as
+// cov_reducer / corr_reducer do (head_reduce_binary.cc:113-135,167-198), one thread per group, in T.
+template <typename T>
+__global__ void __launch_bounds__(256) cov_seq_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                      const int32_t* __restrict__ offsets, uint32_t ngroups,
+                                                      const uint8_t* __restrict__ nonfinite, int op, T* __restrict__ out) {
+#pragma clang fp contract(off)
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups || !nonfinite[g]) return;
+  T mean1 = 0, mean2 = 0, var1 = 0, var2 = 0, cov = 0;
+  long long n = 0;
+  for (int32_t p = offsets[g]; p < offsets[g + 1]; p++) {
+    const double xd = x[p], yd = y[p];
+    if (xd != xd || yd != yd) continue;
+    const T v1 = (T)xd, v2 = (T)yd;
+    n++;
+    const T d1 = v1 - mean1, d2 = v2 - mean2;
+    mean1 += d1 / (T)n;
+    mean2 += d2 / (T)n;
+    const T t1 = v1 - mean1, t2 = v2 - mean2;
+    cov += t1 * d2;
+    var1 += t1 * d1;
+    var2 += t2 * d2;
+  }
+  T r = (T)__builtin_nan("");
+  if (op == 1) { if (n > 1) r = cov / (T)(n - 1); }
+  else { const T vv = var1 * var2; if (n > 1 && vv > 0) r = cov / (T)sqrt((double)vv); }
+  out[g] = r;
+}
+
 int launch_moments(dthip_ctx* ctx, const double* x, const double* y, const uint8_t* bitmap, const uint32_t* tile_first_head,
-                   int64_t n, int op, void* out, int out_f32) {
+                   int64_t n, int op, void* out, int out_f32, const int32_t* offsets, int64_t ngroups) {
   MomArgs a{x, y};
-  MomOut o{out, op, out_f32};
+  MomOut o{out, op, out_f32, nullptr};
   const uint32_t* bm = reinterpret_cast<const uint32_t*>(bitmap);
   if (op == 0) return run_segscan<MomP<1>, 1>(ctx, a, bm, tile_first_head, n, 0, o, "gw_apply_kernel<sd>");
-  return run_segscan<MomP<2>, 1>(ctx, a, bm, tile_first_head, n, 0, o, "gw_apply_kernel<cov>");
+  Scratch sc(ctx);
+  DTHIP_TRY(sc.get<uint8_t>((size_t)ngroups, &o.nonfinite));
+  DTHIP_CHECK_HIP(hipMemsetAsync(o.nonfinite, 0, (size_t)ngroups, ctx->stream));
+  DTHIP_TRY((run_segscan<MomP<2>, 1>(ctx, a, bm, tile_first_head, n, 0, o, "gw_apply_kernel<cov>")));
+  const unsigned grid = (unsigned)((ngroups + 255) / 256);
+  if (out_f32) DTHIP_LAUNCH(ctx, "cov_seq_kernel", cov_seq_kernel<float>, grid, 256, 0, x, y, offsets, (uint32_t)ngroups, o.nonfinite, op,
+                            static_cast<float*>(out));
+  else DTHIP_LAUNCH(ctx, "cov_seq_kernel", cov_seq_kernel<double>, grid, 256, 0, x, y, offsets, (uint32_t)ngroups, o.nonfinite, op,
+                    static_cast<double*>(out));
+  return DTHIP_OK;
 }
 
 // ---- policy: cumulative sum / product / min / max -------------------------------------------------

@@ -125,7 +125,7 @@ def clean(cols):
 def main():
     frames, queries = {}, []
     seed = 0
-    while len(queries) < 260:
+    while len(queries) < 700:
         seed += 1
         spec = make_frame(seed)
         with warnings.catch_warnings():

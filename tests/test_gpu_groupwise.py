@@ -245,3 +245,32 @@ def test_groupwise_large(ctx):
     assert nu[0] == len(np.unique(v))
     med = ctx.reduce("median", v, None, one)
     assert med[0] == np.median(v)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_cov_corr_with_infinities(ctx, dt):
+    """groups holding +-inf among their valid pairs: the reference's sequential update ends in +-inf or NaN
+    depending on where the infinity sits; those groups are re-evaluated sequentially on the GPU"""
+    rng = np.random.default_rng(41)
+    n = 60_000
+    k = rng.integers(0, 3000, n).astype(np.int32)
+    a = (rng.standard_normal(n) * 4).astype(dt)
+    b = (rng.standard_normal(n) * 4).astype(dt)
+    for col in (a, b):
+        m = rng.random(n)
+        col[m < 0.002] = np.inf
+        col[(m >= 0.002) & (m < 0.004)] = -np.inf
+        col[(m >= 0.004) & (m < 0.03)] = np.nan
+    ri, off = o.group([k])
+    assert np.isinf(a).sum() > 50 and np.isinf(b).sum() > 50
+    for op in ("cov", "corr"):
+        want = o.reduce2(op, a, b, ri, off)
+        got = ctx.reduce2(op, a, b, ri, off)
+        close(got, want, op, scale=16.0)
+        assert np.isinf(want).any() or op == "corr"
+    # the last row of a group is the infinity: cov stays +-inf there
+    x = np.array([1.0, 2.0, 3.0, 1.0, 2.0, np.inf], dt)
+    y = np.array([2.0, 1.0, np.inf, 5.0, 7.0, 1.0], dt)
+    off2 = np.array([0, 3, 6], np.int32)
+    for op in ("cov", "corr"):
+        assert_same(ctx.reduce2(op, x, y, None, off2), o.reduce2(op, x, y, None, off2), op)
