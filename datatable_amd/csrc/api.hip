@@ -1147,10 +1147,7 @@ int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrow
   DTHIP_TRY(check_common(ctx, nrows, mem));
   if (!keys || !out) { set_error("null argument"); return DTHIP_EINVAL; }
   const bool remove_na = na_pos == DTHIP_NA_REMOVE;
-  if (remove_na) {
-    if (nkeys != 1) { set_error("na_pos REMOVE takes one key column (as the reference's sort(na_position='remove'))"); return DTHIP_ENOTIMPL; }
-    na_pos = DTHIP_NA_FIRST;      // sorted first, then cut off the front (sort.cc:598-608)
-  }
+  if (remove_na) na_pos = DTHIP_NA_FIRST;      // sorted first, then cut off the front (sort.cc:598-608)
   if (na_pos != DTHIP_NA_FIRST && na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", na_pos); return DTHIP_ENOTIMPL; }
   dthip_result* res = new dthip_result();
   res->nkeys = nkeys;
@@ -1173,20 +1170,29 @@ int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrow
             res->rowindex = g.rowindex;
           }
           if (remove_na) {
-            // NA transforms to 0 and nothing else does: the first group is the NA group iff its key is 0
-            unsigned long long k0 = 0;
-            rc = read_back(ctx, &k0, g.sorted_keys, g.key64 ? 8 : 4);
-            int32_t first_end = 0;
-            if (rc == DTHIP_OK) rc = read_back(ctx, &first_end, g.offsets + 1, sizeof(int32_t));
-            if (rc == DTHIP_OK && k0 == 0) {
-              void* off2 = nullptr;
-              rc = result_alloc(ctx, res, sizeof(int32_t) * (size_t)g.ngroups, &off2);
-              if (rc == DTHIP_OK) rc = launch_offsets_drop_first(ctx, g.offsets, static_cast<int32_t*>(off2), g.ngroups - 1, first_end);
+            // SortContext::get_result_rowindex (sort.cc:598-608) cuts `nacount` rows off the front of the
+            // NA-first ordering, where nacount is taken from the column sorted LAST (the context's current
+            // column after continue_sort).  With one key that is exactly its NA group; with several keys it
+            // is whatever leads the ordering -- reproduced as is.
+            int32_t* scratch_idx = nullptr;
+            int64_t skip = 0;
+            rc = sc.get<int32_t>((size_t)nrows, &scratch_idx);
+            if (rc == DTHIP_OK) {
+              PredArgs p{kd[nkeys - 1].data, kd[nkeys - 1].stype, DTHIP_ISNA, 0.0, 0, 0};
+              rc = launch_compact(ctx, p, nrows, scratch_idx, &skip);
+            }
+            if (rc == DTHIP_OK && skip > 0) {
+              int32_t g0 = 0;              // groups that lie entirely inside the cut
+              void* d_g0 = nullptr;
+              rc = result_alloc(ctx, res, sizeof(int32_t) * ((size_t)g.ngroups + 2), &d_g0);
+              int32_t* off2 = static_cast<int32_t*>(d_g0);
+              if (rc == DTHIP_OK) rc = launch_offsets_drop_rows(ctx, g.offsets, g.ngroups, (int32_t)skip, off2, off2 + g.ngroups + 1);
+              if (rc == DTHIP_OK) rc = read_back(ctx, &g0, off2 + g.ngroups + 1, sizeof(int32_t));
               if (rc == DTHIP_OK) {
-                res->offsets = static_cast<int32_t*>(off2);
-                res->ngroups = g.ngroups - 1;
-                res->nrows = nrows - first_end;
-                if (res->rowindex) res->rowindex += first_end;
+                res->offsets = off2;
+                res->ngroups = g.ngroups - g0;
+                res->nrows = nrows - skip;
+                if (res->rowindex) res->rowindex += skip;
               }
             }
           }

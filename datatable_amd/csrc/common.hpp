@@ -202,7 +202,7 @@ int launch_bitmap_from_offsets(dthip_ctx* ctx, const int32_t* offsets, int64_t n
                                unsigned long long* bitmap, uint32_t* tile_counts, uint32_t* d_total);
 int launch_iota(dthip_ctx* ctx, int32_t* out, int64_t n);
 int launch_ungroup(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int32_t* out);
-int launch_offsets_drop_first(dthip_ctx* ctx, const int32_t* in, int32_t* out, int64_t ng_out, int32_t skip);
+int launch_offsets_drop_rows(dthip_ctx* ctx, const int32_t* in, int64_t ngroups, int32_t skip, int32_t* out, int32_t* g0_out);
 int launch_untransform_keys(dthip_ctx* ctx, const void* sorted_keys, int key64, const int32_t* offsets,
                             int64_t ngroups, const KeyColDev& col, int bits, void* out);
 

@@ -261,15 +261,24 @@ int launch_ungroup(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int6
   return DTHIP_OK;
 }
 
-// NaPosition::REMOVE (sort.cc:598-608): the NA group sorted first is cut off the front
-__global__ void __launch_bounds__(256) offsets_drop_first_kernel(const int32_t* in, int32_t* out, uint32_t ng_out, int32_t skip) {
-  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-  if (g <= ng_out) out[g] = in[g + 1] - skip;
+// NaPosition::REMOVE (sort.cc:598-608): `skip` rows are cut off the front of the ordering.  g0 = groups
+// that end inside the cut; the result's offsets are out[0] = 0, out[i] = in[g0 + i] - skip.
+__global__ void __launch_bounds__(256) offsets_drop_rows_kernel(const int32_t* __restrict__ in, uint32_t ngroups, int32_t skip,
+                                                                int32_t* __restrict__ out, int32_t* __restrict__ g0_out) {
+  uint32_t lo = 0, hi = ngroups;                 // g0 = number of groups with in[g + 1] <= skip
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (in[mid + 1] <= skip) lo = mid + 1; else hi = mid;
+  }
+  const uint32_t g0 = lo;
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) *g0_out = (int32_t)g0;
+  if (i <= ngroups - g0) out[i] = i == 0 ? 0 : in[g0 + i] - skip;
 }
 
-int launch_offsets_drop_first(dthip_ctx* ctx, const int32_t* in, int32_t* out, int64_t ng_out, int32_t skip) {
-  DTHIP_LAUNCH(ctx, "offsets_drop_first_kernel", offsets_drop_first_kernel, (unsigned)((ng_out + 256) / 256), 256, 0,
-               in, out, (uint32_t)ng_out, skip);
+int launch_offsets_drop_rows(dthip_ctx* ctx, const int32_t* in, int64_t ngroups, int32_t skip, int32_t* out, int32_t* g0_out) {
+  DTHIP_LAUNCH(ctx, "offsets_drop_rows_kernel", offsets_drop_rows_kernel, (unsigned)((ngroups + 256) / 256), 256, 0,
+               in, (uint32_t)ngroups, skip, out, g0_out);
   return DTHIP_OK;
 }
 

@@ -33,6 +33,8 @@ __device__ __forceinline__ bool pred_at(const PredArgs& p, uint32_t i) {
     case DTHIP_FLOAT32: { float v = static_cast<const float*>(p.data)[i]; na = v != v; fv = v; isf = true; break; }
     default: { double v = static_cast<const double*>(p.data)[i]; na = v != v; fv = v; isf = true; break; }
   }
+  if (p.cmp == DTHIP_NOTNA) return !na;
+  if (p.cmp == DTHIP_ISNA) return na;
   if (isf) {
     switch (p.cmp) {
       case DTHIP_GT: return !na && fv > p.cf;   case DTHIP_GE: return !na && fv >= p.cf;

@@ -82,6 +82,27 @@ def _cols(cols, stypes=None, desc=None):
     return arr, (L.HOST if mem is None else mem), keep
 
 
+def _cmp_args(cmp, scalar, stype):
+    """(dthip_cmp code, float scalar, int scalar) of `column <cmp> scalar`.  An integer column compared with a
+    non-integral number is compared as numbers, like the reference does (the column is up-cast): == never holds,
+    != always does (NA included, as for any !=), the orderings round the scalar towards the side that keeps the
+    meaning.  INT64_MIN as the integer scalar of == / != is a value no valid element has."""
+    import math
+    code = CMP[cmp]
+    if stype in (L.FLOAT32, L.FLOAT64):
+        return code, float(scalar), 0
+    f = float(scalar)
+    if math.isfinite(f) and f != math.floor(f):
+        if cmp in (">", ">="):
+            return CMP[">="], f, int(math.ceil(f))
+        if cmp in ("<", "<="):
+            return CMP["<="], f, int(math.floor(f))
+        return code, f, -2**63
+    if not math.isfinite(f):
+        raise NotImplementedError("comparison of an integer column with %r" % (scalar,))
+    return code, f, int(scalar)
+
+
 class Result:
     """Device-resident result of a groupby (dthip_result)."""
 
@@ -422,9 +443,8 @@ class Context:
         a, col = _host_col(values, stype)
         out = np.empty(len(a), np.int32)
         k = C.c_int64(0)
-        isf = col.stype in (L.FLOAT32, L.FLOAT64)
-        L.check(self._lib.dthip_filter_cmp(self._h, C.byref(col), len(a), CMP[cmp], float(scalar),
-                                           0 if isf else int(scalar), L.HOST, out.ctypes.data, C.byref(k)))
+        code, cf, ci = _cmp_args(cmp, scalar, col.stype)
+        L.check(self._lib.dthip_filter_cmp(self._h, C.byref(col), len(a), code, cf, ci, L.HOST, out.ctypes.data, C.byref(k)))
         return out[:k.value].copy()
 
     # device-resident variants (raw HBM pointers in, raw HBM pointers out)
@@ -432,9 +452,8 @@ class Context:
         """rows of DevCol `col` with col <cmp> scalar -> ascending int32 RowIndex at out_ptr (room for nrows); returns the count"""
         c = L.Col(col.ptr, col.stype, 0)
         k = C.c_int64(0)
-        isf = col.stype in (L.FLOAT32, L.FLOAT64)
-        L.check(self._lib.dthip_filter_cmp(self._h, C.byref(c), nrows, CMP[cmp], float(scalar), 0 if isf else int(scalar),
-                                           L.DEVICE, C.c_void_p(out_ptr), C.byref(k)))
+        code, cf, ci = _cmp_args(cmp, scalar, col.stype)
+        L.check(self._lib.dthip_filter_cmp(self._h, C.byref(c), nrows, code, cf, ci, L.DEVICE, C.c_void_p(out_ptr), C.byref(k)))
         return k.value
 
     def range_bucket_dev(self, col, nrows, bounds, out_ptr):

@@ -588,6 +588,17 @@ class Frame:
         """Frame.sort(cols): ascending, NA first (src/core/sort.cc:539-558)"""
         return self._sorted(sort(*cols))
 
+    def _by_sort_order(self, ctx, keys, kst, kdesc, srt):
+        """RowIndex that orders the rows by the by-columns, then (inside groups) by the sort() columns"""
+        skeys, sst, sdesc = list(keys), list(kst), list(kdesc)
+        for c, rev in zip(srt.cols, srt.reverse):
+            ci = self._index(c)
+            skeys.append(self._materialized(ci)); sst.append(self._stypes[ci]); sdesc.append(bool(rev) ^ bool(c.desc))
+        res = ctx.groupby(skeys, stypes=sst, desc=sdesc, na_last=srt.na_last)
+        ri = res.rowindex()
+        res.free()
+        return ri
+
     def _groupby(self, j, byx, srt):
         """DT[:, j, by(...)[, sort(...)]]  (EvalContext::evaluate, src/core/expr/eval_context.cc:144-172,
         249-288; evaluate_select :497-508).  The result has one row per group when every j item is a
@@ -669,6 +680,8 @@ class Frame:
                 cols.append(np.zeros(0, ST2NP[kst[k]])); sts.append(kst[k])
             for _, x in items:
                 st = out_stype(x)
+                if isinstance(x, Reducer) and x.op == "median":
+                    st = self._stypes[self._index(x.arg)]      # the reference leaves median's type alone on 0 rows
                 dtp = ST2NP[st]
                 if not one:
                     cols.append(np.zeros(0, dtp))
@@ -683,7 +696,9 @@ class Frame:
             # DT[:, sum(f.v)] without by(): one group over all rows
             keys, kst, kdesc = [np.zeros(self.nrows, np.int8)], [L.INT8], [False]
 
-        fusable = all(isinstance(x, Reducer) and x.op in _FUSED_OPS for x in reducers)
+        # first() / last() see the rows of a group in the order by() + sort() put them in
+        ordered = srt is not None and any(isinstance(x, Reducer) and x.op in ("first", "last") for x in reducers)
+        fusable = all(isinstance(x, Reducer) and x.op in _FUSED_OPS for x in reducers) and not ordered
         if group_level and fusable and (reducers or not items):
             # fused groupby-aggregate: one row per group
             vidx, aggs = [], []
@@ -729,8 +744,13 @@ class Frame:
             # one row per group, with reducers the fused aggregation does not carry (sd, median, nunique,
             # cov, corr), or only by-columns: group once, reduce per item; the by-columns take their value
             # at the first row of each group (eval_context.cc:473-485)
-            g = ctx.groupby(keys, stypes=kst, desc=kdesc)
-            gri, goff = g.rowindex(), g.offsets()
+            if ordered:
+                gri = self._by_sort_order(ctx, keys, kst, kdesc, srt)
+                g = ctx.groupby(keys, stypes=kst, desc=kdesc, want_rowindex=False)
+                goff = g.offsets()
+            else:
+                g = ctx.groupby(keys, stypes=kst, desc=kdesc)
+                gri, goff = g.rowindex(), g.offsets()
             g.free()
             first = ctx.gather(gri, goff[:-1])
             kcols = [ctx.gather(keys[k], first, stype=kst[k]) for k in range(len(kidx))]
@@ -744,16 +764,12 @@ class Frame:
             return Frame._from_columns(cols, sts, names)
 
         # the ordering: by-columns, then (inside groups) the sort() columns
-        skeys, sst, sdesc, na_last = list(keys), list(kst), list(kdesc), False
         if srt is not None:
-            for c, rev in zip(srt.cols, srt.reverse):
-                ci = self._index(c)
-                skeys.append(self._materialized(ci)); sst.append(self._stypes[ci]); sdesc.append(bool(rev) ^ bool(c.desc))
-            na_last = srt.na_last
-        res = ctx.groupby(skeys, stypes=sst, desc=sdesc, na_last=na_last)
-        ri = res.rowindex()
-        goff = res.offsets() if srt is None else None
-        res.free()
+            ri, goff = self._by_sort_order(ctx, keys, kst, kdesc, srt), None
+        else:
+            res = ctx.groupby(keys, stypes=kst, desc=kdesc)
+            ri, goff = res.rowindex(), res.offsets()
+            res.free()
         full_ri = ri if self._ri is None else ctx.gather(self._ri, ri)
 
         if not reducers and not cums:

@@ -95,15 +95,18 @@ enum dthip_cumop {
 
 enum dthip_mem { DTHIP_HOST = 0, DTHIP_DEVICE = 1 };
 
-/* NaPosition, src/core/sort.h:46-50.  REMOVE: dthip_groupby with one key only (the reference's
- * sort(na_position="remove")): rows whose key is NA are left out of the RowIndex and the groups */
+/* NaPosition, src/core/sort.h:46-50.  REMOVE (dthip_groupby; the reference's sort(na_position="remove")):
+ * the rows are ordered NA first and as many rows as the LAST key column has NAs are cut off the front
+ * (SortContext::get_result_rowindex, sort.cc:598-608, reads the NA count of the column sorted last): with
+ * one key exactly its NA rows */
 enum dthip_napos { DTHIP_NA_FIRST = 0, DTHIP_NA_LAST = 1, DTHIP_NA_REMOVE = 2 };
 
 /* SortFlag bits, src/core/sort.h:36-44 */
 #define DTHIP_FLAG_DESCENDING 1
 
 /* comparison codes for dthip_filter_cmp */
-enum dthip_cmp { DTHIP_GT = 0, DTHIP_GE = 1, DTHIP_LT = 2, DTHIP_LE = 3, DTHIP_EQ = 4, DTHIP_NE = 5 };
+enum dthip_cmp { DTHIP_GT = 0, DTHIP_GE = 1, DTHIP_LT = 2, DTHIP_LE = 3, DTHIP_EQ = 4, DTHIP_NE = 5,
+                 DTHIP_NOTNA = 6, DTHIP_ISNA = 7 /* the scalar is ignored: rows whose value is valid / NA */ };
 
 /* one typed column buffer: contiguous T[nrows] with sentinel NAs
  * (SentinelFw_ColumnImpl<T>, src/core/column/sentinel_fw.cc:141-181) */

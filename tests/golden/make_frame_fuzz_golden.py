@@ -42,7 +42,7 @@ def rand_col(st, n, role):
 
 def make_frame(seed):
     rnd.seed(seed)
-    n = rnd.choice([1, 2, 7, 40, 150])
+    n = rnd.choice([1, 2, 7, 40, 150] if seed < 100000 else [0, 1, 3, 20, 90])
     spec = {}
     for i in range(rnd.randint(1, 2)):
         spec["k%d" % i] = (rand_col(rnd.choice([1, 2, 3, 4, 5, 4, 5, 7]), n, "key"), None)
@@ -105,6 +105,45 @@ def rand_query(names):
     return "DT[:, :, %s, sort(f.%s)]" % (bys, rnd.choice(vals))
 
 
+def rand_query2(names):
+    keys = [nm for nm in names if nm.startswith("k")]
+    vals = [nm for nm in names if nm.startswith("v")]
+    kk = rnd.sample(keys, rnd.randint(1, len(keys)))
+    style = rnd.random()
+    if style < 0.3:
+        bys = "by(%s)" % ", ".join("'%s'" % k for k in kk)
+    else:
+        bys = "by(%s)" % ", ".join("f.%s" % k for k in kk)
+    kind = rnd.random()
+    if kind < 0.2:
+        return "DT[:, %s(f[:]), %s]" % (rnd.choice(RED + CUM), bys)
+    if kind < 0.3:
+        return "DT[:, %s(f[:])]" % rnd.choice(RED + CUM)
+    if kind < 0.45:
+        items = ", ".join("'%s': %s(f.%s)" % (nm, rnd.choice(RED), rnd.choice(vals)) for nm in rnd.sample(["a", "b", "v0", "k0", "zz"], rnd.randint(1, 3)))
+        return "DT[:, {%s}, %s]" % (items, bys)
+    if kind < 0.55:
+        return "DT[:, [f.%s, %s(f.%s), count()], %s]" % (rnd.choice(vals), rnd.choice(RED), rnd.choice(vals), bys)
+    if kind < 0.65:
+        return "DT[:, [%s(f.%s), %s(f.%s)], %s, sort(%sf.%s)]" % (rnd.choice(["first", "last", "cumsum", "cummax"]), rnd.choice(vals),
+                                                                    rnd.choice(["first", "last", "cumcount"]).replace("cumcount", "max"), rnd.choice(vals), bys,
+                                                                    rnd.choice(["", "-"]), rnd.choice(vals))
+    if kind < 0.75:
+        v, w = rnd.choice(vals), rnd.choice(vals)
+        return "DT[f.%s %s %s, :][f.%s %s %s, :][:, [count(), %s(f.%s)], %s]" % (
+            v, rnd.choice([">", "<=", "!="]), rnd.choice(["0", "1", "-2"]), w, rnd.choice(["<", ">=", "=="]), rnd.choice(["0", "3", "1.5"]),
+            rnd.choice(RED), rnd.choice(vals), bys)
+    if kind < 0.82:
+        return "DT[:, %s, %s]" % (rnd.choice(["f[:]", "':'".strip("'"), "[f.%s, f.%s]" % (rnd.choice(names), rnd.choice(names))]), bys)
+    if kind < 0.9:
+        return "DT[:, [f.%s, f.%s], sort(f.%s, f.%s, na_position='%s')]" % (rnd.choice(names), rnd.choice(names), rnd.choice(names), rnd.choice(names),
+                                                                          rnd.choice(["first", "last", "remove"]))
+    if kind < 0.95:
+        return "DT[:, [%s(f.%s, f.%s), %s(f.%s, f[:])], %s]" % (rnd.choice(["cov", "corr"]), rnd.choice(vals), rnd.choice(vals),
+                                                                 rnd.choice(["cov", "corr"]), rnd.choice(vals), bys)
+    return "DT[:, [cumcount(), ngroup(), count()], %s]" % bys
+
+
 def clean(cols):
     out = []
     for c in cols:
@@ -122,10 +161,11 @@ def clean(cols):
     return out
 
 
-def main():
+def main(batch=1):
     frames, queries = {}, []
-    seed = 0
-    while len(queries) < 700:
+    seed = 0 if batch == 1 else 100000
+    gen = rand_query if batch == 1 else rand_query2
+    while len(queries) < (700 if batch == 1 else 400):
         seed += 1
         spec = make_frame(seed)
         with warnings.catch_warnings():
@@ -137,7 +177,7 @@ def main():
         fname = "fz%d" % seed
         frames[fname] = {nm: {"values": clean([DT[:, nm].to_list()[0]])[0], "stype": DT.stypes[i].value} for i, nm in enumerate(DT.names)}
         for _ in range(4):
-            q = rand_query(list(DT.names))
+            q = gen(list(DT.names))
             try:
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
@@ -148,7 +188,7 @@ def main():
                                 "columns": clean(R.to_list())})
             except Exception as e:      # the reference refuses the query: record its exception type
                 queries.append({"frame": fname, "query": q, "error": type(e).__name__})
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "frame_fuzz.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "frame_fuzz.json" if batch == 1 else "frame_fuzz2.json")
     json.dump({"frames": frames, "queries": queries}, open(path, "w"))
     nerr = len([q for q in queries if "error" in q])
     print("wrote %s: %d frames, %d queries (%d refused by the reference)" % (path, len(frames), len(queries), nerr))
@@ -157,4 +197,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
