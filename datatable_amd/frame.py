@@ -534,6 +534,13 @@ class Frame:
         if jn is not None:
             if byx or srt or not all_rows:
                 raise NotImplementedError("join() combined with i / by() / sort() is outside the accelerated path")
+            if not (j is None or j is Ellipsis or (isinstance(j, slice) and j == slice(None))):
+                # a name in j refers to the left frame only (the joined columns are `g.` columns in the
+                # reference, outside this mirror): an unknown one is the reference's KeyError
+                items = list(j.values()) if isinstance(j, dict) else (list(j) if isinstance(j, (list, tuple)) else [j])
+                for r in items:
+                    if isinstance(r, (str, ColRef, int, np.integer)):
+                        self._index(r)
             return self._joined(jn.frame)._select(j)
         if isinstance(i, Filter):
             if byx or srt:

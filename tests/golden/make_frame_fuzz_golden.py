@@ -144,6 +144,93 @@ def rand_query2(names):
     return "DT[:, [cumcount(), ngroup(), count()], %s]" % bys
 
 
+def keyed(F, *names):
+    G = F.copy()
+    G.key = names if len(names) > 1 else names[0]
+    return G
+
+
+def batch3():
+    """set functions, unique, keys and natural joins over several frames"""
+    from datatable import union, intersect, setdiff, symdiff, unique, join
+    cases = []
+    rnd.seed(3000)
+    while len(cases) < 300:
+        kind = rnd.random()
+        frames = {}
+        if kind < 0.5:
+            # set functions over 1..4 single-column frames, stypes may differ (rbind up-casts)
+            nsrc = rnd.randint(1, 4)
+            base = rnd.choice([2, 3, 4, 5, 7, 4, 5])
+            for i in range(nsrc):
+                st = base if rnd.random() < 0.7 else rnd.choice([2, 3, 4, 5, 6, 7])
+                n = rnd.choice([0, 1, 5, 30])
+                frames["S%d" % i] = {"c%d" % i: (rand_col(st, n, "key"), st)}
+            fn = rnd.choice(["union", "intersect", "setdiff", "symdiff"])
+            q = "%s(%s)" % (fn, ", ".join(sorted(frames)))
+        elif kind < 0.6:
+            ncol = rnd.randint(1, 3)
+            st = rnd.choice([2, 3, 4, 5, 7])
+            n = rnd.choice([1, 6, 25])
+            frames["DT"] = {"c%d" % i: (rand_col(st if rnd.random() < 0.7 else rnd.choice([4, 5, 7]), n, "key"), None) for i in range(ncol)}
+            q = "unique(DT)"
+        else:
+            nk = rnd.choice([1, 1, 2])
+            jst = [rnd.choice([2, 3, 4, 5, 4, 5, 7]) for _ in range(nk)]
+            xst = [st if rnd.random() < 0.6 else rnd.choice([2, 3, 4, 5, 7]) for st in jst]
+            nj, nx = rnd.choice([0, 1, 8, 30]), rnd.choice([0, 1, 10, 60])
+            tuples = set()
+            for _ in range(nj):
+                tuples.add(tuple((None if rnd.random() < 0.05 else (rnd.randint(-6, 6) if st != 7 else rnd.randint(-12, 12) / 2.0)) for st in jst))
+            tuples = list(tuples)
+            rnd.shuffle(tuples)
+            J = {"K%d" % k: ([t[k] for t in tuples], jst[k]) for k in range(nk)}
+            J["W"] = ([rnd.randint(-99, 99) for _ in tuples], 4)
+            J["Z"] = ([rnd.random() < 0.5 for _ in tuples], 1)
+            X = {"K%d" % k: ([None if rnd.random() < 0.05 else (rnd.randint(-7, 7) if xst[k] != 7 else rnd.randint(-14, 14) / 2.0) for _ in range(nx)], xst[k]) for k in range(nk)}
+            X["P"] = (list(range(nx)), 4)
+            frames = {"X": X, "J": J}
+            names = ", ".join("'K%d'" % k for k in range(nk))
+            q = rnd.choice(["X[:, :, join(keyed(J, %s))]", "keyed(J, %s)", "X[:, ['P', 'W'], join(keyed(J, %s))]"]) % names
+        # build reference frames
+        env = {}
+        ok = True
+        for fname, spec in frames.items():
+            cols, sts, nms = [], [], []
+            for nm, (vals, st) in spec.items():
+                nms.append(nm); cols.append(vals); sts.append(st)
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    F = dt.Frame(cols, names=nms, stypes=[ST[s] if s else None for s in sts]) if any(sts) else dt.Frame(cols, names=nms)
+            except Exception:
+                ok = False
+                break
+            if any(s.value not in ST for s in F.stypes):
+                ok = False
+                break
+            env[fname] = F
+        if not ok:
+            continue
+        ns = dict(env, union=union, intersect=intersect, setdiff=setdiff, symdiff=symdiff, unique=unique, join=join, keyed=keyed)
+        rec = {"frames": {fname: {nm: {"values": clean([F[:, nm].to_list()[0]])[0], "stype": F.stypes[i].value} for i, nm in enumerate(F.names)}
+                          for fname, F in env.items()}, "query": q}
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                R = eval(q, ns)
+            if any(s.value not in ST for s in R.stypes):
+                continue
+            rec.update({"names": list(R.names), "stypes": [s.value for s in R.stypes], "columns": clean(R.to_list()), "nkeys": len(R.key)})
+        except Exception as e:
+            rec.update({"error": type(e).__name__, "message": str(e)[:200]})
+        cases.append(rec)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "frame_fuzz3.json")
+    json.dump({"cases": cases}, open(path, "w"))
+    from collections import Counter
+    print("wrote %s: %d cases; errors: %s" % (path, len(cases), Counter(c.get("error") for c in cases if "error" in c)))
+
+
 def clean(cols):
     out = []
     for c in cols:
@@ -197,4 +284,8 @@ def main(batch=1):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    if b == 3:
+        batch3()
+    else:
+        main(b)

@@ -89,3 +89,45 @@ def test_fuzz_query_matches_reference(qi):
                 assert abs(x - y) <= rel * abs(y) + 1e-9, (q["names"][ci], ri, x, y)
             else:
                 assert x == y and type(x) is type(y), (q["names"][ci], ri, g[:12], e[:12])
+
+
+# ---- set functions, unique, keys, joins over several frames (batch 3 of make_frame_fuzz_golden.py) ------
+FUZZ3 = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_fuzz3.json")))["cases"]
+
+
+@pytest.mark.parametrize("ci", range(len(FUZZ3)), ids=["%d:%s" % (i, c["query"][:50]) for i, c in enumerate(FUZZ3)])
+def test_fuzz_sets_keys_joins_match_reference(ci):
+    """300 seeded random cases: union / intersect / setdiff / symdiff over 1-4 frames of possibly different
+    stypes, unique(), Frame.key, natural joins with 1-2 keys of possibly different stypes -- names, stypes,
+    values, key count, or the exception type, as the unmodified reference produced them"""
+    from datatable_amd import frame as dt
+    from datatable_amd.frame import union, intersect, setdiff, symdiff, unique, join   # noqa: F401
+    c = FUZZ3[ci]
+
+    def keyed(F, *names):
+        G = dt.Frame(F)
+        G.key = list(names) if len(names) > 1 else names[0]
+        return G
+
+    ns = dict(union=union, intersect=intersect, setdiff=setdiff, symdiff=symdiff, unique=unique, join=join, keyed=keyed)
+    for fname, spec in c["frames"].items():
+        ns[fname] = dt.Frame({nm: [_dec2(x) for x in col["values"]] for nm, col in spec.items()},
+                             stypes={nm: col["stype"] for nm, col in spec.items()})
+    if "error" in c:
+        with pytest.raises(Exception) as e:
+            eval(c["query"], ns)
+        assert type(e.value).__name__ == c["error"], (type(e.value).__name__, str(e.value), c["message"])
+        return
+    R = eval(c["query"], ns)
+    assert list(R.names) == c["names"]
+    assert list(R.stypes) == c["stypes"]
+    assert len(R.key) == c["nkeys"]
+    got = R.to_list()
+    assert len(got) == len(c["columns"])
+    for k, (g, e) in enumerate(zip(got, c["columns"])):
+        e = [_dec2(x) for x in e]
+        assert len(g) == len(e), (c["names"][k], len(g), len(e))
+        for x, y in zip(g, e):
+            assert x == y and type(x) is type(y), (c["names"][k], g[:12], e[:12])
+            if isinstance(y, float) and y == 0:
+                assert math.copysign(1, x) == math.copysign(1, y), (c["names"][k], "sign of zero")
