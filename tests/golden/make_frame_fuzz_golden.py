@@ -144,6 +144,34 @@ def rand_query2(names):
     return "DT[:, [cumcount(), ngroup(), count()], %s]" % bys
 
 
+def rand_query4(names):
+    """chains of views: filters, sorts and column selections stacked before a final by() / sort()"""
+    keys = [nm for nm in names if nm.startswith("k")]
+    vals = [nm for nm in names if nm.startswith("v")]
+    q = "DT"
+    for _ in range(rnd.randint(1, 3)):
+        r = rnd.random()
+        if r < 0.5:
+            q += "[f.%s %s %s, :]" % (rnd.choice(names), rnd.choice([">", ">=", "<", "<=", "==", "!="]), rnd.choice(["0", "1", "-1", "2", "0.5", "True"]))
+        elif r < 0.8:
+            q += "[:, :, sort(%s%s)]" % (", ".join("f.%s" % c for c in rnd.sample(names, rnd.randint(1, 2))), rnd.choice(["", ", reverse=True"]))
+        else:
+            q += "[:, :, by(f.%s)]" % rnd.choice(keys)
+    r = rnd.random()
+    k = rnd.choice(keys)
+    if r < 0.35:
+        q += "[:, [%s(f.%s), %s(f.%s), count()], by(f.%s)]" % (rnd.choice(RED), rnd.choice(vals), rnd.choice(RED), rnd.choice(vals), k)
+    elif r < 0.5:
+        q += "[:, [%s(f.%s), %s(f.%s%s)], by(f.%s)]" % (rnd.choice(CUM), rnd.choice(vals), rnd.choice(CUM), rnd.choice(vals), rnd.choice(["", ", reverse=True"]), k)
+    elif r < 0.65:
+        q += "[:, [%s]]" % ", ".join("'%s'" % c for c in rnd.sample(names, rnd.randint(1, len(names))))
+    elif r < 0.8:
+        q += "[:, [%s(f.%s), %s(f.%s)]]" % (rnd.choice(RED), rnd.choice(vals), rnd.choice(RED), rnd.choice(names))
+    elif r < 0.9:
+        q += "[:, f.%s, by(f.%s)]" % (rnd.choice(vals), k)
+    return q
+
+
 def keyed(F, *names):
     G = F.copy()
     G.key = names if len(names) > 1 else names[0]
@@ -250,9 +278,9 @@ def clean(cols):
 
 def main(batch=1):
     frames, queries = {}, []
-    seed = 0 if batch == 1 else 100000
-    gen = rand_query if batch == 1 else rand_query2
-    while len(queries) < (700 if batch == 1 else 400):
+    seed = {1: 0, 2: 100000, 4: 200000}[batch]
+    gen = {1: rand_query, 2: rand_query2, 4: rand_query4}[batch]
+    while len(queries) < {1: 700, 2: 400, 4: 400}[batch]:
         seed += 1
         spec = make_frame(seed)
         with warnings.catch_warnings():
@@ -275,7 +303,7 @@ def main(batch=1):
                                 "columns": clean(R.to_list())})
             except Exception as e:      # the reference refuses the query: record its exception type
                 queries.append({"frame": fname, "query": q, "error": type(e).__name__})
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "frame_fuzz.json" if batch == 1 else "frame_fuzz2.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), {1: "frame_fuzz.json", 2: "frame_fuzz2.json", 4: "frame_fuzz4.json"}[batch])
     json.dump({"frames": frames, "queries": queries}, open(path, "w"))
     nerr = len([q for q in queries if "error" in q])
     print("wrote %s: %d frames, %d queries (%d refused by the reference)" % (path, len(frames), len(queries), nerr))

@@ -52,9 +52,11 @@ def test_frame_query_matches_reference(qi):
 # ---- randomised queries (tests/golden/make_frame_fuzz_golden.py) -----------------------------------
 FUZZ = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_fuzz.json")))
 FUZZ2 = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_fuzz2.json")))     # other query templates (batch 2)
-for _k, _v in FUZZ2["frames"].items():
-    FUZZ["frames"][_k] = _v
-FUZZ["queries"] += FUZZ2["queries"]
+FUZZ4 = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_fuzz4.json")))     # chains of views (batch 4)
+for _F in (FUZZ2, FUZZ4):
+    for _k, _v in _F["frames"].items():
+        FUZZ["frames"][_k] = _v
+    FUZZ["queries"] += _F["queries"]
 
 
 def _dec2(x):
@@ -65,7 +67,7 @@ def _dec2(x):
 
 @pytest.mark.parametrize("qi", range(len(FUZZ["queries"])), ids=["%d:%s" % (i, q["query"][:60]) for i, q in enumerate(FUZZ["queries"])])
 def test_fuzz_query_matches_reference(qi):
-    """1100 seeded random queries over 275 random frames (all fixed-width stypes, NAs, +-inf, -0.0 keys):
+    """1500 seeded random queries over 375 random frames (all fixed-width stypes, NAs, +-inf, -0.0 keys):
     names, stypes and values as the unmodified reference returned them"""
     from datatable_amd import frame as dt
     from datatable_amd.frame import f, by, sort, sum, mean, min, max, count, first, last   # noqa: F401,A004
