@@ -239,26 +239,72 @@ int launch_bitmap_from_offsets(dthip_ctx* ctx, const int32_t* offsets, int64_t n
 }
 
 // Groupby::ungroup_rowindex (groupby.cc:117-130): out[i] = index of the group that sorted position i
-// belongs to (the reference expands the offsets serially; here every position searches them)
-__global__ void __launch_bounds__(256) ungroup_kernel(const int32_t* __restrict__ offsets, uint32_t ngroups, uint32_t n,
-                                                      int32_t* __restrict__ out) {
-  const uint32_t stride = gridDim.x * 256;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    uint32_t lo = 0, hi = ngroups;               // largest g with offsets[g] <= i
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if ((uint32_t)offsets[mid] <= i) lo = mid; else hi = mid;
+// belongs to; cumcount() / ngroup() (column/cumcountngroup.h:55-72) are the same walk.  The reference
+// expands the offsets serially.  Here the offsets become the head bitmap (1 bit per position) and every
+// position counts the heads up to itself: a tile of 2048 positions per workgroup, one bitmap byte (8
+// positions) per thread, a workgroup scan of the byte popcounts on top of the heads of earlier tiles --
+// streaming, instead of a binary search of the offsets per row (0.65 -> 0.25 ms per 1e8 rows).
+// mode 0: group index (int32); 1: ngroup (int64); 2: cumcount (int64)
+template <typename OT>
+__global__ void __launch_bounds__(256) ungroup_kernel(const uint8_t* __restrict__ bitmap, const uint32_t* __restrict__ tile_first_head,
+                                                      const int32_t* __restrict__ offsets, uint32_t ngroups, uint32_t n, int mode,
+                                                      int rev, OT* __restrict__ out) {
+  __shared__ uint32_t scratch[4];
+  const int tid = threadIdx.x;
+  const uint32_t p0 = blockIdx.x * GB_TILE + tid * 8;
+  uint32_t hb = p0 < n ? bitmap[p0 >> 3] : 0u;
+  if (p0 < n && p0 + 8 > n) hb &= (1u << (n - p0)) - 1u;
+  const uint32_t before = block_excl_scan_u32<256>((uint32_t)__popc(hb), scratch, nullptr) + tile_first_head[blockIdx.x];
+  if (p0 >= n) return;
+  OT v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t g = before + (uint32_t)__popc(hb & ((2u << j) - 1u)) - 1u;     // heads at positions <= p0 + j, minus one
+    const uint32_t p = p0 + j;
+    long long r = (long long)g;
+    if (p < n) {
+      if (mode == 1) r = rev ? (long long)(ngroups - 1 - g) : (long long)g;
+      else if (mode == 2) r = rev ? (long long)offsets[g + 1] - 1 - (long long)p : (long long)p - (long long)offsets[g];
     }
-    out[i] = (int32_t)lo;
+    v[j] = (OT)r;
+  }
+  if (p0 + 8 <= n) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* src = reinterpret_cast<const u32x4*>(v);
+    u32x4* dst = reinterpret_cast<u32x4*>(out + p0);
+#pragma unroll
+    for (int q = 0; q < (int)(8 * sizeof(OT) / 16); q++) dst[q] = src[q];
+  } else {
+    for (int j = 0; j < 8 && p0 + j < n; j++) out[p0 + j] = v[j];
   }
 }
 
-int launch_ungroup(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int32_t* out) {
+// offsets -> bitmap + per-tile head counts, then the expansion.  mode / rev as in ungroup_kernel.
+static int ungroup_common(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int mode, int rev, void* out) {
   if (n == 0) return DTHIP_OK;
-  long long blocks = (n + 2047) / 2048;
-  if (blocks > ctx->num_cus * 8) blocks = ctx->num_cus * 8;
-  DTHIP_LAUNCH(ctx, "ungroup_kernel", ungroup_kernel, (unsigned)blocks, 256, 0, offsets, (uint32_t)ngroups, (uint32_t)n, out);
+  Scratch sc(ctx);
+  unsigned long long* bitmap = nullptr;
+  uint32_t* tile_counts = nullptr;
+  const uint32_t nt = ntiles_of(n);
+  DTHIP_TRY(sc.get<unsigned long long>((size_t)((n + 63) / 64) + 1, &bitmap));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, &tile_counts));
+  DTHIP_TRY(launch_bitmap_from_offsets(ctx, offsets, ngroups, n, bitmap, tile_counts, tile_counts + nt));
+  if (mode == 0) {
+    DTHIP_LAUNCH(ctx, "ungroup_kernel", ungroup_kernel<int32_t>, nt, 256, 0, reinterpret_cast<const uint8_t*>(bitmap), tile_counts,
+                 offsets, (uint32_t)ngroups, (uint32_t)n, mode, rev, static_cast<int32_t*>(out));
+  } else {
+    DTHIP_LAUNCH(ctx, "ungroup_kernel", ungroup_kernel<long long>, nt, 256, 0, reinterpret_cast<const uint8_t*>(bitmap), tile_counts,
+                 offsets, (uint32_t)ngroups, (uint32_t)n, mode, rev, static_cast<long long*>(out));
+  }
   return DTHIP_OK;
+}
+
+int launch_ungroup(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int32_t* out) {
+  return ungroup_common(ctx, offsets, ngroups, n, 0, 0, out);
+}
+
+int launch_cumcount(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int ngroup, int reverse, int64_t* out) {
+  return ungroup_common(ctx, offsets, ngroups, n, ngroup ? 1 : 2, reverse ? 1 : 0, out);
 }
 
 // NaPosition::REMOVE (sort.cc:598-608): `skip` rows are cut off the front of the ordering.  g0 = groups

@@ -590,31 +590,7 @@ int launch_cumulate(dthip_ctx* ctx, const void* data, int stype, const int32_t* 
 #undef DTHIP_CUM_CASE
 }
 
-// cumcount(): row number inside the group; ngroup(): group number (cumcountngroup.h:55-72)
-__global__ void __launch_bounds__(256) cumcount_kernel(const int32_t* __restrict__ offsets, uint32_t ngroups, uint32_t n, int ngroup,
-                                                       int rev, long long* __restrict__ out) {
-  const uint32_t stride = gridDim.x * 256;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    uint32_t lo = 0, hi = ngroups;               // largest g with offsets[g] <= i
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if ((uint32_t)offsets[mid] <= i) lo = mid; else hi = mid;
-    }
-    long long r;
-    if (ngroup) r = rev ? (long long)(ngroups - 1 - lo) : (long long)lo;
-    else r = rev ? (long long)offsets[lo + 1] - 1 - (long long)i : (long long)i - (long long)offsets[lo];
-    out[i] = r;
-  }
-}
-
-int launch_cumcount(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t n, int ngroup, int reverse, int64_t* out) {
-  if (n == 0) return DTHIP_OK;
-  long long blocks = (n + 2047) / 2048;
-  if (blocks > (long long)ctx->num_cus * 8) blocks = (long long)ctx->num_cus * 8;
-  DTHIP_LAUNCH(ctx, "cumcount_kernel", cumcount_kernel, (unsigned)blocks, 256, 0, offsets, (uint32_t)ngroups, (uint32_t)n, ngroup,
-               reverse ? 1 : 0, reinterpret_cast<long long*>(out));
-  return DTHIP_OK;
-}
+// cumcount() / ngroup(): launch_cumcount in group.hip (the head-bitmap expansion shared with ungroup)
 
 // ---- median / nunique over rows sorted by (group, value), NA first ---------------------------------
 template <typename T> struct NaOf;
