@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdthip.so")
+LIB_PATH = os.environ.get("DTHIP_LIB") or os.path.join(_HERE, "libdthip.so")   # DTHIP_LIB: an alternative build, for A/B measurements
 
 # stype codes == the reference's SType values (src/core/stype.h:41-62)
 BOOL, INT8, INT16, INT32, INT64, FLOAT32, FLOAT64 = 1, 2, 3, 4, 5, 6, 7
