@@ -47,6 +47,55 @@ def test_reduce_out_stype_rules():
     assert lib.dthip_reduce_out_stype(L.COUNT0, L.FLOAT64) == L.INT64
 
 
+def test_out_stype_rules_of_the_groupwise_operators():
+    # head_reduce_unary.cc:221-229,484-491 (sd, median: float32 stays float32, else float64), :392-399 (nunique int64),
+    # head_reduce_binary.cc:47-51 (cov/corr), fexpr_cumsumprod.cc:72-99, fexpr_cumminmax.cc:87-101, cumcountngroup.h
+    from datatable_amd import _lib as L
+    lib = L.load()
+    for st in (L.BOOL, L.INT8, L.INT16, L.INT32, L.INT64, L.FLOAT64):
+        assert lib.dthip_reduce_out_stype(L.SD, st) == L.FLOAT64
+        assert lib.dthip_reduce_out_stype(L.MEDIAN, st) == L.FLOAT64
+        assert lib.dthip_reduce_out_stype(L.NUNIQUE, st) == L.INT64
+        assert lib.dthip_cumulate_out_stype(L.CUMMIN, st) == st and lib.dthip_cumulate_out_stype(L.CUMMAX, st) == st
+        assert lib.dthip_cumulate_out_stype(L.CUMCOUNT, st) == L.INT64 and lib.dthip_cumulate_out_stype(L.NGROUP, st) == L.INT64
+    for st in (L.BOOL, L.INT8, L.INT16, L.INT32, L.INT64):
+        assert lib.dthip_cumulate_out_stype(L.CUMSUM, st) == L.INT64 and lib.dthip_cumulate_out_stype(L.CUMPROD, st) == L.INT64
+    assert lib.dthip_reduce_out_stype(L.SD, L.FLOAT32) == L.FLOAT32 and lib.dthip_reduce_out_stype(L.MEDIAN, L.FLOAT32) == L.FLOAT32
+    assert lib.dthip_cumulate_out_stype(L.CUMSUM, L.FLOAT32) == L.FLOAT32 and lib.dthip_cumulate_out_stype(L.CUMPROD, L.FLOAT64) == L.FLOAT64
+    assert lib.dthip_reduce2_out_stype(L.FLOAT32, L.FLOAT32) == L.FLOAT32
+    assert lib.dthip_reduce2_out_stype(L.FLOAT32, L.FLOAT64) == L.FLOAT64 and lib.dthip_reduce2_out_stype(L.INT8, L.INT64) == L.FLOAT64
+
+
+@pytest.mark.gpu
+def test_argument_errors_of_the_groupwise_entry_points(ctx):
+    """bad arguments come back as DTHIP_EINVAL / ENOTIMPL with a message (-> ValueError / NotImplementedError),
+    like the reference's C API returns NULL/-1 with an exception set (api.cc:34-38)"""
+    import numpy as np
+    from datatable_amd import _lib as L
+    lib = ctx._lib
+    v = np.arange(6, dtype=np.float64)
+    off = np.array([0, 3, 6], np.int32)
+    out = np.zeros(6, np.float64)
+    col = L.Col(v.ctypes.data, L.FLOAT64, 0)
+    assert lib.dthip_reduce(ctx._h, 99, C.byref(col), None, off.ctypes.data, 2, 6, L.HOST, out.ctypes.data) == L.EINVAL
+    assert b"bad reducer op" in lib.dthip_last_error()
+    assert lib.dthip_reduce2(ctx._h, 7, C.byref(col), C.byref(col), None, off.ctypes.data, 2, 6, L.HOST, out.ctypes.data) == L.EINVAL
+    assert lib.dthip_cumulate(ctx._h, 42, C.byref(col), None, off.ctypes.data, 2, 6, 0, L.HOST, out.ctypes.data) == L.EINVAL
+    assert lib.dthip_cumulate(ctx._h, L.CUMSUM, None, None, off.ctypes.data, 2, 6, 0, L.HOST, out.ctypes.data) == L.EINVAL
+    assert lib.dthip_reduce(ctx._h, L.SD, C.byref(col), None, off.ctypes.data, 7, 6, L.HOST, out.ctypes.data) == L.EINVAL   # ngroups > nrows
+    cum = (C.c_int64 * 2)(3, 5)                                            # does not add up to nrows
+    idx, k = np.zeros(6, np.int32), C.c_int64(0)
+    assert lib.dthip_setop(ctx._h, L.UNION, C.byref(col), cum, 2, 6, L.HOST, idx.ctypes.data, C.byref(k)) == L.EINVAL
+    cum = (C.c_int64 * 2)(3, 6)
+    assert lib.dthip_setop(ctx._h, 9, C.byref(col), cum, 2, 6, L.HOST, idx.ctypes.data, C.byref(k)) == L.EINVAL
+    cols9 = (L.Col * 9)(*[col] * 9)
+    assert lib.dthip_join_index(ctx._h, cols9, cols9, 9, 6, 6, L.HOST, idx.ctypes.data) == L.EINVAL      # > 8 key columns
+    bad = L.Col(v.ctypes.data, 11, 0)                                      # a string stype: outside the path
+    assert lib.dthip_reduce(ctx._h, L.SD, C.byref(bad), None, off.ctypes.data, 2, 6, L.HOST, out.ctypes.data) in (L.EINVAL, L.ENOTIMPL)
+    # and the context is still usable afterwards
+    assert ctx.reduce("sum", v, None, off).tolist() == [3.0, 12.0]
+
+
 def test_no_cpu_fallback_without_gpu():
     from datatable_amd import _lib as L
     lib = L.load()
