@@ -41,7 +41,22 @@ cs = tb.group_cumulate_tensor(ctx, "cumsum", v, ri, off)
 last = cs[(off[1:] - 1).long()]
 assert int(last.sum().item()) == total, "last cumsum of every group must be the group sum"
 print("rowindex + cumsum ok", flush=True)
-del cs, last, ri, off
+del cs, last
+# sd per group, ngroup and the natural-join index at the same size
+sd = tb.group_reduce_tensor(ctx, "sd", v, ri, off)
+# ~215 uniform integers of [-1000, 1000) per group: sd = 577 +- 28 per group, 1e7 groups
+assert sd.numel() == ng and abs(float(sd.mean().item()) - 577.0) < 3.0 and bool((sd > 350).all()) and bool((sd < 800).all())
+ngr = tb.group_cumulate_tensor(ctx, "ngroup", None, None, off)
+assert int(ngr[-1].item()) == ng - 1 and int(ngr[0].item()) == 0 and bool((ngr[1:] >= ngr[:-1]).all())
+del sd, ngr, ri, off
+from datatable_amd.engine import DevCol
+jk = torch.arange(0, ng, dtype=torch.int64, device=dev)                 # keyed frame: every key once, ascending
+jidx = torch.empty(n, dtype=torch.int32, device=dev)
+ctx.join_index_dev([DevCol(k.data_ptr(), L.INT64)], [DevCol(jk.data_ptr(), L.INT64)], n, ng, jidx.data_ptr())
+torch.cuda.synchronize()
+assert bool((jidx[:100_000_000].long() == k[:100_000_000]).all()) and bool((jidx[-100_000_000:].long() == k[-100_000_000:]).all())
+print("sd + ngroup + join_index ok", flush=True)
+del jk, jidx
 # one more row is refused (int32 RowIndex), not silently wrapped like the reference (sort.cc:505-506)
 import ctypes as C
 h = C.c_void_p()
