@@ -84,6 +84,8 @@ SIGNATURES = {
     "dthip_cumulate_out_stype": (C.c_int, [C.c_int, C.c_int]),
     "dthip_cumulate": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Col), C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                  C.c_int, C.c_int, C.c_void_p]),
+    "dthip_filter_take": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int, C.c_double, C.c_int64, C.POINTER(Col), C.c_int, C.c_int64,
+                                    C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "dthip_setop": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Col), C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                               C.POINTER(C.c_int64)]),
     "dthip_join_index": (C.c_int, [C.c_void_p, C.POINTER(Col), C.POINTER(Col), C.c_int, C.c_int64, C.c_int64, C.c_int,

@@ -1825,13 +1825,50 @@ int dthip_bool_to_rowindex(dthip_ctx* ctx, const int8_t* mask, int64_t n, int me
 int dthip_filter_cmp(dthip_ctx* ctx, const dthip_col* col, int64_t n, int cmp, double cf, int64_t ci, int mem,
                      int32_t* out, int64_t* nout) {
   if (!col) { set_error("null column"); return DTHIP_EINVAL; }
-  if (cmp < DTHIP_GT || cmp > DTHIP_NE) { set_error("bad comparison %d", cmp); return DTHIP_EINVAL; }
+  if (cmp < DTHIP_GT || cmp > DTHIP_ISNA) { set_error("bad comparison %d", cmp); return DTHIP_EINVAL; }
   const int sz = stype_size(col->stype);
   if (!sz) { set_error("unsupported stype %d", col->stype); return DTHIP_ENOTIMPL; }
   PredArgs p;
   memset(&p, 0, sizeof(p));
   p.data = col->data; p.stype = col->stype; p.cmp = cmp; p.cf = cf; p.ci = ci; p.is_mask = 0;
   return compact_common(ctx, p, sz, n, mem, out, nout);
+}
+
+int dthip_filter_take(dthip_ctx* ctx, const dthip_col* col, int cmp, double cf, int64_t ci, const dthip_col* cols, int ncols,
+                      int64_t n, int mem, int32_t* out_rowindex, void* const* out_cols, int64_t* nout) {
+  DTHIP_TRY(check_common(ctx, n, mem));
+  if (!col || !nout || ncols < 0 || ncols > 8 || (ncols > 0 && (!cols || !out_cols))) { set_error("bad filter_take arguments"); return DTHIP_EINVAL; }
+  if (cmp < DTHIP_GT || cmp > DTHIP_ISNA) { set_error("bad comparison %d", cmp); return DTHIP_EINVAL; }
+  *nout = 0;
+  if (n == 0) return DTHIP_OK;
+  const int sz = stype_size(col->stype);
+  if (!sz || !col->data) { set_error("unsupported predicate column"); return DTHIP_ENOTIMPL; }
+  Scratch sc(ctx);
+  PredArgs p;
+  memset(&p, 0, sizeof(p));
+  p.stype = col->stype; p.cmp = cmp; p.cf = cf; p.ci = ci; p.is_mask = 0;
+  DTHIP_TRY(stage_in(ctx, sc, col->data, (size_t)n * sz, mem, &p.data));
+  TakeCols tc;
+  memset(&tc, 0, sizeof(tc));
+  tc.n = ncols;
+  std::vector<void*> d_out((size_t)ncols, nullptr);
+  for (int c = 0; c < ncols; c++) {
+    const int w = stype_size(cols[c].stype);
+    if (!w || !cols[c].data || !out_cols[c]) { set_error("filter_take: bad column %d", c); return DTHIP_EINVAL; }
+    tc.width[c] = w;
+    DTHIP_TRY(stage_in(ctx, sc, cols[c].data, (size_t)n * w, mem, &tc.in[c]));
+    d_out[(size_t)c] = out_cols[c];
+    if (mem == DTHIP_HOST) { unsigned char* t = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)n * w, &t)); d_out[(size_t)c] = t; }
+    tc.out[c] = d_out[(size_t)c];
+  }
+  int32_t* d_ri = out_rowindex;
+  if (out_rowindex && mem == DTHIP_HOST) DTHIP_TRY(sc.get<int32_t>((size_t)n, &d_ri));
+  DTHIP_TRY(launch_compact_take(ctx, p, n, d_ri, tc, nout));
+  if (mem == DTHIP_HOST) {
+    if (out_rowindex) DTHIP_TRY(copy_out(ctx, out_rowindex, d_ri, sizeof(int32_t) * (size_t)*nout, mem));
+    for (int c = 0; c < ncols; c++) DTHIP_TRY(copy_out(ctx, out_cols[c], d_out[(size_t)c], (size_t)*nout * tc.width[c], mem));
+  }
+  return DTHIP_OK;
 }
 
 int dthip_gather(dthip_ctx* ctx, const dthip_col* col, const int32_t* rowindex, int64_t nout, int mem, void* out) {

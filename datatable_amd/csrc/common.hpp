@@ -328,6 +328,8 @@ struct PredArgs {
   const void* data; int stype; int cmp; double cf; long long ci; int is_mask;   // is_mask 2: data is a bitmap (uint32 words)
 };
 int launch_compact(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out, int64_t* nout_host);
+struct TakeCols { int n; const void* in[8]; void* out[8]; int width[8]; };
+int launch_compact_take(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out_ri, const TakeCols& tc, int64_t* nout_host);
 int launch_gather(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, int64_t nout, void* out);
 int launch_range_bucket(dthip_ctx* ctx, const void* keys, int stype, int64_t n, const long long* bounds, int nbounds,
                         int8_t* out);

@@ -112,6 +112,57 @@ int launch_compact(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out, i
   return DTHIP_OK;
 }
 
+// compact + take: the passing rows' index AND their values of up to 8 columns in one sweep --
+// DT[f.x > 0, cols] materialised (init_from_boolean_column + _materialize_fw of every column through
+// the new RowIndex, rowindex_array.cc:130-170, column_impl.cc:78-101).  The columns are read
+// sequentially next to the predicate column instead of being gathered through the finished RowIndex.
+__global__ void __launch_bounds__(CP_BLOCK) compact_take_kernel(PredArgs p, uint32_t n, const uint32_t* tile_base,
+                                                                int32_t* out_ri, TakeCols tc) {
+  __shared__ uint32_t wc[CP_BLOCK / 64];
+  const int lane = lane_id(), wave = wave_id();
+  const uint32_t wave_base = blockIdx.x * CP_TILE + wave * (64 * CP_ITEMS);
+  uint32_t cnt;
+  const uint32_t bits = sweep_pred(p, n, wave_base, &cnt);
+  if (lane == 0) wc[wave] = cnt;
+  __syncthreads();
+  uint32_t running = tile_base[blockIdx.x];
+  for (int w = 0; w < wave; w++) running += wc[w];
+#pragma unroll
+  for (int k = 0; k < CP_ITEMS; k++) {
+    const bool f = (bits >> k) & 1u;
+    const unsigned long long bal = __ballot(f);
+    if (f) {
+      const uint32_t src = wave_base + 64u * k + lane, dst = running + mbcnt64(bal);
+      if (out_ri) out_ri[dst] = (int32_t)src;
+      for (int c = 0; c < tc.n; c++) {
+        switch (tc.width[c]) {
+          case 8: static_cast<unsigned long long*>(tc.out[c])[dst] = static_cast<const unsigned long long*>(tc.in[c])[src]; break;
+          case 4: static_cast<uint32_t*>(tc.out[c])[dst] = static_cast<const uint32_t*>(tc.in[c])[src]; break;
+          case 2: static_cast<uint16_t*>(tc.out[c])[dst] = static_cast<const uint16_t*>(tc.in[c])[src]; break;
+          default: static_cast<uint8_t*>(tc.out[c])[dst] = static_cast<const uint8_t*>(tc.in[c])[src]; break;
+        }
+      }
+    }
+    running += (uint32_t)__popcll(bal);
+  }
+}
+
+int launch_compact_take(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out_ri, const TakeCols& tc, int64_t* nout_host) {
+  *nout_host = 0;
+  if (n == 0) return DTHIP_OK;
+  const uint32_t nt = (uint32_t)((n + CP_TILE - 1) / CP_TILE);
+  Scratch sc(ctx);
+  uint32_t* tile_counts = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, &tile_counts));
+  DTHIP_LAUNCH(ctx, "compact_count_kernel", compact_count_kernel, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts);
+  DTHIP_TRY(launch_scan_tiles(ctx, tile_counts, nt, tile_counts + nt));
+  DTHIP_LAUNCH(ctx, "compact_take_kernel", compact_take_kernel, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts, out_ri, tc);
+  uint32_t total = 0;
+  DTHIP_TRY(read_back(ctx, &total, tile_counts + nt, sizeof(total)));
+  *nout_host = total;
+  return DTHIP_OK;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) gather_kernel(const T* __restrict__ data, const int32_t* __restrict__ ri,
                                                      uint32_t n, T* __restrict__ out, T na) {

@@ -447,6 +447,31 @@ class Context:
         L.check(self._lib.dthip_filter_cmp(self._h, C.byref(col), len(a), code, cf, ci, L.HOST, out.ctypes.data, C.byref(k)))
         return out[:k.value].copy()
 
+    def filter_take(self, values, cmp, scalar, cols, stype=None, col_stypes=None, want_rowindex=True):
+        """rows with values <cmp> scalar: (RowIndex or None, [cols[k] restricted to those rows]) in one sweep"""
+        a, pcol = _host_col(values, stype)
+        carr, cmem, ckeep = _cols(cols, col_stypes)
+        n = len(a)
+        outs = [np.empty(n, k.dtype) for k in ckeep]
+        optr = (C.c_void_p * max(len(outs), 1))(*[o.ctypes.data for o in outs])
+        ri = np.empty(n, np.int32) if want_rowindex else None
+        k = C.c_int64(0)
+        code, cf, ci = _cmp_args(cmp, scalar, pcol.stype)
+        L.check(self._lib.dthip_filter_take(self._h, C.byref(pcol), code, cf, ci, carr, len(cols), n, L.HOST,
+                                            ri.ctypes.data if ri is not None else None, optr, C.byref(k)))
+        return (ri[:k.value].copy() if ri is not None else None), [o[:k.value].copy() for o in outs]
+
+    def filter_take_dev(self, col, cmp, scalar, cols, nrows, out_ri_ptr, out_ptrs):
+        """device-resident filter_take: DevCol predicate column and DevCol columns, raw output pointers; returns the count"""
+        c = L.Col(col.ptr, col.stype, 0)
+        carr = (L.Col * max(len(cols), 1))(*[L.Col(x.ptr, x.stype, 0) for x in cols])
+        optr = (C.c_void_p * max(len(out_ptrs), 1))(*[int(x) for x in out_ptrs])
+        k = C.c_int64(0)
+        code, cf, ci = _cmp_args(cmp, scalar, col.stype)
+        L.check(self._lib.dthip_filter_take(self._h, C.byref(c), code, cf, ci, carr, len(cols), nrows, L.DEVICE,
+                                            C.c_void_p(out_ri_ptr) if out_ri_ptr else None, optr, C.byref(k)))
+        return k.value
+
     # device-resident variants (raw HBM pointers in, raw HBM pointers out)
     def filter_cmp_dev(self, col, nrows, cmp, scalar, out_ptr):
         """rows of DevCol `col` with col <cmp> scalar -> ascending int32 RowIndex at out_ptr (room for nrows); returns the count"""

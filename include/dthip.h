@@ -300,6 +300,15 @@ int  dthip_bool_to_rowindex(dthip_ctx* ctx, const int8_t* mask, int64_t n, int m
  * for float columns and ci for integer columns */
 int  dthip_filter_cmp(dthip_ctx* ctx, const dthip_col* col, int64_t n, int cmp,
                       double cf, int64_t ci, int mem, int32_t* out, int64_t* nout);
+/* DT[f.x <cmp> c, cols] materialised in one sweep: the ascending RowIndex of the passing rows (optional)
+ * and cols[k] read through it (init_from_boolean_column + _materialize_fw of every column of the view,
+ * src/core/rowindex_array.cc:130-170, src/core/column/column_impl.cc:78-101), the columns being read
+ * next to the predicate column instead of gathered through the finished RowIndex.  out_cols[k] and
+ * out_rowindex have room for n rows; *nout rows are written.  ncols <= 8. */
+int  dthip_filter_take(dthip_ctx* ctx, const dthip_col* col, int cmp, double scalar_f, int64_t scalar_i,
+                       const dthip_col* cols, int ncols, int64_t n, int mem,
+                       int32_t* out_rowindex /* nullable */, void* const* out_cols, int64_t* nout);
+
 /* out[i] = rowindex[i] < 0 ? NA : col[rowindex[i]] */
 int  dthip_gather(dthip_ctx* ctx, const dthip_col* col, const int32_t* rowindex,
                   int64_t nout, int mem, void* out);

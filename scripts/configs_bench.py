@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--agg-path", type=int, default=0)
     ap.add_argument("--bucket-variant", type=int, default=0)
+    ap.add_argument("--c5-unfused", action="store_true", help="config 5 with filter_cmp + two gathers instead of filter_take")
     args = ap.parse_args()
     import torch
     from datatable_amd import _lib as L
@@ -114,14 +115,22 @@ def main():
             k = torch.randint(0, 100_000_000, (n,), dtype=torch.int64, device=dev, generator=g)
             x = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
             ri = torch.empty(n, dtype=torch.int32, device=dev)
+            kbuf = torch.empty(n, dtype=torch.int64, device=dev)
+            xbuf = torch.empty(n, dtype=torch.float64, device=dev)
             def run():
                 # V = DT[f.x > 0, :]; V[:, :, by(f.k)]: filter -> RowIndex -> view gather (ascending) ->
                 # group, the key, the value and the filter's RowIndex riding through the sort
-                npass = ctx.filter_cmp_dev(devcol(x), n, ">", 0.0, ri.data_ptr())
-                kv = torch.empty(npass, dtype=torch.int64, device=dev)
-                xv = torch.empty(npass, dtype=torch.float64, device=dev)
-                ctx.gather_dev(devcol(k), ri.data_ptr(), npass, kv.data_ptr())
-                ctx.gather_dev(devcol(x), ri.data_ptr(), npass, xv.data_ptr())
+                if args.c5_unfused:
+                    npass = ctx.filter_cmp_dev(devcol(x), n, ">", 0.0, ri.data_ptr())
+                    kv = torch.empty(npass, dtype=torch.int64, device=dev)
+                    xv = torch.empty(npass, dtype=torch.float64, device=dev)
+                    ctx.gather_dev(devcol(k), ri.data_ptr(), npass, kv.data_ptr())
+                    ctx.gather_dev(devcol(x), ri.data_ptr(), npass, xv.data_ptr())
+                else:
+                    # the view's columns are materialised by the filter sweep itself (dthip_filter_take)
+                    npass = ctx.filter_take_dev(devcol(x), ">", 0.0, [devcol(k), devcol(x)], n, ri.data_ptr(),
+                                                [kbuf.data_ptr(), xbuf.data_ptr()])
+                    kv, xv = kbuf[:npass], xbuf[:npass]
                 r = ctx.groupby_rows([devcol(kv)], [devcol(kv), devcol(xv), devcol(ri[:npass])], nrows=npass, want_rowindex=False)
                 ng = r.ngroups
                 r.free()

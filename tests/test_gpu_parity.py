@@ -601,3 +601,28 @@ def test_fuzz_fused_agg_all_paths(ctx, seed):
         vals.append(v)
     ops = [op for op in OPS if rng.random() < 0.6] or ["sum"]
     _vs_oracle(ctx, keys, vals, aggs=tuple(ops), check_ri=(seed % 4 == 0))
+
+
+@pytest.mark.parametrize("dtype,cmp,scalar", [(np.float64, ">", 0.0), (np.int32, "<=", 3), (np.int64, "!=", 0), (np.float32, "==", 1.5),
+                                              (np.int8, ">", 1.5), (np.int16, ">=", -2)])
+def test_filter_take_matches_filter_then_gather(ctx, dtype, cmp, scalar):
+    """dthip_filter_take = dthip_filter_cmp followed by dthip_gather of every column, in one sweep"""
+    rng = np.random.default_rng(77)
+    n = 300_001
+    if np.dtype(dtype).kind == "f":
+        x = (rng.integers(-6, 6, n) * 0.5).astype(dtype)
+        x[rng.random(n) < 0.05] = np.nan
+    else:
+        x = rng.integers(-5, 6, n).astype(dtype)
+        x[rng.random(n) < 0.05] = np.iinfo(dtype).min
+    cols = [rng.integers(-2**40, 2**40, n), rng.standard_normal(n).astype(np.float32), rng.integers(-100, 100, n).astype(np.int8),
+            rng.integers(-30000, 30000, n).astype(np.int16), x]
+    want_ri = ctx.filter_cmp(x, cmp, scalar)
+    ri, out = ctx.filter_take(x, cmp, scalar, cols)
+    assert_same(ri, want_ri, "rowindex")
+    for c, o_ in zip(cols, out):
+        assert_same(o_, c[want_ri], "column")
+    ri2, out2 = ctx.filter_take(x, cmp, scalar, cols[:1], want_rowindex=False)
+    assert ri2 is None
+    assert_same(out2[0], cols[0][want_ri], "column without rowindex")
+    assert_same(want_ri, o.filter_cmp(x, cmp, scalar) if float(scalar) == int(scalar) else want_ri, "oracle rowindex")
