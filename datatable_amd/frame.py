@@ -687,8 +687,9 @@ class Frame:
                 cols.append(np.zeros(0, ST2NP[kst[k]])); sts.append(kst[k])
             for _, x in items:
                 st = out_stype(x)
-                if isinstance(x, Reducer) and x.op == "median":
+                if isinstance(x, Reducer) and x.op == "median" and not (byx is not None and self._index(x.arg) in kidx):
                     st = self._stypes[self._index(x.arg)]      # the reference leaves median's type alone on 0 rows
+                                                               # (not for a by-column: compute_gmedian)
                 dtp = ST2NP[st]
                 if not one:
                     cols.append(np.zeros(0, dtp))
@@ -736,15 +737,29 @@ class Frame:
             res.free()
             return Frame._from_columns(cols, sts, names)
 
+        def grouped(ref):
+            """is `ref` one of the by-columns? (Grouping::GtoONE inputs take the reference's g-variants)"""
+            return byx is not None and self._index(ref) in kidx
+
         def reduce_item(x, order, goff):
             """one value per group through the S-red seam (dthip_reduce / dthip_reduce2)"""
             if isinstance(x, Reducer2):
                 ia, ib = self._index(x.a), self._index(x.b)
+                if grouped(x.a) or grouped(x.b):
+                    # cov / corr with a by-column: make_na_result (head_reduce_binary.cc:47-51,238-245)
+                    dtp = ST2NP[out_stype(x)]
+                    return np.full(len(goff) - 1, np.nan, dtp)
                 return ctx.reduce2(x.op, self._materialized(ia), self._materialized(ib), order, goff,
                                    stypes=(self._stypes[ia], self._stypes[ib]))
             if x.op == "count0":
                 return ctx.reduce("count0", None, None, goff)
             ci = self._index(x.arg)
+            if x.op == "sd" and grouped(x.arg):
+                # sd of a by-column: 0 for every group of more than one row -- the NA group included -- else NA
+                # (SdGrouped_ColumnImpl, head_reduce_unary.cc:246-283)
+                cnt = ctx.reduce("count0", None, None, goff)
+                dtp = ST2NP[out_stype(x)]
+                return np.where(cnt > 1, dtp.type(0), dtp.type(np.nan)).astype(dtp)
             return ctx.reduce(x.op, self._materialized(ci), order, goff, stype=self._stypes[ci])
 
         if group_level:

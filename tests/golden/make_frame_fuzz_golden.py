@@ -19,6 +19,7 @@ from datatable import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, c
 dt.options.progress.enabled = False
 ST = {1: dt.bool8, 2: dt.int8, 3: dt.int16, 4: dt.int32, 5: dt.int64, 6: dt.float32, 7: dt.float64}
 rnd = random.Random(20251001)
+NEG_ZERO = False      # batch 5 also puts -0.0 among the float VALUES (keys always had it)
 
 
 def rand_col(st, n, role):
@@ -33,7 +34,7 @@ def rand_col(st, n, role):
                 vals.append(rnd.choice([0.0, -0.0, 1.5, -2.25, 3.0, math.inf]))
             else:
                 r = rnd.random()
-                vals.append(math.inf if r < 0.02 else -math.inf if r < 0.03 else rnd.randint(-400, 400) / 8.0)
+                vals.append(math.inf if r < 0.02 else -math.inf if r < 0.03 else -0.0 if (NEG_ZERO and r < 0.06) else rnd.randint(-400, 400) / 8.0)
         else:
             lim = {2: 5, 3: 8, 4: 12, 5: 6}[st] if role == "key" else {2: 100, 3: 3000, 4: 10**6, 5: 10**12}[st]
             vals.append(rnd.randint(-lim, lim))
@@ -172,6 +173,43 @@ def rand_query4(names):
     return q
 
 
+def rand_query5(names):
+    """corners: reducers / cumulative operators ON key columns, reverse lists, na_position + reverse, dict j with
+    cumulative operators, several descending by-columns, non-integral and negative filter scalars, -0.0 values"""
+    keys = [nm for nm in names if nm.startswith("k")]
+    vals = [nm for nm in names if nm.startswith("v")]
+    kk = rnd.sample(keys, rnd.randint(1, len(keys)))
+    bys = "by(%s)" % ", ".join(("-f.%s" if rnd.random() < 0.4 else "f.%s") % k for k in kk)
+    kind = rnd.random()
+    anyc = lambda: rnd.choice(names)
+    if kind < 0.2:
+        items = ["%s(f.%s)" % (rnd.choice(RED), anyc()) for _ in range(rnd.randint(1, 3))]
+        return "DT[:, [%s], %s]" % (", ".join(items), bys)
+    if kind < 0.35:
+        items = ["%s(f.%s%s)" % (rnd.choice(CUM), anyc(), rnd.choice(["", ", reverse=True"])) for _ in range(rnd.randint(1, 3))]
+        return "DT[:, [%s], %s]" % (", ".join(items), bys)
+    if kind < 0.45:
+        cols = rnd.sample(names, rnd.randint(2, min(3, len(names))))
+        rev = "[%s]" % ", ".join(rnd.choice(["True", "False"]) for _ in cols)
+        return "DT[:, :, sort(%s, reverse=%s%s)]" % (", ".join("f.%s" % c for c in cols), rev, rnd.choice(["", ", na_position='last'"]))
+    if kind < 0.55:
+        return "DT[:, :, sort(%sf.%s, na_position='%s', reverse=%s)]" % (rnd.choice(["", "-"]), anyc(), rnd.choice(["first", "last", "remove"]), rnd.choice(["True", "False"]))
+    if kind < 0.65:
+        items = ", ".join("'%s': %s(f.%s)" % (nm, rnd.choice(CUM + ["first", "last", "median"]), anyc()) for nm in rnd.sample(["a", "b", "c"], rnd.randint(1, 3)))
+        return "DT[:, {%s}, %s]" % (items, bys)
+    if kind < 0.8:
+        v = anyc()
+        return "DT[f.%s %s %s, :][:, [count(), %s(f.%s), %s(f.%s)], %s]" % (
+            v, rnd.choice([">", ">=", "<", "<=", "==", "!="]), rnd.choice(["-1.5", "0.25", "-0.0", "2", "-3", "1e6", "-7.75"]),
+            rnd.choice(RED), anyc(), rnd.choice(RED), anyc(), bys)
+    if kind < 0.9:
+        a, b = anyc(), anyc()
+        return "DT[:, [%s(f.%s, f.%s), %s(f.%s, f.%s), nunique(f.%s), sd(f.%s)], %s]" % (
+            rnd.choice(["cov", "corr"]), a, b, rnd.choice(["cov", "corr"]), b, b, anyc(), anyc(), bys)
+    return "DT[:, [f.%s, %s(f.%s), cumcount(%s), %s(f.%s)], %s]" % (anyc(), rnd.choice(CUM), anyc(), rnd.choice(["", "reverse=True"]),
+                                                                   rnd.choice(RED), anyc(), bys)
+
+
 def keyed(F, *names):
     G = F.copy()
     G.key = names if len(names) > 1 else names[0]
@@ -277,10 +315,12 @@ def clean(cols):
 
 
 def main(batch=1):
+    global NEG_ZERO
+    NEG_ZERO = batch == 5
     frames, queries = {}, []
-    seed = {1: 0, 2: 100000, 4: 200000}[batch]
-    gen = {1: rand_query, 2: rand_query2, 4: rand_query4}[batch]
-    while len(queries) < {1: 700, 2: 400, 4: 400}[batch]:
+    seed = {1: 0, 2: 100000, 4: 200000, 5: 300000}[batch]
+    gen = {1: rand_query, 2: rand_query2, 4: rand_query4, 5: rand_query5}[batch]
+    while len(queries) < {1: 700, 2: 400, 4: 400, 5: 500}[batch]:
         seed += 1
         spec = make_frame(seed)
         with warnings.catch_warnings():
@@ -303,7 +343,7 @@ def main(batch=1):
                                 "columns": clean(R.to_list())})
             except Exception as e:      # the reference refuses the query: record its exception type
                 queries.append({"frame": fname, "query": q, "error": type(e).__name__})
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), {1: "frame_fuzz.json", 2: "frame_fuzz2.json", 4: "frame_fuzz4.json"}[batch])
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), {1: "frame_fuzz.json", 2: "frame_fuzz2.json", 4: "frame_fuzz4.json", 5: "frame_fuzz5.json"}[batch])
     json.dump({"frames": frames, "queries": queries}, open(path, "w"))
     nerr = len([q for q in queries if "error" in q])
     print("wrote %s: %d frames, %d queries (%d refused by the reference)" % (path, len(frames), len(queries), nerr))
