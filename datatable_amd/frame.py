@@ -707,6 +707,8 @@ class Frame:
         # first() / last() see the rows of a group in the order by() + sort() put them in
         ordered = srt is not None and any(isinstance(x, Reducer) and x.op in ("first", "last") for x in reducers)
         fusable = all(isinstance(x, Reducer) and x.op in _FUSED_OPS for x in reducers) and not ordered
+        # sort(..., na_position="last") next to by() also moves the NA groups of the by-columns last
+        na_last = srt is not None and srt.na_last
         if group_level and fusable and (reducers or not items):
             # fused groupby-aggregate: one row per group
             vidx, aggs = [], []
@@ -725,7 +727,7 @@ class Frame:
                 fkeys = [DevCol(self._dev[c].ptr, self._dev[c].stype, kdesc[j], keepalive=self._dev[c].keepalive)
                          for j, c in enumerate(kidx)]
             res = ctx.groupby_agg(fkeys, vals, aggs, nrows=self.nrows, key_stypes=kst,
-                                  value_stypes=[self._stypes[c] for c in vidx], desc=kdesc)
+                                  value_stypes=[self._stypes[c] for c in vidx], desc=kdesc, na_last=na_last)
             kcols = [res.key(k) for k in range(len(kidx))]
             cols, sts, a = list(kcols), list(kst[:len(kidx)]), 0
             for _, x in items:
@@ -768,10 +770,10 @@ class Frame:
             # at the first row of each group (eval_context.cc:473-485)
             if ordered:
                 gri = self._by_sort_order(ctx, keys, kst, kdesc, srt)
-                g = ctx.groupby(keys, stypes=kst, desc=kdesc, want_rowindex=False)
+                g = ctx.groupby(keys, stypes=kst, desc=kdesc, na_last=na_last, want_rowindex=False)
                 goff = g.offsets()
             else:
-                g = ctx.groupby(keys, stypes=kst, desc=kdesc)
+                g = ctx.groupby(keys, stypes=kst, desc=kdesc, na_last=na_last)
                 gri, goff = g.rowindex(), g.offsets()
             g.free()
             first = ctx.gather(gri, goff[:-1])
@@ -807,7 +809,7 @@ class Frame:
         # within their group only (the by-columns are the leading sort keys), so the by-only offsets
         # delimit the same groups in `ri`.
         if goff is None:
-            g = ctx.groupby(keys, stypes=kst, desc=kdesc, want_rowindex=False)
+            g = ctx.groupby(keys, stypes=kst, desc=kdesc, na_last=na_last, want_rowindex=False)
             goff = g.offsets()
             g.free()
         bcast = ctx.ungroup(goff) if reducers else None

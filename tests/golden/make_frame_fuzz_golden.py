@@ -210,6 +210,37 @@ def rand_query5(names):
                                                                    rnd.choice(RED), anyc(), bys)
 
 
+def rand_query6(names):
+    """no-by mixtures (reducers broadcast next to plain columns), f[:] forms of every operator, duplicate sort
+    columns, by()+sort() with na_position, dict j whose names collide with columns, 3 by-columns"""
+    keys = [nm for nm in names if nm.startswith("k")]
+    vals = [nm for nm in names if nm.startswith("v")]
+    anyc = lambda: rnd.choice(names)
+    kk = rnd.sample(names, rnd.randint(1, min(3, len(names))))
+    bys = "by(%s)" % ", ".join("f.%s" % k for k in kk)
+    kind = rnd.random()
+    if kind < 0.15:
+        return "DT[:, [f.%s, %s(f.%s), %s(f.%s)]]" % (anyc(), rnd.choice(RED), anyc(), rnd.choice(CUM), anyc())
+    if kind < 0.3:
+        return "DT[:, %s(f[:])%s]" % (rnd.choice(RED + CUM), rnd.choice(["", ", " + bys]))
+    if kind < 0.4:
+        c = anyc()
+        return "DT[:, :, sort(f.%s, f.%s, f.%s%s)]" % (c, anyc(), c, rnd.choice(["", ", na_position='last'", ", reverse=True"]))
+    if kind < 0.55:
+        return "DT[:, [%s(f.%s), %s(f.%s), f.%s], %s, sort(f.%s, na_position='%s')]" % (
+            rnd.choice(["first", "last", "cumsum", "cummin", "sum", "median"]), anyc(), rnd.choice(["first", "last", "max", "count"]), anyc(), anyc(),
+            "by(f.%s)" % rnd.choice(keys), anyc(), rnd.choice(["first", "last"]))
+    if kind < 0.7:
+        nm = rnd.sample(names + ["count", "C0", "x"], rnd.randint(1, 3))
+        items = ", ".join("'%s': %s(f.%s)" % (n_, rnd.choice(RED + CUM), anyc()) for n_ in nm)
+        return "DT[:, {%s}, %s]" % (items, "by(f.%s)" % rnd.choice(keys))
+    if kind < 0.85:
+        return "DT[:, [%s(f.%s), %s(f.%s), count(), %s(f.%s)], %s]" % (rnd.choice(RED), anyc(), rnd.choice(RED), anyc(), rnd.choice(RED), anyc(), bys)
+    return "DT[f.%s %s %s, :][:, :, sort(f.%s%s)][:, [%s(f.%s), f.%s], by(f.%s)]" % (
+        anyc(), rnd.choice(["==", "!=", ">", "<"]), rnd.choice(["True", "False", "0", "1"]), anyc(), rnd.choice(["", ", reverse=True"]),
+        rnd.choice(CUM + ["first", "last"]), anyc(), anyc(), rnd.choice(keys))
+
+
 def keyed(F, *names):
     G = F.copy()
     G.key = names if len(names) > 1 else names[0]
@@ -316,11 +347,11 @@ def clean(cols):
 
 def main(batch=1):
     global NEG_ZERO
-    NEG_ZERO = batch == 5
+    NEG_ZERO = batch >= 5
     frames, queries = {}, []
-    seed = {1: 0, 2: 100000, 4: 200000, 5: 300000}[batch]
-    gen = {1: rand_query, 2: rand_query2, 4: rand_query4, 5: rand_query5}[batch]
-    while len(queries) < {1: 700, 2: 400, 4: 400, 5: 500}[batch]:
+    seed = {1: 0, 2: 100000, 4: 200000, 5: 300000, 6: 400000}[batch]
+    gen = {1: rand_query, 2: rand_query2, 4: rand_query4, 5: rand_query5, 6: rand_query6}[batch]
+    while len(queries) < {1: 700, 2: 400, 4: 400, 5: 500, 6: 500}[batch]:
         seed += 1
         spec = make_frame(seed)
         with warnings.catch_warnings():
@@ -343,7 +374,7 @@ def main(batch=1):
                                 "columns": clean(R.to_list())})
             except Exception as e:      # the reference refuses the query: record its exception type
                 queries.append({"frame": fname, "query": q, "error": type(e).__name__})
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), {1: "frame_fuzz.json", 2: "frame_fuzz2.json", 4: "frame_fuzz4.json", 5: "frame_fuzz5.json"}[batch])
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), {1: "frame_fuzz.json", 2: "frame_fuzz2.json", 4: "frame_fuzz4.json", 5: "frame_fuzz5.json", 6: "frame_fuzz6.json"}[batch])
     json.dump({"frames": frames, "queries": queries}, open(path, "w"))
     nerr = len([q for q in queries if "error" in q])
     print("wrote %s: %d frames, %d queries (%d refused by the reference)" % (path, len(frames), len(queries), nerr))

@@ -54,7 +54,8 @@ FUZZ = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_fuzz.json")))
 FUZZ2 = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_fuzz2.json")))     # other query templates (batch 2)
 FUZZ4 = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_fuzz4.json")))     # chains of views (batch 4)
 FUZZ5 = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_fuzz5.json")))     # corner cases (batch 5)
-for _F in (FUZZ2, FUZZ4, FUZZ5):
+FUZZ6 = json.load(open(os.path.join(ROOT, "tests", "golden", "frame_fuzz6.json")))     # no-by mixtures, f[:] forms (batch 6)
+for _F in (FUZZ2, FUZZ4, FUZZ5, FUZZ6):
     for _k, _v in _F["frames"].items():
         FUZZ["frames"][_k] = _v
     FUZZ["queries"] += _F["queries"]
@@ -68,7 +69,7 @@ def _dec2(x):
 
 @pytest.mark.parametrize("qi", range(len(FUZZ["queries"])), ids=["%d:%s" % (i, q["query"][:60]) for i, q in enumerate(FUZZ["queries"])])
 def test_fuzz_query_matches_reference(qi):
-    """2000 seeded random queries over 500 random frames (all fixed-width stypes, NAs, +-inf, -0.0 keys):
+    """2500 seeded random queries over 625 random frames (all fixed-width stypes, NAs, +-inf, -0.0 keys):
     names, stypes and values as the unmodified reference returned them"""
     from datatable_amd import frame as dt
     from datatable_amd.frame import f, by, sort, sum, mean, min, max, count, first, last   # noqa: F401,A004
