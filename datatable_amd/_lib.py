@@ -20,7 +20,7 @@ UNION, INTERSECT, SETDIFF, SYMDIFF = 0, 1, 2, 3     # enum dthip_setfn
 HOST, DEVICE = 0, 1
 NA_FIRST, NA_LAST, NA_REMOVE = 0, 1, 2
 FLAG_DESCENDING = 1
-GT, GE, LT, LE, EQ, NE = 0, 1, 2, 3, 4, 5
+GT, GE, LT, LE, EQ, NE, NOTNA, ISNA = 0, 1, 2, 3, 4, 5, 6, 7
 
 EINVAL, ENOTIMPL, ENOMEM, EDEVICE = -1, -2, -3, -4
 

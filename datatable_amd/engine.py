@@ -88,6 +88,11 @@ def _cmp_args(cmp, scalar, stype):
     != always does (NA included, as for any !=), the orderings round the scalar towards the side that keeps the
     meaning.  INT64_MIN as the integer scalar of == / != is a value no valid element has."""
     import math
+    if scalar is None:
+        # f.x == None / f.x != None: the NA rows / the valid rows
+        if cmp not in ("==", "!="):
+            raise TypeError("an ordering comparison with None")
+        return (L.ISNA if cmp == "==" else L.NOTNA), 0.0, 0
     code = CMP[cmp]
     if stype in (L.FLOAT32, L.FLOAT64):
         return code, float(scalar), 0

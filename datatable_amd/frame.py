@@ -542,6 +542,21 @@ class Frame:
                     if isinstance(r, (str, ColRef, int, np.integer)):
                         self._index(r)
             return self._joined(jn.frame)._select(j)
+        if isinstance(i, np.ndarray) and i.dtype == np.bool_:
+            i = Frame([i])
+        if isinstance(i, Frame):
+            # a boolean column as row selector (init_from_boolean_column, rowindex_array.cc:130-170)
+            if byx or srt or jn is not None:
+                raise NotImplementedError("a boolean row selector combined with by() / sort() / join() is outside the accelerated path")
+            if i.ncols != 1 or i._stypes[0] != L.BOOL:
+                raise TypeError("Filter expression must be boolean, instead it was of type %s" % (i._stypes[:1],))
+            if i.nrows != self.nrows:
+                raise ValueError("i selector has %d rows, but applied to a Frame with %d rows" % (i.nrows, self.nrows))
+            ctx = self._context()
+            ri = ctx.bool_to_rowindex(i._materialized(0))
+            fr = Frame(self)
+            fr._ri = ri if self._ri is None else ctx.gather(self._ri, ri)
+            return fr._select(j)
         if isinstance(i, Filter):
             if byx or srt:
                 # the reference cannot do this either: src/core/expr/fexpr_func.cc:61-73

@@ -4,6 +4,7 @@ the same way against datatable_amd.frame.  String columns and computed f-express
 (f.A + f.B, prod, ...) are outside the accelerated path and are left out or replaced by an
 integer column where the test is about grouping, not strings.  file:line of every original is
 given.  Every evaluation runs on the GPU through the C ABI."""
+import builtins
 import math
 import random
 
@@ -11,6 +12,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+builtins_sum, builtins_min = builtins.sum, builtins.min
 
 
 @pytest.fixture(scope="module")
@@ -652,3 +654,301 @@ def test_join_view_and_issue1800(dt):                   # test-join.py:247-256,2
     X2 = dt.Frame(A=[0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5])
     assert X2[:, :, dt.join(X1)].to_dict() == {"A": [0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5],
                                                 "B": [0.1, 0.1, 0.2, 0.2, 0.3, 0.3, 0.4, 0.4, 0.5, 0.5, None, None]}
+
+
+# ---- tests/ijby/test-sort.py:125-260,462-515,845-935: int32 / int64 / multi-column sorts -----------------
+
+def test_int32_small(dt):                                # test-sort.py:130-138
+    d0 = dt.Frame([17, 2, 96, 245, 847569, 34, -45, None, 1])
+    assert d0.stypes == (I32,)
+    d1 = d0.sort(0)
+    assert d1.stypes == d0.stypes
+    assert d1.to_list() == [[None, -45, 1, 2, 17, 34, 96, 245, 847569]]
+
+
+def test_int32_small_stable(dt):                         # test-sort.py:141-151
+    d0 = dt.Frame([[5, 3, 5, None, 1000000, None, 3, None], [1, 5, 10, 20, 50, 100, 200, 500]], names=["A", "B"])
+    assert d0.sort("A").to_list() == [[None, None, None, 3, 3, 5, 5, 1000000], [20, 100, 500, 5, 200, 1, 10, 50]]
+
+
+def test_int32_large(dt):                                # test-sort.py:154-165
+    p1, p2 = 1000003, 2000003
+    src = ((np.arange(p1, dtype=np.int64) + 1) * p2 % p1).astype(np.int32)
+    d0 = dt.Frame([src])
+    assert d0.stypes == (I32,)
+    assert np.array_equal(d0.sort(0).to_numpy_columns()[0], np.arange(p1, dtype=np.int32))
+
+
+@pytest.mark.parametrize("n", [30, 300, 3000, 30000, 60000, 120000])
+def test_int32_large_stable(dt, n):                      # test-sort.py:168-177
+    src = [None, 100, 100000] * (n // 3)
+    d0 = dt.Frame([src, list(range(n))], names=["A", "B"])
+    assert d0.stypes[0] == I32
+    d1 = d0[:, "B", dt.sort("A")]
+    assert d1.to_list() == [list(range(0, n, 3)) + list(range(1, n, 3)) + list(range(2, n, 3))]
+
+
+@pytest.mark.parametrize("n", [5, 100, 500, 2500, 32767, 32768, 32769, 200000])
+def test_int32_constant(dt, n):                          # test-sort.py:180-188
+    tbl0 = [[100000] * n, list(range(n))]
+    d0 = dt.Frame(tbl0)
+    d1 = d0.sort(0)
+    assert d1.stypes == d0.stypes
+    assert d1.to_list() == tbl0
+
+
+def test_int32_reverse_list(dt):                         # test-sort.py:191-198
+    step = 10
+    d0 = dt.Frame([np.arange(1000000, 0, -step, dtype=np.int32)])
+    d1 = d0.sort(0)
+    assert d1.stypes == d0.stypes
+    assert np.array_equal(d1.to_numpy_columns()[0], np.arange(step, 1000000 + step, step, dtype=np.int32))
+
+
+@pytest.mark.parametrize("b", [32767, 1000000])
+def test_int32_upper_range(dt, b):                       # test-sort.py:201-210
+    d0 = dt.Frame([b, b - 1, b + 1] * 1000)
+    assert d0.stypes[0] == I32
+    assert d0.sort(0).to_list() == [[b - 1] * 1000 + [b] * 1000 + [b + 1] * 1000]
+
+
+@pytest.mark.parametrize("dc", [32765, 32766, 32767, 32768, 65533, 65534, 65535, 65536])
+def test_int32_u2range(dt, dc):                          # test-sort.py:213-225
+    a = 100000
+    b, c = a + 10, a + dc
+    d0 = dt.Frame([c, b, a] * 1000)
+    assert d0.stypes[0] == I32
+    assert d0.sort(0).to_list() == [[a] * 1000 + [b] * 1000 + [c] * 1000]
+
+
+def test_int32_unsigned(dt):                             # test-sort.py:228-241
+    tbl = builtins_sum(([t] * 100 for t in [0x00000000, 0x00000001, 0x00007FFF, 0x00008000, 0x00008001, 0x0000FFFF,
+                                             0x7FFF0000, 0x7FFF0001, 0x7FFF7FFF, 0x7FFF8000, 0x7FFF8001, 0x7FFFFFFF]), [])
+    d0 = dt.Frame(tbl)
+    assert d0.stypes == (I32,)
+    assert d0.sort(0).to_list() == [tbl]
+
+
+def test_int32_issue220(dt):                             # test-sort.py:244-248
+    d0 = dt.Frame([None] + [1000000] * 200 + [None])
+    assert d0.sort(0).to_list() == [[None, None] + [1000000] * 200]
+
+
+def test_int64_small(dt):                                # test-sort.py:467-474
+    d0 = dt.Frame([10**(i * 101 % 13) for i in range(13)] + [None])
+    assert d0.stypes == (I64,)
+    d1 = d0.sort(0)
+    assert d1.stypes == d0.stypes
+    assert d1.to_list() == [[None] + [10**i for i in range(13)]]
+
+
+def test_int64_small_stable(dt):                         # test-sort.py:477-483
+    d0 = dt.Frame([[0, None, -1000, 11**11] * 3, list(range(12))])
+    assert d0.stypes == (I64, I32)
+    assert d0[:, 1, dt.sort(0)].to_list() == [[1, 5, 9, 2, 6, 10, 0, 4, 8, 3, 7, 11]]
+
+
+@pytest.mark.parametrize("n", [16, 20, 30, 40, 50, 100, 500, 1000])
+def test_int64_large0(dt, n):                            # test-sort.py:486-500
+    a, b = -6654966461866573261, -6655043958000990616
+    c, d = 5207085498673612884, 5206891724645893889
+    d0 = dt.Frame([c, d, a, b] * n)
+    d1 = d0.sort(0)
+    assert b < a < d < c
+    assert d0.to_list() == [[c, d, a, b] * n]
+    assert d1.to_list() == [[b] * n + [a] * n + [d] * n + [c] * n]
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_int64_large_random(dt, seed):                   # test-sort.py:503-511
+    random.seed(seed)
+    m = 2**63 - 1
+    tbl = [random.randint(-m, m) for i in range(1000)]
+    d0 = dt.Frame(tbl)
+    assert d0.stypes == (I64,)
+    assert d0.sort(0).to_list() == [sorted(tbl)]
+
+
+def test_int32_small_multi(dt):                          # test-sort.py:848-860
+    src = [[1, 3, 2, 7, 2, 1, 1, 7, 2, 1, 1, 7], [5, 1, 9, 4, 1, 0, 3, 2, 7, 5, 8, 1]]
+    d0 = dt.Frame(src, names=["A", "B"])
+    d1 = d0.sort("A", "B")
+    order = sorted(range(len(src[0])), key=lambda i: (src[0][i], src[1][i]))
+    assert d1.names == d0.names
+    assert d1.to_list() == [[src[0][i] for i in order], [src[1][i] for i in order]]
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_bool8_2cols_multi(dt, seed):                    # test-sort.py:863-876
+    random.seed(seed)
+    n = int(random.expovariate(0.001) + 200)
+    data = [[random.choice([True, False]) for _ in range(n)] for j in range(2)]
+    n0 = builtins_sum(data[0])
+    n10 = builtins_sum(data[1][i] for i in range(n) if data[0][i] is False)
+    n11 = builtins_sum(data[1][i] for i in range(n) if data[0][i] is True)
+    d1 = dt.Frame(data).sort(0, 1)
+    assert d1.to_list() == [[False] * (n - n0) + [True] * n0,
+                            [False] * (n - n0 - n10) + [True] * n10 + [False] * (n0 - n11) + [True] * n11]
+
+
+@pytest.mark.parametrize("seed", [9])
+def test_bool8_manycols_multi(dt, seed):                 # test-sort.py:879-890 (rows compared as tuples instead of CSV lines)
+    random.seed(seed)
+    nrows = int(random.expovariate(0.005) + 100)
+    ncols = builtins_min(int(random.expovariate(0.01) + 2), 8)          # the C ABI takes up to 8 key columns
+    data = [[random.choice([True, False]) for _ in range(nrows)] for j in range(ncols)]
+    d1 = dt.Frame(data).sort(*list(range(ncols)))
+    assert list(zip(*d1.to_list())) == sorted(zip(*data))
+
+
+@pytest.mark.parametrize("seed", [10])
+def test_multisort_bool_real(dt, seed):                  # test-sort.py:893-906
+    random.seed(seed)
+    n = int(random.expovariate(0.001) + 200)
+    col0 = [random.choice([True, False]) for _ in range(n)]
+    col1 = [random.randint(1, 10) / 97 for _ in range(n)]
+    d1 = dt.Frame([col0, col1]).sort(0, 1)
+    n0 = builtins_sum(col0)
+    assert d1.to_list() == [[False] * (n - n0) + [True] * n0,
+                            sorted([col1[i] for i in range(n) if col0[i] is False]) +
+                            sorted([col1[i] for i in range(n) if col0[i] is True])]
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_sort_random_multi(dt, seed):                    # test-sort.py:909-935 (string columns -> int codes)
+    fns = [lambda: random.choice([True, False]), lambda: random.randint(-10, 10),
+           lambda: random.choice([-1.95, 0.1, 0.3, 1.1, 7.3, -2.99, 9.13, 4.555]), lambda: random.randint(0, 11)]
+    random.seed(seed)
+    n = int(random.expovariate(0.01) + 2)
+    data = [[random.choice(fns)() for _ in range(n)] for _ in range(5)]
+    for j in range(5):        # one generator per column, as in the original
+        fn = random.choice(fns)
+        data[j] = [fn() for _ in range(n)]
+    data.append([random.random() for _ in range(n)])
+    order = sorted(list(range(n)), key=lambda x: (data[1][x], data[2][x], data[3][x], x))
+    d0 = dt.Frame(data, names=list("ABCDEF"))
+    assert d0.sort("B", "C", "D").to_list() == [[col[j] for j in order] for col in data]
+
+
+# ---- tests/test-groups.py: the remaining tests of :33-130, :211-430 that stay inside the path ---------------
+
+@pytest.mark.parametrize("seed", [21])
+def test_groups4(dt, seed):                              # test-groups.py:94-115 (hex strings -> their integer values)
+    random.seed(seed)
+    n = 1000
+    src = [random.getrandbits(8) for _ in range(n)]
+    f1 = dt.Frame(A=src, B=list(range(n)))[:, :, dt.by("A")]
+    assert f1.shape == (n, 2) and f1.names == ("A", "B")
+    f1A, f1B = f1.to_list()
+    f1A.append(None)
+    curr_value, group_start = f1A[0], 0
+    for i in range(n + 1):
+        if f1A[i] != curr_value:
+            group = f1B[group_start:i]
+            assert group == sorted(group)
+            curr_value, group_start = f1A[i], i
+    assert group_start == n and curr_value is None
+
+
+def test_group_boolean2_3(dt):                           # test-groups.py:250-261
+    DT = dt.Frame(A=[True, False, False] * 500 + [None, True])
+    assert_equals(DT[:, dt.count(), dt.by(dt.f.A)], dt.Frame(A=[None, False, True], count=[1, 1000, 501], stypes={"count": I64}))
+    DT = dt.Frame(A=[True] * 1234)
+    assert_equals(DT[:, dt.count(), dt.by(dt.f.A)], dt.Frame(A=[True], count=[1234], stypes={"count": I64}))
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_groupby_large_random_integers(dt, seed):        # test-groups.py:339-355 (nunique1 -> nunique)
+    random.seed(seed)
+    ngrps1 = random.choice([1, 1, 2, 2, 2, 3, 4, 5])
+    n0 = 1 << random.choice([1, 1, 2, 2, 2, 3, 3, 3, 4, 5, 6, 7])
+    chunks = ([random.sample(range(n0), random.randint(1, n0))] +
+              [random.sample([0] * 100 + list(range(256)), random.randint(1, 20)) for i in range(ngrps1)])
+    n = builtins_min(int(random.expovariate(0.0001)) + 10, 200000)
+    sample = [builtins_sum(random.choice(chunks[i]) << (8 * i) for i in range(len(chunks))) for _ in range(n)]
+    nuniques = len(set(sample))
+    f0 = dt.Frame(A=sample)
+    assert f0[:, dt.nunique(dt.f.A)].to_list() == [[nuniques]]
+    assert dt.unique(f0).nrows == nuniques
+    assert f0[:, dt.count(), dt.by(dt.f.A)].nrows == nuniques
+
+
+def test_groupby_multi(dt):                              # test-groups.py:376-381
+    DT = dt.Frame(A=[1, 2, 3] * 3, B=[1, 2] * 4 + [1], C=list(range(9)))
+    assert DT[:, dt.sum(dt.f.C), dt.by("A", "B")].to_list() == [[1, 1, 2, 2, 3, 3], [1, 2, 1, 2, 1, 2], [6, 3, 4, 8, 10, 5]]
+
+
+@pytest.mark.parametrize("seed", [41])
+def test_groupby_multi_large(dt, seed):                  # test-groups.py:391-416 (letters -> their index)
+    random.seed(seed)
+    n = builtins_min(100 + int(random.expovariate(0.0001)), 100000)
+    col0 = [random.choice([True, False]) for _ in range(n)]
+    col1 = [random.randint(-10, 10) for _ in range(n)]
+    col2 = [random.randint(0, 13) for _ in range(n)]
+    col3 = [random.random() for _ in range(n)]
+    rows = sorted((col0[i], col1[i], col2[i], col3[i]) for i in range(n))
+    grouped, lastkey, sumval = [], rows[0][:3], 0
+    for i in range(n):
+        if rows[i][:3] != lastkey:
+            grouped.append(lastkey + (sumval,))
+            lastkey, sumval = rows[i][:3], 0
+        sumval += rows[i][3]
+    grouped.append(lastkey + (sumval,))
+    DT1 = dt.Frame([col0, col1, col2, col3], names=["A", "B", "C", "D"])[:, dt.sum(dt.f.D), dt.by(dt.f.A, dt.f.B, dt.f.C)]
+    want = [list(c) for c in zip(*grouped)]
+    got = DT1.to_list()
+    assert got[:3] == want[:3]
+    assert np.allclose(got[3], want[3], rtol=1e-9)
+
+
+def test_groupby_on_view(dt):                            # test-groups.py:419-430 (column C: 'b','d' -> 1, 3)
+    DT = dt.Frame(A=[1, 2, 3, 1, 2, 3], B=[3, 6, 2, 4, 3, 1], C=[1, 3, 1, 1, 3, 1])
+    V = DT[dt.f.A != 1, :]
+    assert_equals(V, dt.Frame(A=[2, 3, 2, 3], B=[6, 2, 3, 1], C=[3, 1, 3, 1]))
+    assert_equals(V[:, dt.max(dt.f.B), dt.by(dt.f.C)], dt.Frame(C=[1, 3], B=[2, 6]))
+
+
+# ---- tests/test-reduce.py:518-537 and tests/munging/test-dt-rows.py:405-416,555-566,690-710 -------------------
+
+def test_mean_simple_and_empty(dt):                      # test-reduce.py:518-537
+    DT_mean = dt.Frame(A=list(range(5)))[:, dt.mean(dt.f.A)]
+    assert DT_mean.stypes == (F64,) and DT_mean.to_list() == [[2.0]]
+    DT = dt.Frame([[]] * 4, names=list("ABCD"), stypes=(B8, I32, F32, F64))
+    assert DT.shape == (0, 4)
+    DT_mean = DT[:, dt.mean(dt.f[:])]
+    assert DT_mean.shape == (1, 4) and DT_mean.names == ("A", "B", "C", "D")
+    assert DT_mean.stypes == (F64, F64, F32, F64) and DT_mean.to_list() == [[None]] * 4
+
+
+def _dt0(dt):
+    T, F = True, False
+    return dt.Frame([[F, T, T, None, F, F, T, None, T, T], [7, -11, 9, 10000, None, 0, 0, -1, 1, None],
+                     [5, 1, 1.3, 0.1, 1e5, 0, -2.6, -14, math.nan, 2]], names=["colA", "colB", "colC"])
+
+
+def test_rows_bool_column(dt):                           # test-dt-rows.py:407-416,419-422
+    dt0 = _dt0(dt)
+    col = dt.Frame([True, False, True, True, None, False, None, True, True, False])
+    dt1 = dt0[col, :]
+    assert dt1.shape == (5, 3) and dt1.names == ("colA", "colB", "colC")
+    assert dt1.stypes == (B8, I32, F64)
+    assert dt1.to_list()[1] == [7, 9, 10000, -1, 1]
+    with pytest.raises(ValueError, match="i selector has 20 rows, but applied to a Frame with 10 rows"):
+        dt0[dt.Frame([bool(i % 2) for i in range(20)]), :]
+
+
+def test_rows_bool_numpy_array(dt):                      # test-dt-rows.py:557-566
+    arr = np.array([True, False, True, True, False, False, True, False, False, True])
+    dt1 = _dt0(dt)[arr, :]
+    assert dt1.shape == (5, 3) and dt1.names == ("colA", "colB", "colC")
+    assert dt1.to_list()[1] == [7, 9, 10000, 0, None]
+
+
+def test_rows_compare_to_scalar(dt):                     # test-dt-rows.py:691-710
+    df1 = dt.Frame([[0, 1, 2, 3, 4, 5, 6, None, 7, None, 9], [3, 2, 1, 3, 4, 0, 2, None, None, 8, 9.0]], names=["A", "B"])
+    assert df1.stypes == (I32, F64)
+    r = df1[dt.f.A > 3, :]
+    assert r.names == df1.names and r.to_list() == [[4, 5, 6, 7, 9], [4, 0, 2, None, 9]]
+    assert df1[dt.f.A < 3, :].to_list() == [[0, 1, 2], [3, 2, 1]]
+    assert df1[dt.f.A == None, :].to_list() == [[None, None], [None, 8]]       # noqa: E711
+    assert df1[dt.f.B != None, :].to_list()[0] == [0, 1, 2, 3, 4, 5, 6, None, 9]   # noqa: E711
