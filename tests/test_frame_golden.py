@@ -74,11 +74,25 @@ def test_fuzz_query_matches_reference(qi):
     from datatable_amd import frame as dt
     from datatable_amd.frame import f, by, sort, sum, mean, min, max, count, first, last   # noqa: F401,A004
     from datatable_amd.frame import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup  # noqa: F401
-    q = FUZZ["queries"][qi]
+    _run_fuzz_query(FUZZ["queries"][qi], resident=False)
+
+
+@pytest.mark.parametrize("qi", range(0, 700, 2), ids=["%d" % i for i in range(0, 700, 2)])
+def test_fuzz_query_on_resident_frame(qi):
+    """every second query of batch 1 again, on a Frame whose columns were moved to HBM first (Frame.to_device)"""
+    _run_fuzz_query(FUZZ["queries"][qi], resident=True)
+
+
+def _run_fuzz_query(q, resident):
+    from datatable_amd import frame as dt
+    from datatable_amd.frame import f, by, sort, sum, mean, min, max, count, first, last   # noqa: F401,A004
+    from datatable_amd.frame import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup  # noqa: F401
     spec = FUZZ["frames"][q["frame"]]
     DT = dt.Frame({nm: [_dec2(x) for x in c["values"]] for nm, c in spec.items()},
                   stypes={nm: c["stype"] for nm, c in spec.items()})
     assert list(DT.stypes) == [c["stype"] for c in spec.values()]
+    if resident:
+        DT.to_device()
     R = eval(q["query"])
     assert list(R.names) == q["names"]
     assert list(R.stypes) == q["stypes"]
