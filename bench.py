@@ -9,18 +9,24 @@ Workload = BASELINE.json configs[2] ("C3"): 1e9 rows, one int64 key with 1e7 gro
 sum(float64) -- `DT[:, sum(f.v), by(f.k)]`.  It fits one GPU (16 GB of input), so it is
 the N=1 workload too; for N>1 the SAME 1e9 rows are row-sharded over the ranks (strong
 scaling, as the north star states "1e9 rows at 1/2/4/8"): local fused groupby-sum,
-range-partitioned all-to-all of partials over RCCL, merge on the owner (datatable_amd/dist.py).
+range-partitioned all-to-all of partials over RCCL, merge on the owner.
 
-A step = one full pass of the hot path over the (HBM-resident) batch.  Default path (dense
-integer key range): sampled key range, per-tile bucket histogram (which verifies the range),
-one 1024-way partition of (slot key, value), LDS-table aggregation per bucket, compaction of
-the non-empty slots into (group key, sum) columns.  `--agg-path 1` takes the general path:
-exact key range, key transform + digit histograms, stable LSD radix passes carrying the value,
-run heads -> offsets, segmented sum.  Inputs are in HBM before the timed region; outputs stay in HBM.
-One JSON line on rank 0.  `roofline` is for the dominant kernel of the timed region (the one
-with the largest total time: bucket_partition_kernel on the default path), timed with HIP events
-around every launch; `cpu_baseline` is the CPU oracle (oracle/, a port of the reference's
-algorithm) on a bounded sample, rank 0, N=1.
+A step = one full pass of the hot path over the (HBM-resident) batch.  Inputs are in HBM before the
+timed region; outputs stay in HBM.  One JSON line on rank 0:
+
+  roofline      the dominant kernel of the timed region (largest total time), timed with HIP events
+                around every launch on the stream the library launches on
+  cpu_baseline  kind "reference": the UNMODIFIED reference (oracle/_ref, built by oracle/build_ref.sh)
+                evaluating the same query with its own thread pool on the FIRST `--cpu-sample` rows of the
+                very tensors the GPU leg ran on (copied to the host), fresh Frame per run; the rate of the
+                CPU restatement (oracle/, OpenMP) is kept as `port`
+  parity        outside the timed region: (1) GPU vs the reference on that sample -- group keys bit-exact,
+                sums <= 1e-6; (2) GPU vs the OpenMP port on ALL rows of the workload -- keys and group
+                sizes bit-exact, sums <= 1e-6.  A mismatch aborts the bench.
+  configs       the other BASELINE.json configs (C1, C2, C4, C5) and the hard-keys variant of C3 at their
+                largest single-GPU sizes: ms, rows/s, algorithmic GB/s (SURVEY 8(d) byte formulas), fraction
+                of 8 TB/s and the dominant kernel of each
+  host_mode     PCIe-inclusive rate of the host-pointer mode (never `value`)
 """
 import argparse
 import json
@@ -33,43 +39,214 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_ROW = 16         # key 8 B + value 8 B read once (+ ng*(8+8) written)
+RTOL, ATOL = 1e-6, 1e-9        # float64 sums: BASELINE.json's tolerance (+ an absolute floor for sums near 0)
 
 
-def cpu_baseline(sample_rows, groups, seed, threads):
-    """Oracle (oracle/dt_oracle.c: restatement of group() + sum reducer) on the host cores: the rate on
-    `threads` OpenMP threads (chunked radix passes and per-group reducers, as the reference parallelises
-    them) over `sample_rows` rows, plus the single-thread rate on a fifth of that sample."""
+def to_host(t, chunk=1 << 27):
+    """device tensor -> numpy, through a pinned bounce buffer (the inputs of the CPU legs are the GPU leg's)"""
+    import numpy as np
+    import torch
+    out = np.empty(t.numel(), dtype={torch.int64: np.int64, torch.float64: np.float64, torch.int32: np.int32}[t.dtype])
+    ot = torch.from_numpy(out)
+    pin = torch.empty(min(chunk, t.numel()), dtype=t.dtype).pin_memory()
+    for s in range(0, t.numel(), chunk):
+        e = min(s + chunk, t.numel())
+        pin[:e - s].copy_(t[s:e]); torch.cuda.synchronize()
+        ot[s:e].copy_(pin[:e - s])
+    return out
+
+
+def sums_close(got, exp):
+    import numpy as np
+    d = np.abs(got - exp)
+    ok = bool(np.all(d <= ATOL + RTOL * np.abs(exp)))
+    big = np.abs(exp) > 1e-3
+    return ok, float(d.max()) if len(d) else 0.0, float((d[big] / np.abs(exp[big])).max()) if big.any() else 0.0
+
+
+def gpu_groupby_sum(ctx, keys, vals, with_counts=False):
+    """(group keys, sums[, counts]) of DT[:, sum(f.v)[, count()], by(f.k)] on device tensors, as numpy"""
+    import torch
+    from datatable_amd.torch_bridge import devcol
+    aggs = [("sum", 0)] + ([("count0", None)] if with_counts else [])
+    r = ctx.groupby_agg([devcol(keys)], [devcol(vals)], aggs, nrows=keys.numel())
+    ng = r.ngroups
+    gk = torch.empty(ng, dtype=torch.int64, device=keys.device)
+    gs = torch.empty(ng, dtype=torch.float64, device=keys.device)
+    r.key_into(0, gk.data_ptr()); r.agg_into(0, gs.data_ptr())
+    out = [gk, gs]
+    if with_counts:
+        gc = torch.empty(ng, dtype=torch.int64, device=keys.device)
+        r.agg_into(1, gc.data_ptr()); out.append(gc)
+    torch.cuda.synchronize()
+    r.free()
+    return [t.cpu().numpy() for t in out]
+
+
+def reference_leg(ctx, keys, vals, sample_rows, thread_list):
+    """cpu_baseline (kind "reference") + parity vs the reference on the first `sample_rows` rows."""
+    import numpy as np
+    from oracle import ref
+    dt = ref.load()
+    if dt is None:
+        return None, None
+    S = min(sample_rows, keys.numel())
+    hk, hv = to_host(keys[:S]), to_host(vals[:S])
+    ncpu = os.cpu_count() or 1
+    by_threads, res = {}, None
+    for t in thread_list:
+        nt = ncpu if t == 0 else min(t, ncpu)
+        if str(nt) in by_threads:
+            continue
+        res, sec = ref.groupby_agg({"k": hk, "v": hv}, ["k"], [("sum", "v")], nthreads=nt, reps=1)
+        by_threads[str(nt)] = {"seconds": sec, "rows_per_s": S / sec}
+    best = max(by_threads, key=lambda k: by_threads[k]["rows_per_s"])
+    rk = res[:, 0].to_numpy().ravel()
+    rs = res[:, 1].to_numpy().ravel()
+    gk, gs = gpu_groupby_sum(ctx, keys[:S], vals[:S])
+    keys_ok = bool(rk.dtype == np.int64 and np.array_equal(gk, rk))
+    s_ok, max_abs, max_rel = sums_close(gs, rs) if keys_ok else (False, None, None)
+    parity = {"against": "reference (oracle/_ref, unmodified h2oai/datatable %s)" % dt.__version__,
+              "rows": S, "groups": int(len(rk)), "keys_bit_exact": keys_ok, "sums_within_tol": s_ok,
+              "sum_max_abs_err": max_abs, "sum_max_rel_err": max_rel, "rtol": RTOL, "atol": ATOL}
+    base = {"value": by_threads[best]["rows_per_s"], "unit": "rows/s", "cores": int(best), "kind": "reference",
+            "sample": "first %d rows (%.0f%%) of the workload's own key/value tensors copied to the host: "
+                      "DT[:, sum(f.v), by(f.k)] on datatable %s (oracle/_ref), dt.options.nthreads=%s, fresh Frame, "
+                      "%.1f s" % (S, 100.0 * S / keys.numel(), dt.__version__, best, by_threads[best]["seconds"]),
+            "by_threads": by_threads, "cpu_model": ref.cpu_model(), "host_cores_available": ncpu,
+            "groups_in_sample": int(len(rk))}
+    return base, parity
+
+
+def port_leg(ctx, keys, vals, last_gpu, threads):
+    """full-size parity: the OpenMP restatement (oracle/dt_oracle.c) on ALL rows vs the GPU result; its rate is
+    the `port` CPU number."""
     import numpy as np
     from oracle import oracle as o
     o.lib()
-    rng = np.random.default_rng(seed)
-    k = rng.integers(0, groups, sample_rows, dtype=np.int64)
-    v = rng.standard_normal(sample_rows)
-
-    def run(kk, vv, t):
-        o.set_threads(t)
-        t0 = time.perf_counter()
-        ri, off = o.group([kk])
-        s = o.reduce("sum", vv, ri, off)
-        dt = time.perf_counter() - t0
-        assert len(s) == len(off) - 1
-        return dt
-
-    n1 = max(sample_rows // 5, 1)
+    hk, hv = to_host(keys), to_host(vals)
+    n = len(hk)
+    o.set_threads(threads)
     try:
-        dt1 = run(k[:n1], v[:n1], 1)
-        dtn = run(k, v, threads) if threads > 1 else None
+        t0 = time.perf_counter()
+        ri, off = o.group([hk])
+        es = o.reduce("sum", hv, ri, off)
+        sec = time.perf_counter() - t0
+        ek = hk[ri[off[:-1]]]
+        ec = np.diff(off).astype(np.int64)
     finally:
         o.set_threads(1)
-    if dtn is None:
-        value, cores, rows_used, dt = n1 / dt1, 1, n1, dt1
-    else:
-        value, cores, rows_used, dt = sample_rows / dtn, threads, sample_rows, dtn
-    return {"value": value, "unit": "rows/s", "cores": cores, "kind": "port",
-            "sample": "%d rows (%.0f%% of the workload), int64 key uniform in [0,%d), float64 N(0,1): oracle group()+sum "
-                      "on %d host thread(s), %.2f s" % (rows_used, 100.0 * rows_used / 1e9, groups, cores, dt),
-            "single_thread_value": n1 / dt1, "single_thread_sample_rows": n1,
-            "host_cores_available": os.cpu_count()}
+    del ri, hk, hv
+    gk, gs, gc = last_gpu
+    keys_ok = bool(np.array_equal(gk, ek))
+    cnt_ok = bool(keys_ok and np.array_equal(gc, ec))
+    s_ok, max_abs, max_rel = sums_close(gs, es) if keys_ok else (False, None, None)
+    parity = {"against": "oracle/dt_oracle.c (OpenMP restatement, pinned to reference goldens)", "rows": n,
+              "groups": int(len(ek)), "keys_bit_exact": keys_ok, "group_sizes_bit_exact": cnt_ok,
+              "sums_within_tol": s_ok, "sum_max_abs_err": max_abs, "sum_max_rel_err": max_rel, "rtol": RTOL, "atol": ATOL}
+    port = {"value": n / sec, "unit": "rows/s", "cores": threads, "kind": "port",
+            "sample": "all %d rows: oracle group()+sum on %d OpenMP threads, %.2f s" % (n, threads, sec)}
+    return port, parity
+
+
+# ---- the other BASELINE configs: driver-visible timings -----------------------------------------------------
+def run_configs(ctx, dev, which, steps, scale):
+    import torch
+    from datatable_amd.torch_bridge import devcol
+    g = torch.Generator(device=dev)
+    out = {}
+
+    def measure(name, n, alg_bytes, run, desc):
+        run(); torch.cuda.synchronize()                      # warm-up: allocator, first touch
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ng = run()
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / steps
+        ctx.profile_reset(); ctx.profile(True); run(); torch.cuda.synchronize(); ctx.profile(False)
+        prof = {nm: ctx.profile_get(nm) for nm in ctx.profile_names()}
+        dom = max(prof, key=lambda k: prof[k][0]) if prof else None
+        out[name] = {"workload": desc, "rows": n, "groups": int(ng), "ms": sec * 1e3, "rows_s": n / sec,
+                     "alg_bytes": alg_bytes, "alg_GBs": alg_bytes / sec / 1e9, "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS,
+                     "dominant_kernel": dom, "dominant_ms": prof[dom][0] if dom else None,
+                     "kernel_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]}}
+        torch.cuda.empty_cache(); ctx.trim()
+
+    for c in which:
+        if c == "C1":
+            n = int(1e6 * scale); g.manual_seed(1235)
+            k = torch.randint(0, 100, (n,), dtype=torch.int32, device=dev, generator=g)
+            v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            def run():
+                r = ctx.groupby_agg([devcol(k)], [devcol(v)], [("sum", 0)], nrows=n); ng = r.ngroups; r.free(); return ng
+            measure(c, n, n * 12 + 100 * 12, run, "DT[:, sum(f.v), by(f.k)], int32 key in [0,100), float64")
+            del k, v
+        elif c == "C2":
+            n = int(1e8 * scale); g.manual_seed(1236)
+            k = torch.randint(0, 100_000, (n,), dtype=torch.int64, device=dev, generator=g)
+            vs = [torch.randn(n, dtype=torch.float64, device=dev, generator=g) for _ in range(4)]
+            aggs = [(op, i) for op in ("sum", "mean", "min", "max") for i in range(4)]
+            def run():
+                r = ctx.groupby_agg([devcol(k)], [devcol(x) for x in vs], aggs, nrows=n); ng = r.ngroups; r.free(); return ng
+            measure(c, n, n * 40 + 100_000 * 136, run, "DT[:, [sum,mean,min,max](f[1:]), by(f.k)], int64 key in [0,1e5), 4 x float64")
+            del k, vs
+        elif c in ("C3_hard",):
+            n = int(1e9 * scale); g.manual_seed(1240)
+            pool = torch.randint(-2**62, 2**62, (10_000_000,), dtype=torch.int64, device=dev, generator=g)
+            k = pool[torch.randint(0, 10_000_000, (n,), dtype=torch.int64, device=dev, generator=g)]
+            del pool
+            v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            def run():
+                r = ctx.groupby_agg([devcol(k)], [devcol(v)], [("sum", 0)], nrows=n); ng = r.ngroups; r.free(); return ng
+            measure(c, n, n * 16 + 10_000_000 * 16, run, "C3 with 63-bit keys drawn from a pool of 1e7 values (SURVEY 8(d) hard keys)")
+            del k, v
+        elif c == "C4":
+            n = int(1e9 * scale); g.manual_seed(1238)
+            a = torch.randint(0, 3163, (n,), dtype=torch.int32, device=dev, generator=g)
+            b = torch.randint(0, 3163, (n,), dtype=torch.int32, device=dev, generator=g)
+            v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            def run():
+                r = ctx.groupby_agg([devcol(a), devcol(b)], [devcol(v)], [("count0", None), ("sum", 0)], nrows=n)
+                ng = r.ngroups; r.free(); return ng
+            measure(c, n, n * 16 + 10_004_569 * 24, run, "DT[:, [count(), sum(f.v)], by(f.a, f.b)], 2 x int32 keys in [0,3163), float64")
+            del a, b, v
+        elif c == "C5":
+            n = int(1e9 * scale); g.manual_seed(1239)
+            k = torch.randint(0, 100_000_000, (n,), dtype=torch.int64, device=dev, generator=g)
+            x = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            ri = torch.empty(n, dtype=torch.int32, device=dev)
+            kbuf = torch.empty(n, dtype=torch.int64, device=dev)
+            xbuf = torch.empty(n, dtype=torch.float64, device=dev)
+            def run():
+                # V = DT[f.x > 0, :]; V[:, :, by(f.k)] (two-step form, SURVEY F6): filter -> RowIndex + the view's
+                # columns in one sweep, then the rows in grouped order (key, x and the RowIndex ride through the sort)
+                npass = ctx.filter_take_dev(devcol(x), ">", 0.0, [devcol(k), devcol(x)], n, ri.data_ptr(),
+                                            [kbuf.data_ptr(), xbuf.data_ptr()])
+                kv, xv = kbuf[:npass], xbuf[:npass]
+                r = ctx.groupby_rows([devcol(kv)], [devcol(kv), devcol(xv), devcol(ri[:npass])], nrows=npass, want_rowindex=False)
+                ng = r.ngroups; r.free(); return ng
+            measure(c, n, int(n * 30.4), run, "V = DT[f.x > 0, :]; V[:, :, by(f.k)], int64 key in [0,1e8), float64 x, ~50% pass")
+            del k, x, ri, kbuf, xbuf
+        torch.cuda.empty_cache()
+    return out
+
+
+def host_mode_leg(ctx, rows):
+    """PCIe-inclusive: numpy buffers in, numpy results out (DTHIP_HOST) -- what the reference-side shim uses"""
+    import numpy as np
+    rng = np.random.default_rng(99)
+    k = rng.integers(0, 1_000_000, rows, dtype=np.int64)
+    v = rng.standard_normal(rows)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = ctx.groupby_agg([k], [v], [("sum", 0)])
+        s = r.agg(0); kk = r.key(0)
+        r.free()
+        sec = time.perf_counter() - t0
+        best = sec if best is None or sec < best else best
+    return {"rows": rows, "groups": int(len(kk)), "ms": best * 1e3, "rows_s": rows / best, "input_GBs": rows * 16 / best / 1e9,
+            "note": "DTHIP_HOST mode: pageable numpy buffers in, numpy results out; includes PCIe both ways"}
 
 
 def main():
@@ -79,9 +256,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--groups", type=int, default=10_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=500_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="rows of the workload the reference is timed on")
+    ap.add_argument("--ref-threads", default="0,1", help="dt.options.nthreads values to time (0 = all host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: min(host cores, 64))")
+    ap.add_argument("--no-full-parity", action="store_true", help="skip the all-rows GPU vs OpenMP-port comparison")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the OpenMP port (0: min(host cores, 64))")
+    ap.add_argument("--configs", default="C1,C2,C4,C5,C3_hard", help="other BASELINE configs to time after C3 ('' = none)")
+    ap.add_argument("--config-steps", type=int, default=3)
+    ap.add_argument("--config-scale", type=float, default=1.0)
+    ap.add_argument("--host-rows", type=int, default=100_000_000, help="rows of the host-pointer (PCIe-inclusive) leg, 0 = skip")
     ap.add_argument("--no-check", action="store_true", help="skip the result sanity check (kernel timing experiments)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--agg-path", type=int, default=0, help="dthip option agg_path: 0 auto, 1 sort, 2 bucketed")
@@ -165,8 +348,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    per_kernel = {}
+    for nm in ctx.profile_names():
+        ms, cnt = ctx.profile_get(nm)
+        per_kernel[nm] = {"launches": cnt, "avg_ms": ms / max(cnt, 1), "total_ms": ms}
+    # the dominant kernel = largest share of the timed region
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms"]) if per_kernel else None
+    rp_ms, rp_n = (per_kernel[dom]["total_ms"], per_kernel[dom]["launches"]) if dom else (0.0, 0)
+
     # sanity of the last result (outside the timed region): keys strictly ascending, totals agree,
     # and (one extra untimed call with count()) every row counted exactly once
+    parity = {}
     if not sharded:
         ng = last.ngroups
         sums = torch.empty(ng, dtype=torch.float64, device=dev)
@@ -176,8 +368,8 @@ def main():
         torch.cuda.synchronize()
         if not args.no_check:
             assert bool((gkeys[1:] > gkeys[:-1]).all())
-            total, ref = float(sums.sum().item()), float(vals.sum().item())
-            assert abs(total - ref) <= 1e-9 * float(vals.abs().sum().item()), (total, ref)
+            total, ref_total = float(sums.sum().item()), float(vals.sum().item())
+            assert abs(total - ref_total) <= 1e-9 * float(vals.abs().sum().item()), (total, ref_total)
             rc = ctx.groupby_agg([kcol], [vcol], [("count0", None), ("sum", 0)], nrows=n_local)
             cnt = torch.empty(rc.ngroups, dtype=torch.int64, device=dev)
             s2 = torch.empty(rc.ngroups, dtype=torch.float64, device=dev)
@@ -186,6 +378,11 @@ def main():
             torch.cuda.synchronize()
             assert rc.ngroups == ng and int(cnt.sum().item()) == n_local
             assert bool(torch.allclose(s2, sums, rtol=1e-9, atol=1e-9))
+            parity["properties"] = {"rows": n_local, "keys_strictly_ascending": True, "group_sizes_sum_to_rows": True,
+                                    "sum_of_group_sums_equals_sum_of_values": True}
+            last_gpu = (gkeys.cpu().numpy(), sums.cpu().numpy(), cnt.cpu().numpy())
+            del cnt, s2
+        del sums, gkeys
     else:
         gk, out = last
         ng_t = torch.tensor([gk[0].numel()], dtype=torch.int64, device=dev)
@@ -194,14 +391,7 @@ def main():
         ng = int(ng_t.item())
         assert abs(float(tot[0]) - float(tot[1])) <= 1e-9 * float(tot[2]), tot.tolist()
 
-    per_kernel = {}
-    for nm in ctx.profile_names():
-        ms, cnt = ctx.profile_get(nm)
-        per_kernel[nm] = {"launches": cnt, "avg_ms": ms / max(cnt, 1), "total_ms": ms}
-    # the dominant kernel = largest share of the timed region
-    dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms"]) if per_kernel else None
-    rp_ms, rp_n = (per_kernel[dom]["total_ms"], per_kernel[dom]["launches"]) if dom else (0.0, 0)
-
+    line = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = n_total * args.steps / dt
@@ -239,12 +429,33 @@ def main():
                        "parallelism": "row-sharded x%d, range-partitioned all-to-all of partials" % world if world > 1 else "single GPU"},
             "roofline": roof,
             "kernels": per_kernel,
+            "cpu_baseline": None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not sharded and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
-            line["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, n_total), args.groups, 1234 + 3, threads)
-        else:
-            line["cpu_baseline"] = None
+            base, par = reference_leg(ctx, keys, vals, args.cpu_sample, [int(t) for t in args.ref_threads.split(",") if t != ""])
+            if base is not None:
+                line["cpu_baseline"] = base
+                parity["vs_reference"] = par
+                assert par["keys_bit_exact"] and par["sums_within_tol"], par
+            if not args.no_full_parity and not args.no_check:
+                port, par = port_leg(ctx, keys, vals, last_gpu, threads)
+                parity["vs_port_all_rows"] = par
+                assert par["keys_bit_exact"] and par["group_sizes_bit_exact"] and par["sums_within_tol"], par
+                if line["cpu_baseline"] is None:
+                    line["cpu_baseline"] = port          # no oracle/_ref on this machine: the port is all there is
+                else:
+                    line["cpu_baseline"]["port"] = port
+        line["parity"] = parity or None
+    del keys, vals, kcol, vcol
+    torch.cuda.empty_cache(); ctx.trim()
+    if rank == 0 and world == 1 and not sharded:
+        which = [c for c in args.configs.split(",") if c]
+        if which:
+            line["configs"] = run_configs(ctx, dev, which, args.config_steps, args.config_scale)
+        if args.host_rows:
+            line["host_mode"] = host_mode_leg(ctx, args.host_rows)
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if sharded:
         dist.barrier()

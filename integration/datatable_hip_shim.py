@@ -158,13 +158,16 @@ def _col(frame, c):
     return L.Col(dt.internal.frame_column_data_r(frame, c).value, frame.stypes[c].value, 0)
 
 
-def _finish(frame, keys, cols, names):
+def _finish(frame, keys, cols, names, bool_cols=()):
+    """numpy result buffers -> the result Frame.  bool8 columns (keys, and min/max/first/last/cummin/cummax of a
+    bool8 column: the reference keeps the stype, fexpr_minmax.cc:47-68) travel as int8 with NA = -128 and are
+    cast back here (int8 -> bool8 keeps NA)."""
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", dt.exceptions.DatatableWarning)     # duplicate names are mangled, as in the reference
         res = dt.Frame(cols, names=names)                                   # "" -> auto-named C<k> by the reference
-    for i, k in enumerate(keys):                                            # bool8 keys travel as int8
-        if frame.stypes[k] == dt.stype.bool8:
-            res[:, i] = dt.Frame(res[:, i].to_numpy().astype(np.bool_))
+    bools = set(bool_cols) | {i for i, k in enumerate(keys) if frame.stypes[k] == dt.stype.bool8}
+    for i in sorted(bools):
+        res[:, i] = dt.as_type(dt.f[i], dt.bool8)
     return res
 
 
@@ -187,7 +190,7 @@ def run_sred(frame, keys, aggs, ctx=None):
     finally:
         lib.dthip_result_free(ctx._h, h)
     rowwise = bool(aggs) and len(aggs[0]) == 3
-    cols, names = [], []
+    cols, names, bool_cols = [], [], []
     sel = ri if rowwise else ri[off[:-1]]              # the by-columns: every row / first row of each group
     for k in keys:
         out = np.empty(len(sel), ST2NP[frame.stypes[k].value])
@@ -199,6 +202,8 @@ def run_sred(frame, keys, aggs, ctx=None):
         if rowwise:
             st = lib.dthip_cumulate_out_stype(CUMOPS[op], L.INT64 if c is None else frame.stypes[c].value)
             out = np.empty(n, ST2NP[st])
+            if st == L.BOOL:
+                bool_cols.append(len(cols))
             vc = _col(frame, c) if c is not None else None
             if n:
                 L.check(lib.dthip_cumulate(ctx._h, CUMOPS[op], C.byref(vc) if vc is not None else None,
@@ -219,13 +224,16 @@ def run_sred(frame, keys, aggs, ctx=None):
             names.append("count")
         else:
             vc = _col(frame, c)
-            out = np.empty(ng, ST2NP[lib.dthip_reduce_out_stype(OPS[op], vc.stype)])
+            st = lib.dthip_reduce_out_stype(OPS[op], vc.stype)
+            out = np.empty(ng, ST2NP[st])
+            if st == L.BOOL:
+                bool_cols.append(len(cols))
             if ng:
                 L.check(lib.dthip_reduce(ctx._h, OPS[op], C.byref(vc), ri.ctypes.data, off.ctypes.data, ng, n, L.HOST,
                                          out.ctypes.data))
             names.append(frame.names[c])
         cols.append(out)
-    return _finish(frame, keys, cols, names)
+    return _finish(frame, keys, cols, names, bool_cols)
 
 
 def run(frame, keys, aggs, ctx=None):
@@ -245,18 +253,21 @@ def run(frame, keys, aggs, ctx=None):
                                   L.NA_FIRST, L.HOST, C.byref(h)))
     try:
         ng = lib.dthip_result_ngroups(h)
-        cols, names = [], []
+        cols, names, bool_cols = [], [], []
         for i, k in enumerate(keys):
             out = np.empty(ng, ST2NP[frame.stypes[k].value])
             L.check(lib.dthip_result_copy_key(ctx._h, h, i, out.ctypes.data, L.HOST))
             cols.append(out); names.append(frame.names[k])
         for a, (op, c) in enumerate(aggs):
-            out = np.empty(ng, ST2NP[lib.dthip_result_agg_stype(h, a)])
+            st = lib.dthip_result_agg_stype(h, a)
+            out = np.empty(ng, ST2NP[st])
+            if st == L.BOOL:
+                bool_cols.append(len(cols))
             L.check(lib.dthip_result_copy_agg(ctx._h, h, a, out.ctypes.data, L.HOST))
             cols.append(out); names.append("count" if c is None else frame.names[c])
     finally:
         lib.dthip_result_free(ctx._h, h)
-    return _finish(frame, keys, cols, names)
+    return _finish(frame, keys, cols, names, bool_cols)
 
 
 class Frame(dt.Frame):

@@ -1,0 +1,60 @@
+#!/bin/bash
+# oracle/build_ref.sh -- build the UNMODIFIED reference (h2oai/datatable, /root/reference) into
+# oracle/_ref/ so that it can serve as (1) the parity checker of last resort and (2) the timed CPU
+# baseline (bench.py: cpu_baseline.kind == "reference") on the GPU box, where /root/reference does not
+# exist.  TEST INFRASTRUCTURE ONLY: nothing under datatable_amd/ may import oracle/_ref.
+#
+# Recipe: the reference tree is read-only and its build writes into itself
+# (build/, src/datatable/lib/, src/core/documentation.cc, src/datatable/_build_info.py), so the tree is
+# copied to a scratch directory OUTSIDE the repo, built there with the reference's own driver
+# (`python ci/ext.py build`, ci/ext.py:209-330: g++ -std=c++14 -O3, 327 TUs, no third-party
+# dependencies), and only the OUTPUTS are placed under oracle/_ref/:
+#     oracle/_ref/datatable/                 the Python package of the build (src/datatable)
+#     oracle/_ref/datatable/lib/_datatable*.so   stripped (82 MB -> ~8 MB)
+# oracle/_ref/ is git-ignored (no reference sources enter the history) but NOT gpurun-ignored: it
+# travels to the GPU box like libdthip.so does.
+#
+#   usage: oracle/build_ref.sh [--force]
+#   env:   DT_REF_SRC  (default /root/reference)   DT_REF_WORK (default /tmp/dt_ref_build)
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+SRC="${DT_REF_SRC:-/root/reference}"
+WORK="${DT_REF_WORK:-/tmp/dt_ref_build}"
+OUT="$HERE/_ref"
+FORCE=0; [ "${1:-}" = "--force" ] && FORCE=1
+
+if [ ! -d "$SRC/src/core" ]; then
+  echo "build_ref: $SRC not present (GPU box?) -- using the prebuilt oracle/_ref as is" >&2
+  exit 0
+fi
+SO_OUT=$(ls "$OUT"/datatable/lib/_datatable*.so 2>/dev/null | head -1 || true)
+if [ -n "$SO_OUT" ] && [ $FORCE -eq 0 ]; then
+  echo "build_ref: $SO_OUT already present (use --force to rebuild)"; exit 0
+fi
+
+if [ ! -d "$WORK/src/core" ]; then
+  mkdir -p "$WORK"
+  cp -r "$SRC"/. "$WORK"/
+  chmod -R u+w "$WORK"
+fi
+cd "$WORK"
+if ! ls src/datatable/lib/_datatable*.so >/dev/null 2>&1 || [ $FORCE -eq 1 ]; then
+  python ci/ext.py build > "$WORK/build_ref.log" 2>&1 || { tail -30 "$WORK/build_ref.log"; exit 1; }
+fi
+SO=$(ls src/datatable/lib/_datatable*.so | head -1)
+
+rm -rf "$OUT"; mkdir -p "$OUT"
+# the package (python sources of the BUILD, incl. the generated _build_info.py) -- outputs only, git-ignored
+(cd src && find datatable -name __pycache__ -prune -o -type f \( -name '*.py' -o -name '*.h' \) -print0 | \
+   xargs -0 -I{} cp --parents {} "$OUT"/)
+cp "$SO" "$OUT/datatable/lib/"
+strip --strip-unneeded "$OUT/datatable/lib/$(basename "$SO")"
+# provenance: what was built from what
+{
+  echo "reference: $SRC"
+  echo "version: $(cat "$SRC/VERSION.txt" 2>/dev/null || true)"
+  echo "built: $(date -u +%Y-%m-%dT%H:%M:%SZ) by oracle/build_ref.sh (python ci/ext.py build, $(g++ --version | head -1))"
+  echo "src/core sha256 (sorted file list): $(cd "$SRC/src/core" && find . -type f \( -name '*.cc' -o -name '*.h' \) | LC_ALL=C sort | xargs sha256sum | sha256sum | cut -d' ' -f1)"
+} > "$OUT/PROVENANCE.txt"
+PYTHONPATH="$OUT" python -c "import datatable as dt; print('build_ref: oracle/_ref ok, datatable', dt.__version__)"
+du -sh "$OUT" | sed 's/^/build_ref: /'

@@ -1,17 +1,15 @@
 """The reference-side binding of INTEGRATION.md (integration/datatable_hip_shim.py): query
-matching, pointer/stype extraction and fall-through, exercised against the REAL reference when a
-build of it is importable in this container (DT_REFERENCE_SRC, default /tmp/dt_oracle/src).
-No GPU needed: nothing here calls a compute entry point of libdthip."""
-import os
-import sys
-
+matching, pointer/stype extraction and fall-through, exercised against the REAL reference as built
+into oracle/_ref by oracle/build_ref.sh (skipped only when that build was never made).
+No GPU needed: nothing here calls a compute entry point of libdthip (tests/test_shim_e2e.py does, on the GPU)."""
 import numpy as np
 import pytest
 
-SRC = os.environ.get("DT_REFERENCE_SRC", "/tmp/dt_oracle/src")
-if os.path.isdir(SRC) and SRC not in sys.path:
-    sys.path.insert(0, SRC)
-dt = pytest.importorskip("datatable", reason="the reference is not importable here")
+from oracle import ref
+
+dt = ref.load()
+if dt is None:
+    pytest.skip("oracle/_ref (the reference build) is not present: run oracle/build_ref.sh", allow_module_level=True)
 
 
 def test_match_and_fallthrough():

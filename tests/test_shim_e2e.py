@@ -1,0 +1,168 @@
+"""End-to-end run of the reference-side binding ON HARDWARE: a real `datatable.Frame` (the unmodified
+reference built into oracle/_ref by oracle/build_ref.sh), `integration.datatable_hip_shim.Frame.__getitem__`
+for the fused (run) and S-red (run_sred) routes, compared IN THE SAME PROCESS with what the reference's own
+`Frame.__getitem__` returns for the same query -- with the comparison rules of the reference's test-suite
+(`assert_equals`, /root/reference/tests/__init__.py:100-146: shape, names, types, values; floats by
+relative tolerance -- 1e-6 here, BASELINE.json's bound for float64 reductions).
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from oracle import ref
+    dt = ref.load()
+    if dt is None:
+        pytest.fail("oracle/_ref (the reference build) is missing: run oracle/build_ref.sh where /root/reference exists")
+    from integration import datatable_hip_shim as shim
+    return dt, shim
+
+
+def assert_frames_equal(dt, got, exp, rel_tol=1e-6, abs_tol=1e-9):
+    assert type(got) is dt.Frame and type(exp) is dt.Frame
+    assert got.shape == exp.shape, (got.shape, exp.shape)
+    assert got.names == exp.names, (got.names, exp.names)
+    assert got.stypes == exp.stypes, (got.stypes, exp.stypes)
+    for i in range(exp.ncols):
+        a, b = got[:, i].to_list()[0], exp[:, i].to_list()[0]
+        for j, (x, y) in enumerate(zip(a, b)):
+            if x == y:
+                continue
+            if isinstance(x, float) and isinstance(y, float) and (math.isclose(x, y, rel_tol=rel_tol, abs_tol=abs_tol)
+                                                                  or (math.isnan(x) and math.isnan(y))):
+                continue
+            raise AssertionError("column %d %r row %d: shim %r, reference %r" % (i, exp.names[i], j, x, y))
+
+
+def both(dt, shim, DT, j, bycols):
+    """the shim's answer and the reference's own answer for DT[:, j, by(bycols)]"""
+    plan = shim.match(DT, (slice(None), j, shim.by(*bycols)))
+    assert plan is not None, "query not routed to libdthip"
+    got = DT[:, j, shim.by(*bycols)]
+    exp = dt.Frame.__getitem__(DT, (slice(None), j, dt.by(*bycols)))
+    return got, exp
+
+
+def make_frame(shim, n, seed, key="int64", ngroups=50, na=True):
+    rng = np.random.default_rng(seed)
+    cols = {}
+    if key == "int64":
+        k = rng.integers(-ngroups // 2, ngroups // 2, n).astype(np.int64) * 1_000_003
+    elif key == "int32":
+        k = rng.integers(0, ngroups, n).astype(np.int32)
+    elif key == "float64":
+        k = rng.integers(0, ngroups, n).astype(np.float64) / 4 - 3
+    elif key == "bool":
+        k = rng.integers(0, 2, n).astype(np.bool_)
+    cols["k"] = k
+    cols["k2"] = rng.integers(0, 7, n).astype(np.int32)
+    cols["f8"] = rng.standard_normal(n)
+    cols["f4"] = rng.standard_normal(n).astype(np.float32)
+    cols["i8"] = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    cols["i4"] = rng.integers(-1000, 1000, n).astype(np.int32)
+    cols["i2"] = rng.integers(-300, 300, n).astype(np.int16)
+    cols["i1"] = rng.integers(-100, 100, n).astype(np.int8)
+    cols["b"] = rng.integers(0, 2, n).astype(np.bool_)
+    DT = shim.Frame(cols)
+    if na and n >= 8:
+        idx = rng.choice(n, max(n // 16, 1), replace=False)
+        # NAs through the reference's own assignment, so the buffers hold ITS sentinels
+        for c in ("f8", "f4", "i8", "i4", "i2", "i1", "b") + (("k",) if key != "bool" else ()):
+            sel = [int(x) for x in idx[rng.random(len(idx)) < 0.5]]
+            if sel:
+                DT[sel, c] = None
+        DT[int(idx[0]), "f8"] = math.inf
+        DT[int(idx[-1]), "f8"] = -math.inf
+    return DT
+
+
+@pytest.mark.parametrize("key", ["int64", "int32", "float64", "bool"])
+@pytest.mark.parametrize("n", [1, 37, 5000, 300_000])
+def test_fused_route_all_reducers(env, key, n):
+    dt, shim = env
+    from datatable import f, sum, mean, min, max, count
+    DT = make_frame(shim, n, seed=n + len(key), key=key)
+    j = [op(f[c]) for c in ("f8", "f4", "i8", "i4", "i2", "i1", "b") for op in (sum, mean, min, max, count)] + [count()]
+    got, exp = both(dt, shim, DT, j, [f.k])
+    assert_frames_equal(dt, got, exp)
+
+
+def test_fused_route_two_keys_and_names(env):
+    dt, shim = env
+    from datatable import f, sum, mean, min, count
+    DT = make_frame(shim, 20_000, seed=5)
+    got, exp = both(dt, shim, DT, [sum(f.f8), sum(f.f8), mean(f["i4"]), min(f[2]), count(f.i8), count()], [f.k, f.k2])
+    assert_frames_equal(dt, got, exp)
+    got, exp = both(dt, shim, DT, sum(f.i4), ["k2"])
+    assert_frames_equal(dt, got, exp)
+
+
+def test_fused_route_c1_shape_at_scale(env):
+    """BASELINE config C1 (1e6 rows, int32 key with 100 groups, sum(float64)) and a 5e6-row high-cardinality case
+    through the whole drop-in: numpy -> dt.Frame -> shim -> libdthip -> dt.Frame"""
+    dt, shim = env
+    from datatable import f, sum, count
+    rng = np.random.default_rng(1235)
+    DT = shim.Frame(k=rng.integers(0, 100, 10**6, dtype=np.int32), v=rng.standard_normal(10**6))
+    got, exp = both(dt, shim, DT, sum(f.v), [f.k])
+    assert_frames_equal(dt, got, exp)
+    n = 5 * 10**6
+    DT = shim.Frame(k=rng.integers(0, 10**6, n, dtype=np.int64), v=rng.standard_normal(n))
+    got, exp = both(dt, shim, DT, [sum(f.v), count()], [f.k])
+    assert got.shape == exp.shape and got.names == exp.names and got.stypes == exp.stypes
+    assert np.array_equal(got[:, 0].to_numpy(), exp[:, 0].to_numpy())
+    assert np.array_equal(got[:, 2].to_numpy(), exp[:, 2].to_numpy())
+    assert np.allclose(got[:, 1].to_numpy(), exp[:, 1].to_numpy(), rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("n", [1, 29, 4000, 120_000])
+def test_sred_route_reducers(env, n):
+    dt, shim = env
+    import datatable
+    from datatable import f
+    DT = make_frame(shim, n, seed=100 + n)
+    j = [datatable.sd(f.f8), datatable.sd(f.i4), datatable.median(f.f8), datatable.median(f.i2), datatable.nunique(f.i1),
+         datatable.nunique(f.f4), datatable.first(f.f8), datatable.last(f.i8), datatable.first(f.b), datatable.last(f.b),
+         datatable.cov(f.f8, f.i4), datatable.corr(f.f4, f.f8), datatable.count()]
+    got, exp = both(dt, shim, DT, j, [f.k])
+    assert_frames_equal(dt, got, exp, rel_tol=1e-6 if n < 100_000 else 5e-5)
+
+
+@pytest.mark.parametrize("n", [1, 29, 4000, 120_000])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_sred_route_cumulative(env, n, reverse):
+    dt, shim = env
+    import datatable
+    from datatable import f
+    DT = make_frame(shim, n, seed=200 + n)
+    DT[:, "f8"] = DT[:, dt.ifelse(dt.math.isinf(f.f8), 1.0, f.f8)]     # running sums through inf - inf are order dependent
+    j = [datatable.cumsum(f.f8, reverse=reverse), datatable.cumsum(f.i4, reverse=reverse),
+         datatable.cummin(f.f4, reverse=reverse), datatable.cummax(f.i8, reverse=reverse),
+         datatable.cummax(f.b, reverse=reverse), datatable.cumprod(f.i1, reverse=reverse),
+         datatable.cumcount(reverse=reverse), datatable.ngroup(reverse=reverse)]
+    got, exp = both(dt, shim, DT, j, [f.k, f.k2])
+    assert_frames_equal(dt, got, exp)
+
+
+def test_fallthrough_and_views(env):
+    dt, shim = env
+    from datatable import f, sum
+    DT = shim.Frame(k=[3, 1, 3, None, 1], v=[1.0, 2.0, 4.0, 8.0, None], s=["a", "b", "a", "c", "b"])
+    R = DT[:, sum(f.v), shim.by(f.s)]                       # string key -> the reference
+    assert R.to_list() == [["a", "b", "c"], [5.0, 2.0, 8.0]]
+    V = shim.Frame(DT[f.v > 1.5, :])                        # a filter view: virtual columns are materialised by the
+    got = V[:, sum(f.v), shim.by(f.k)]                      # reference before the pointers are borrowed
+    exp = dt.Frame.__getitem__(V, (slice(None), sum(f.v), dt.by(f.k)))
+    assert_frames_equal(dt, got, exp)
+    # Appendix B of SURVEY.md through the shim
+    DT = shim.Frame(k=np.array([3, -2**31, 1, 3, 1, -2**31, 2, 3], np.int32))
+    DT = shim.Frame(k=[3, None, 1, 3, 1, None, 2, 3], v=[1.5, 2.0, None, 4.0, None, 8.0, 16.0, math.inf])
+    got = DT[:, [dt.sum(f.v), dt.mean(f.v), dt.min(f.v), dt.max(f.v), dt.count(f.v), dt.count()], shim.by(f.k)]
+    assert got.names == ("k", "v", "v.0", "v.1", "v.2", "v.3", "count")
+    assert got.to_list() == [[None, 1, 2, 3], [10.0, 0.0, 16.0, math.inf], [5.0, None, 16.0, math.inf],
+                             [2.0, None, 16.0, 1.5], [8.0, None, 16.0, math.inf], [2, 0, 1, 3], [2, 2, 1, 3]]
