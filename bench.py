@@ -257,7 +257,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--groups", type=int, default=10_000_000)
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="rows of the workload the reference is timed on")
-    ap.add_argument("--ref-threads", default="0,1", help="dt.options.nthreads values to time (0 = all host cores)")
+    ap.add_argument("--ref-threads", default="16,1",
+                    help="dt.options.nthreads values to time (0 = all host cores; on the 256-thread box the reference is fastest at 16 and 40x slower at 256: profiles/r02a_bench_refsweep.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-parity", action="store_true", help="skip the all-rows GPU vs OpenMP-port comparison")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the OpenMP port (0: min(host cores, 64))")

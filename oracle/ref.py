@@ -48,13 +48,14 @@ def provenance():
 
 
 def set_threads(n):
-    """dt.options.nthreads is process-global and is also sort.nthreads' default (src/core/sort.cc:264)"""
+    """Both thread counts of the path: dt.options.nthreads (the pool every parallel_for of the reducers uses) and
+    sort.nthreads (group()'s own team size; its default is the hardware concurrency, src/core/sort.cc:264, and it
+    does NOT follow options.nthreads).  The setter stores the value through a uint8_t cast (sort.cc:337), so 256
+    becomes 0 and group() then divides by it (sort.cc:918-919: SIGFPE, observed on the 256-thread GPU box):
+    sort.nthreads is clamped to 255 here."""
     dt = load()
     dt.options.nthreads = int(n)
-    try:
-        dt.options.sort.nthreads = int(n)
-    except Exception:
-        pass
+    dt.options.sort.nthreads = max(1, min(int(n), 255))
     return dt.options.nthreads
 
 
