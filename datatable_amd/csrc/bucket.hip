@@ -113,6 +113,32 @@ __device__ __forceinline__ void load_tile_x(const KeyXform& kx, uint32_t tile_ba
   }
 }
 
+// The same for ONE key column of a vector-load mode, split into the loads (raw registers) and the transform, so that
+// a persistent kernel can have the next tile's loads in flight while it works on the current one.
+template <int BLOCK, int ITEMS, int KM>
+__device__ __forceinline__ void load_raw1(const KeyColDev& c, uint32_t tile_base, int tid, bu32x4 (&w)[ITEMS / KmVW<KM>::value]) {
+  constexpr int VW = KmVW<KM>::value;
+  const bu32x4* src = reinterpret_cast<const bu32x4*>(static_cast<const unsigned char*>(c.data) + (size_t)tile_base * (16 / VW));
+#pragma unroll
+  for (int q = 0; q < ITEMS / VW; q++) w[q] = src[(uint32_t)q * BLOCK + tid];
+}
+template <int BLOCK, int ITEMS, int KM>
+__device__ __forceinline__ void xform_raw1(const KeyColDev& c, const bu32x4 (&w)[ITEMS / KmVW<KM>::value], uint32_t (&x)[ITEMS], bool& bad) {
+  constexpr int VW = KmVW<KM>::value;
+#pragma unroll
+  for (int q = 0; q < ITEMS / VW; q++) {
+    if (KM == 1) {
+      x[2 * q] = xf_int(c, (long long)((u64)w[q].x | ((u64)w[q].y << 32)), INT64_MIN, bad) << c.shift;
+      x[2 * q + 1] = xf_int(c, (long long)((u64)w[q].z | ((u64)w[q].w << 32)), INT64_MIN, bad) << c.shift;
+    } else {
+      x[4 * q] = xf_int(c, (long long)(int32_t)w[q].x, INT32_MIN, bad) << c.shift;
+      x[4 * q + 1] = xf_int(c, (long long)(int32_t)w[q].y, INT32_MIN, bad) << c.shift;
+      x[4 * q + 2] = xf_int(c, (long long)(int32_t)w[q].z, INT32_MIN, bad) << c.shift;
+      x[4 * q + 3] = xf_int(c, (long long)(int32_t)w[q].w, INT32_MIN, bad) << c.shift;
+    }
+  }
+}
+
 // payload column values of the thread's items (PT = uint32_t / u64), same row assignment
 template <int BLOCK, int ITEMS, int KM, typename PT>
 __device__ __forceinline__ void load_tile_vals(const PT* __restrict__ src, uint32_t nvalid, bool full, int tid,
@@ -184,7 +210,8 @@ struct HistArgs {
   uint32_t* P; uint32_t* gtot; uint32_t* bad;
 };
 
-template <int BLOCK, int ITEMS, int KM, bool CL>
+// PIPE (one key column, vector-load key mode): the next tile's loads are issued before the current tile is counted.
+template <int BLOCK, int ITEMS, int KM, bool CL, bool PIPE>
 __global__ void __launch_bounds__(BLOCK) bucket_hist_kernel(HistArgs a) {
   constexpr uint32_t TILE = BLOCK * ITEMS;
   constexpr int NB = 2048 / BLOCK;          // bins per thread (F <= 2048)
@@ -205,13 +232,26 @@ __global__ void __launch_bounds__(BLOCK) bucket_hist_kernel(HistArgs a) {
   __syncthreads();
   const uint32_t t0 = blockIdx.x * a.tpg;
   const uint32_t t1 = (t0 + a.tpg < a.ntiles) ? t0 + a.tpg : a.ntiles;
+  constexpr int NRAW = PIPE ? ITEMS / KmVW<KM>::value : 1;
+  bu32x4 raw[NRAW];
+  bool have = false;
+  if (PIPE && t0 < t1 && a.n - t0 * TILE >= TILE) { load_raw1<BLOCK, ITEMS, KM>(a.kx.cols[0], t0 * TILE, tid, reinterpret_cast<bu32x4(&)[ITEMS / KmVW<KM>::value]>(raw)); have = true; }
   for (uint32_t t = t0; t < t1; t++) {
     uint32_t* cnt = cnt2 + ((t - t0) & 1u) * Fp;
     const uint32_t tile_base = t * TILE;
     const uint32_t nvalid = (a.n - tile_base < TILE) ? (a.n - tile_base) : TILE;
     const bool full = nvalid == TILE;
     uint32_t x[ITEMS];
-    load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x, bad);
+    if (PIPE && have) {
+      xform_raw1<BLOCK, ITEMS, KM>(a.kx.cols[0], reinterpret_cast<const bu32x4(&)[ITEMS / KmVW<KM>::value]>(raw), x, bad);
+      have = false;
+      if (t + 1 < t1 && a.n - (tile_base + TILE) >= TILE) {
+        load_raw1<BLOCK, ITEMS, KM>(a.kx.cols[0], tile_base + TILE, tid, reinterpret_cast<bu32x4(&)[ITEMS / KmVW<KM>::value]>(raw));
+        have = true;
+      }
+    } else {
+      load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x, bad);
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS; j++)
       if (full || item_row<BLOCK, KM>(j, tid) < nvalid) {
@@ -317,6 +357,23 @@ struct PartArgs {
 };
 
 template <int BLOCK, int ITEMS, int KM, typename PT>
+__device__ __forceinline__ void place_payload(const PT (&v)[ITEMS], PT* __restrict__ pout, unsigned char* stage,
+                                              uint32_t nvalid, bool full, int tid, const uint32_t (&lpos)[ITEMS],
+                                              const uint32_t (&gpos)[ITEMS]) {
+  PT* st = reinterpret_cast<PT*>(stage);
+  __syncthreads();                                   // previous users of `stage` are done
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++)
+    if (full || item_row<BLOCK, KM>(j, tid) < nvalid) st[lpos[j]] = v[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < ITEMS; j++) {
+    const uint32_t s = (uint32_t)j * BLOCK + tid;
+    if (s < nvalid) pout[gpos[j]] = st[s];
+  }
+}
+
+template <int BLOCK, int ITEMS, int KM, typename PT>
 __device__ __forceinline__ void move_payload(const PT* __restrict__ pin, PT* __restrict__ pout, unsigned char* stage,
                                              uint32_t nvalid, bool full, int tid, const uint32_t (&lpos)[ITEMS],
                                              const uint32_t (&gpos)[ITEMS]) {
@@ -335,7 +392,9 @@ __device__ __forceinline__ void move_payload(const PT* __restrict__ pin, PT* __r
   }
 }
 
-template <int BLOCK, int ITEMS, int KM, bool CL>
+// PF: the first payload column is 8 bytes wide and its tile is loaded together with the keys, BEFORE the LDS
+// phases -- one workgroup fills a CU (LDS), so nothing else hides the latency of a load issued after them.
+template <int BLOCK, int ITEMS, int KM, bool CL, bool PF>
 __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
   constexpr uint32_t TILE = BLOCK * ITEMS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -355,9 +414,23 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
   const bool full = nvalid == TILE;
 
   for (uint32_t b = tid; b < F; b += BLOCK) cnt[b] = 0;
+  // global start of this tile's run of every bucket this thread scans below: issued first, needed after the ranking
+  const uint32_t K = (F + BLOCK - 1) / BLOCK;            // consecutive bins per thread
+  uint32_t gstart[2048 / BLOCK];
+  {
+    const uint32_t g = tile / a.tpg;
+#pragma unroll
+    for (int k = 0; k < 2048 / BLOCK; k++) {
+      const uint32_t b = (uint32_t)tid * K + k;
+      gstart[k] = ((uint32_t)k < K && b < F) ? a.gpre[(size_t)g * F + b] + a.P[(size_t)tile * F + b] : 0u;
+    }
+  }
   uint32_t x[ITEMS];
   bool bad = false;     // out-of-range keys were reported by the histogram pass; here they are just key 0 again
   load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x, bad);
+  u64 pv[PF ? ITEMS : 1];
+  if (PF) load_tile_vals<BLOCK, ITEMS, KM, u64>(static_cast<const u64*>(a.pay.in[0]) + tile_base, nvalid, full, tid,
+                                                 reinterpret_cast<u64(&)[ITEMS]>(pv));
   __syncthreads();
 
   // rank of every row inside its bucket (arrival order: buckets are unordered sets)
@@ -372,7 +445,6 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
 
   // exclusive scan of the bucket counts; global position of every bucket's run
   {
-    const uint32_t K = (F + BLOCK - 1) / BLOCK;          // consecutive bins per thread
     uint32_t c[2048 / BLOCK], s = 0;
 #pragma unroll
     for (int k = 0; k < 2048 / BLOCK; k++) {
@@ -381,13 +453,12 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
       s += c[k];
     }
     uint32_t e = block_excl_scan_u32<BLOCK>(s, misc, nullptr);
-    const uint32_t g = tile / a.tpg;
 #pragma unroll
     for (int k = 0; k < 2048 / BLOCK; k++) {
       const uint32_t b = (uint32_t)tid * K + k;
       if ((uint32_t)k < K && b < F) {
         cnt[b] = e;
-        delta[b] = a.gpre[(size_t)g * F + b] + a.P[(size_t)tile * F + b] - e;
+        delta[b] = gstart[k] - e;
         e += c[k];
       }
     }
@@ -418,7 +489,9 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
   }
 
   // value columns follow the same permutation
-  for (int c = 0; c < a.pay.n; c++) {
+  if (PF) place_payload<BLOCK, ITEMS, KM, u64>(reinterpret_cast<const u64(&)[ITEMS]>(pv), static_cast<u64*>(a.pay.out[0]), stage,
+                                               nvalid, full, tid, lpos, gpos);
+  for (int c = PF ? 1 : 0; c < a.pay.n; c++) {
     if (a.pay.width[c] == 8)
       move_payload<BLOCK, ITEMS, KM, u64>(static_cast<const u64*>(a.pay.in[c]) + tile_base,
                                           static_cast<u64*>(a.pay.out[c]), stage, nvalid, full, tid, lpos, gpos);
@@ -468,7 +541,12 @@ void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom
 
 template <int BLOCK, int ITEMS, int KM, bool CL>
 static int hist_t(dthip_ctx* ctx, const HistArgs& a, uint32_t G) {
-  DTHIP_LAUNCH(ctx, "bucket_hist_kernel", (bucket_hist_kernel<BLOCK, ITEMS, KM, CL>), G, BLOCK, (size_t)((a.F + 3u) & ~3u) * 8 + 16, a);
+  const size_t lds = (size_t)((a.F + 3u) & ~3u) * 8 + 16;
+  if (KM != 0 && !CL && a.kx.ncols == 1 && ctx->bucket_variant != 2) {
+    DTHIP_LAUNCH(ctx, "bucket_hist_kernel", (bucket_hist_kernel<BLOCK, ITEMS, KM, CL, (KM != 0 && !CL)>), G, BLOCK, lds, a);
+    return DTHIP_OK;
+  }
+  DTHIP_LAUNCH(ctx, "bucket_hist_kernel", (bucket_hist_kernel<BLOCK, ITEMS, KM, CL, false>), G, BLOCK, lds, a);
   return DTHIP_OK;
 }
 
@@ -491,9 +569,9 @@ int launch_bucket_plan(dthip_ctx* ctx, const uint32_t* tot, uint32_t F, uint32_t
   return DTHIP_OK;
 }
 
-template <int BLOCK, int ITEMS, int KM, bool CL>
-static int part_t(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds) {
-  auto kfn = bucket_partition_kernel<BLOCK, ITEMS, KM, CL>;
+template <int BLOCK, int ITEMS, int KM, bool CL, bool PF>
+static int part_launch(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds) {
+  auto kfn = bucket_partition_kernel<BLOCK, ITEMS, KM, CL, PF>;
   static bool attr_set = false;
   if (!attr_set) {
     DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -502,6 +580,14 @@ static int part_t(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds
   }
   DTHIP_LAUNCH(ctx, "bucket_partition_kernel", kfn, ntiles, BLOCK, lds, a);
   return DTHIP_OK;
+}
+
+template <int BLOCK, int ITEMS, int KM, bool CL>
+static int part_t(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds) {
+  // early load of payload 0: vector-load key modes only (their tiles are read with 16-byte loads)
+  if (KM != 0 && !CL && a.pay.n >= 1 && a.pay.width[0] == 8 && ctx->bucket_variant != 2)
+    return part_launch<BLOCK, ITEMS, KM, CL, true>(ctx, a, ntiles, lds);
+  return part_launch<BLOCK, ITEMS, KM, CL, false>(ctx, a, ntiles, lds);
 }
 
 int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
