@@ -97,7 +97,26 @@ SIGNATURES = {
     "dthip_filter_cmp": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int64, C.c_int, C.c_double, C.c_int64, C.c_int,
                                    C.c_void_p, C.POINTER(C.c_int64)]),
     "dthip_gather": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    # multi-GPU (comm.hip)
+    "dthip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dthip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dthip_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "dthip_comm_destroy": (C.c_int, [C.c_void_p]),
+    "dthip_comm_rank": (C.c_int, [C.c_void_p]),
+    "dthip_comm_world": (C.c_int, [C.c_void_p]),
+    "dthip_sharded_groupby_agg": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int, C.POINTER(Col), C.c_int, C.POINTER(Agg), C.c_int,
+                                            C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dthip_sharded_groupby_agg_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.POINTER(Col)), C.c_int,
+                                                  C.POINTER(C.POINTER(Col)), C.c_int, C.POINTER(Agg), C.c_int,
+                                                  C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dthip_sharded_groupby_rows": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int, C.POINTER(Col), C.c_int, C.c_int64, C.c_int64,
+                                             C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dthip_sharded_groupby_rows_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.POINTER(Col)), C.c_int,
+                                                   C.POINTER(C.POINTER(Col)), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                                   C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
 }
+COMM_ID_BYTES = 128
+FLAG_NONA = 2
 
 _lib = None
 
@@ -116,8 +135,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dthip_abi_version() != 2:
-        raise ImportError("libdthip.so ABI version %d != 2" % lib.dthip_abi_version())
+    if lib.dthip_abi_version() != 3:
+        raise ImportError("libdthip.so ABI version %d != 3" % lib.dthip_abi_version())
     _lib = lib
     return lib
 

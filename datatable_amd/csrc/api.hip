@@ -371,24 +371,11 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
 
 using namespace dthip;
 
-struct dthip_result {
-  int64_t nrows = 0, ngroups = 0;
-  int32_t* rowindex = nullptr;
-  int32_t* offsets = nullptr;
-  int nkeys = 0;
-  void* key[MAX_KEYCOLS] = {};
-  int key_stype[MAX_KEYCOLS] = {};
-  int naggs = 0;
-  std::vector<void*> agg;
-  std::vector<int> agg_stype;
-  std::vector<void*> col;        // dthip_groupby_rows: columns permuted into grouped order
-  std::vector<int> col_stype;
-  std::vector<void*> owned;
-};
+static_assert(MAX_KEYCOLS == 8, "dthip_result::key is sized for MAX_KEYCOLS");
 
 namespace dthip {
 
-static int result_alloc(dthip_ctx* ctx, dthip_result* r, size_t bytes, void** out) {
+int result_alloc(dthip_ctx* ctx, dthip_result* r, size_t bytes, void** out) {
   DTHIP_TRY(dev_alloc(ctx, bytes, out));
   r->owned.push_back(*out);
   return DTHIP_OK;
@@ -399,7 +386,7 @@ static void result_adopt(Scratch& sc, dthip_result* r, void* p) {
   r->owned.push_back(p);
 }
 
-static void result_destroy(dthip_ctx* ctx, dthip_result* r) {
+void result_destroy(dthip_ctx* ctx, dthip_result* r) {
   for (void* p : r->owned) dev_release(ctx, p);
   delete r;
 }
@@ -520,8 +507,8 @@ static int reduce_outs_for(int op, void* dst, ReduceOuts* o) {
 
 // ---- bucketed aggregation (bucket.hip): DT[:, aggs, by(keys)] without a sort -------------
 // Accumulators each value column needs for the requested reducers.
-static int acc_flags_for(const dthip_agg* aggs, int naggs, int col, int vstype) {
-  int f = 0;
+static int acc_flags_for(const dthip_agg* aggs, int naggs, int col, int vstype, int colflags = 0) {
+  int f = (colflags & DTHIP_FLAG_NONA) ? ACC_NONA : 0;
   const bool isf = stype_is_float(vstype);
   for (int a = 0; a < naggs; a++) {
     if (aggs[a].op == DTHIP_COUNT0 || aggs[a].col != col) continue;
@@ -665,7 +652,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   bool first = true;
   for (int c : used) {
     AggTable& t = tabs[c];
-    int f = acc_flags_for(aggs, naggs, c, vd[c].stype);
+    int f = acc_flags_for(aggs, naggs, c, vd[c].stype, vd[c].flags);
     if (first) { f |= first_flag; if (need_cnt) t.cnt = d_cnt; else t.pres = d_cnt; }
     tflags[c] = f;
     if (f & ACC_SUM) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.sum)); DTHIP_CHECK_HIP(hipMemsetAsync(t.sum, 0, nslots * 8, ctx->stream)); }
@@ -794,6 +781,7 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   const int nkeys = plan.nkeys;
   if (ctx->hash_mode == 1 || ctx->in_merge || ctx->agg_path == 1) return DTHIP_NOT_APPLICABLE;
   if (plan.nstages != 1 || used.size() > 1) return DTHIP_NOT_APPLICABLE;
+  for (int c : used) if (vd[c].flags & DTHIP_FLAG_NONA) return DTHIP_NOT_APPLICABLE;
   if (ctx->hash_mode != 2 && n < (1 << 22)) return DTHIP_NOT_APPLICABLE;
   const int c0 = used.empty() ? -1 : used[0];
   if (c0 >= 0 && stype_size(vd[c0].stype) != 4 && stype_size(vd[c0].stype) != 8) return DTHIP_NOT_APPLICABLE;
@@ -905,7 +893,8 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   std::vector<dthip_col> v2;
   std::vector<dthip_agg> a2;
   int iSUM = -1, iFSUM = -1, iMIN = -1, iMAX = -1, iVCNT = -1, iCNT = -1;
-  auto add_col = [&](void* data, int st, int op) { v2.push_back(dthip_col{data, st, 0}); a2.push_back(dthip_agg{op, (int32_t)v2.size() - 1}); return (int)a2.size() - 1; };
+  // partial SUMS are merged with DTHIP_FLAG_NONA: a partial that is NaN (inf - inf) or wrapped to INT64_MIN is a value
+  auto add_col = [&](void* data, int st, int op) { v2.push_back(dthip_col{data, st, op == DTHIP_SUM ? DTHIP_FLAG_NONA : 0}); a2.push_back(dthip_agg{op, (int32_t)v2.size() - 1}); return (int)a2.size() - 1; };
   if (flags & ACC_SUM) { DTHIP_TRY(sc.get<unsigned long long>((size_t)np + 2, &pa.o_sum)); iSUM = add_col(pa.o_sum, isf ? DTHIP_FLOAT64 : DTHIP_INT64, DTHIP_SUM); }
   if (flags & ACC_FSUM) { DTHIP_TRY(sc.get<double>((size_t)np + 2, &pa.o_fsum)); iFSUM = add_col(pa.o_fsum, DTHIP_FLOAT64, DTHIP_SUM); }
   if (flags & ACC_MIN) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)np * 8 + 16, &b)); pa.o_min = b; iMIN = add_col(b, vst, DTHIP_MIN); }
@@ -1014,6 +1003,7 @@ int dthip_init(int device, void* stream, dthip_ctx** out) {
 int dthip_destroy(dthip_ctx* ctx) {
   if (!ctx) return DTHIP_OK;
   (void)hipSetDevice(ctx->device);
+  (void)dthip_comm_destroy(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   prof_flush(ctx);
   dev_trim(ctx);
@@ -1403,7 +1393,7 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
       if (rc != DTHIP_OK) break;
       if (any_seg)
         rc = launch_reduce(ctx, sorted_val[c], vd[c].stype, gather_ri, reinterpret_cast<const uint8_t*>(g.bitmap),
-                           g.tile_first, nrows, ro);
+                           g.tile_first, nrows, ro, (vd[c].flags & DTHIP_FLAG_NONA) ? 1 : 0);
       if (rc != DTHIP_OK) break;
       for (auto& d : dups) {
         if (hipMemcpyAsync(res->agg[d.first], res->agg[d.second], (size_t)ng * stype_size(res->agg_stype[d.first]),

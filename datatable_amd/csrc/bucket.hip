@@ -699,7 +699,7 @@ __device__ __forceinline__ void acc_wave_uniform(const LdsTab& t, int flags, uin
   if (lead && (flags & ACC_CNT)) atomicAdd(&t.cnt[slot], 64u);
   if (lead && (flags & ACC_PRES)) atomicOr(&t.pres[slot >> 5], 1u << (slot & 31));
   if (!(flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM))) return;
-  const bool ok = !ValTraits<VT>::isna(v);
+  const bool ok = (flags & ACC_NONA) || !ValTraits<VT>::isna(v);
   const uint32_t nok = (uint32_t)__popcll(__ballot(ok));
   if (nok == 0) return;
   if (lead && (flags & ACC_VCNT)) atomicAdd(&t.vcnt[slot], nok);
@@ -726,7 +726,7 @@ __device__ __forceinline__ void acc_row(const LdsTab& t, int flags, uint32_t slo
   if (flags & ACC_CNT) atomicAdd(&t.cnt[slot], 1u);
   if (flags & ACC_PRES) atomicOr(&t.pres[slot >> 5], 1u << (slot & 31));
   if (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) {
-    if (!ValTraits<VT>::isna(v)) {
+    if ((flags & ACC_NONA) || !ValTraits<VT>::isna(v)) {
       if (flags & ACC_VCNT) atomicAdd(&t.vcnt[slot], 1u);
       if (ValTraits<VT>::is_float) {
         const double d = (double)v;

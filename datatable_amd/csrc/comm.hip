@@ -1,0 +1,780 @@
+// comm.hip -- multi-GPU DT[:, aggs, by(keys)] and DT[:, cols, by(keys)] INSIDE libdthip.so: one context per GPU,
+// RCCL called directly (ncclAllGather for the few control words, ncclSend/ncclRecv inside one group for the
+// all-to-all-v of the data), no PyTorch anywhere on the path.
+//
+// The reference is single-process; this exchange step is new.  Design = SURVEY 8(e):
+//   * rows are sharded by row block (rank r owns a contiguous block of rows of the frame);
+//   * aggregates: every rank first runs the fused local groupby-aggregate (the COMBINER: at most one partial per
+//     local group crosses the fabric), partials are RANGE-partitioned on the first key and exchanged with one
+//     all-to-all-v, the owner merges the <= world partials of each group with the same HIP kernels
+//     (sum of sums, min of mins, ...; mean = sum(mean_i * n_i) / sum(n_i));
+//   * row-returning queries: every row gets its destination from the same range partition, a stable local
+//     partition by destination builds per-destination slabs in sender row order, one all-to-all-v moves them;
+//     slabs arrive in source-rank order = global row order, so ONE stable local dthip_groupby_rows reproduces the
+//     reference's permutation exactly (global row ids travel as a payload column);
+//   * key-range (not hash) partitioning keeps the global group order = concatenation of the ranks' results in rank
+//     order -- what the reference returns (groups ascending, NA group first / last);
+//   * the splitters balance the destinations: a 4096-bin histogram of the order-preserving 64-bit image of the first
+//     key, min-subtracted, summed over all ranks, is cut at the world-quantiles (a plain even split of [min, max]
+//     sends skewed keys to one rank).
+// Collectives per call: 3 small all-gathers (key range 16 B, histogram 32 KB, send counts 8 B x world per rank) and
+// one grouped all-to-all-v over all columns.  xGMI is point-to-point: the grouped send/recv keeps all 7 links of a
+// GPU busy at once.
+//
+// A LOCAL communicator (dthip_comm_init_local) binds `world` contexts of one process -- on any devices, also all on
+// the same one -- and runs exactly the same phases with device-to-device copies as the exchange: it is how the
+// algorithm is tested on a single GPU (G logical shards) and has no RCCL dependency.
+//
+// librccl is opened with dlopen at dthip_comm_init: single-GPU users of libdthip.so never load it.
+#include <dlfcn.h>
+#include <algorithm>
+#include <rccl/rccl.h>
+#include "common.hpp"
+
+struct dthip_comm {
+  int kind = 0;                       // 0: RCCL, 1: local (one process holds every rank)
+  int world = 1;
+  ncclComm_t nccl = nullptr;
+  std::vector<dthip_ctx*> ranks;      // local: context of every rank
+  int refs = 0;
+};
+
+namespace dthip {
+
+typedef unsigned long long u64;
+
+// ---- RCCL through dlopen ----------------------------------------------------------------------
+struct NcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static NcclApi g_nccl;
+
+static int nccl_load() {
+  if (g_nccl.handle) return DTHIP_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+  if (!h) { set_error("librccl.so could not be loaded: %s", dlerror()); return DTHIP_EDEVICE; }
+#define NCCL_SYM(field, sym)                                                                  \
+  g_nccl.field = reinterpret_cast<decltype(g_nccl.field)>(dlsym(h, #sym));                    \
+  if (!g_nccl.field) { set_error("librccl: symbol %s missing", #sym); dlclose(h); return DTHIP_EDEVICE; }
+  NCCL_SYM(GetUniqueId, ncclGetUniqueId)
+  NCCL_SYM(CommInitRank, ncclCommInitRank)
+  NCCL_SYM(CommDestroy, ncclCommDestroy)
+  NCCL_SYM(AllGather, ncclAllGather)
+  NCCL_SYM(Send, ncclSend)
+  NCCL_SYM(Recv, ncclRecv)
+  NCCL_SYM(GroupStart, ncclGroupStart)
+  NCCL_SYM(GroupEnd, ncclGroupEnd)
+  NCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef NCCL_SYM
+  g_nccl.handle = h;
+  return DTHIP_OK;
+}
+
+#define DTHIP_CHECK_NCCL(expr)                                                                           \
+  do {                                                                                                   \
+    ncclResult_t _r = (expr);                                                                            \
+    if (_r != ncclSuccess) {                                                                             \
+      set_error("%s failed: %s (%s:%d)", #expr, g_nccl.GetErrorString(_r), __FILE__, __LINE__);          \
+      return DTHIP_EDEVICE;                                                                              \
+    }                                                                                                    \
+  } while (0)
+
+// ---- kernels -------------------------------------------------------------------------------------
+// Order-preserving 64-bit image of a key column's values: ascending integers / floats keep their order, NA maps to
+// `na_img` (0 when the NA group comes first, ~0 when last).  Valid images are never 0 or ~0.
+__device__ __forceinline__ u64 key_image(const void* data, int stype, uint32_t i, u64 na_img) {
+  switch (stype) {
+    case DTHIP_BOOL: case DTHIP_INT8: { const int8_t v = static_cast<const int8_t*>(data)[i]; return v == INT8_MIN ? na_img : ((u64)(long long)v ^ 0x8000000000000000ULL); }
+    case DTHIP_INT16: { const int16_t v = static_cast<const int16_t*>(data)[i]; return v == INT16_MIN ? na_img : ((u64)(long long)v ^ 0x8000000000000000ULL); }
+    case DTHIP_INT32: { const int32_t v = static_cast<const int32_t*>(data)[i]; return v == INT32_MIN ? na_img : ((u64)(long long)v ^ 0x8000000000000000ULL); }
+    case DTHIP_INT64: { const long long v = static_cast<const long long*>(data)[i]; return v == INT64_MIN ? na_img : ((u64)v ^ 0x8000000000000000ULL); }
+    case DTHIP_FLOAT32: {
+      const float f = static_cast<const float*>(data)[i];
+      if (f != f) return na_img;
+      const u64 t = (u64)__double_as_longlong((double)f);
+      return t ^ (0x8000000000000000ULL | (0ULL - (t >> 63)));
+    }
+    default: {
+      const double d = static_cast<const double*>(data)[i];
+      if (d != d) return na_img;
+      const u64 t = (u64)__double_as_longlong(d);
+      return t ^ (0x8000000000000000ULL | (0ULL - (t >> 63)));
+    }
+  }
+}
+
+struct RangeAcc { u64 lo, hi, nvalid; };   // lo starts at ~0, hi at 0
+
+__global__ void __launch_bounds__(256) key_image_kernel(const void* data, int stype, uint32_t n, u64 na_img, u64* img, RangeAcc* acc) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  u64 lo = ~0ULL, hi = 0ULL; uint32_t ok = 0;
+  if (i < n) {
+    const u64 v = key_image(data, stype, i, na_img);
+    img[i] = v;
+    if (v != na_img) { lo = v; hi = v; ok = 1; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const u64 l2 = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(lo >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)lo, o, 64);
+    const u64 h2 = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(hi >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)hi, o, 64);
+    lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+  }
+  const u64 b = __ballot(ok != 0);
+  if ((threadIdx.x & 63) == 0 && b) {
+    atomicMin(&acc->lo, lo); atomicMax(&acc->hi, hi); atomicAdd(&acc->nvalid, (u64)__popcll(b));
+  }
+}
+
+constexpr int SPLIT_BINS = 4096;
+
+// histogram of the valid images over [gmin, gmax] in SPLIT_BINS bins of 2^shift
+__global__ void __launch_bounds__(256) image_hist_kernel(const u64* img, uint32_t n, u64 na_img, u64 gmin, int shift, u64* hist) {
+  __shared__ uint32_t h[SPLIT_BINS];
+  for (int b = threadIdx.x; b < SPLIT_BINS; b += 256) h[b] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const u64 v = img[i];
+    if (v != na_img) atomicAdd(&h[(uint32_t)((v - gmin) >> shift)], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < SPLIT_BINS; b += 256) if (h[b]) atomicAdd(&hist[b], (u64)h[b]);
+}
+
+// cuts[j] = first position of the ASCENDING image sequence whose image is >= bounds[j]
+__global__ void lower_bound_kernel(const u64* img, uint32_t n, const u64* bounds, int nb, uint32_t* cuts) {
+  const int j = threadIdx.x;
+  if (j >= nb) return;
+  const u64 b = bounds[j];
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (img[mid] < b) lo = mid + 1; else hi = mid; }
+  cuts[j] = lo;
+}
+
+// destination rank of every row: number of boundaries <= image (int8: world <= 127)
+__global__ void __launch_bounds__(256) image_dest_kernel(const u64* img, uint32_t n, const u64* bounds, int nb, int8_t* dest) {
+  __shared__ u64 sb[128];
+  if ((int)threadIdx.x < nb) sb[threadIdx.x] = bounds[threadIdx.x];
+  __syncthreads();
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const u64 v = img[i];
+  int lo = 0, hi = nb;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (sb[mid] <= v) lo = mid + 1; else hi = mid; }
+  dest[i] = (int8_t)lo;
+}
+
+// weighted partial of a mean: mean_i * n_i (0 for an all-NA partial), float64
+template <typename MT>
+__global__ void __launch_bounds__(256) mean_weight_kernel(const MT* mean, const long long* cnt, uint32_t n, double* out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = cnt[i] > 0 ? (double)mean[i] * (double)cnt[i] : 0.0;
+}
+
+__global__ void __launch_bounds__(256) dest_count_kernel(const int8_t* dest, uint32_t n, u64* cnt) {
+  __shared__ uint32_t h[128];
+  if (threadIdx.x < 128) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) atomicAdd(&h[(uint32_t)dest[i] & 127u], 1u);
+  __syncthreads();
+  if (threadIdx.x < 128 && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (u64)h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256) iota64_kernel(long long* out, uint32_t n, long long first) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = first + (long long)i;
+}
+
+// ---- one rank's state ---------------------------------------------------------------------------
+struct XCol { const void* send = nullptr; void* recv = nullptr; int elem = 0; int stype = 0; };
+
+struct Job {
+  dthip_ctx* ctx = nullptr;
+  int rank = 0;
+  // small host blobs of the all-gathers
+  std::vector<unsigned char> xin, xout;
+  // all-to-all-v layout, in rows
+  std::vector<int64_t> send_cnt, send_off, recv_cnt, recv_off;
+  int64_t nsend = 0, nrecv = 0;
+  std::vector<XCol> cols;
+  // first-key images of the rows / partial groups that will be sent
+  u64* img = nullptr; int64_t nimg = 0;
+  u64 na_img = 0;
+  RangeAcc range{~0ULL, 0ULL, 0ULL};
+  std::vector<u64> bounds;
+  Scratch* sc = nullptr;
+  dthip_result* local = nullptr;       // the local partial result (agg) / the per-destination slabs (rows)
+  dthip_result* out = nullptr;
+  int rc = DTHIP_OK;
+};
+
+// ---- exchange primitives -------------------------------------------------------------------------
+// every job's xin (same size on all ranks) -> every job's xout = concatenation over ranks
+static int exchange_allgather(dthip_comm* comm, std::vector<Job>& jobs) {
+  const size_t bytes = jobs[0].xin.size();
+  if (comm->kind == 1) {
+    for (auto& j : jobs) {
+      j.xout.resize(bytes * comm->world);
+      for (auto& s : jobs) memcpy(j.xout.data() + (size_t)s.rank * bytes, s.xin.data(), bytes);
+    }
+    return DTHIP_OK;
+  }
+  Job& j = jobs[0];
+  dthip_ctx* ctx = j.ctx;
+  Scratch sc(ctx);
+  unsigned char* ds = nullptr; unsigned char* dr = nullptr;
+  DTHIP_TRY(sc.get<unsigned char>(bytes, &ds));
+  DTHIP_TRY(sc.get<unsigned char>(bytes * comm->world, &dr));
+  DTHIP_CHECK_HIP(hipMemcpyAsync(ds, j.xin.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+  DTHIP_CHECK_NCCL(g_nccl.AllGather(ds, dr, bytes, ncclInt8, comm->nccl, ctx->stream));
+  j.xout.resize(bytes * comm->world);
+  DTHIP_CHECK_HIP(hipMemcpyAsync(j.xout.data(), dr, bytes * comm->world, hipMemcpyDeviceToHost, ctx->stream));
+  DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return DTHIP_OK;
+}
+
+// all-to-all-v of every column of every job (send_off / send_cnt / recv_off / recv_cnt in rows)
+static int exchange_alltoallv(dthip_comm* comm, std::vector<Job>& jobs) {
+  if (comm->kind == 1) {
+    for (auto& s : jobs) { DTHIP_CHECK_HIP(hipSetDevice(s.ctx->device)); DTHIP_CHECK_HIP(hipStreamSynchronize(s.ctx->stream)); }
+    for (auto& d : jobs) {
+      DTHIP_CHECK_HIP(hipSetDevice(d.ctx->device));
+      for (auto& s : jobs) {
+        const int64_t cnt = s.send_cnt[d.rank];
+        if (cnt == 0) continue;
+        for (size_t c = 0; c < d.cols.size(); c++) {
+          const int e = d.cols[c].elem;
+          const unsigned char* src = static_cast<const unsigned char*>(s.cols[c].send) + (size_t)s.send_off[d.rank] * e;
+          unsigned char* dst = static_cast<unsigned char*>(d.cols[c].recv) + (size_t)d.recv_off[s.rank] * e;
+          if (s.ctx->device == d.ctx->device)
+            DTHIP_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)cnt * e, hipMemcpyDeviceToDevice, d.ctx->stream));
+          else
+            DTHIP_CHECK_HIP(hipMemcpyPeerAsync(dst, d.ctx->device, src, s.ctx->device, (size_t)cnt * e, d.ctx->stream));
+        }
+      }
+    }
+    for (auto& d : jobs) { DTHIP_CHECK_HIP(hipSetDevice(d.ctx->device)); DTHIP_CHECK_HIP(hipStreamSynchronize(d.ctx->stream)); }
+    return DTHIP_OK;
+  }
+  Job& j = jobs[0];
+  DTHIP_CHECK_NCCL(g_nccl.GroupStart());
+  for (size_t c = 0; c < j.cols.size(); c++) {
+    const int e = j.cols[c].elem;
+    for (int p = 0; p < comm->world; p++) {
+      if (j.send_cnt[p]) {
+        const unsigned char* src = static_cast<const unsigned char*>(j.cols[c].send) + (size_t)j.send_off[p] * e;
+        DTHIP_CHECK_NCCL(g_nccl.Send(src, (size_t)j.send_cnt[p] * e, ncclInt8, p, comm->nccl, j.ctx->stream));
+      }
+      if (j.recv_cnt[p]) {
+        unsigned char* dst = static_cast<unsigned char*>(j.cols[c].recv) + (size_t)j.recv_off[p] * e;
+        DTHIP_CHECK_NCCL(g_nccl.Recv(dst, (size_t)j.recv_cnt[p] * e, ncclInt8, p, comm->nccl, j.ctx->stream));
+      }
+    }
+  }
+  DTHIP_CHECK_NCCL(g_nccl.GroupEnd());
+  return DTHIP_OK;
+}
+
+// ---- shared phases --------------------------------------------------------------------------------
+// images of the first key of what will be sent + local range; the blob of the first all-gather
+static int phase_images(Job& j, const void* key0, int stype, int64_t n, int na_pos) {
+  dthip_ctx* ctx = j.ctx;
+  j.na_img = (na_pos == DTHIP_NA_LAST) ? ~0ULL : 0ULL;
+  j.nimg = n;
+  j.range = RangeAcc{~0ULL, 0ULL, 0ULL};
+  if (n > 0) {
+    DTHIP_TRY(j.sc->get<u64>((size_t)n, &j.img));
+    RangeAcc* d_acc = nullptr;
+    DTHIP_TRY(j.sc->get<RangeAcc>(1, &d_acc));
+    DTHIP_CHECK_HIP(hipMemcpyAsync(d_acc, &j.range, sizeof(RangeAcc), hipMemcpyHostToDevice, ctx->stream));
+    DTHIP_LAUNCH(ctx, "key_image_kernel", key_image_kernel, (unsigned)((n + 255) / 256), 256, 0, key0, stype, (uint32_t)n, j.na_img, j.img, d_acc);
+    DTHIP_TRY(read_back(ctx, &j.range, d_acc, sizeof(RangeAcc)));
+  }
+  j.xin.resize(sizeof(RangeAcc));
+  memcpy(j.xin.data(), &j.range, sizeof(RangeAcc));
+  return DTHIP_OK;
+}
+
+struct GlobalRange { u64 gmin, gmax, nvalid; int shift; };
+
+static GlobalRange reduce_ranges(const Job& j, int world) {
+  GlobalRange g{~0ULL, 0ULL, 0ULL, 0};
+  for (int r = 0; r < world; r++) {
+    RangeAcc a;
+    memcpy(&a, j.xout.data() + (size_t)r * sizeof(RangeAcc), sizeof(RangeAcc));
+    if (a.nvalid) { g.gmin = std::min(g.gmin, a.lo); g.gmax = std::max(g.gmax, a.hi); g.nvalid += a.nvalid; }
+  }
+  if (g.nvalid == 0) { g.gmin = 1; g.gmax = 1; }
+  const u64 width = g.gmax - g.gmin;
+  int bits = 0; for (u64 w = width; w; w >>= 1) bits++;
+  g.shift = bits > 12 ? bits - 12 : 0;          // (width >> shift) < 4096
+  return g;
+}
+
+static int phase_hist(Job& j, const GlobalRange& g) {
+  dthip_ctx* ctx = j.ctx;
+  j.xin.assign(sizeof(u64) * SPLIT_BINS, 0);
+  if (j.nimg > 0 && g.nvalid > 0) {
+    u64* d_hist = nullptr;
+    DTHIP_TRY(j.sc->get<u64>(SPLIT_BINS, &d_hist));
+    DTHIP_CHECK_HIP(hipMemsetAsync(d_hist, 0, sizeof(u64) * SPLIT_BINS, ctx->stream));
+    const unsigned grid = (unsigned)std::min<int64_t>((j.nimg + 255) / 256, 2048);
+    DTHIP_LAUNCH(ctx, "image_hist_kernel", image_hist_kernel, grid, 256, 0, j.img, (uint32_t)j.nimg, j.na_img, g.gmin, g.shift, d_hist);
+    DTHIP_TRY(read_back(ctx, j.xin.data(), d_hist, sizeof(u64) * SPLIT_BINS));
+  }
+  return DTHIP_OK;
+}
+
+// world-1 ascending boundary images from the summed histogram: images < bounds[j] belong to ranks <= j
+static void splitters(Job& j, const GlobalRange& g, int world) {
+  std::vector<u64> h(SPLIT_BINS, 0);
+  for (int r = 0; r < world; r++) {
+    const u64* hr = reinterpret_cast<const u64*>(j.xout.data() + (size_t)r * sizeof(u64) * SPLIT_BINS);
+    for (int b = 0; b < SPLIT_BINS; b++) h[b] += hr[b];
+  }
+  u64 total = 0;
+  for (int b = 0; b < SPLIT_BINS; b++) total += h[b];
+  j.bounds.assign(world > 1 ? world - 1 : 0, ~0ULL);
+  if (total == 0) return;
+  u64 cum = 0; int b = 0;
+  for (int k = 1; k < world; k++) {
+    const u64 target = (u64)(((unsigned __int128)total * (unsigned)k) / (unsigned)world);
+    while (b < SPLIT_BINS && cum + h[b] <= target) { cum += h[b]; b++; }
+    // bins [0, b) hold <= target rows: boundary = start of bin b
+    const unsigned __int128 edge = (unsigned __int128)g.gmin + ((unsigned __int128)(u64)b << g.shift);
+    j.bounds[k - 1] = edge >= (unsigned __int128)~0ULL ? ~0ULL - 1 : (u64)edge;
+  }
+}
+
+static void layout_from_counts(Job& j, int world) {
+  // xout = world x world matrix of send counts (row = sender); recv counts = column `rank`
+  j.recv_cnt.assign(world, 0); j.recv_off.assign(world, 0);
+  const int64_t* m = reinterpret_cast<const int64_t*>(j.xout.data());
+  int64_t off = 0;
+  for (int s = 0; s < world; s++) { j.recv_cnt[s] = m[(size_t)s * world + j.rank]; j.recv_off[s] = off; off += j.recv_cnt[s]; }
+  j.nrecv = off;
+}
+
+static int counts_blob(Job& j, int world) {
+  j.xin.resize(sizeof(int64_t) * world);
+  memcpy(j.xin.data(), j.send_cnt.data(), sizeof(int64_t) * world);
+  return DTHIP_OK;
+}
+
+// ---- aggregates -------------------------------------------------------------------------------------
+struct AggPlan {
+  std::vector<dthip_agg> partial;                 // local partial reducers (deduplicated)
+  struct Rec { int kind; int a, b; };             // kind: 0 copy partial a, 1 mean from (wsum a, count b)
+  std::vector<Rec> recipe;
+};
+
+static int plan_partials(const dthip_agg* aggs, int naggs, AggPlan* p) {
+  auto need = [&](int op, int col) {
+    for (size_t i = 0; i < p->partial.size(); i++) if (p->partial[i].op == op && p->partial[i].col == col) return (int)i;
+    p->partial.push_back(dthip_agg{op, col});
+    return (int)p->partial.size() - 1;
+  };
+  for (int a = 0; a < naggs; a++) {
+    const int op = aggs[a].op, col = aggs[a].col;
+    switch (op) {
+      case DTHIP_SUM: case DTHIP_MIN: case DTHIP_MAX: case DTHIP_COUNT: p->recipe.push_back({0, need(op, col), -1}); break;
+      case DTHIP_COUNT0: p->recipe.push_back({0, need(DTHIP_COUNT0, -1), -1}); break;
+      case DTHIP_MEAN: { const int m = need(DTHIP_MEAN, col); const int c = need(DTHIP_COUNT, col); p->recipe.push_back({1, m, c}); break; }
+      default: set_error("sharded groupby: reducer op %d needs the row order of a whole group (first/last) and is not distributed", op); return DTHIP_ENOTIMPL;
+    }
+  }
+  return DTHIP_OK;
+}
+
+struct AggArgs {
+  const dthip_col* keys; int nkeys; const dthip_col* values; int nvalues; const dthip_agg* aggs; int naggs;
+  int64_t nrows; int na_pos; int mem;
+};
+
+static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::vector<AggArgs>& args, const AggPlan& plan) {
+  const int world = comm->world;
+  const int nkeys = args[0].nkeys;
+  const int np = (int)plan.partial.size();
+  std::vector<std::vector<double*>> wsum(jobs.size());
+  // ---- local combiner + first-key images of the partial groups
+  for (size_t q = 0; q < jobs.size(); q++) {
+    Job& j = jobs[q]; const AggArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
+    DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    const int saved = ctx->agg_offsets;
+    ctx->agg_offsets = 0;
+    const int rc = dthip_groupby_agg(ctx, a.keys, nkeys, a.values, a.nvalues, plan.partial.data(), np, a.nrows, a.na_pos, a.mem, &j.local);
+    ctx->agg_offsets = saved;
+    DTHIP_TRY(rc);
+    const int64_t ng = j.local->ngroups;
+    // mean partials travel as weighted sums
+    wsum[q].assign(np, nullptr);
+    for (int i = 0; i < np; i++) {
+      if (plan.partial[i].op != DTHIP_MEAN || ng == 0) continue;
+      int ci = -1;
+      for (int t = 0; t < np; t++) if (plan.partial[t].op == DTHIP_COUNT && plan.partial[t].col == plan.partial[i].col) ci = t;
+      DTHIP_TRY(j.sc->get<double>((size_t)ng, &wsum[q][i]));
+      const long long* cnt = static_cast<const long long*>(j.local->agg[ci]);
+      if (j.local->agg_stype[i] == DTHIP_FLOAT32)
+        DTHIP_LAUNCH(ctx, "mean_weight_kernel", mean_weight_kernel<float>, (unsigned)((ng + 255) / 256), 256, 0, static_cast<const float*>(j.local->agg[i]), cnt, (uint32_t)ng, wsum[q][i]);
+      else
+        DTHIP_LAUNCH(ctx, "mean_weight_kernel", mean_weight_kernel<double>, (unsigned)((ng + 255) / 256), 256, 0, static_cast<const double*>(j.local->agg[i]), cnt, (uint32_t)ng, wsum[q][i]);
+    }
+    DTHIP_TRY(phase_images(j, j.local->key[0], a.keys[0].stype, ng, a.na_pos));
+  }
+  DTHIP_TRY(exchange_allgather(comm, jobs));
+  const GlobalRange g = reduce_ranges(jobs[0], world);
+  for (auto& j : jobs) { DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device)); DTHIP_TRY(phase_hist(j, g)); }
+  DTHIP_TRY(exchange_allgather(comm, jobs));
+  // ---- splitters -> contiguous slabs of the (ascending) partial groups
+  for (auto& j : jobs) {
+    dthip_ctx* ctx = j.ctx;
+    DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    splitters(j, g, world);
+    std::vector<uint32_t> cuts(world + 1, 0);
+    cuts[world] = (uint32_t)j.nimg;
+    if (world > 1 && j.nimg > 0) {
+      u64* d_b = nullptr; uint32_t* d_c = nullptr;
+      DTHIP_TRY(j.sc->get<u64>(world, &d_b));
+      DTHIP_TRY(j.sc->get<uint32_t>(world, &d_c));
+      DTHIP_CHECK_HIP(hipMemcpyAsync(d_b, j.bounds.data(), sizeof(u64) * (world - 1), hipMemcpyHostToDevice, ctx->stream));
+      DTHIP_LAUNCH(ctx, "lower_bound_kernel", lower_bound_kernel, 1, 128, 0, j.img, (uint32_t)j.nimg, d_b, world - 1, d_c);
+      DTHIP_TRY(read_back(ctx, cuts.data() + 1, d_c, sizeof(uint32_t) * (world - 1)));
+    } else {
+      for (int k = 1; k < world; k++) cuts[k] = 0;
+    }
+    j.send_cnt.assign(world, 0); j.send_off.assign(world, 0);
+    for (int k = 0; k < world; k++) { j.send_off[k] = cuts[k]; j.send_cnt[k] = (int64_t)cuts[k + 1] - (int64_t)cuts[k]; }
+    j.nsend = j.nimg;
+    counts_blob(j, world);
+  }
+  DTHIP_TRY(exchange_allgather(comm, jobs));
+  // ---- receive buffers, all-to-all-v of keys + partial columns
+  for (size_t q = 0; q < jobs.size(); q++) {
+    Job& j = jobs[q]; const AggArgs& a = args[q];
+    DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device));
+    layout_from_counts(j, world);
+    j.cols.clear();
+    for (int k = 0; k < nkeys; k++) {
+      XCol c; c.stype = a.keys[k].stype; c.elem = stype_size(c.stype); c.send = j.local->key[k];
+      unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r;
+      j.cols.push_back(c);
+    }
+    for (int i = 0; i < np; i++) {
+      XCol c;
+      if (plan.partial[i].op == DTHIP_MEAN) { c.stype = DTHIP_FLOAT64; c.send = wsum[q][i]; }
+      else { c.stype = j.local->agg_stype[i]; c.send = j.local->agg[i]; }
+      c.elem = stype_size(c.stype);
+      unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r;
+      j.cols.push_back(c);
+    }
+  }
+  DTHIP_TRY(exchange_alltoallv(comm, jobs));
+  // ---- merge on the owner
+  for (size_t q = 0; q < jobs.size(); q++) {
+    Job& j = jobs[q]; const AggArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
+    DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    std::vector<dthip_col> mk(nkeys), mv(np);
+    std::vector<dthip_agg> ma(np);
+    for (int k = 0; k < nkeys; k++) mk[k] = dthip_col{j.cols[k].recv, a.keys[k].stype, a.keys[k].flags};
+    for (int i = 0; i < np; i++) {
+      const int op = plan.partial[i].op;
+      const bool summed = op == DTHIP_SUM || op == DTHIP_MEAN || op == DTHIP_COUNT || op == DTHIP_COUNT0;
+      // partial sums are VALUES (a NaN / INT64_MIN partial must not be skipped as NA): DTHIP_FLAG_NONA
+      mv[i] = dthip_col{j.cols[nkeys + i].recv, j.cols[nkeys + i].stype, summed ? DTHIP_FLAG_NONA : 0};
+      ma[i] = dthip_agg{summed ? DTHIP_SUM : op, i};
+    }
+    dthip_result* m = nullptr;
+    const int saved = ctx->agg_offsets; const bool saved_merge = ctx->in_merge;
+    ctx->agg_offsets = 0; ctx->in_merge = true;
+    const int rc = dthip_groupby_agg(ctx, mk.data(), nkeys, mv.data(), np, ma.data(), np, j.nrecv, a.na_pos, DTHIP_DEVICE, &m);
+    ctx->agg_offsets = saved; ctx->in_merge = saved_merge;
+    DTHIP_TRY(rc);
+    // the merged result becomes the output: requested aggregates point at (or are computed from) its columns
+    const int64_t ng = m->ngroups;
+    std::vector<void*> pa = m->agg;
+    std::vector<int> ps = m->agg_stype;
+    m->naggs = a.naggs;
+    m->agg.assign(a.naggs, nullptr); m->agg_stype.assign(a.naggs, 0);
+    m->offsets = nullptr;
+    j.out = m;
+    for (int t = 0; t < a.naggs; t++) {
+      const AggPlan::Rec& r = plan.recipe[t];
+      const int ost = dthip_reduce_out_stype(a.aggs[t].op, a.aggs[t].op == DTHIP_COUNT0 ? DTHIP_INT64 : a.values[a.aggs[t].col].stype);
+      m->agg_stype[t] = ost;
+      if (r.kind == 0) { m->agg[t] = pa[r.a]; continue; }
+      void* o = nullptr;
+      DTHIP_TRY(result_alloc(ctx, m, (size_t)ng * stype_size(ost) + 16, &o));
+      m->agg[t] = o;
+      if (ng) DTHIP_TRY(launch_mean_div(ctx, static_cast<const double*>(pa[r.a]), static_cast<const long long*>(pa[r.b]), ng, o, ost == DTHIP_FLOAT32));
+    }
+    m->nrows = a.nrows;
+  }
+  return DTHIP_OK;
+}
+
+// ---- rows in grouped order ---------------------------------------------------------------------------
+struct RowsArgs {
+  const dthip_col* keys; int nkeys; const dthip_col* cols; int ncols;
+  int64_t nrows; int64_t row_offset; int na_pos; int mem;
+};
+
+static int stage_dev(dthip_ctx* ctx, Scratch& sc, const dthip_col& c, int64_t n, int mem, dthip_col* out) {
+  *out = c;
+  if (mem == DTHIP_DEVICE || n == 0) return DTHIP_OK;
+  unsigned char* d = nullptr;
+  const size_t bytes = (size_t)n * stype_size(c.stype);
+  DTHIP_TRY(sc.get<unsigned char>(bytes, &d));
+  DTHIP_CHECK_HIP(hipMemcpyAsync(d, c.data, bytes, hipMemcpyHostToDevice, ctx->stream));
+  out->data = d;
+  return DTHIP_OK;
+}
+
+static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std::vector<RowsArgs>& args) {
+  const int world = comm->world;
+  const int nkeys = args[0].nkeys, ncols = args[0].ncols;
+  std::vector<std::vector<dthip_col>> kd(jobs.size()), cd(jobs.size());
+  std::vector<long long*> rowid(jobs.size(), nullptr);
+  for (size_t q = 0; q < jobs.size(); q++) {
+    Job& j = jobs[q]; const RowsArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
+    DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    kd[q].resize(nkeys); cd[q].resize(ncols);
+    for (int k = 0; k < nkeys; k++) DTHIP_TRY(stage_dev(ctx, *j.sc, a.keys[k], a.nrows, a.mem, &kd[q][k]));
+    for (int c = 0; c < ncols; c++) DTHIP_TRY(stage_dev(ctx, *j.sc, a.cols[c], a.nrows, a.mem, &cd[q][c]));
+    if (a.nrows) {
+      DTHIP_TRY(j.sc->get<long long>((size_t)a.nrows, &rowid[q]));
+      DTHIP_LAUNCH(ctx, "iota64_kernel", iota64_kernel, (unsigned)((a.nrows + 255) / 256), 256, 0, rowid[q], (uint32_t)a.nrows, (long long)a.row_offset);
+    }
+    DTHIP_TRY(phase_images(j, kd[q][0].data, kd[q][0].stype, a.nrows, a.na_pos));
+  }
+  DTHIP_TRY(exchange_allgather(comm, jobs));
+  const GlobalRange g = reduce_ranges(jobs[0], world);
+  for (auto& j : jobs) { DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device)); DTHIP_TRY(phase_hist(j, g)); }
+  DTHIP_TRY(exchange_allgather(comm, jobs));
+  // ---- destination of every row, slabs in sender row order
+  const int npay = nkeys + ncols + 1;                 // keys, columns, global row id
+  for (size_t q = 0; q < jobs.size(); q++) {
+    Job& j = jobs[q]; const RowsArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
+    DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    splitters(j, g, world);
+    j.send_cnt.assign(world, 0); j.send_off.assign(world, 0);
+    j.cols.assign(npay, XCol());
+    for (int k = 0; k < nkeys; k++) { j.cols[k].stype = kd[q][k].stype; j.cols[k].send = kd[q][k].data; }
+    for (int c = 0; c < ncols; c++) { j.cols[nkeys + c].stype = cd[q][c].stype; j.cols[nkeys + c].send = cd[q][c].data; }
+    j.cols[npay - 1].stype = DTHIP_INT64; j.cols[npay - 1].send = rowid[q];
+    for (auto& c : j.cols) c.elem = stype_size(c.stype);
+    if (world > 1 && a.nrows > 0) {
+      int8_t* dest = nullptr; u64* d_b = nullptr;
+      DTHIP_TRY(j.sc->get<int8_t>((size_t)a.nrows, &dest));
+      DTHIP_TRY(j.sc->get<u64>(world, &d_b));
+      DTHIP_CHECK_HIP(hipMemcpyAsync(d_b, j.bounds.data(), sizeof(u64) * (world - 1), hipMemcpyHostToDevice, ctx->stream));
+      DTHIP_LAUNCH(ctx, "image_dest_kernel", image_dest_kernel, (unsigned)((a.nrows + 255) / 256), 256, 0, j.img, (uint32_t)a.nrows, d_b, world - 1, dest);
+      // stable partition by destination: the library's own rows-in-grouped-order on the int8 destination
+      dthip_col dk{dest, DTHIP_INT8, 0};
+      std::vector<dthip_col> pay(npay);
+      for (int c = 0; c < npay; c++) pay[c] = dthip_col{j.cols[c].send, j.cols[c].stype, 0};
+      DTHIP_TRY(dthip_groupby_rows(ctx, &dk, 1, pay.data(), npay, a.nrows, DTHIP_NA_FIRST, DTHIP_DEVICE, 0, &j.local));
+      // slabs are contiguous and in ascending destination order: their sizes are the destination counts
+      u64* d_cnt = nullptr;
+      DTHIP_TRY(j.sc->get<u64>(128, &d_cnt));
+      DTHIP_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(u64) * 128, ctx->stream));
+      DTHIP_LAUNCH(ctx, "dest_count_kernel", dest_count_kernel, (unsigned)std::min<int64_t>((a.nrows + 255) / 256, 2048), 256, 0, dest, (uint32_t)a.nrows, d_cnt);
+      u64 cnt[128];
+      DTHIP_TRY(read_back(ctx, cnt, d_cnt, sizeof(cnt)));
+      int64_t off = 0;
+      for (int d = 0; d < world; d++) { j.send_off[d] = off; j.send_cnt[d] = (int64_t)cnt[d]; off += (int64_t)cnt[d]; }
+      for (int c = 0; c < npay; c++) j.cols[c].send = j.local->col[c];
+    } else if (world == 1) {
+      j.send_cnt[0] = a.nrows;
+    }
+    j.nsend = a.nrows;
+    counts_blob(j, world);
+  }
+  DTHIP_TRY(exchange_allgather(comm, jobs));
+  for (auto& j : jobs) {
+    DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device));
+    layout_from_counts(j, world);
+    for (auto& c : j.cols) { unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r; }
+  }
+  DTHIP_TRY(exchange_alltoallv(comm, jobs));
+  // ---- one stable local grouping of what arrived (source-rank order = global row order)
+  for (size_t q = 0; q < jobs.size(); q++) {
+    Job& j = jobs[q]; const RowsArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
+    DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+    std::vector<dthip_col> mk(nkeys), mc(ncols + 1);
+    for (int k = 0; k < nkeys; k++) mk[k] = dthip_col{j.cols[k].recv, a.keys[k].stype, a.keys[k].flags};
+    for (int c = 0; c <= ncols; c++) mc[c] = dthip_col{j.cols[nkeys + c].recv, j.cols[nkeys + c].stype, 0};
+    DTHIP_TRY(dthip_groupby_rows(ctx, mk.data(), nkeys, mc.data(), ncols + 1, j.nrecv, a.na_pos, DTHIP_DEVICE, 0, &j.out));
+  }
+  return DTHIP_OK;
+}
+
+static int check_jobs(dthip_comm* comm, dthip_ctx* const* ctxs, int n) {
+  if (!comm) { set_error("context is not part of a communicator: call dthip_comm_init / dthip_comm_init_local first"); return DTHIP_EINVAL; }
+  if (comm->kind == 1 && n != comm->world) { set_error("local communicator of %d ranks called with %d contexts", comm->world, n); return DTHIP_EINVAL; }
+  if (comm->kind == 0 && n != 1) { set_error("an RCCL communicator is driven one rank per call"); return DTHIP_EINVAL; }
+  for (int i = 0; i < n; i++) if (!ctxs[i] || ctxs[i]->comm != comm) { set_error("contexts belong to different communicators"); return DTHIP_EINVAL; }
+  return DTHIP_OK;
+}
+
+}  // namespace dthip
+
+using namespace dthip;
+
+extern "C" {
+
+int dthip_comm_unique_id(void* id_out) {
+  if (!id_out) { set_error("null id buffer"); return DTHIP_EINVAL; }
+  DTHIP_TRY(nccl_load());
+  static_assert(sizeof(ncclUniqueId) == DTHIP_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  DTHIP_CHECK_NCCL(g_nccl.GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return DTHIP_OK;
+}
+
+int dthip_comm_init(dthip_ctx* ctx, int rank, int world, const void* id) {
+  if (!ctx || !id || world < 1 || rank < 0 || rank >= world) { set_error("bad communicator arguments"); return DTHIP_EINVAL; }
+  if (world > 127) { set_error("at most 127 ranks (destinations are int8)"); return DTHIP_EINVAL; }
+  if (ctx->comm) { set_error("context already belongs to a communicator"); return DTHIP_EINVAL; }
+  DTHIP_TRY(nccl_load());
+  DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  dthip_comm* c = new dthip_comm();
+  c->kind = 0; c->world = world; c->refs = 1;
+  ncclResult_t r = g_nccl.CommInitRank(&c->nccl, world, uid, rank);
+  if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", g_nccl.GetErrorString(r)); delete c; return DTHIP_EDEVICE; }
+  ctx->comm = c; ctx->comm_rank = rank;
+  return DTHIP_OK;
+}
+
+int dthip_comm_init_local(dthip_ctx* const* ctxs, int world) {
+  if (!ctxs || world < 1 || world > 127) { set_error("bad communicator arguments"); return DTHIP_EINVAL; }
+  for (int i = 0; i < world; i++) {
+    if (!ctxs[i] || ctxs[i]->comm) { set_error("context %d is null or already belongs to a communicator", i); return DTHIP_EINVAL; }
+    for (int k = 0; k < i; k++) if (ctxs[k] == ctxs[i]) { set_error("every rank needs its own context"); return DTHIP_EINVAL; }
+  }
+  dthip_comm* c = new dthip_comm();
+  c->kind = 1; c->world = world; c->refs = world;
+  c->ranks.assign(ctxs, ctxs + world);
+  for (int i = 0; i < world; i++) { ctxs[i]->comm = c; ctxs[i]->comm_rank = i; }
+  return DTHIP_OK;
+}
+
+int dthip_comm_destroy(dthip_ctx* ctx) {
+  if (!ctx || !ctx->comm) return DTHIP_OK;
+  dthip_comm* c = ctx->comm;
+  ctx->comm = nullptr; ctx->comm_rank = 0;
+  if (--c->refs > 0) return DTHIP_OK;
+  if (c->kind == 0 && c->nccl) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)g_nccl.CommDestroy(c->nccl);
+  }
+  delete c;
+  return DTHIP_OK;
+}
+
+int dthip_comm_rank(const dthip_ctx* ctx) { return (ctx && ctx->comm) ? ctx->comm_rank : -1; }
+int dthip_comm_world(const dthip_ctx* ctx) { return (ctx && ctx->comm) ? ctx->comm->world : 0; }
+
+static int sharded_agg_impl(dthip_ctx* const* ctxs, int n, const std::vector<AggArgs>& args, dthip_result** outs) {
+  if (!ctxs || !outs || n < 1) { set_error("null argument"); return DTHIP_EINVAL; }
+  dthip_comm* comm = ctxs[0] ? ctxs[0]->comm : nullptr;
+  DTHIP_TRY(check_jobs(comm, ctxs, n));
+  for (int i = 0; i < n; i++) {
+    const AggArgs& a = args[i];
+    if (!a.keys || a.nkeys < 1 || a.nkeys > MAX_KEYCOLS || (a.naggs > 0 && !a.aggs) || a.nrows < 0 || a.nrows > (int64_t)INT32_MAX) { set_error("bad argument"); return DTHIP_EINVAL; }
+    if (a.keys[0].flags & DTHIP_FLAG_DESCENDING) { set_error("sharded groupby: the first key must be ascending (range partition)"); return DTHIP_ENOTIMPL; }
+    if (a.nkeys != args[0].nkeys || a.naggs != args[0].naggs) { set_error("ranks disagree on the query"); return DTHIP_EINVAL; }
+  }
+  AggPlan plan;
+  DTHIP_TRY(plan_partials(args[0].aggs, args[0].naggs, &plan));
+  std::vector<Job> jobs(n);
+  std::vector<Scratch*> scs;
+  for (int i = 0; i < n; i++) { jobs[i].ctx = ctxs[i]; jobs[i].rank = ctxs[i]->comm_rank; scs.push_back(new Scratch(ctxs[i])); jobs[i].sc = scs.back(); }
+  std::sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return a.rank < b.rank; });
+  std::vector<AggArgs> sorted_args(n);
+  for (int i = 0; i < n; i++) for (int q = 0; q < n; q++) if (jobs[q].ctx == ctxs[i]) sorted_args[q] = args[i];
+  const int rc = run_sharded_agg(comm, jobs, sorted_args, plan);
+  for (auto& j : jobs) {
+    (void)hipSetDevice(j.ctx->device);
+    if (j.local) dthip_result_free(j.ctx, j.local);
+    if (rc != DTHIP_OK && j.out) { dthip_result_free(j.ctx, j.out); j.out = nullptr; }
+  }
+  for (int i = 0; i < n; i++) for (int q = 0; q < n; q++) if (jobs[q].ctx == ctxs[i]) outs[i] = jobs[q].out;
+  for (auto* s : scs) { (void)hipSetDevice(s->ctx->device); delete s; }
+  return rc;
+}
+
+int dthip_sharded_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dthip_col* values, int nvalues,
+                              const dthip_agg* aggs, int naggs, int64_t nrows_local, int na_pos, int mem, dthip_result** out) {
+  std::vector<AggArgs> args(1);
+  args[0] = AggArgs{keys, nkeys, values, nvalues, aggs, naggs, nrows_local, na_pos, mem};
+  return sharded_agg_impl(&ctx, 1, args, out);
+}
+
+int dthip_sharded_groupby_agg_local(dthip_ctx* const* ctxs, int world, const dthip_col* const* keys, int nkeys,
+                                    const dthip_col* const* values, int nvalues, const dthip_agg* aggs, int naggs,
+                                    const int64_t* nrows, int na_pos, int mem, dthip_result** outs) {
+  if (!keys || !nrows || (nvalues > 0 && !values)) { set_error("null argument"); return DTHIP_EINVAL; }
+  std::vector<AggArgs> args(world);
+  for (int r = 0; r < world; r++) args[r] = AggArgs{keys[r], nkeys, nvalues > 0 ? values[r] : nullptr, nvalues, aggs, naggs, nrows[r], na_pos, mem};
+  return sharded_agg_impl(ctxs, world, args, outs);
+}
+
+static int sharded_rows_impl(dthip_ctx* const* ctxs, int n, const std::vector<RowsArgs>& args, dthip_result** outs) {
+  if (!ctxs || !outs || n < 1) { set_error("null argument"); return DTHIP_EINVAL; }
+  dthip_comm* comm = ctxs[0] ? ctxs[0]->comm : nullptr;
+  DTHIP_TRY(check_jobs(comm, ctxs, n));
+  for (int i = 0; i < n; i++) {
+    const RowsArgs& a = args[i];
+    if (!a.keys || a.nkeys < 1 || a.nkeys > MAX_KEYCOLS || a.ncols < 0 || (a.ncols > 0 && !a.cols) || a.nrows < 0 || a.nrows > (int64_t)INT32_MAX) {
+      set_error("bad argument"); return DTHIP_EINVAL;
+    }
+    if (a.keys[0].flags & DTHIP_FLAG_DESCENDING) { set_error("sharded groupby: the first key must be ascending (range partition)"); return DTHIP_ENOTIMPL; }
+  }
+  std::vector<Job> jobs(n);
+  std::vector<Scratch*> scs;
+  for (int i = 0; i < n; i++) { jobs[i].ctx = ctxs[i]; jobs[i].rank = ctxs[i]->comm_rank; scs.push_back(new Scratch(ctxs[i])); jobs[i].sc = scs.back(); }
+  std::sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return a.rank < b.rank; });
+  std::vector<RowsArgs> sorted_args(n);
+  for (int i = 0; i < n; i++) for (int q = 0; q < n; q++) if (jobs[q].ctx == ctxs[i]) sorted_args[q] = args[i];
+  const int rc = run_sharded_rows(comm, jobs, sorted_args);
+  for (auto& j : jobs) {
+    (void)hipSetDevice(j.ctx->device);
+    if (j.local) dthip_result_free(j.ctx, j.local);
+    if (rc != DTHIP_OK && j.out) { dthip_result_free(j.ctx, j.out); j.out = nullptr; }
+  }
+  for (int i = 0; i < n; i++) for (int q = 0; q < n; q++) if (jobs[q].ctx == ctxs[i]) outs[i] = jobs[q].out;
+  for (auto* s : scs) { (void)hipSetDevice(s->ctx->device); delete s; }
+  return rc;
+}
+
+int dthip_sharded_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dthip_col* cols, int ncols,
+                               int64_t nrows_local, int64_t row_offset, int na_pos, int mem, dthip_result** out) {
+  std::vector<RowsArgs> args(1);
+  args[0] = RowsArgs{keys, nkeys, cols, ncols, nrows_local, row_offset, na_pos, mem};
+  return sharded_rows_impl(&ctx, 1, args, out);
+}
+
+int dthip_sharded_groupby_rows_local(dthip_ctx* const* ctxs, int world, const dthip_col* const* keys, int nkeys,
+                                     const dthip_col* const* cols, int ncols, const int64_t* nrows, const int64_t* row_offsets,
+                                     int na_pos, int mem, dthip_result** outs) {
+  if (!keys || !nrows || !row_offsets || (ncols > 0 && !cols)) { set_error("null argument"); return DTHIP_EINVAL; }
+  std::vector<RowsArgs> args(world);
+  for (int r = 0; r < world; r++) args[r] = RowsArgs{keys[r], nkeys, ncols > 0 ? cols[r] : nullptr, ncols, nrows[r], row_offsets[r], na_pos, mem};
+  return sharded_rows_impl(ctxs, world, args, outs);
+}
+
+}  // extern "C"

@@ -48,6 +48,7 @@ struct ProfAcc { double ms = 0; int64_t n = 0; };
 
 }  // namespace dthip
 
+struct dthip_comm;
 struct dthip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -76,9 +77,32 @@ struct dthip_ctx {
   bool in_merge = false;     // internal: the merge of partial groups must not take the hash path again
   int cluster_mode = 0;      // clustered-key kernel variants: 0 decide from a sample, 1 never, 2 always
   int agg_offsets = 1;       // dthip_groupby_agg results carry group offsets (= sizes) even when no count() asks for them
+  // multi-GPU (comm.hip): the communicator this context is a rank of
+  struct dthip_comm* comm = nullptr;
+  int comm_rank = 0;
+};
+
+// device-resident result of a groupby (dthip.h: dthip_result); every buffer in `owned` goes back to the context's
+// cache on dthip_result_free
+struct dthip_result {
+  int64_t nrows = 0, ngroups = 0;
+  int32_t* rowindex = nullptr;
+  int32_t* offsets = nullptr;
+  int nkeys = 0;
+  void* key[8] = {};
+  int key_stype[8] = {};
+  int naggs = 0;
+  std::vector<void*> agg;
+  std::vector<int> agg_stype;
+  std::vector<void*> col;        // dthip_groupby_rows: columns permuted into grouped order
+  std::vector<int> col_stype;
+  std::vector<void*> owned;
 };
 
 namespace dthip {
+
+int result_alloc(dthip_ctx* ctx, dthip_result* r, size_t bytes, void** out);
+void result_destroy(dthip_ctx* ctx, dthip_result* r);
 
 int dev_alloc(dthip_ctx* ctx, size_t bytes, void** out);
 void dev_release(dthip_ctx* ctx, void* p);   // back to the cache
@@ -220,7 +244,8 @@ struct BucketGeom {
   int km;                 // key load mode: 0 generic, 1 one aligned int64 column, 2 one aligned int32 column
 };
 struct WorkItem { uint32_t bucket, begin, end, single; };
-enum { ACC_CNT = 1, ACC_SUM = 2, ACC_MIN = 4, ACC_MAX = 8, ACC_VCNT = 16, ACC_FSUM = 32, ACC_PRES = 64 };
+enum { ACC_CNT = 1, ACC_SUM = 2, ACC_MIN = 4, ACC_MAX = 8, ACC_VCNT = 16, ACC_FSUM = 32, ACC_PRES = 64,
+       ACC_NONA = 128 /* DTHIP_FLAG_NONA: every bit pattern of the value column is a value */ };
 // dense accumulator arrays of F*S slots (slot index == transformed key)
 struct AggTable {
   uint32_t* cnt = nullptr;              // rows per slot
@@ -295,7 +320,7 @@ struct ReduceOuts {
 };
 int launch_reduce(dthip_ctx* ctx, const void* values, int stype, const int32_t* rowindex,
                   const uint8_t* bitmap, const uint32_t* tile_first_head, int64_t nrows,
-                  const ReduceOuts& outs);
+                  const ReduceOuts& outs, int nona = 0);
 int launch_count0(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t* out);
 
 constexpr int DTHIP_NOT_APPLICABLE = 2;     // internal: this path does not fit, take the next one

@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
                                                               const uint8_t* __restrict__ bitmap,
                                                               const uint32_t* __restrict__ tile_first_head,
                                                               uint32_t n, OutsT<T> outs,
-                                                              TileSide<typename VT<T>::St>* side) {
+                                                              TileSide<typename VT<T>::St>* side, int nona) {
   typedef typename VT<T>::St St;
   __shared__ St w_val[SR_BLOCK / 64];
   __shared__ uint32_t w_flag[SR_BLOCK / 64];
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
     for (int j = 0; j < NV; j++) v[j] = src[j];
     const T* vt = reinterpret_cast<const T*>(v);
 #pragma unroll
-    for (int j = 0; j < SR_ITEMS; j++) { x[j] = vt[j]; ok[j] = !VT<T>::isna(x[j]); }
+    for (int j = 0; j < SR_ITEMS; j++) { x[j] = vt[j]; ok[j] = nona || !VT<T>::isna(x[j]); }
   } else if (whole && ri && ((reinterpret_cast<uintptr_t>(ri) & 15) == 0)) {
     ru32x4 rv[2];
     const ru32x4* rsrc = reinterpret_cast<const ru32x4*>(ri + p0);
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
       const int32_t r = rr[j];
       ok[j] = r >= 0;
       x[j] = ok[j] ? vals[r] : T(0);
-      if (ok[j] && VT<T>::isna(x[j])) ok[j] = false;
+      if (ok[j] && !nona && VT<T>::isna(x[j])) ok[j] = false;
     }
   } else {
 #pragma unroll
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
         } else {
           x[j] = vals[p]; ok[j] = true;
         }
-        if (ok[j] && VT<T>::isna(x[j])) ok[j] = false;
+        if (ok[j] && !nona && VT<T>::isna(x[j])) ok[j] = false;
       } else {
         hb &= ~(1u << j);
       }
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) seg_fixup_kernel(const TileSide<typename 
 
 template <typename T>
 static int reduce_t(dthip_ctx* ctx, const void* values, const int32_t* ri, const uint8_t* bitmap,
-                    const uint32_t* tile_first_head, int64_t nrows, const ReduceOuts& o) {
+                    const uint32_t* tile_first_head, int64_t nrows, const ReduceOuts& o, int nona) {
   typedef typename VT<T>::St St;
   const uint32_t nt = (uint32_t)((nrows + SR_TILE - 1) / SR_TILE);
   if (nt == 0) return DTHIP_OK;
@@ -360,21 +360,21 @@ static int reduce_t(dthip_ctx* ctx, const void* values, const int32_t* ri, const
   outs.mx = static_cast<T*>(o.mx);
   outs.count = reinterpret_cast<long long*>(o.count);
   DTHIP_LAUNCH(ctx, "seg_reduce_kernel", seg_reduce_kernel<T>, nt, SR_BLOCK, 0,
-               static_cast<const T*>(values), ri, bitmap, tile_first_head, (uint32_t)nrows, outs, side);
+               static_cast<const T*>(values), ri, bitmap, tile_first_head, (uint32_t)nrows, outs, side, nona);
   DTHIP_LAUNCH(ctx, "seg_fixup_kernel", seg_fixup_kernel<T>, (nt + 3) / 4, 256, 0, side, nt, outs);
   return DTHIP_OK;
 }
 
 int launch_reduce(dthip_ctx* ctx, const void* values, int stype, const int32_t* rowindex,
                   const uint8_t* bitmap, const uint32_t* tile_first_head, int64_t nrows,
-                  const ReduceOuts& outs) {
+                  const ReduceOuts& outs, int nona) {
   switch (stype) {
-    case DTHIP_BOOL: case DTHIP_INT8: return reduce_t<int8_t>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
-    case DTHIP_INT16: return reduce_t<int16_t>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
-    case DTHIP_INT32: return reduce_t<int32_t>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
-    case DTHIP_INT64: return reduce_t<long long>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
-    case DTHIP_FLOAT32: return reduce_t<float>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
-    case DTHIP_FLOAT64: return reduce_t<double>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs);
+    case DTHIP_BOOL: case DTHIP_INT8: return reduce_t<int8_t>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, nona);
+    case DTHIP_INT16: return reduce_t<int16_t>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, nona);
+    case DTHIP_INT32: return reduce_t<int32_t>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, nona);
+    case DTHIP_INT64: return reduce_t<long long>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, nona);
+    case DTHIP_FLOAT32: return reduce_t<float>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, nona);
+    case DTHIP_FLOAT64: return reduce_t<double>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, nona);
     default: set_error("reduce: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
   }
 }

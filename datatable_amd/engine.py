@@ -208,7 +208,64 @@ class Result:
             pass
 
 
-class Context:
+# ---- multi-GPU: the exchange runs inside libdthip.so (csrc/comm.hip) ------------------------------------------
+def comm_unique_id():
+    """128 bytes created on rank 0 (ncclGetUniqueId) to be handed to every rank"""
+    lib = L.load()
+    buf = C.create_string_buffer(L.COMM_ID_BYTES)
+    L.check(lib.dthip_comm_unique_id(buf))
+    return buf.raw
+
+
+def _agg_array(aggs):
+    aarr = (L.Agg * max(len(aggs), 1))()
+    for i, (op, col) in enumerate(aggs):
+        aarr[i] = L.Agg(OPS[op] if isinstance(op, str) else int(op), -1 if col is None else int(col))
+    return aarr
+
+
+class _ShardMixin:
+    def comm_init(self, rank, world, comm_id):
+        """collective: this context becomes rank `rank` of a `world`-rank RCCL communicator (one rank per GPU)"""
+        L.check(self._lib.dthip_comm_init(self._h, int(rank), int(world), comm_id))
+
+    def comm_destroy(self):
+        L.check(self._lib.dthip_comm_destroy(self._h))
+
+    @property
+    def comm_rank(self):
+        return self._lib.dthip_comm_rank(self._h)
+
+    @property
+    def comm_world(self):
+        return self._lib.dthip_comm_world(self._h)
+
+    def sharded_groupby_agg(self, keys, values, aggs, nrows=None, key_stypes=None, value_stypes=None, na_last=False):
+        """collective DT[:, aggs, by(keys)] over row shards: this rank's rows in, this rank's key range out"""
+        karr, kmem, kkeep = _cols(keys, key_stypes)
+        varr, vmem, vkeep = _cols(values, value_stypes)
+        if values and kmem != vmem:
+            raise ValueError("keys and values must live in the same memory space")
+        if nrows is None:
+            nrows = len(kkeep[0])
+        h = C.c_void_p()
+        L.check(self._lib.dthip_sharded_groupby_agg(self._h, karr, len(keys), varr, len(values), _agg_array(aggs), len(aggs), nrows,
+                                                    L.NA_LAST if na_last else L.NA_FIRST, kmem, C.byref(h)))
+        return Result(self, h, [karr[i].stype for i in range(len(keys))], len(aggs))
+
+    def sharded_groupby_rows(self, keys, cols, row_offset, nrows=None, key_stypes=None, col_stypes=None, na_last=False):
+        """collective DT[:, cols, by(keys)] over row shards; result columns: cols..., then the global row ids (int64)"""
+        karr, kmem, kkeep = _cols(keys, key_stypes)
+        carr, cmem, ckeep = _cols(cols, col_stypes)
+        if nrows is None:
+            nrows = len(kkeep[0])
+        h = C.c_void_p()
+        L.check(self._lib.dthip_sharded_groupby_rows(self._h, karr, len(keys), carr, len(cols), nrows, int(row_offset),
+                                                     L.NA_LAST if na_last else L.NA_FIRST, kmem, C.byref(h)))
+        return Result(self, h, [karr[i].stype for i in range(len(keys))], 0, [carr[i].stype for i in range(len(cols))] + [L.INT64])
+
+
+class Context(_ShardMixin):
     """One device + one HIP stream + cached workspace (dthip_ctx)."""
 
     def __init__(self, device=0, stream=None):
@@ -527,6 +584,56 @@ class Context:
 
 
 _default_ctx = None
+
+
+class LocalComm:
+    """`world` logical shards driven from ONE process (dthip_comm_init_local): every rank has its own Context (all on
+    `device` unless `devices` says otherwise); the exchange is device-to-device copies.  Same phases as the RCCL path."""
+
+    def __init__(self, world, device=0, devices=None):
+        self.ctxs = [Context(devices[r] if devices else device) for r in range(world)]
+        self.world = world
+        self._lib = self.ctxs[0]._lib
+        self._harr = (C.c_void_p * world)(*[c._h for c in self.ctxs])
+        L.check(self._lib.dthip_comm_init_local(self._harr, world))
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+
+    def _percol(self, lists, stypes=None):
+        """[[cols of rank 0], [cols of rank 1], ...] -> (Col** array, mem, keepalive)"""
+        arrs, keep, mem = [], [], L.HOST
+        for cols in lists:
+            a, mem, k = _cols(cols, stypes)
+            arrs.append(a); keep.append(k)
+        pp = (C.POINTER(L.Col) * len(lists))(*[C.cast(a, C.POINTER(L.Col)) for a in arrs])
+        return pp, mem, (arrs, keep)
+
+    def groupby_agg(self, keys, values, aggs, key_stypes=None, value_stypes=None, na_last=False):
+        """keys[r] / values[r]: rank r's columns (numpy arrays).  Returns one Result per rank (rank order = key order)."""
+        kpp, kmem, kk = self._percol(keys, key_stypes)
+        vpp, vmem, vk = self._percol(values, value_stypes)
+        nrows = (C.c_int64 * self.world)(*[len(k[0]) for k in keys])
+        outs = (C.c_void_p * self.world)()
+        L.check(self._lib.dthip_sharded_groupby_agg_local(self._harr, self.world, kpp, len(keys[0]), vpp, len(values[0]) if values else 0,
+                                                          _agg_array(aggs), len(aggs), nrows, L.NA_LAST if na_last else L.NA_FIRST,
+                                                          kmem, outs))
+        kst = [kk[0][0][i].stype for i in range(len(keys[0]))]
+        return [Result(self.ctxs[r], C.c_void_p(outs[r]), kst, len(aggs)) for r in range(self.world)]
+
+    def groupby_rows(self, keys, cols, row_offsets, key_stypes=None, col_stypes=None, na_last=False):
+        kpp, kmem, kk = self._percol(keys, key_stypes)
+        cpp, cmem, ck = self._percol(cols, col_stypes)
+        nrows = (C.c_int64 * self.world)(*[len(k[0]) for k in keys])
+        offs = (C.c_int64 * self.world)(*[int(x) for x in row_offsets])
+        outs = (C.c_void_p * self.world)()
+        L.check(self._lib.dthip_sharded_groupby_rows_local(self._harr, self.world, kpp, len(keys[0]), cpp, len(cols[0]) if cols else 0,
+                                                           nrows, offs, L.NA_LAST if na_last else L.NA_FIRST, kmem, outs))
+        kst = [kk[0][0][i].stype for i in range(len(keys[0]))]
+        cst = [ck[0][0][i].stype for i in range(len(cols[0]))] + [L.INT64]
+        return [Result(self.ctxs[r], C.c_void_p(outs[r]), kst, 0, cst) for r in range(self.world)]
 
 
 def default_context():

@@ -52,7 +52,9 @@
 extern "C" {
 #endif
 
-#define DTHIP_ABI_VERSION 2   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10 */
+#define DTHIP_ABI_VERSION 3   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10
+                                 3: + dthip_comm_*, dthip_sharded_groupby_* (multi-GPU inside the library), DTHIP_FLAG_NONA,
+                                    dthip_host_register / dthip_host_unregister */
 
 /* error codes */
 #define DTHIP_OK        0
@@ -69,7 +71,12 @@ enum dthip_stype {
 
 /* reducers */
 enum dthip_op {
-  DTHIP_SUM = 0, DTHIP_MEAN = 1, DTHIP_MIN = 2, DTHIP_MAX = 3,
+  DTHIP_SUM = 0,     /* sum(col): NA skipped, empty / all-NA group -> 0; int -> int64 (wraps), float64 -> float64.
+                        DEVIATION (documented): float32 sums are ACCUMULATED IN float64 and rounded to
+                        float32 once; the reference accumulates in float32 row by row (column/sumprod.h:48-55), so
+                        its result carries its own rounding (~1e-7 x sum|v| per group) that this one does not:
+                        the two agree to ~1e-4 relative on long groups, exactly on short ones */
+  DTHIP_MEAN = 1, DTHIP_MIN = 2, DTHIP_MAX = 3,
   DTHIP_COUNT = 4,   /* count(col): non-NA rows per group   (count.h:35-58) */
   DTHIP_COUNT0 = 5,  /* count():    rows per group          (count.h:61-88) */
   DTHIP_FIRST = 6,   /* first(col): element of the group's first row, NA included */
@@ -101,8 +108,13 @@ enum dthip_mem { DTHIP_HOST = 0, DTHIP_DEVICE = 1 };
  * one key exactly its NA rows */
 enum dthip_napos { DTHIP_NA_FIRST = 0, DTHIP_NA_LAST = 1, DTHIP_NA_REMOVE = 2 };
 
-/* SortFlag bits, src/core/sort.h:36-44 */
+/* SortFlag bits, src/core/sort.h:36-44 (key columns) */
 #define DTHIP_FLAG_DESCENDING 1
+/* value columns of dthip_groupby_agg: the column holds NO NA -- INT*_MIN / NaN are ordinary values that take part
+ * in sum / count (the library's own merges of partial sums use it: a partial int64 sum that wrapped to INT64_MIN, or
+ * a partial float sum that is NaN because +inf and -inf met, must not be skipped like an NA; the reference has no
+ * such step, its reducers see every row of a group in one loop, column/sumprod.h:34-59) */
+#define DTHIP_FLAG_NONA 2
 
 /* comparison codes for dthip_filter_cmp */
 enum dthip_cmp { DTHIP_GT = 0, DTHIP_GE = 1, DTHIP_LT = 2, DTHIP_LE = 3, DTHIP_EQ = 4, DTHIP_NE = 5,
@@ -113,7 +125,7 @@ enum dthip_cmp { DTHIP_GT = 0, DTHIP_GE = 1, DTHIP_LT = 2, DTHIP_LE = 3, DTHIP_E
 typedef struct dthip_col {
   const void* data;
   int32_t stype;   /* enum dthip_stype */
-  int32_t flags;   /* DTHIP_FLAG_* (keys only) */
+  int32_t flags;   /* DTHIP_FLAG_* */
 } dthip_col;
 
 /* one requested aggregate: op applied to values[col] (col ignored for COUNT0) */
@@ -291,6 +303,51 @@ int  dthip_ungroup(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int6
  * dthip_groupby_rows on `out` then groups the rows by destination in their original order. */
 int  dthip_range_bucket(dthip_ctx* ctx, const dthip_col* key, int64_t nrows,
                         const int64_t* bounds, int nbounds, int mem, int8_t* out);
+
+/* ---- multi-GPU: one context per GPU, the exchange inside the library -------------------------
+ * The reference is single-process; there is no seam to cite.  Rows are sharded by row block over the ranks
+ * (rank r holds a contiguous block of the frame's rows); key-RANGE partitioning of the first key keeps the
+ * global group order equal to the concatenation of the ranks' results in rank order -- the order the reference
+ * returns (sort.cc:1411-1495: groups ascending, NA first / last).  Splitters come from an all-gathered 4096-bin
+ * histogram of the first key, so skewed keys are spread evenly.  datatable_amd/csrc/comm.hip. */
+#define DTHIP_COMM_ID_BYTES 128
+/* rank 0 creates the id (ncclGetUniqueId) and hands its bytes to every rank by whatever means the application has
+ * (a file, MPI, a TCP store, ...); loads librccl.so on first use */
+int  dthip_comm_unique_id(void* id_out /* DTHIP_COMM_ID_BYTES */);
+/* collective over all ranks: binds ctx (its device and its stream) as rank `rank` of a `world`-rank RCCL
+ * communicator (ncclCommInitRank).  One rank per GPU, at most 127 ranks. */
+int  dthip_comm_init(dthip_ctx* ctx, int rank, int world, const void* id);
+/* binds `world` distinct contexts of ONE process (on any devices, also all on the same GPU) as ranks 0..world-1 of a
+ * LOCAL communicator: the same phases, the exchange being device-to-device copies, no RCCL.  For logical shards
+ * on one GPU and for tests; driven with the *_local entry points below (all ranks in one call). */
+int  dthip_comm_init_local(dthip_ctx* const* ctxs, int world);
+int  dthip_comm_destroy(dthip_ctx* ctx);
+int  dthip_comm_rank(const dthip_ctx* ctx);     /* -1 when ctx belongs to no communicator */
+int  dthip_comm_world(const dthip_ctx* ctx);    /* 0 when ctx belongs to no communicator */
+
+/* DT[:, aggs, by(keys)] over the sharded rows (collective: every rank calls it with its own rows and the same
+ * query).  Local fused groupby-aggregate (the combiner) -> range-partitioned all-to-all-v of the partial groups
+ * (ncclSend/ncclRecv in one group) -> merge on the owner.  The result of rank r holds the groups of the r-th key
+ * range: group-key columns and one column per agg (no offsets; ask for count() to get group sizes).  Reducers:
+ * sum / mean / min / max / count / count(); integer results and min/max are exact, float sums are re-associated
+ * (<= 1e-6).  The first key must be ascending. */
+int  dthip_sharded_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys,
+                               const dthip_col* values, int nvalues, const dthip_agg* aggs, int naggs,
+                               int64_t nrows_local, int na_pos, int mem, dthip_result** out);
+/* the same for a local communicator: keys[r] / values[r] / nrows[r] are rank r's, outs[r] its result */
+int  dthip_sharded_groupby_agg_local(dthip_ctx* const* ctxs, int world, const dthip_col* const* keys, int nkeys,
+                                     const dthip_col* const* values, int nvalues, const dthip_agg* aggs, int naggs,
+                                     const int64_t* nrows, int na_pos, int mem, dthip_result** outs);
+/* DT[:, cols, by(keys)] -- rows in grouped order -- over the sharded rows: every row travels ONCE to the owner of
+ * its key range (slabs arrive in source-rank order = global row order), one stable local grouping there.  The
+ * result of rank r holds offsets, cols[c] in grouped order (dthip_result_col(c), c < ncols) and, as column
+ * `ncols`, the GLOBAL row id (int64, row_offset + local row number) of every output row: the concatenation of the
+ * ranks' row-id columns is the reference's RowIndex of the whole frame. */
+int  dthip_sharded_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dthip_col* cols, int ncols,
+                                int64_t nrows_local, int64_t row_offset, int na_pos, int mem, dthip_result** out);
+int  dthip_sharded_groupby_rows_local(dthip_ctx* const* ctxs, int world, const dthip_col* const* keys, int nkeys,
+                                      const dthip_col* const* cols, int ncols, const int64_t* nrows,
+                                      const int64_t* row_offsets, int na_pos, int mem, dthip_result** outs);
 
 /* ---- RowIndex construction / application ---------------------------------- */
 /* ascending ARR32 of rows whose mask is 1 and not NA; out has room for n */
