@@ -48,6 +48,8 @@ SIGNATURES = {
     "dthip_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dthip_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dthip_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dthip_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dthip_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dthip_timer_start": (C.c_int, [C.c_void_p]),
     "dthip_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "dthip_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1088,6 +1088,20 @@ int dthip_memcpy_d2h(dthip_ctx* ctx, void* dst, const void* src, size_t bytes) {
   return DTHIP_OK;
 }
 
+int dthip_host_register(dthip_ctx* ctx, void* ptr, size_t bytes) {
+  if (!ctx || !ptr || !bytes) { set_error("null argument"); return DTHIP_EINVAL; }
+  DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  DTHIP_CHECK_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return DTHIP_OK;
+}
+
+int dthip_host_unregister(dthip_ctx* ctx, void* ptr) {
+  if (!ctx || !ptr) { set_error("null argument"); return DTHIP_EINVAL; }
+  DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+  DTHIP_CHECK_HIP(hipHostUnregister(ptr));
+  return DTHIP_OK;
+}
+
 int dthip_timer_start(dthip_ctx* ctx) {
   if (!ctx) return DTHIP_EINVAL;
   DTHIP_CHECK_HIP(hipEventRecord(ctx->t0, ctx->stream));

@@ -116,23 +116,30 @@ __device__ __forceinline__ u64 key_image(const void* data, int stype, uint32_t i
 
 struct RangeAcc { u64 lo, hi, nvalid; };   // lo starts at ~0, hi at 0
 
+// grid-stride; one set of global atomics per workgroup (every wave hitting the same three addresses cost 5 ms per 1e7 keys)
 __global__ void __launch_bounds__(256) key_image_kernel(const void* data, int stype, uint32_t n, u64 na_img, u64* img, RangeAcc* acc) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  __shared__ u64 s_lo[4], s_hi[4];
+  __shared__ uint32_t s_n[4];
   u64 lo = ~0ULL, hi = 0ULL; uint32_t ok = 0;
-  if (i < n) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const u64 v = key_image(data, stype, i, na_img);
     img[i] = v;
-    if (v != na_img) { lo = v; hi = v; ok = 1; }
+    if (v != na_img) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; ok++; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const u64 l2 = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(lo >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)lo, o, 64);
     const u64 h2 = ((u64)(uint32_t)__shfl_xor((int)(uint32_t)(hi >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)hi, o, 64);
     lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    ok += (uint32_t)__shfl_xor((int)ok, o, 64);
   }
-  const u64 b = __ballot(ok != 0);
-  if ((threadIdx.x & 63) == 0 && b) {
-    atomicMin(&acc->lo, lo); atomicMax(&acc->hi, hi); atomicAdd(&acc->nvalid, (u64)__popcll(b));
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_lo[w] = lo; s_hi[w] = hi; s_n[w] = ok; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t cnt = 0;
+    for (int k = 0; k < 4; k++) { lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; cnt += s_n[k]; }
+    if (cnt) { atomicMin(&acc->lo, lo); atomicMax(&acc->hi, hi); atomicAdd(&acc->nvalid, (u64)cnt); }
   }
 }
 
@@ -297,7 +304,7 @@ static int phase_images(Job& j, const void* key0, int stype, int64_t n, int na_p
     RangeAcc* d_acc = nullptr;
     DTHIP_TRY(j.sc->get<RangeAcc>(1, &d_acc));
     DTHIP_CHECK_HIP(hipMemcpyAsync(d_acc, &j.range, sizeof(RangeAcc), hipMemcpyHostToDevice, ctx->stream));
-    DTHIP_LAUNCH(ctx, "key_image_kernel", key_image_kernel, (unsigned)((n + 255) / 256), 256, 0, key0, stype, (uint32_t)n, j.na_img, j.img, d_acc);
+    DTHIP_LAUNCH(ctx, "key_image_kernel", key_image_kernel, (unsigned)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, key0, stype, (uint32_t)n, j.na_img, j.img, d_acc);
     DTHIP_TRY(read_back(ctx, &j.range, d_acc, sizeof(RangeAcc)));
   }
   j.xin.resize(sizeof(RangeAcc));

@@ -105,7 +105,20 @@ def _cmp_args(cmp, scalar, stype):
         return code, f, -2**63
     if not math.isfinite(f):
         raise NotImplementedError("comparison of an integer column with %r" % (scalar,))
-    return code, f, int(scalar)
+    iv = int(scalar)
+    if iv > 2**63 - 1 or iv < -2**63 + 1:
+        # outside int64 (a ctypes c_int64 argument would wrap silently): the comparison is decided by the sign alone.
+        # "every valid row": NOTNA; "no row": x > INT64_MAX, or == INT64_MIN (the NA sentinel, which no valid element
+        # equals and NA never compares equal); != holds for every row, NA included, like any !=
+        above = iv > 0
+        if cmp == "!=":
+            return CMP["!="], f, -2**63
+        if cmp == "==":
+            return CMP["=="], f, -2**63
+        if (cmp in ("<", "<=")) == above:
+            return L.NOTNA, 0.0, 0
+        return CMP[">"], f, 2**63 - 1
+    return code, f, iv
 
 
 class Result:
@@ -312,6 +325,13 @@ class Context(_ShardMixin):
             L.check(self._lib.dthip_memcpy_h2d(self._h, p, a.ctypes.data, a.nbytes))
         return DevCol(p.value, col.stype, keepalive=buf)
 
+    def host_register(self, a):
+        """page-lock a numpy array's buffer so DTHIP_HOST calls DMA from it directly (dthip_host_register)"""
+        L.check(self._lib.dthip_host_register(self._h, a.ctypes.data, a.nbytes))
+
+    def host_unregister(self, a):
+        L.check(self._lib.dthip_host_unregister(self._h, a.ctypes.data))
+
     # ---- timing -----------------------------------------------------------
     def timer_start(self):
         L.check(self._lib.dthip_timer_start(self._h))
@@ -477,7 +497,7 @@ class Context(_ShardMixin):
         """int8 destination of every row in the range partition given by ascending `bounds` (host arrays)"""
         a, col = _host_col(values, stype)
         out = np.empty(len(a), np.int8)
-        b = (C.c_int64 * max(len(bounds), 1))(*[int(x) for x in bounds])
+        b = (C.c_int64 * max(len(bounds), 1))(*[min(max(int(x), -2**63), 2**63 - 1) for x in bounds])
         L.check(self._lib.dthip_range_bucket(self._h, C.byref(col), len(a), b, len(bounds), L.HOST, out.ctypes.data))
         return out
 
@@ -546,7 +566,7 @@ class Context(_ShardMixin):
     def range_bucket_dev(self, col, nrows, bounds, out_ptr):
         """int8 destination (number of boundaries <= key) of every row of DevCol `col` at out_ptr"""
         c = L.Col(col.ptr, col.stype, 0)
-        b = (C.c_int64 * max(len(bounds), 1))(*[int(x) for x in bounds])
+        b = (C.c_int64 * max(len(bounds), 1))(*[min(max(int(x), -2**63), 2**63 - 1) for x in bounds])
         L.check(self._lib.dthip_range_bucket(self._h, C.byref(c), nrows, b, len(bounds), L.DEVICE, C.c_void_p(out_ptr)))
 
     # device-resident forms of the S-red seam: every pointer is a device address, nothing is copied
@@ -583,7 +603,8 @@ class Context(_ShardMixin):
         return out
 
 
-_default_ctx = None
+import threading
+_default_ctx = threading.local()
 
 
 class LocalComm:
@@ -637,9 +658,11 @@ class LocalComm:
 
 
 def default_context():
-    """Process-wide context on device LOCAL_RANK (or 0)."""
-    global _default_ctx
-    if _default_ctx is None:
+    """The calling THREAD's context on device LOCAL_RANK (or 0).  A Context (dthip_ctx: stream, allocator cache, pinned
+    read-back buffer) is thread-compatible, not thread-safe, and ctypes releases the GIL during calls -- so every
+    Python thread gets its own."""
+    ctx = getattr(_default_ctx, "ctx", None)
+    if ctx is None:
         import os
-        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
-    return _default_ctx
+        ctx = _default_ctx.ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return ctx

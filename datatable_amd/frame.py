@@ -483,6 +483,7 @@ class Frame:
         self._cols, self._stypes, self._names = newcols, [self._stypes[c] for c in order], [self._names[c] for c in order]
         self._ri = None
         self._nkeys = len(kidx)
+        self._dev = None            # the resident copies hold the OLD column order and row order: drop them
 
     def _joined(self, J):
         """X[:, :, join(J)]: X's columns, then J's non-key columns read through the join index"""

@@ -180,6 +180,13 @@ int  dthip_free(dthip_ctx* ctx, void* dptr);
 int  dthip_memcpy_h2d(dthip_ctx* ctx, void* dst, const void* src, size_t bytes);
 int  dthip_memcpy_d2h(dthip_ctx* ctx, void* dst, const void* src, size_t bytes);
 
+/* DTHIP_HOST data: pageable buffers are staged by the HIP runtime through its own pinned bounce buffers (a CPU copy per
+ * byte); a buffer registered here (hipHostRegister: page-locked and mapped once, ~0.2 s per GB) is DMA-read directly,
+ * which pays when the same column buffers are queried repeatedly (the reference-side shim registers a Frame's
+ * numpy-backed columns on request).  Either way the mode is bounded by the PCIe link (Gen5 x16: ~55 GB/s), not by HBM. */
+int  dthip_host_register(dthip_ctx* ctx, void* ptr, size_t bytes);
+int  dthip_host_unregister(dthip_ctx* ctx, void* ptr);
+
 /* stream timers (HIP events on the context's stream) */
 int  dthip_timer_start(dthip_ctx* ctx);
 int  dthip_timer_stop(dthip_ctx* ctx, float* elapsed_ms);   /* synchronises */

@@ -202,3 +202,24 @@ def test_resident_frame_matches_host_frame():
     # a view of a resident frame falls back to the host path (its rows are a gather)
     V = D[f.v > 0, :]
     assert V[:, count(), by(f.a)].to_list() == H[f.v > 0, :][:, count(), by(f.a)].to_list()
+
+
+def test_resident_frame_after_key_assignment():
+    """`DT.to_device(); DT.key = "b"` reorders columns (key first) and rows in place -- the resident
+    copies must not survive it (they held the old column and row order): the by() query agrees with a host frame"""
+    import numpy as np
+    from datatable_amd.frame import Frame, f, by, sum, count   # noqa: A004
+    rng = np.random.default_rng(4)
+    n = 50_000
+    a = rng.integers(0, 100, n).astype(np.int32)
+    b = rng.permutation(n).astype(np.int64)           # unique: a valid key
+    v = rng.standard_normal(n)
+    D = Frame(a=a, b=b, v=v).to_device()
+    D.key = "b"
+    H = Frame(a=a, b=b, v=v)
+    H.key = "b"
+    assert D.names == H.names == ("b", "a", "v")
+    R1, R2 = D[:, [sum(f.v), count()], by(f.a)], H[:, [sum(f.v), count()], by(f.a)]
+    assert R1.names == R2.names and R1.stypes == R2.stypes
+    for c1, c2 in zip(R1.to_numpy_columns(), R2.to_numpy_columns()):
+        assert np.allclose(c1, c2, rtol=1e-9, atol=1e-9) if c1.dtype.kind == "f" else np.array_equal(c1, c2)

@@ -626,3 +626,28 @@ def test_filter_take_matches_filter_then_gather(ctx, dtype, cmp, scalar):
     assert ri2 is None
     assert_same(out2[0], cols[0][want_ri], "column without rowindex")
     assert_same(want_ri, o.filter_cmp(x, cmp, scalar) if float(scalar) == int(scalar) else want_ri, "oracle rowindex")
+
+
+def test_partial_sums_that_look_like_na_on_the_hash_path(ctx):
+    """the hash combiner merges partial sums; a partial that is NaN (+inf and -inf in one group) or an
+    int64 partial that wrapped to INT64_MIN is a VALUE there (DTHIP_FLAG_NONA), not an NA to skip -- the group's
+    sum / mean must come out as on the sort and bucket paths (and as in the reference: NaN / INT64_MIN)."""
+    k = np.array([2**40, 2**40, 5, 5, 2**50, 2**50, 2**50, 2**40], np.int64)
+    v = np.array([np.inf, -np.inf, 1.0, 2.0, 1.0, 2.0, 3.0, 7.0])
+    w = np.array([-2**62, -2**62, 1, 2, 3, 4, 5, 0], np.int64)
+    ri, off = o.group([k])
+    for col, vals in ((0, v), (1, w)):
+        for opn in ("sum", "mean", "count"):
+            exp = o.reduce(opn, vals, ri, off)
+            for hm in (0, 2):
+                ctx.set_option("hash_mode", hm)
+                try:
+                    r = ctx.groupby_agg([k], [v, w], [(opn, col)])
+                finally:
+                    ctx.set_option("hash_mode", 0)
+                got = r.agg(0)
+                r.free()
+                if exp.dtype.kind == "f":
+                    assert got.dtype == exp.dtype and np.array_equal(got, exp, equal_nan=True), (opn, col, hm, got, exp)
+                else:
+                    assert_same(got, exp, "%s(v%d) hash_mode=%d" % (opn, col, hm))

@@ -46,3 +46,19 @@ def test_cmp_args():
     assert _cmp_args("==", 1.5, i32) == (CMP["=="], 1.5, -2**63)        # no valid element equals the NA sentinel
     assert _cmp_args("!=", 1.5, i32) == (CMP["!="], 1.5, -2**63)
     assert _cmp_args("==", True, L.BOOL) == (CMP["=="], 1.0, 1)
+
+
+def test_filter_scalars_outside_int64_do_not_wrap():
+    """`DT[f.x < 1e19, :]` on an integer column: a scalar beyond int64 decides the comparison by its sign
+    (ctypes would wrap it silently): every valid row / no row; != keeps every row, == none"""
+    from datatable_amd.engine import _cmp_args, CMP
+    from datatable_amd import _lib as L
+    big, small = 10**19, -10**19
+    assert _cmp_args("<", big, L.INT64)[0] == L.NOTNA and _cmp_args("<=", big, L.INT32)[0] == L.NOTNA
+    assert _cmp_args(">", small, L.INT64)[0] == L.NOTNA and _cmp_args(">=", small, L.INT64)[0] == L.NOTNA
+    for cmp, s in ((">", big), (">=", big), ("<", small), ("<=", small)):
+        code, _, ci = _cmp_args(cmp, s, L.INT64)
+        assert (code, ci) == (CMP[">"], 2**63 - 1)          # x > INT64_MAX: never
+    assert _cmp_args("==", big, L.INT64)[::2] == (CMP["=="], -2**63)
+    assert _cmp_args("!=", small, L.INT64)[::2] == (CMP["!="], -2**63)
+    assert _cmp_args("<", 2**63 - 1, L.INT64) == (CMP["<"], float(2**63 - 1), 2**63 - 1)     # in range: unchanged
