@@ -1326,10 +1326,30 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
       // first attempt: key ranges guessed from a sample (verified by the bucketed path); if that
       // path does not apply, or the guess was wrong, plan again with the exact ranges
       int slot_bits = 0;
-      bool done = false;
+      bool done = false, hash_tried = false;
       for (int attempt = (ctx->agg_path == 1 ? 1 : 0); attempt < 2 && !done; attempt++) {
         if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan, attempt == 0)) != DTHIP_OK) break;
         if (attempt == 0 && !plan.speculative) attempt = 1;      // nothing was guessed: this IS the exact plan
+        if (attempt == 0 && nkeys == 1 && kd[0].stype == DTHIP_INT64 && !(kd[0].flags & DTHIP_FLAG_DESCENDING) &&
+            na_pos == DTHIP_NA_FIRST && plan.stage_bits[0] >= 36 && !hash_tried) {
+          // one wide int64 key: the guessed range already rules the bucketed path out (the exact range is at most a
+          // bit narrower), and the hash combiner needs no range at all -- x = key - (INT64_MIN + 1) + 1 covers every
+          // valid key in 64 bits -- so the exact min/max scan of the whole column (1.6 ms per 1e9 rows) is skipped
+          // unless the hash path turns the query down
+          KeyPlan full = plan;
+          full.speculative = false;
+          full.col[0].edge = (unsigned long long)(INT64_MIN + 1); full.col[0].inc = 1; full.col[0].na_repl = 0;
+          full.col[0].xmax = ~0ULL; full.col[0].shift = 0;
+          full.nsig[0] = 64; full.nstages = 1; full.stage_first[0] = 0; full.stage_last[0] = 0; full.stage_bits[0] = 64;
+          hash_tried = true;
+          rc = hash_groupby_agg(ctx, sc, res, full, kd, vd, used, aggs, naggs, nrows, na_pos);
+          if (rc == DTHIP_OK) { done = true; break; }
+          if (rc != DTHIP_NOT_APPLICABLE) break;
+          rc = DTHIP_OK;
+          for (void* p : res->owned) dev_release(ctx, p);
+          res->owned.clear();
+          continue;
+        }
         if (bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &slot_bits)) {
           rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits);
           if (rc == DTHIP_RETRY_EXACT && attempt == 0) { rc = DTHIP_OK; continue; }
@@ -1339,7 +1359,8 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
       }
       if (rc != DTHIP_OK || done) break;
       // sparse keys (exact plan at this point): hash combiner + merge, when its tables are large enough
-      rc = hash_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, na_pos);
+      if (!hash_tried) rc = hash_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, na_pos);
+      else rc = DTHIP_NOT_APPLICABLE;
       if (rc == DTHIP_OK) break;
       if (rc != DTHIP_NOT_APPLICABLE) break;
       rc = DTHIP_OK;
