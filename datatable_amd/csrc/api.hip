@@ -617,7 +617,34 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   bool clustered = ctx->cluster_mode == 2;
   if (ctx->cluster_mode == 0 && n >= (1 << 20)) DTHIP_TRY(launch_bucket_cluster_sample(ctx, kx, n, g.r, d_clustered, &clustered));
   int src = 1;
-  if (g.d > 0) {
+  // TILE-LOCAL layout: no histogram pass.  Every partition tile writes its rows, ordered by bucket, into its own row
+  // range plus a 2-byte directory entry per bucket; the aggregation walks one short segment per tile.  Keys are read
+  // once (16 B/row less HBM traffic for C3).  Random row order only: for sorted / clustered keys a bucket's rows sit in
+  // few tiles and the exact-position layout (with its clustered kernel variants and row-range work items) is better.
+  const uint16_t* dirT = nullptr; uint32_t dstride = 0;
+  const bool tile_local = g.d > 0 && !clustered && ctx->bucket_variant != 2 && g.block == 1024 &&
+                          (n >= (1 << 22) || ctx->bucket_variant == 3);     // variant 3: also for small inputs (tests)
+  if (tile_local) {
+    uint16_t* dir = nullptr; uint16_t* dT = nullptr; uint32_t* tot = nullptr;
+    dstride = (g.ntiles + 63u) & ~63u;
+    DTHIP_TRY(sc.get<uint16_t>((size_t)g.ntiles * (g.F + 1) + 8, &dir));
+    DTHIP_TRY(sc.get<uint16_t>((size_t)dstride * (g.F + 2) + 8, &dT));
+    DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 1, &tot));
+    PayCols pc;
+    memset(&pc, 0, sizeof(pc));
+    DTHIP_TRY(sc.get<uint16_t>((size_t)g.ntiles * g.tile + 8, &kpart));
+    for (int c : used) {
+      unsigned char* vb = nullptr;
+      const int w = stype_size(vd[c].stype);
+      DTHIP_TRY(sc.get<unsigned char>((size_t)g.ntiles * g.tile * w + 64, &vb));
+      pc.in[pc.n] = vd[c].data; pc.out[pc.n] = vb; pc.width[pc.n] = w; pc.n++;
+      vsrc[c] = vb;
+    }
+    src = 2;
+    DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, nullptr, nullptr, kpart, pc, false, dir, d_bad));
+    DTHIP_TRY(launch_dir_prepare(ctx, dir, g.ntiles, g.F, dT, dstride, tot, M, items, nitems));
+    dirT = dT;
+  } else if (g.d > 0) {
     uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.ntiles * g.F, &P));
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.G * g.F, &gtot));
@@ -660,6 +687,15 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     if (f & ACC_MAX) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.mx)); DTHIP_CHECK_HIP(hipMemsetAsync(t.mx, 0, nslots * 8, ctx->stream)); }
     if (f & ACC_FSUM) { DTHIP_TRY(sc.get<double>(nslots, &t.fsum)); DTHIP_CHECK_HIP(hipMemsetAsync(t.fsum, 0, nslots * 8, ctx->stream)); }
     if (f & ACC_VCNT) { DTHIP_TRY(sc.get<uint32_t>(nslots, &t.vcnt)); DTHIP_CHECK_HIP(hipMemsetAsync(t.vcnt, 0, nslots * 4, ctx->stream)); }
+    if (src == 2) {
+      TableAggSegArgs sa;
+      memset(&sa, 0, sizeof(sa));
+      sa.items = items; sa.nitems = nitems; sa.max_items = max_items; sa.kpart = kpart; sa.val = vsrc[c]; sa.vstype = vd[c].stype;
+      sa.dirT = dirT; sa.dstride = dstride; sa.tile_rows = g.tile; sa.S = g.S; sa.flags = f; sa.tab = t;
+      DTHIP_TRY(launch_table_agg_seg(ctx, sa));
+      first = false;
+      continue;
+    }
     TableAggArgs ta;
     memset(&ta, 0, sizeof(ta));
     ta.items = items; ta.nitems = nitems; ta.max_items = max_items; ta.src = src;
@@ -667,7 +703,14 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     DTHIP_TRY(launch_table_agg(ctx, ta));
     first = false;
   }
-  if (first) {   // no value column at all: row counts (or key presence) alone
+  if (first && src == 2) {
+    TableAggSegArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.items = items; sa.nitems = nitems; sa.max_items = max_items; sa.kpart = kpart; sa.val = nullptr; sa.vstype = DTHIP_INT32;
+    sa.dirT = dirT; sa.dstride = dstride; sa.tile_rows = g.tile; sa.S = g.S; sa.flags = first_flag;
+    if (need_cnt) sa.tab.cnt = d_cnt; else sa.tab.pres = d_cnt;
+    DTHIP_TRY(launch_table_agg_seg(ctx, sa));
+  } else if (first) {   // no value column at all: row counts (or key presence) alone
     TableAggArgs ta;
     memset(&ta, 0, sizeof(ta));
     ta.items = items; ta.nitems = nitems; ta.max_items = max_items; ta.src = src;

@@ -354,6 +354,10 @@ struct PartArgs {
   const uint32_t* P; const uint32_t* gpre;      // gpre[g][b]: global position of group g's first row of bucket b
   uint16_t* kout;
   PayCols pay;
+  // TILE-LOCAL layout (no histogram pass): the tile's rows, ordered by bucket, are written to the tile's OWN row
+  // range of the outputs; dir[tile][b] (b <= F) = first position of bucket b inside the tile.  With no histogram pass
+  // before it, this kernel also reports keys outside a guessed key range (*bad).
+  uint16_t* dir; uint32_t* bad;
 };
 
 template <int BLOCK, int ITEMS, int KM, typename PT>
@@ -417,7 +421,8 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
   // global start of this tile's run of every bucket this thread scans below: issued first, needed after the ranking
   const uint32_t K = (F + BLOCK - 1) / BLOCK;            // consecutive bins per thread
   uint32_t gstart[2048 / BLOCK];
-  {
+  const bool tl = a.dir != nullptr;
+  if (!tl) {
     const uint32_t g = tile / a.tpg;
 #pragma unroll
     for (int k = 0; k < 2048 / BLOCK; k++) {
@@ -428,6 +433,7 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
   uint32_t x[ITEMS];
   bool bad = false;     // out-of-range keys were reported by the histogram pass; here they are just key 0 again
   load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x, bad);
+  if (tl && __ballot(bad) && (tid & 63) == 0) atomicOr(a.bad, 1u);
   u64 pv[PF ? ITEMS : 1];
   if (PF) load_tile_vals<BLOCK, ITEMS, KM, u64>(static_cast<const u64*>(a.pay.in[0]) + tile_base, nvalid, full, tid,
                                                  reinterpret_cast<u64(&)[ITEMS]>(pv));
@@ -458,10 +464,12 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
       const uint32_t b = (uint32_t)tid * K + k;
       if ((uint32_t)k < K && b < F) {
         cnt[b] = e;
-        delta[b] = gstart[k] - e;
+        if (tl) { delta[b] = tile_base; a.dir[(size_t)tile * (F + 1) + b] = (uint16_t)e; }
+        else delta[b] = gstart[k] - e;
         e += c[k];
       }
     }
+    if (tl && tid == 0) a.dir[(size_t)tile * (F + 1) + F] = (uint16_t)nvalid;
   }
   __syncthreads();
 
@@ -591,10 +599,10 @@ static int part_t(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds
 }
 
 int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
-                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay, bool clustered) {
+                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay, bool clustered, uint16_t* dir, uint32_t* bad) {
   PartArgs a;
   a.kx = kx; a.n = (uint32_t)n; a.r = g.r; a.F = g.F; a.tpg = g.tpg; a.P = P; a.gpre = gpre;
-  a.kout = kout; a.pay = pay;
+  a.kout = kout; a.pay = pay; a.dir = dir; a.bad = bad;
   int maxw = 4;
   for (int c = 0; c < pay.n; c++) maxw = pay.width[c] > maxw ? pay.width[c] : maxw;
   const uint32_t Fp = (g.F + 3u) & ~3u;
@@ -750,6 +758,52 @@ __device__ __forceinline__ void acc_row(const LdsTab& t, int flags, uint32_t slo
   }
 }
 
+// LDS table -> dense accumulator arrays: plain stores when the bucket has a single part, global atomics otherwise
+__device__ __forceinline__ void flush_table(const LdsTab& t, const AggTable& tab, uint32_t bucket, uint32_t S, int flags,
+                                            bool single, int isfloat, int tid) {
+  const size_t base = (size_t)bucket * S;
+  if (single) {
+    for (uint32_t s = tid; s < S; s += TA_BLOCK) {
+      if (flags & ACC_CNT) tab.cnt[base + s] = t.cnt[s];
+      if (flags & ACC_VCNT) tab.vcnt[base + s] = t.vcnt[s];
+      if (flags & ACC_SUM) tab.sum[base + s] = t.sum[s];
+      if (flags & ACC_MIN) tab.mn[base + s] = t.mn[s];
+      if (flags & ACC_MAX) tab.mx[base + s] = t.mx[s];
+      if (flags & ACC_FSUM) tab.fsum[base + s] = t.fsum[s];
+    }
+    if (flags & ACC_PRES) for (uint32_t s = tid; s < (S + 31) / 32; s += TA_BLOCK) tab.pres[base / 32 + s] = t.pres[s];
+  } else {
+    if (flags & ACC_PRES)
+      for (uint32_t s = tid; s < (S + 31) / 32; s += TA_BLOCK) { const uint32_t w = t.pres[s]; if (w) atomicOr(&tab.pres[base / 32 + s], w); }
+    for (uint32_t s = tid; s < S; s += TA_BLOCK) {
+      if (flags & ACC_CNT) { const uint32_t c = t.cnt[s]; if (c) atomicAdd(&tab.cnt[base + s], c); }
+      if (flags & ACC_VCNT) { const uint32_t c = t.vcnt[s]; if (c) atomicAdd(&tab.vcnt[base + s], c); }
+      if (flags & ACC_SUM) {
+        const u64 w = t.sum[s];
+        if (w) {
+          if (isfloat) atomicAdd(reinterpret_cast<double*>(&tab.sum[base + s]), __longlong_as_double((long long)w));
+          else atomicAdd(&tab.sum[base + s], w);
+        }
+      }
+      if (flags & ACC_MIN) { const u64 w = t.mn[s]; if (w != ~0ULL) atomicMin(&tab.mn[base + s], w); }
+      if (flags & ACC_MAX) { const u64 w = t.mx[s]; if (w) atomicMax(&tab.mx[base + s], w); }
+      if (flags & ACC_FSUM) { const double w = t.fsum[s]; if (w != 0.0) atomicAdd(&tab.fsum[base + s], w); }
+    }
+  }
+}
+
+__device__ __forceinline__ void init_table(const LdsTab& t, uint32_t S, int flags, int tid) {
+  for (uint32_t s = tid; s < S; s += TA_BLOCK) {
+    if (flags & ACC_SUM) t.sum[s] = 0;
+    if (flags & ACC_MIN) t.mn[s] = ~0ULL;
+    if (flags & ACC_MAX) t.mx[s] = 0;
+    if (flags & ACC_FSUM) t.fsum[s] = 0.0;
+    if (flags & ACC_CNT) t.cnt[s] = 0;
+    if (flags & ACC_VCNT) t.vcnt[s] = 0;
+  }
+  if (flags & ACC_PRES) for (uint32_t s = tid; s < (S + 31) / 32; s += TA_BLOCK) t.pres[s] = 0;
+}
+
 struct TableAggDev {
   const WorkItem* items; const uint32_t* nitems;
   const uint16_t* kpart; KeyXform kx;
@@ -771,15 +825,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
   const int flags = a.flags;
   const uint32_t S = a.S;
   const LdsTab t = carve_tab(smem, S, flags);
-  for (uint32_t s = tid; s < S; s += TA_BLOCK) {
-    if (flags & ACC_SUM) t.sum[s] = 0;
-    if (flags & ACC_MIN) t.mn[s] = ~0ULL;
-    if (flags & ACC_MAX) t.mx[s] = 0;
-    if (flags & ACC_FSUM) t.fsum[s] = 0.0;
-    if (flags & ACC_CNT) t.cnt[s] = 0;
-    if (flags & ACC_VCNT) t.vcnt[s] = 0;
-  }
-  if (flags & ACC_PRES) for (uint32_t s = tid; s < (S + 31) / 32; s += TA_BLOCK) t.pres[s] = 0;
+  init_table(t, S, flags, tid);
   __syncthreads();
   const VT* __restrict__ val = static_cast<const VT*>(a.val);
   const bool hasval = (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) != 0;
@@ -832,36 +878,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
     }
   }
   __syncthreads();
-  // table -> dense accumulators
-  const size_t base = (size_t)it.bucket * S;
-  if (it.single) {
-    for (uint32_t s = tid; s < S; s += TA_BLOCK) {
-      if (flags & ACC_CNT) a.tab.cnt[base + s] = t.cnt[s];
-      if (flags & ACC_VCNT) a.tab.vcnt[base + s] = t.vcnt[s];
-      if (flags & ACC_SUM) a.tab.sum[base + s] = t.sum[s];
-      if (flags & ACC_MIN) a.tab.mn[base + s] = t.mn[s];
-      if (flags & ACC_MAX) a.tab.mx[base + s] = t.mx[s];
-      if (flags & ACC_FSUM) a.tab.fsum[base + s] = t.fsum[s];
-    }
-    if (flags & ACC_PRES) for (uint32_t s = tid; s < (S + 31) / 32; s += TA_BLOCK) a.tab.pres[base / 32 + s] = t.pres[s];
-  } else {
-    if (flags & ACC_PRES)
-      for (uint32_t s = tid; s < (S + 31) / 32; s += TA_BLOCK) { const uint32_t w = t.pres[s]; if (w) atomicOr(&a.tab.pres[base / 32 + s], w); }
-    for (uint32_t s = tid; s < S; s += TA_BLOCK) {
-      if (flags & ACC_CNT) { const uint32_t c = t.cnt[s]; if (c) atomicAdd(&a.tab.cnt[base + s], c); }
-      if (flags & ACC_VCNT) { const uint32_t c = t.vcnt[s]; if (c) atomicAdd(&a.tab.vcnt[base + s], c); }
-      if (flags & ACC_SUM) {
-        const u64 w = t.sum[s];
-        if (w) {
-          if (a.isfloat) atomicAdd(reinterpret_cast<double*>(&a.tab.sum[base + s]), __longlong_as_double((long long)w));
-          else atomicAdd(&a.tab.sum[base + s], w);
-        }
-      }
-      if (flags & ACC_MIN) { const u64 w = t.mn[s]; if (w != ~0ULL) atomicMin(&a.tab.mn[base + s], w); }
-      if (flags & ACC_MAX) { const u64 w = t.mx[s]; if (w) atomicMax(&a.tab.mx[base + s], w); }
-      if (flags & ACC_FSUM) { const double w = t.fsum[s]; if (w != 0.0) atomicAdd(&a.tab.fsum[base + s], w); }
-    }
-  }
+  flush_table(t, a.tab, it.bucket, S, flags, it.single != 0, a.isfloat, tid);
 }
 
 template <typename VT, int SRC, bool UNI>
@@ -901,6 +918,187 @@ int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a) {
     default: set_error("table_agg: unsupported value stype %d", a.vstype); return DTHIP_ENOTIMPL;
   }
 #undef TA_GO
+}
+
+
+// ---------------------------------------------------------------------------------------
+// The same aggregation over the TILE-LOCAL layout: bucket b's rows are one short segment per partition tile
+// (12 rows on average for C3), located by the transposed directory dirT[b][tile].  An item = (bucket, tile
+// range).  A wave takes 64 tiles at a time (lane = tile: coalesced directory reads), then walks their segments four
+// at a time, 16 lanes per segment.  Items are dealt to XCDs in contiguous bucket ranges: the 64-byte sectors that
+// straddle two neighbouring buckets' segments are then fetched from HBM once and hit in that XCD's L2 the second time.
+// ---------------------------------------------------------------------------------------
+struct TableAggSegDev {
+  const WorkItem* items; const uint32_t* nitems;
+  const uint16_t* kpart; const void* val;
+  const uint16_t* dirT; uint32_t dstride; uint32_t tile_rows;
+  uint32_t S; int flags; int isfloat;
+  AggTable tab;
+};
+
+template <typename VT>
+__global__ void __launch_bounds__(TA_BLOCK) table_agg_seg_kernel(TableAggSegDev a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t nit = *a.nitems;
+  const uint32_t bi = blockIdx.x, xq = nit / 8, xr = nit % 8, xc = bi % 8, q0 = bi / 8;
+  if (q0 >= xq + (xc < xr ? 1u : 0u)) return;
+  const WorkItem it = a.items[xc * xq + (xc < xr ? xc : xr) + q0];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, sub = lane & 15;
+  const int flags = a.flags;
+  const uint32_t S = a.S;
+  const LdsTab t = carve_tab(smem, S, flags);
+  init_table(t, S, flags, tid);
+  __syncthreads();
+  const VT* __restrict__ val = static_cast<const VT*>(a.val);
+  const uint16_t* __restrict__ kp = a.kpart;
+  const bool hasval = (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) != 0;
+  const uint16_t* __restrict__ ds = a.dirT + (size_t)it.bucket * a.dstride;
+  const uint16_t* __restrict__ de = ds + a.dstride;
+  const uint32_t t0 = it.begin, t1 = it.end;
+  const uint32_t tr = a.tile_rows;
+  // directory entries of the wave's first 64 tiles; the next chunk's are loaded while the current one is processed
+  uint32_t c = t0 + (uint32_t)wave * 64u;
+  uint32_t st_n = 0, ln_n = 0;
+  if (c + (uint32_t)lane < t1) { st_n = ds[c + lane]; ln_n = (uint32_t)de[c + lane] - st_n; }
+  for (; c < t1; c += (TA_BLOCK / 64) * 64u) {
+    const uint32_t st = st_n, ln = ln_n;
+    {
+      const uint32_t tn = c + (TA_BLOCK / 64) * 64u + (uint32_t)lane;
+      st_n = 0; ln_n = 0;
+      if (tn < t1) { st_n = ds[tn]; ln_n = (uint32_t)de[tn] - st_n; }
+    }
+    // all 64 segments' first chunks (16 rows each, 16 lanes per segment) in flight, then the DS atomics
+    uint32_t slot[16];
+    VT v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int seg = q * 4 + grp;
+      const uint32_t sst = (uint32_t)__shfl((int)st, seg, 64), sln = (uint32_t)__shfl((int)ln, seg, 64);
+      const uint32_t row = (c + (uint32_t)seg) * tr + sst + (uint32_t)sub;
+      slot[q] = 0; v[q] = VT(0);
+      if ((uint32_t)sub < sln) {
+        slot[q] = kp[row];
+        if (hasval) v[q] = val[row];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int seg = q * 4 + grp;
+      const uint32_t sln = (uint32_t)__shfl((int)ln, seg, 64);
+      if ((uint32_t)sub < sln) acc_row<VT, false>(t, flags, slot[q], v[q]);
+      if (__ballot(sln > 16u)) {                                          // segments longer than 16 rows
+        const uint32_t sst = (uint32_t)__shfl((int)st, seg, 64);
+        const uint32_t base = (c + (uint32_t)seg) * tr + sst;
+        for (uint32_t j = (uint32_t)sub + 16u; j < sln; j += 16u)
+          acc_row<VT, false>(t, flags, kp[base + j], hasval ? val[base + j] : VT(0));
+      }
+    }
+  }
+  __syncthreads();
+  flush_table(t, a.tab, it.bucket, S, flags, it.single != 0, a.isfloat, tid);
+}
+
+template <typename VT>
+static int table_agg_seg_t(dthip_ctx* ctx, const TableAggSegDev& d, uint32_t grid, size_t lds) {
+  auto kfn = table_agg_seg_kernel<VT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+    attr_set = true;
+  }
+  DTHIP_LAUNCH(ctx, "table_agg_seg_kernel", kfn, grid, TA_BLOCK, lds, d);
+  return DTHIP_OK;
+}
+
+int launch_table_agg_seg(dthip_ctx* ctx, const TableAggSegArgs& a) {
+  if (a.max_items == 0) return DTHIP_OK;
+  TableAggSegDev d;
+  d.items = a.items; d.nitems = a.nitems; d.kpart = a.kpart; d.val = a.val; d.dirT = a.dirT; d.dstride = a.dstride;
+  d.tile_rows = a.tile_rows; d.S = a.S; d.flags = a.flags; d.isfloat = stype_is_float(a.vstype) ? 1 : 0; d.tab = a.tab;
+  const size_t lds = table_agg_lds_bytes(a.flags, a.S);
+  if (lds > 160 * 1024 - 256) { set_error("table_agg_seg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
+  const uint32_t grid = (a.max_items + 7u) & ~7u;
+  switch (a.val ? a.vstype : DTHIP_INT32) {
+    case DTHIP_INT32: return table_agg_seg_t<int32_t>(ctx, d, grid, lds);
+    case DTHIP_INT64: return table_agg_seg_t<long long>(ctx, d, grid, lds);
+    case DTHIP_FLOAT32: return table_agg_seg_t<float>(ctx, d, grid, lds);
+    case DTHIP_FLOAT64: return table_agg_seg_t<double>(ctx, d, grid, lds);
+    default: set_error("table_agg_seg: unsupported value stype %d", a.vstype); return DTHIP_ENOTIMPL;
+  }
+}
+
+// dir[tile][F+1] -> dirT[F+1][dstride] (64 x 64 blocks through LDS)
+__global__ void __launch_bounds__(256) dir_transpose_kernel(const uint16_t* __restrict__ dir, uint32_t ntiles, uint32_t F1,
+                                                            uint16_t* __restrict__ dirT, uint32_t dstride) {
+  __shared__ uint16_t blk[64][66];
+  const uint32_t tb = blockIdx.x * 64u, bb = blockIdx.y * 64u;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const uint32_t t = tb + (uint32_t)r, b = bb + (uint32_t)tx;
+    blk[r][tx] = (t < ntiles && b < F1) ? dir[(size_t)t * F1 + b] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const uint32_t b = bb + (uint32_t)r, t = tb + (uint32_t)tx;
+    if (b < F1 && t < dstride) dirT[(size_t)b * dstride + t] = blk[tx][r];
+  }
+}
+
+// rows of every bucket: tot[b] = sum over tiles of dirT[b+1][t] - dirT[b][t]
+__global__ void __launch_bounds__(256) dir_totals_kernel(const uint16_t* __restrict__ dirT, uint32_t ntiles, uint32_t dstride, uint32_t* tot) {
+  __shared__ uint32_t part[4];
+  const uint32_t b = blockIdx.x;
+  const uint16_t* r0 = dirT + (size_t)b * dstride; const uint16_t* r1 = r0 + dstride;
+  uint32_t s = 0;
+  for (uint32_t t = threadIdx.x; t < ntiles; t += 256) s += (uint32_t)r1[t] - (uint32_t)r0[t];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) tot[b] = part[0] + part[1] + part[2] + part[3];
+}
+
+// work list over the tile-local layout: bucket b in ceil(tot[b] / M) parts of equal TILE ranges
+__global__ void __launch_bounds__(1024) seg_plan_kernel(const uint32_t* tot, uint32_t F, uint32_t ntiles, uint32_t M,
+                                                        WorkItem* items, uint32_t* nitems) {
+  __shared__ uint32_t scratch[16];
+  const int tid = threadIdx.x;
+  uint32_t np[2], ps = 0;
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint32_t b = (uint32_t)tid * 2 + k;
+    np[k] = b < F ? (tot[b] + M - 1) / M : 0u;
+    if (np[k] > ntiles) np[k] = ntiles;
+    ps += np[k];
+  }
+  uint32_t ptot;
+  uint32_t pe = block_excl_scan_u32<1024>(ps, scratch, &ptot);
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint32_t b = (uint32_t)tid * 2 + k;
+    for (uint32_t i = 0; i < np[k]; i++) {
+      WorkItem it;
+      it.bucket = b;
+      it.begin = (uint32_t)(((unsigned long long)i * ntiles) / np[k]);
+      it.end = (uint32_t)(((unsigned long long)(i + 1) * ntiles) / np[k]);
+      it.single = np[k] == 1 ? 1u : 0u;
+      items[pe + i] = it;
+    }
+    pe += np[k];
+  }
+  if (tid == 0) *nitems = ptot;
+}
+
+int launch_dir_prepare(dthip_ctx* ctx, const uint16_t* dir, uint32_t ntiles, uint32_t F, uint16_t* dirT, uint32_t dstride,
+                       uint32_t* tot, uint32_t M, WorkItem* items, uint32_t* nitems) {
+  if (F > 2048) { set_error("seg plan: F=%u > 2048", F); return DTHIP_EINVAL; }
+  dim3 grid((dstride + 63) / 64, (F + 1 + 63) / 64);
+  DTHIP_LAUNCH(ctx, "dir_transpose_kernel", dir_transpose_kernel, grid, 256, 0, dir, ntiles, F + 1, dirT, dstride);
+  DTHIP_LAUNCH(ctx, "dir_totals_kernel", dir_totals_kernel, F, 256, 0, dirT, ntiles, dstride, tot);
+  DTHIP_LAUNCH(ctx, "seg_plan_kernel", seg_plan_kernel, 1, 1024, 0, tot, F, ntiles, M, items, nitems);
+  return DTHIP_OK;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -268,7 +268,18 @@ int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uin
 int launch_bucket_plan(dthip_ctx* ctx, const uint32_t* tot, uint32_t F, uint32_t n_raw, uint32_t M,
                        uint32_t* bbase, WorkItem* items, uint32_t* nitems);
 int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
-                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay, bool clustered);
+                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay, bool clustered, uint16_t* dir = nullptr,
+                            uint32_t* bad = nullptr);
+// tile-local layout (no histogram pass): directory transpose + bucket totals + work list, and the aggregation over it
+int launch_dir_prepare(dthip_ctx* ctx, const uint16_t* dir, uint32_t ntiles, uint32_t F, uint16_t* dirT, uint32_t dstride,
+                       uint32_t* tot, uint32_t M, WorkItem* items, uint32_t* nitems);
+struct TableAggSegArgs {
+  const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
+  const uint16_t* kpart; const void* val; int vstype;
+  const uint16_t* dirT; uint32_t dstride; uint32_t tile_rows;
+  uint32_t S; int flags; AggTable tab;
+};
+int launch_table_agg_seg(dthip_ctx* ctx, const TableAggSegArgs& a);
 struct TableAggArgs {
   const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
   int src;                    // 0: kpart + val of the partitioned rows, 1: raw rows (kx + val)

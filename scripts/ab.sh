@@ -7,6 +7,6 @@ for v in $1; do
 import json,sys
 d=json.loads(sys.stdin.readline())
 k=d['kernels']
-print('variant $v: %.3f ms/step  ' % d['ms_per_step'] + ' '.join('%s=%.3f' % (n.replace('_kernel','').replace('bucket_',''), k[n]['avg_ms']) for n in ('bucket_hist_kernel','bucket_partition_kernel','table_agg_kernel') if n in k))
+print('variant $v: %.3f ms/step  ' % d['ms_per_step'] + ' '.join('%s=%.3f' % (n.replace('_kernel','').replace('bucket_',''), k[n]['avg_ms']) for n in sorted(k, key=lambda n:-k[n]['total_ms']) if k[n]['total_ms']/d['steps'] > 0.03))
 "
 done; done
