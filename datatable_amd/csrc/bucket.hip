@@ -178,25 +178,50 @@ __device__ __forceinline__ void load_tile_vals(const PT* __restrict__ src, uint3
 // 65536 evenly spaced row pairs decide; the histogram and partition kernels then count a
 // wave-uniform bucket with one DS atomic per wave instead of 64 serialised ones.  For random keys
 // the per-row uniformity test would cost ~8 % of those kernels, hence the switch.
-__global__ void __launch_bounds__(256) bucket_cluster_sample_kernel(KeyXform kx, uint32_t n, int r, uint32_t nsamp, uint32_t* acc) {
+__global__ void __launch_bounds__(256) bucket_cluster_sample_kernel(KeyXform kx, uint32_t n, int r, uint32_t nsamp, uint32_t* acc,
+                                                                    uint32_t* bcnt, uint32_t F) {
   const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
   bool same = false;
   if (gid < nsamp && n > 1) {
     const uint32_t p = (uint32_t)(((unsigned long long)gid * (n - 1)) / nsamp);
     const unsigned long long x0 = packed_key(kx.cols, kx.ncols, p), x1 = packed_key(kx.cols, kx.ncols, p + 1);
     same = (x0 >> r) == (x1 >> r);
+    // how evenly do the rows spread over the buckets?  (keys outside a guessed range land in bucket 0 like everywhere)
+    if (bcnt) { const unsigned long long b = x0 >> r; atomicAdd(&bcnt[b < F ? (uint32_t)b : 0u], 1u); }
   }
   const unsigned long long b = __ballot(same);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(&acc[1], (uint32_t)__popcll(b));
 }
 
-int launch_bucket_cluster_sample(dthip_ctx* ctx, const KeyXform& kx, int64_t n, int r, uint32_t* flag2, bool* clustered) {
+// *clustered: neighbouring rows mostly share a bucket.  *even (nullable): no bucket holds more than ~2.5x its fair share
+// of the sampled rows (the tile-local layout is only worth it then: its segments are short and all alike).
+int launch_bucket_cluster_sample(dthip_ctx* ctx, const KeyXform& kx, int64_t n, int r, uint32_t* flag2, bool* clustered,
+                                 uint32_t F, bool* even) {
   const uint32_t nsamp = 65536;
-  DTHIP_CHECK_HIP(hipMemsetAsync(flag2, 0, 2 * sizeof(uint32_t), ctx->stream));
-  DTHIP_LAUNCH(ctx, "bucket_cluster_sample_kernel", bucket_cluster_sample_kernel, nsamp / 256, 256, 0, kx, (uint32_t)n, r, nsamp, flag2);
-  uint32_t same = 0;
-  DTHIP_TRY(read_back(ctx, &same, flag2 + 1, sizeof(same)));
-  *clustered = same * 4u > nsamp;
+  Scratch sc(ctx);
+  uint32_t* bcnt = nullptr;
+  if (even) {
+    DTHIP_TRY(sc.get<uint32_t>((size_t)F + 2, &bcnt));
+    DTHIP_CHECK_HIP(hipMemsetAsync(bcnt, 0, sizeof(uint32_t) * ((size_t)F + 2), ctx->stream));
+    flag2 = bcnt + F;
+  } else {
+    DTHIP_CHECK_HIP(hipMemsetAsync(flag2, 0, 2 * sizeof(uint32_t), ctx->stream));
+  }
+  DTHIP_LAUNCH(ctx, "bucket_cluster_sample_kernel", bucket_cluster_sample_kernel, nsamp / 256, 256, 0, kx, (uint32_t)n, r, nsamp, flag2,
+               bcnt, F);
+  if (!even) {
+    uint32_t same = 0;
+    DTHIP_TRY(read_back(ctx, &same, flag2 + 1, sizeof(same)));
+    *clustered = same * 4u > nsamp;
+    return DTHIP_OK;
+  }
+  std::vector<uint32_t> h((size_t)F + 2);
+  DTHIP_TRY(read_back(ctx, h.data(), bcnt, sizeof(uint32_t) * h.size()));
+  *clustered = h[F + 1] * 4u > nsamp;
+  // fair share = sampled rows / buckets that got any (a key range that is not a power of two leaves the top buckets empty)
+  uint32_t mx = 0, used = 0;
+  for (uint32_t b = 0; b < F; b++) { mx = h[b] > mx ? h[b] : mx; used += h[b] ? 1u : 0u; }
+  *even = (unsigned long long)mx * used * 2ull <= 5ull * nsamp + 64ull * used;
   return DTHIP_OK;
 }
 
@@ -961,6 +986,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_seg_kernel(TableAggSegDev 
   uint32_t c = t0 + (uint32_t)wave * 64u;
   uint32_t st_n = 0, ln_n = 0;
   if (c + (uint32_t)lane < t1) { st_n = ds[c + lane]; ln_n = (uint32_t)de[c + lane] - st_n; }
+  const bool long_mode = (it.single & 2u) != 0;      // this bucket's segments are long (few buckets, or a hot bucket)
   for (; c < t1; c += (TA_BLOCK / 64) * 64u) {
     const uint32_t st = st_n, ln = ln_n;
     {
@@ -968,35 +994,67 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_seg_kernel(TableAggSegDev 
       st_n = 0; ln_n = 0;
       if (tn < t1) { st_n = ds[tn]; ln_n = (uint32_t)de[tn] - st_n; }
     }
-    // all 64 segments' first chunks (16 rows each, 16 lanes per segment) in flight, then the DS atomics
-    uint32_t slot[16];
-    VT v[16];
+    if (long_mode) {
+      // one segment at a time with the whole wave: coalesced 512-byte loads, four of them in flight per lane
+      const uint32_t nseg = (t1 - c < 64u) ? (t1 - c) : 64u;
+      for (uint32_t sg = 0; sg < nseg; sg++) {
+        const uint32_t sst = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)sg), sln = (uint32_t)__builtin_amdgcn_readlane((int)ln, (int)sg);
+        const uint32_t base = (c + sg) * tr + sst;
+        for (uint32_t j0 = 0; j0 < sln; j0 += 256u) {
+          uint32_t slot[4];
+          VT v[4];
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const int seg = q * 4 + grp;
-      const uint32_t sst = (uint32_t)__shfl((int)st, seg, 64), sln = (uint32_t)__shfl((int)ln, seg, 64);
-      const uint32_t row = (c + (uint32_t)seg) * tr + sst + (uint32_t)sub;
-      slot[q] = 0; v[q] = VT(0);
-      if ((uint32_t)sub < sln) {
-        slot[q] = kp[row];
-        if (hasval) v[q] = val[row];
+          for (int u = 0; u < 4; u++) {
+            const uint32_t j = j0 + (uint32_t)u * 64u + (uint32_t)lane;
+            slot[u] = 0; v[u] = VT(0);
+            if (j < sln) { slot[u] = kp[base + j]; if (hasval) v[u] = val[base + j]; }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (j0 + (uint32_t)u * 64u + (uint32_t)lane < sln) acc_row<VT, false>(t, flags, slot[u], v[u]);
+        }
       }
+      continue;
     }
+    // 16 lanes per segment, four segments per wave instruction.  The first 32 rows of 32 segments are loaded (two
+    // loads per lane and segment) before their DS atomics start, so the usual segment (12 .. 25 rows) never waits on a
+    // second, dependent round of loads; longer ones finish in a plain loop.
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-      const int seg = q * 4 + grp;
-      const uint32_t sln = (uint32_t)__shfl((int)ln, seg, 64);
-      if ((uint32_t)sub < sln) acc_row<VT, false>(t, flags, slot[q], v[q]);
-      if (__ballot(sln > 16u)) {                                          // segments longer than 16 rows
-        const uint32_t sst = (uint32_t)__shfl((int)st, seg, 64);
-        const uint32_t base = (c + (uint32_t)seg) * tr + sst;
-        for (uint32_t j = (uint32_t)sub + 16u; j < sln; j += 16u)
-          acc_row<VT, false>(t, flags, kp[base + j], hasval ? val[base + j] : VT(0));
+    for (int h = 0; h < 2; h++) {
+      uint32_t slot[8][2];
+      VT v[8][2];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int seg = (h * 8 + q) * 4 + grp;
+        const uint32_t sst = (uint32_t)__shfl((int)st, seg, 64), sln = (uint32_t)__shfl((int)ln, seg, 64);
+        const uint32_t row = (c + (uint32_t)seg) * tr + sst + (uint32_t)sub;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          slot[q][k] = 0; v[q][k] = VT(0);
+          if ((uint32_t)sub + 16u * k < sln) {
+            slot[q][k] = kp[row + 16u * k];
+            if (hasval) v[q][k] = val[row + 16u * k];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int seg = (h * 8 + q) * 4 + grp;
+        const uint32_t sln = (uint32_t)__shfl((int)ln, seg, 64);
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+          if ((uint32_t)sub + 16u * k < sln) acc_row<VT, false>(t, flags, slot[q][k], v[q][k]);
+        if (__ballot(sln > 32u)) {
+          const uint32_t sst = (uint32_t)__shfl((int)st, seg, 64);
+          const uint32_t base = (c + (uint32_t)seg) * tr + sst;
+          for (uint32_t j = (uint32_t)sub + 32u; j < sln; j += 16u)
+            acc_row<VT, false>(t, flags, kp[base + j], hasval ? val[base + j] : VT(0));
+        }
       }
     }
   }
   __syncthreads();
-  flush_table(t, a.tab, it.bucket, S, flags, it.single != 0, a.isfloat, tid);
+  flush_table(t, a.tab, it.bucket, S, flags, (it.single & 1u) != 0, a.isfloat, tid);
 }
 
 template <typename VT>
@@ -1083,7 +1141,9 @@ __global__ void __launch_bounds__(1024) seg_plan_kernel(const uint32_t* tot, uin
       it.bucket = b;
       it.begin = (uint32_t)(((unsigned long long)i * ntiles) / np[k]);
       it.end = (uint32_t)(((unsigned long long)(i + 1) * ntiles) / np[k]);
-      it.single = np[k] == 1 ? 1u : 0u;
+      // bit 0: the bucket has a single part (plain stores of the table); bit 1: its segments average more than 48
+      // rows per tile (few buckets, or a hot bucket): whole-wave streaming instead of 16 lanes per segment
+      it.single = (np[k] == 1 ? 1u : 0u) | ((unsigned long long)tot[b] > 48ull * ntiles ? 2u : 0u);
       items[pe + i] = it;
     }
     pe += np[k];

@@ -261,7 +261,8 @@ void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom
 int launch_bucket_hist(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, uint32_t* P, uint32_t* gtot,
                        uint32_t* bad, bool clustered);
 // *clustered <- neighbouring rows mostly share a bucket (65536 sampled row pairs; synchronises); flag2: 2 words of scratch
-int launch_bucket_cluster_sample(dthip_ctx* ctx, const KeyXform& kx, int64_t n, int r, uint32_t* flag2, bool* clustered);
+int launch_bucket_cluster_sample(dthip_ctx* ctx, const KeyXform& kx, int64_t n, int r, uint32_t* flag2, bool* clustered,
+                                 uint32_t F = 0, bool* even = nullptr);
 // phase 0: tot[F] <- bucket sizes; phase 1: gtot <- bbase + exclusive prefix over groups (in place)
 int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uint32_t* tot, const uint32_t* bbase, int phase);
 // tot (nullable: one bucket of n_raw rows) -> bbase[F+1], work items of <= M rows, *nitems
