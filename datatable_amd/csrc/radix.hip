@@ -258,8 +258,9 @@ __device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t
 
 // RB   = number of ballot rounds (>= bits of every pass run with this instance)
 // P0W  = byte width of payload column 0 when it is prefetched with the keys (0: none / iota)
-template <typename KeyT, int RB, int P0W>
-__global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a) {
+// P1W  = the same for payload column 1 (only with P0W == 8): both columns' loads are in flight before the ranking
+template <typename KeyT, int RB, int P0W, int P1W = 0>
+__global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) radix_pass_kernel(PassArgsT<KeyT> a) {
   constexpr int BLOCK = RP_BLOCK, ITEMS = RP_ITEMS;
   constexpr int WAVES = BLOCK / 64, TILE = BLOCK * ITEMS;
   constexpr int GROUPS = ITEMS / 4;     // each thread owns GROUPS groups of 4 consecutive tile-sorted slots
@@ -298,6 +299,16 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a)
     for (int i = 0; i < ITEMS; i++) {
       const uint32_t loc = wbase + 64u * i;
       pay0[i] = (loc < nvalid) ? pin[tile_base + loc] : P0T(0);
+    }
+  }
+  typedef typename std::conditional<P1W == 8, unsigned long long, uint32_t>::type P1T;
+  P1T pay1[P1W ? ITEMS : 1];
+  if (P1W) {
+    const P1T* pin = static_cast<const P1T*>(a.pay.in[1]);
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const uint32_t loc = wbase + 64u * i;
+      pay1[i] = (loc < nvalid) ? pin[tile_base + loc] : P1T(0);
     }
   }
   if (full) {
@@ -406,6 +417,7 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a)
           uint32_t v;
           if (c == 0 && a.iota) v = tile_base + loc;
           else if (c == 0 && P0W == 4) v = (uint32_t)pay0[i];
+          else if (c == 1 && P1W == 4) v = (uint32_t)pay1[i];
           else v = pin[tile_base + loc];
           e4[pos[i]] = v;
         }
@@ -430,6 +442,7 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_pass_kernel(PassArgsT<KeyT> a)
         if (loc < nvalid) {
           unsigned long long v;
           if (c == 0 && P0W == 8) v = (unsigned long long)pay0[i];
+          else if (c == 1 && P1W == 8) v = (unsigned long long)pay1[i];
           else v = pin[tile_base + loc];
           e8[pos[i]] = v;
         }
@@ -463,7 +476,7 @@ int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t
   return DTHIP_OK;
 }
 
-template <typename KeyT, int RB, int P0W>
+template <typename KeyT, int RB, int P0W, int P1W = 0>
 static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
   PassArgsT<KeyT> a;
   a.kin = static_cast<const KeyT*>(p.kin); a.kout = static_cast<KeyT*>(p.kout);
@@ -473,7 +486,7 @@ static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
   for (int c = 0; c < p.pay.n; c++) maxw = p.pay.width[c] > maxw ? p.pay.width[c] : maxw;
   const int bins = 1 << p.bits;
   const size_t lds = (size_t)((RP_BLOCK / 64) * bins + 2 * bins + 16) * 4 + (size_t)RP_TILE * maxw;
-  auto kfn = radix_pass_kernel<KeyT, RB, P0W>;
+  auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W>;
   static bool attr_set = false;
   if (!attr_set) {
     DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -488,11 +501,16 @@ static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
 template <typename KeyT>
 static int launch_pass_k(dthip_ctx* ctx, const RadixPass& p) {
   const int p0w = (p.pay.n > 0 && !p.iota) ? p.pay.width[0] : 0;
+  const int p1w = (p0w == 8 && p.pay.n > 1) ? p.pay.width[1] : 0;
   if (p.bits > 8) {
+    if (p0w == 8 && p1w == 8) return launch_pass_t<KeyT, 9, 8, 8>(ctx, p);
+    if (p0w == 8 && p1w == 4) return launch_pass_t<KeyT, 9, 8, 4>(ctx, p);
     if (p0w == 8) return launch_pass_t<KeyT, 9, 8>(ctx, p);
     if (p0w == 4) return launch_pass_t<KeyT, 9, 4>(ctx, p);
     return launch_pass_t<KeyT, 9, 0>(ctx, p);
   }
+  if (p0w == 8 && p1w == 8) return launch_pass_t<KeyT, 8, 8, 8>(ctx, p);
+  if (p0w == 8 && p1w == 4) return launch_pass_t<KeyT, 8, 8, 4>(ctx, p);
   if (p0w == 8) return launch_pass_t<KeyT, 8, 8>(ctx, p);
   if (p0w == 4) return launch_pass_t<KeyT, 8, 4>(ctx, p);
   return launch_pass_t<KeyT, 8, 0>(ctx, p);
