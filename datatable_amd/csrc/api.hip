@@ -260,11 +260,11 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
   const int key64 = bits > 32;
   const size_t ksz = key64 ? 8 : 4;
   out->key64 = key64;
-  // digits of at most 8 bits for 32-bit radix keys: a 9-bit pass (512 bins, 9 ballot rounds) measured
-  // 2x slower per byte than an 8-bit one there, so 27 significant bits are 4 passes of 7.  With
-  // 64-bit radix keys the pass is payload-bound (9-bit: +10 %) and one pass fewer wins (63 bits: 7 x 9).
+  // digits of up to 9 bits (512 bins) whenever that saves a pass: 27 significant bits are 3 passes of 9, 63 bits 7 x 9.
+  // (Round 1 kept 32-bit keys at 8 bits -- a 9-bit pass measured 2x slower there: its per-wave histograms left LDS
+  // for one workgroup per CU only; they are 16-bit words now.)
   int npass = (bits + 7) / 8;
-  if (key64 && (bits + 8) / 9 < npass) npass = (bits + 8) / 9;
+  if ((bits + 8) / 9 < npass) npass = (bits + 8) / 9;
   if (npass > MAX_PASSES) npass = MAX_PASSES;
   XformArgs xa;
   memset(&xa, 0, sizeof(xa));

@@ -267,15 +267,17 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(4
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bins = 1 << a.bits;
   const uint32_t dmask = (uint32_t)bins - 1u;
-  uint32_t* wh = reinterpret_cast<uint32_t*>(smem);   // [WAVES][bins] per-wave digit counts
-  uint32_t* bin_excl = wh + WAVES * bins;              // [bins] tile-local exclusive digit start
+  // per-wave digit counts as 16-bit words (a wave holds 64 x ITEMS = 1024 keys, a tile 8192): at 512 bins the
+  // 32-bit form took the LDS a second workgroup per CU needs, which is what made a 9-bit pass twice as slow
+  uint16_t* wh = reinterpret_cast<uint16_t*>(smem);   // [WAVES][bins] per-wave digit counts
+  uint32_t* bin_excl = reinterpret_cast<uint32_t*>(wh + WAVES * bins);   // [bins] tile-local exclusive digit start
   uint32_t* bin_delta = bin_excl + bins;               // [bins] global start - local start
   uint32_t* misc = bin_delta + bins;                   // [16]
   unsigned char* exch = reinterpret_cast<unsigned char*>(misc + 16);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  for (int i = tid; i < WAVES * bins; i += BLOCK) wh[i] = 0;
+  for (int i = tid; i < WAVES * bins / 2; i += BLOCK) reinterpret_cast<uint32_t*>(wh)[i] = 0;
   __syncthreads();
   // tiles are dealt to XCDs (block b runs on XCD b % 8: speed only) in contiguous ranges, so the
   // neighbouring runs of a digit are completed in one XCD's L2
@@ -333,7 +335,7 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(4
   }
 
   // ---- stable rank of every key among equal digits of its wave --------------
-  volatile uint32_t* mywh = wh + wave * bins;
+  volatile uint16_t* mywh = wh + wave * bins;
   uint32_t pos[ITEMS];
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(4
     uint32_t prev = 0;
     if (valid) prev = mywh[d];
     pos[i] = prev + below;
-    if (valid && below == 0) mywh[d] = prev + cnt;
+    if (valid && below == 0) mywh[d] = (uint16_t)(prev + cnt);
   }
   __syncthreads();
 
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
     for (int w = 0; w < WAVES; w++) {
       const uint32_t c = wh[w * bins + tid];
-      wh[w * bins + tid] = s;
+      wh[w * bins + tid] = (uint16_t)s;
       s += c;
     }
     tcount = s;
@@ -485,7 +487,7 @@ static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
   int maxw = (int)sizeof(KeyT);
   for (int c = 0; c < p.pay.n; c++) maxw = p.pay.width[c] > maxw ? p.pay.width[c] : maxw;
   const int bins = 1 << p.bits;
-  const size_t lds = (size_t)((RP_BLOCK / 64) * bins + 2 * bins + 16) * 4 + (size_t)RP_TILE * maxw;
+  const size_t lds = (size_t)(RP_BLOCK / 64) * bins * 2 + (size_t)(2 * bins + 16) * 4 + (size_t)RP_TILE * maxw;
   auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W>;
   static bool attr_set = false;
   if (!attr_set) {
