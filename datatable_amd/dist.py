@@ -1,4 +1,9 @@
-"""Multi-GPU DT[:, aggs, by(keys)]: one process per GPU, torch.distributed (RCCL over xGMI).
+"""LEGACY Python wrapper of the multi-GPU exchange (round 1).  The product path is INSIDE libdthip.so since round 2
+(datatable_amd/csrc/comm.hip: dthip_comm_* / dthip_sharded_groupby_*, RCCL called directly, histogram splitters; bench.py
+--gpus N and engine.Context.sharded_groupby_agg use that).  This module stays for its CPU-testable exchange logic
+(tests/test_dist_gloo.py, gloo, world_size 2) and as documentation of the algorithm in 100 lines of Python.
+
+Multi-GPU DT[:, aggs, by(keys)]: one process per GPU, torch.distributed (RCCL over xGMI).
 
 The reference is single-process; this exchange step is new.  Design
 (SURVEY §8e): rows are sharded by row block; every rank first runs the fused local
