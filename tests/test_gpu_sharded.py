@@ -175,3 +175,31 @@ def test_rccl_transport_one_rank(ctx):
     assert_same(r.col(0), e.col(0), "rows"); assert_same(r.col(1).astype(np.int32), e.rowindex(), "row ids")
     r.free(); e.free(); exp.free()
     c.close()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("na_last", [False, True])
+def test_logical_shards_rows_two_keys_small_columns(ctx, comms, world, na_last):
+    """rows in grouped order with a composite key (the range partition is on the FIRST key only), NA groups first / last,
+    and payload columns of 1, 2 and 4 bytes next to the 8-byte ones"""
+    rng = np.random.default_rng(900 + world)
+    n = 150_000
+    a = rng.integers(-40, 40, n).astype(np.int32)
+    a[rng.random(n) < 0.03] = -2**31
+    b = rng.integers(0, 9, n).astype(np.int64)
+    c1 = rng.integers(-100, 100, n).astype(np.int8)
+    c2 = rng.integers(-3000, 3000, n).astype(np.int16)
+    c4 = rng.standard_normal(n).astype(np.float32)
+    c8 = rng.standard_normal(n)
+    cols = [c1, c2, c4, c8, a]
+    single = ctx.groupby_rows([a, b], cols, want_rowindex=True, na_last=na_last)
+    ksh, cuts = shard([a, b], world, uneven=True)
+    csh, _ = shard(cols, world, uneven=True)
+    res = comms[world].groupby_rows(ksh, csh, cuts[:-1], na_last=na_last)
+    assert sum(r.ngroups for r in res) == single.ngroups
+    for c in range(len(cols)):
+        assert_same(concat(res, lambda r: r.col(c)), single.col(c), "column %d" % c)
+    assert_same(concat(res, lambda r: r.col(len(cols))).astype(np.int32), single.rowindex(), "global row ids")
+    for r in res:
+        r.free()
+    single.free()
