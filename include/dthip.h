@@ -182,8 +182,8 @@ int  dthip_memcpy_d2h(dthip_ctx* ctx, void* dst, const void* src, size_t bytes);
 
 /* DTHIP_HOST data: pageable buffers are staged by the HIP runtime through its own pinned bounce buffers (a CPU copy per
  * byte); a buffer registered here (hipHostRegister: page-locked and mapped once, ~0.2 s per GB) is DMA-read directly,
- * which pays when the same column buffers are queried repeatedly (the reference-side shim registers a Frame's
- * numpy-backed columns on request).  Either way the mode is bounded by the PCIe link (Gen5 x16: ~55 GB/s), not by HBM. */
+ * which can pay when the same column buffers are queried repeatedly.  Measured on MI355X / PCIe Gen5 x16 (bench.py
+ * host_mode): 53.8 GB/s of input pageable, 54.5 GB/s registered -- either way the mode is bounded by the link, not by HBM. */
 int  dthip_host_register(dthip_ctx* ctx, void* ptr, size_t bytes);
 int  dthip_host_unregister(dthip_ctx* ctx, void* ptr);
 
