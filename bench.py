@@ -290,6 +290,13 @@ def main():
                     help="1: the result also carries group sizes (not part of DT[:, sum(f.v), by(f.k)]'s result Frame)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: gloo and RCCL announce themselves on the C-level stdout (RCCL's banner
+    # even after the line, when its buffer is flushed at exit), so fd 1 is pointed at stderr for the whole run and the
+    # line goes to a private copy of the original stdout
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from datatable_amd.torch_bridge import context_for_current_stream, devcol
@@ -311,10 +318,11 @@ def main():
             dist.init_process_group("gloo", rank=0, world_size=1)
         else:
             dist.init_process_group("gloo")
-    ctx = context_for_current_stream(local_rank)
-    if sharded:
         box = [comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
+        dist.barrier()
+    ctx = context_for_current_stream(local_rank)
+    if sharded:
         ctx.comm_init(rank, world, box[0])
     ctx.set_option("agg_path", args.agg_path)
     ctx.set_option("bucket_variant", args.bucket_variant)
@@ -494,7 +502,7 @@ def main():
         if args.host_rows:
             line["host_mode"] = host_mode_leg(ctx, args.host_rows)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
