@@ -63,9 +63,59 @@ __device__ __forceinline__ uint32_t sweep_pred(const PredArgs& p, uint32_t n, ui
   return bits;
 }
 
+typedef uint32_t cu32x4 __attribute__((ext_vector_type(4)));
+
+// passing rows of one full tile of an 8-byte column, counted with 16-byte loads (the order of the rows does not matter
+// for a count; the generic sweep reads 8 bytes per lane and instruction: 3.9 instead of 5+ TB/s)
+// the predicate on an already loaded element of a float64 / int64 column
+__device__ __forceinline__ bool pred_val8(const PredArgs& p, unsigned long long bitsv) {
+  if (p.stype == DTHIP_FLOAT64) {
+    const double d = __longlong_as_double((long long)bitsv);
+    const bool na = d != d;
+    switch (p.cmp) {
+      case DTHIP_GT: return !na && d > p.cf;   case DTHIP_GE: return !na && d >= p.cf;
+      case DTHIP_LT: return !na && d < p.cf;   case DTHIP_LE: return !na && d <= p.cf;
+      case DTHIP_EQ: return !na && d == p.cf;  case DTHIP_NE: return na || d != p.cf;
+      case DTHIP_NOTNA: return !na;            default: return na;
+    }
+  }
+  const long long iv = (long long)bitsv;
+  const bool na = iv == INT64_MIN;
+  switch (p.cmp) {
+    case DTHIP_GT: return !na && iv > p.ci;   case DTHIP_GE: return !na && iv >= p.ci;
+    case DTHIP_LT: return !na && iv < p.ci;   case DTHIP_LE: return !na && iv <= p.ci;
+    case DTHIP_EQ: return !na && iv == p.ci;  case DTHIP_NE: return na || iv != p.ci;
+    case DTHIP_NOTNA: return !na;             default: return na;
+  }
+}
+__device__ __forceinline__ bool pred_fast8(const PredArgs& p, uint32_t n, uint32_t tile_base) {
+  return !p.is_mask && (p.stype == DTHIP_FLOAT64 || p.stype == DTHIP_INT64) && n - tile_base >= (uint32_t)CP_TILE &&
+         (reinterpret_cast<uintptr_t>(p.data) & 15) == 0;
+}
+
+template <typename T>
+__device__ __forceinline__ uint32_t count_tile16(const PredArgs& p, uint32_t tile_base) {
+  const cu32x4* src = reinterpret_cast<const cu32x4*>(static_cast<const T*>(p.data) + tile_base);
+  cu32x4 w[CP_ITEMS / 2];
+#pragma unroll
+  for (int q = 0; q < CP_ITEMS / 2; q++) w[q] = src[q * CP_BLOCK + threadIdx.x];
+  const T* v = reinterpret_cast<const T*>(w);
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < CP_ITEMS; j++) c += pred_val8(p, v[j]) ? 1u : 0u;
+  return c;
+}
+
 __global__ void __launch_bounds__(CP_BLOCK) compact_count_kernel(PredArgs p, uint32_t n, uint32_t* tile_counts) {
   __shared__ uint32_t wc[CP_BLOCK / 64];
   uint32_t cnt;
+  const uint32_t tile_base = blockIdx.x * CP_TILE;
+  if (pred_fast8(p, n, tile_base)) {
+    uint32_t c = count_tile16<unsigned long long>(p, tile_base);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
+    cnt = c;
+  } else
   sweep_pred(p, n, blockIdx.x * CP_TILE + wave_id() * (64 * CP_ITEMS), &cnt);
   if (lane_id() == 0) wc[wave_id()] = cnt;
   __syncthreads();
@@ -121,6 +171,49 @@ __global__ void __launch_bounds__(CP_BLOCK) compact_take_kernel(PredArgs p, uint
   __shared__ uint32_t wc[CP_BLOCK / 64];
   const int lane = lane_id(), wave = wave_id();
   const uint32_t wave_base = blockIdx.x * CP_TILE + wave * (64 * CP_ITEMS);
+  if (pred_fast8(p, n, blockIdx.x * CP_TILE)) {
+    // 8-byte predicate column, full tile: 16-byte loads (two consecutive rows per lane), and a taken column that IS the
+    // predicate column is written from the registers instead of being read again
+    const cu32x4* src = reinterpret_cast<const cu32x4*>(static_cast<const unsigned long long*>(p.data) + wave_base);
+    cu32x4 w[CP_ITEMS / 2];
+#pragma unroll
+    for (int q = 0; q < CP_ITEMS / 2; q++) w[q] = src[q * 64 + lane];
+    const unsigned long long* pv = reinterpret_cast<const unsigned long long*>(w);
+    bool f[CP_ITEMS];
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < CP_ITEMS; j++) { f[j] = pred_val8(p, pv[j]); c += (uint32_t)__popcll(__ballot(f[j])); }
+    if (lane == 0) wc[wave] = c;
+    __syncthreads();
+    uint32_t running = tile_base[blockIdx.x];
+    for (int ww = 0; ww < wave; ww++) running += wc[ww];
+#pragma unroll
+    for (int q = 0; q < CP_ITEMS / 2; q++) {
+      const unsigned long long b0 = __ballot(f[2 * q]), b1 = __ballot(f[2 * q + 1]);
+      const uint32_t below = mbcnt64(b0) + mbcnt64(b1);
+#pragma unroll
+      for (int sidx = 0; sidx < 2; sidx++) {
+        if (f[2 * q + sidx]) {
+          const uint32_t srcrow = wave_base + ((uint32_t)q * 64u + (uint32_t)lane) * 2u + (uint32_t)sidx;
+          const uint32_t dst = running + below + (sidx ? (f[2 * q] ? 1u : 0u) : 0u);
+          if (out_ri) out_ri[dst] = (int32_t)srcrow;
+          for (int cc = 0; cc < tc.n; cc++) {
+            switch (tc.width[cc]) {
+              case 8:
+                static_cast<unsigned long long*>(tc.out[cc])[dst] =
+                    tc.in[cc] == p.data ? pv[2 * q + sidx] : static_cast<const unsigned long long*>(tc.in[cc])[srcrow];
+                break;
+              case 4: static_cast<uint32_t*>(tc.out[cc])[dst] = static_cast<const uint32_t*>(tc.in[cc])[srcrow]; break;
+              case 2: static_cast<uint16_t*>(tc.out[cc])[dst] = static_cast<const uint16_t*>(tc.in[cc])[srcrow]; break;
+              default: static_cast<uint8_t*>(tc.out[cc])[dst] = static_cast<const uint8_t*>(tc.in[cc])[srcrow]; break;
+            }
+          }
+        }
+      }
+      running += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
+    }
+    return;
+  }
   uint32_t cnt;
   const uint32_t bits = sweep_pred(p, n, wave_base, &cnt);
   if (lane == 0) wc[wave] = cnt;
