@@ -563,6 +563,8 @@ class Frame:
                 # the reference cannot do this either: src/core/expr/fexpr_func.cc:61-73
                 raise NotImplementedError("FExpr_Func::evaluate_iby() not implemented yet")
             return self._filter(i)._select(j)
+        if isinstance(i, (int, np.integer)) and not isinstance(i, (bool, np.bool_)) and byx is not None:
+            return self._group_nth(int(i), j, byx, srt)
         if not all_rows:
             raise NotImplementedError("row selector %r is outside the accelerated path" % (i,))
         if byx is not None:
@@ -610,6 +612,39 @@ class Frame:
     def sort(self, *cols):
         """Frame.sort(cols): ascending, NA first (src/core/sort.cc:539-558)"""
         return self._sorted(sort(*cols))
+
+    def _group_nth(self, i, j, byx, srt):
+        """DT[i, j, by(...)] with an integer i: the i-th row of every group that has one, counted from the group's
+        end for negative i (/root/reference/tests/test-groups.py:486-495).  group() -> offsets and RowIndex on the
+        device, the picked rows are a gather; the by-columns lead the result like in every by() query."""
+        ctx = self._context()
+        kidx = [self._index(c) for c in byx.cols]
+        kdesc = [bool(c.desc) for c in byx.cols]
+        keys = [self._materialized(k) for k in kidx]
+        kst = [self._stypes[k] for k in kidx]
+        sel_all = j is None or j is Ellipsis or (isinstance(j, slice) and j == slice(None))
+        items = [] if sel_all else (list(j) if isinstance(j, (list, tuple)) else [j])
+        if any(not isinstance(x, (ColRef, str, int, np.integer)) or isinstance(x, AllCols) for x in items):
+            raise NotImplementedError("an integer row selector with by() takes plain columns in j")
+        jidx = [c for c in range(self.ncols) if c not in kidx] if sel_all else [self._index(x) for x in items]
+        na_last = srt is not None and srt.na_last
+        if self.nrows == 0:
+            sel = np.zeros(0, np.int32)
+        else:
+            if srt is not None:
+                gri = self._by_sort_order(ctx, keys, kst, kdesc, srt)
+                g = ctx.groupby(keys, stypes=kst, desc=kdesc, na_last=na_last, want_rowindex=False)
+                goff = g.offsets()
+            else:
+                g = ctx.groupby(keys, stypes=kst, desc=kdesc, na_last=na_last)
+                gri, goff = g.rowindex(), g.offsets()
+            g.free()
+            sizes = np.diff(goff)
+            pos = (goff[:-1][sizes > i] + i) if i >= 0 else (goff[1:][sizes >= -i] + i)
+            sel = ctx.gather(gri, pos.astype(np.int32)) if len(pos) else np.zeros(0, np.int32)
+        fr = Frame(self)
+        fr._ri = sel if self._ri is None else (ctx.gather(self._ri, sel) if len(sel) else sel)
+        return fr._select([self._names[c] for c in kidx + jidx])
 
     def _by_sort_order(self, ctx, keys, kst, kdesc, srt):
         """RowIndex that orders the rows by the by-columns, then (inside groups) by the sort() columns"""

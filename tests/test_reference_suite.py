@@ -908,6 +908,22 @@ def test_groupby_on_view(dt):                            # test-groups.py:419-43
     assert_equals(V[:, dt.max(dt.f.B), dt.by(dt.f.C)], dt.Frame(C=[1, 3], B=[2, 6]))
 
 
+def test_int_row_with_by(dt):                            # test-groups.py:486-495
+    DT = dt.Frame(A=[1, 2, 3, 1, 2, 1], B=range(6))
+    by, f = dt.by, dt.f
+    I32 = DT.stypes[1]
+    assert_equals(DT[0, :, by(f.A)], dt.Frame(A=[1, 2, 3], B=[0, 1, 2]))
+    assert_equals(DT[1, :, by(f.A)], dt.Frame(A=[1, 2], B=[3, 4]))
+    assert_equals(DT[2, :, by(f.A)], dt.Frame(A=[1], B=[5]))
+    R = DT[3, :, by(f.A)]
+    assert R.shape == (0, 2) and R.names == ("A", "B") and R.stypes == (I32, I32)
+    assert_equals(DT[-1, :, by(f.A)], dt.Frame(A=[1, 2, 3], B=[5, 4, 2]))
+    assert_equals(DT[-2, :, by(f.A)], dt.Frame(A=[1, 2], B=[3, 1]))
+    assert_equals(DT[-3, :, by(f.A)], dt.Frame(A=[1], B=[0]))
+    R = DT[-4, :, by(f.A)]
+    assert R.shape == (0, 2) and R.stypes == (I32, I32)
+
+
 # ---- tests/test-reduce.py:518-537 and tests/munging/test-dt-rows.py:405-416,555-566,690-710 -------------------
 
 def test_mean_simple_and_empty(dt):                      # test-reduce.py:518-537
