@@ -171,49 +171,6 @@ __global__ void __launch_bounds__(CP_BLOCK) compact_take_kernel(PredArgs p, uint
   __shared__ uint32_t wc[CP_BLOCK / 64];
   const int lane = lane_id(), wave = wave_id();
   const uint32_t wave_base = blockIdx.x * CP_TILE + wave * (64 * CP_ITEMS);
-  if (pred_fast8(p, n, blockIdx.x * CP_TILE)) {
-    // 8-byte predicate column, full tile: 16-byte loads (two consecutive rows per lane), and a taken column that IS the
-    // predicate column is written from the registers instead of being read again
-    const cu32x4* src = reinterpret_cast<const cu32x4*>(static_cast<const unsigned long long*>(p.data) + wave_base);
-    cu32x4 w[CP_ITEMS / 2];
-#pragma unroll
-    for (int q = 0; q < CP_ITEMS / 2; q++) w[q] = src[q * 64 + lane];
-    const unsigned long long* pv = reinterpret_cast<const unsigned long long*>(w);
-    bool f[CP_ITEMS];
-    uint32_t c = 0;
-#pragma unroll
-    for (int j = 0; j < CP_ITEMS; j++) { f[j] = pred_val8(p, pv[j]); c += (uint32_t)__popcll(__ballot(f[j])); }
-    if (lane == 0) wc[wave] = c;
-    __syncthreads();
-    uint32_t running = tile_base[blockIdx.x];
-    for (int ww = 0; ww < wave; ww++) running += wc[ww];
-#pragma unroll
-    for (int q = 0; q < CP_ITEMS / 2; q++) {
-      const unsigned long long b0 = __ballot(f[2 * q]), b1 = __ballot(f[2 * q + 1]);
-      const uint32_t below = mbcnt64(b0) + mbcnt64(b1);
-#pragma unroll
-      for (int sidx = 0; sidx < 2; sidx++) {
-        if (f[2 * q + sidx]) {
-          const uint32_t srcrow = wave_base + ((uint32_t)q * 64u + (uint32_t)lane) * 2u + (uint32_t)sidx;
-          const uint32_t dst = running + below + (sidx ? (f[2 * q] ? 1u : 0u) : 0u);
-          if (out_ri) out_ri[dst] = (int32_t)srcrow;
-          for (int cc = 0; cc < tc.n; cc++) {
-            switch (tc.width[cc]) {
-              case 8:
-                static_cast<unsigned long long*>(tc.out[cc])[dst] =
-                    tc.in[cc] == p.data ? pv[2 * q + sidx] : static_cast<const unsigned long long*>(tc.in[cc])[srcrow];
-                break;
-              case 4: static_cast<uint32_t*>(tc.out[cc])[dst] = static_cast<const uint32_t*>(tc.in[cc])[srcrow]; break;
-              case 2: static_cast<uint16_t*>(tc.out[cc])[dst] = static_cast<const uint16_t*>(tc.in[cc])[srcrow]; break;
-              default: static_cast<uint8_t*>(tc.out[cc])[dst] = static_cast<const uint8_t*>(tc.in[cc])[srcrow]; break;
-            }
-          }
-        }
-      }
-      running += (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
-    }
-    return;
-  }
   uint32_t cnt;
   const uint32_t bits = sweep_pred(p, n, wave_base, &cnt);
   if (lane == 0) wc[wave] = cnt;
