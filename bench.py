@@ -479,7 +479,11 @@ def main():
         }
         if world == 1 and not sharded and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
-            base, par = reference_leg(ctx, keys, vals, args.cpu_sample, [int(t) for t in args.ref_threads.split(",") if t != ""])
+            try:
+                base, par = reference_leg(ctx, keys, vals, args.cpu_sample, [int(t) for t in args.ref_threads.split(",") if t != ""])
+            except Exception as e:       # the reference build could not be imported / run here: report it, keep the port
+                base, par = None, None
+                parity["vs_reference"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             if base is not None:
                 line["cpu_baseline"] = base
                 parity["vs_reference"] = par
