@@ -827,25 +827,37 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
                             const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int na_pos) {
   const int nkeys = plan.nkeys;
   if (ctx->hash_mode == 1 || ctx->in_merge || ctx->agg_path == 1) return DTHIP_NOT_APPLICABLE;
-  if (plan.nstages != 1 || used.size() > 1) return DTHIP_NOT_APPLICABLE;
-  for (int c : used) if (vd[c].flags & DTHIP_FLAG_NONA) return DTHIP_NOT_APPLICABLE;
+  // Several value columns (round 2): the rows are partitioned ONCE with every value column as payload; each column
+  // then gets its own pass of LDS hash tables over the partitioned (key, value) rows and its own merge.  Every merge
+  // orders the same set of keys, so the per-column results line up group by group.
+  if (plan.nstages != 1 || (int)used.size() > MAX_PAYCOLS - 1) return DTHIP_NOT_APPLICABLE;
+  for (int c : used) {
+    if (vd[c].flags & DTHIP_FLAG_NONA) return DTHIP_NOT_APPLICABLE;
+    if (stype_size(vd[c].stype) != 4 && stype_size(vd[c].stype) != 8) return DTHIP_NOT_APPLICABLE;
+  }
   if (ctx->hash_mode != 2 && n < (1 << 22)) return DTHIP_NOT_APPLICABLE;
-  const int c0 = used.empty() ? -1 : used[0];
-  if (c0 >= 0 && stype_size(vd[c0].stype) != 4 && stype_size(vd[c0].stype) != 8) return DTHIP_NOT_APPLICABLE;
   const bool need_cnt = bucket_need_counts(ctx, aggs, naggs);
-  const int vst = c0 >= 0 ? vd[c0].stype : DTHIP_INT32;
-  const int flags = (c0 >= 0 ? acc_flags_for(aggs, naggs, c0, vst) : 0) | (need_cnt ? ACC_CNT : 0);
-  const size_t entry = hash_agg_entry_bytes(flags);
-  uint32_t C = (uint32_t)((158 * 1024) / entry) - 1;                // the whole LDS of a CU for one table ...
-  for (;; C--) {                                                     // ... with a prime number of entries (double hashing)
-    bool prime = C % 2 != 0;
-    for (uint32_t q = 3; prime && q * q <= C; q += 2) prime = C % q != 0;
-    if (prime) break;
+  const int ncolpass = used.empty() ? 1 : (int)used.size();      // passes of hash tables (one with no value column at all)
+  std::vector<int> cflags(ncolpass);
+  std::vector<uint32_t> cC(ncolpass);
+  uint32_t Cmin = ~0u;
+  for (int i = 0; i < ncolpass; i++) {
+    const int c = used.empty() ? -1 : used[i];
+    cflags[i] = (c >= 0 ? acc_flags_for(aggs, naggs, c, vd[c].stype) : 0) | ((need_cnt && i == 0) ? ACC_CNT : 0);
+    const size_t entry = hash_agg_entry_bytes(cflags[i]);
+    uint32_t C = (uint32_t)((158 * 1024) / entry) - 1;                // the whole LDS of a CU for one table ...
+    for (;; C--) {                                                     // ... with a prime number of entries (double hashing)
+      bool prime = C % 2 != 0;
+      for (uint32_t q = 3; prime && q * q <= C; q += 2) prime = C % q != 0;
+      if (prime) break;
+    }
+    cC[i] = C;
+    Cmin = std::min(Cmin, C);
   }
   const uint32_t F = 1u << (HASH_PK_BITS - HASH_R);
   double est = 0;
   DTHIP_TRY(estimate_distinct(ctx, kd, nkeys, n, na_pos, &est));
-  if (est * 1.05 > 0.75 * (double)F * (double)C) return DTHIP_NOT_APPLICABLE;      // expected load factor <= 0.75
+  if (est * 1.05 > 0.75 * (double)F * (double)Cmin) return DTHIP_NOT_APPLICABLE;      // expected load factor <= 0.75
 
   KeyXform kx;
   memset(&kx, 0, sizeof(kx));
@@ -862,7 +874,7 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   pkx.cols[0].data = pk; pkx.cols[0].stype = DTHIP_INT32; pkx.cols[0].desc = 0; pkx.cols[0].edge = 0;
   pkx.cols[0].na_repl = 0; pkx.cols[0].inc = 0; pkx.cols[0].xmax = ~0ULL; pkx.cols[0].shift = 0;
   int km = 2;
-  if (c0 >= 0 && (reinterpret_cast<uintptr_t>(vd[c0].data) & 15)) km = 0;
+  for (int c : used) if (reinterpret_cast<uintptr_t>(vd[c].data) & 15) km = 0;
   BucketGeom g;
   bucket_geometry(ctx, n, HASH_PK_BITS, HASH_R, km, &g);
   uint32_t* bbase = nullptr;
@@ -897,111 +909,128 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   PayCols pc;
   memset(&pc, 0, sizeof(pc));
   pc.in[0] = xs; pc.out[0] = xs_part; pc.width[0] = 8; pc.n = 1;
-  unsigned char* v_part = nullptr;
-  if (c0 >= 0) {
-    const int w = stype_size(vst);
-    DTHIP_TRY(sc.get<unsigned char>((size_t)n * w + 64, &v_part));
-    pc.in[1] = vd[c0].data; pc.out[1] = v_part; pc.width[1] = w; pc.n = 2;
+  std::vector<unsigned char*> v_part(ncolpass, nullptr);
+  for (size_t i = 0; i < used.size(); i++) {
+    const int w = stype_size(vd[used[i]].stype);
+    DTHIP_TRY(sc.get<unsigned char>((size_t)n * w + 64, &v_part[i]));
+    pc.in[pc.n] = vd[used[i]].data; pc.out[pc.n] = v_part[i]; pc.width[pc.n] = w; pc.n++;
   }
   DTHIP_TRY(launch_bucket_partition(ctx, pkx, n, g, P, gtot, kslot, pc, false));
 
-  // partial groups
-  const size_t out_cap = std::min<size_t>((size_t)n, (size_t)max_items * (C + 1));
-  HashAggArgs ha;
-  memset(&ha, 0, sizeof(ha));
-  ha.items = items; ha.nitems = nitems; ha.max_items = max_items; ha.xs = xs_part; ha.val = v_part; ha.vstype = vst;
-  ha.C = C; ha.flags = flags; ha.out_n = d_outn; ha.out_cap = (uint32_t)out_cap; ha.overflow = d_ovf;
-  DTHIP_TRY(sc.get<unsigned long long>(out_cap, &ha.o_key));
-  if (flags & ACC_CNT) DTHIP_TRY(sc.get<uint32_t>(out_cap, &ha.o_tab.cnt));
-  if (flags & ACC_VCNT) DTHIP_TRY(sc.get<uint32_t>(out_cap, &ha.o_tab.vcnt));
-  if (flags & ACC_SUM) DTHIP_TRY(sc.get<unsigned long long>(out_cap, &ha.o_tab.sum));
-  if (flags & ACC_MIN) DTHIP_TRY(sc.get<unsigned long long>(out_cap, &ha.o_tab.mn));
-  if (flags & ACC_MAX) DTHIP_TRY(sc.get<unsigned long long>(out_cap, &ha.o_tab.mx));
-  if (flags & ACC_FSUM) DTHIP_TRY(sc.get<double>(out_cap, &ha.o_tab.fsum));
-  DTHIP_TRY(launch_hash_agg(ctx, ha));
-  uint32_t hn[2] = {0, 0};
-  DTHIP_TRY(read_back(ctx, hn, d_outn, sizeof(hn)));       // {number of partial groups, overflow bits}
-  if (hn[1]) return DTHIP_NOT_APPLICABLE;                    // a table filled up: the sort path takes over
-  const int64_t np = hn[0];
+  int64_t ng_all = -1;
+  for (int i = 0; i < ncolpass; i++) {
+    Scratch sci(ctx);                        // this column's partial groups
+    const int c0 = used.empty() ? -1 : used[i];
+    const int vst = c0 >= 0 ? vd[c0].stype : DTHIP_INT32;
+    const int flags = cflags[i];
+    const uint32_t C = cC[i];
+    DTHIP_CHECK_HIP(hipMemsetAsync(d_outn, 0, 2 * sizeof(uint32_t), ctx->stream));
+    // partial groups
+    const size_t out_cap = std::min<size_t>((size_t)n, (size_t)max_items * (C + 1));
+    HashAggArgs ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.items = items; ha.nitems = nitems; ha.max_items = max_items; ha.xs = xs_part; ha.val = v_part[i]; ha.vstype = vst;
+    ha.C = C; ha.flags = flags; ha.out_n = d_outn; ha.out_cap = (uint32_t)out_cap; ha.overflow = d_ovf;
+    DTHIP_TRY(sci.get<unsigned long long>(out_cap, &ha.o_key));
+    if (flags & ACC_CNT) DTHIP_TRY(sci.get<uint32_t>(out_cap, &ha.o_tab.cnt));
+    if (flags & ACC_VCNT) DTHIP_TRY(sci.get<uint32_t>(out_cap, &ha.o_tab.vcnt));
+    if (flags & ACC_SUM) DTHIP_TRY(sci.get<unsigned long long>(out_cap, &ha.o_tab.sum));
+    if (flags & ACC_MIN) DTHIP_TRY(sci.get<unsigned long long>(out_cap, &ha.o_tab.mn));
+    if (flags & ACC_MAX) DTHIP_TRY(sci.get<unsigned long long>(out_cap, &ha.o_tab.mx));
+    if (flags & ACC_FSUM) DTHIP_TRY(sci.get<double>(out_cap, &ha.o_tab.fsum));
+    DTHIP_TRY(launch_hash_agg(ctx, ha));
+    uint32_t hn[2] = {0, 0};
+    DTHIP_TRY(read_back(ctx, hn, d_outn, sizeof(hn)));       // {number of partial groups, overflow bits}
+    if (hn[1]) return DTHIP_NOT_APPLICABLE;                    // a table filled up: the sort path takes over
+    const int64_t np = hn[0];
 
-  // typed columns of the partial groups
-  std::vector<dthip_col> k2(nkeys);
-  for (int k = 0; k < nkeys; k++) {
-    unsigned char* b = nullptr;
-    DTHIP_TRY(sc.get<unsigned char>((size_t)np * stype_size(kd[k].stype) + 16, &b));
-    DTHIP_TRY(launch_untransform_keys(ctx, ha.o_key, 1, nullptr, np, plan.col[k], plan.nsig[k], b));
-    k2[k] = kd[k];
-    k2[k].data = b;
-  }
-  const bool isf = stype_is_float(vst);
-  PartialColsArgs pa;
-  memset(&pa, 0, sizeof(pa));
-  pa.tab = ha.o_tab; pa.n = (uint32_t)np; pa.vstype = vst;
-  std::vector<dthip_col> v2;
-  std::vector<dthip_agg> a2;
-  int iSUM = -1, iFSUM = -1, iMIN = -1, iMAX = -1, iVCNT = -1, iCNT = -1;
-  // partial SUMS are merged with DTHIP_FLAG_NONA: a partial that is NaN (inf - inf) or wrapped to INT64_MIN is a value
-  auto add_col = [&](void* data, int st, int op) { v2.push_back(dthip_col{data, st, op == DTHIP_SUM ? DTHIP_FLAG_NONA : 0}); a2.push_back(dthip_agg{op, (int32_t)v2.size() - 1}); return (int)a2.size() - 1; };
-  if (flags & ACC_SUM) { DTHIP_TRY(sc.get<unsigned long long>((size_t)np + 2, &pa.o_sum)); iSUM = add_col(pa.o_sum, isf ? DTHIP_FLOAT64 : DTHIP_INT64, DTHIP_SUM); }
-  if (flags & ACC_FSUM) { DTHIP_TRY(sc.get<double>((size_t)np + 2, &pa.o_fsum)); iFSUM = add_col(pa.o_fsum, DTHIP_FLOAT64, DTHIP_SUM); }
-  if (flags & ACC_MIN) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)np * 8 + 16, &b)); pa.o_min = b; iMIN = add_col(b, vst, DTHIP_MIN); }
-  if (flags & ACC_MAX) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)np * 8 + 16, &b)); pa.o_max = b; iMAX = add_col(b, vst, DTHIP_MAX); }
-  if (flags & ACC_VCNT) { DTHIP_TRY(sc.get<int64_t>((size_t)np + 2, &pa.o_vcnt)); iVCNT = add_col(pa.o_vcnt, DTHIP_INT64, DTHIP_SUM); }
-  if (flags & ACC_CNT) { DTHIP_TRY(sc.get<int64_t>((size_t)np + 2, &pa.o_cnt)); iCNT = add_col(pa.o_cnt, DTHIP_INT64, DTHIP_SUM); }
-  DTHIP_TRY(launch_partial_columns(ctx, pa));
+    // typed columns of the partial groups
+    std::vector<dthip_col> k2(nkeys);
+    for (int k = 0; k < nkeys; k++) {
+      unsigned char* bb = nullptr;
+      DTHIP_TRY(sci.get<unsigned char>((size_t)np * stype_size(kd[k].stype) + 16, &bb));
+      DTHIP_TRY(launch_untransform_keys(ctx, ha.o_key, 1, nullptr, np, plan.col[k], plan.nsig[k], bb));
+      k2[k] = kd[k];
+      k2[k].data = bb;
+    }
+    const bool isf = stype_is_float(vst);
+    PartialColsArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.tab = ha.o_tab; pa.n = (uint32_t)np; pa.vstype = vst;
+    std::vector<dthip_col> v2;
+    std::vector<dthip_agg> a2;
+    int iSUM = -1, iFSUM = -1, iMIN = -1, iMAX = -1, iVCNT = -1, iCNT = -1;
+    // partial SUMS are merged with DTHIP_FLAG_NONA: a partial that is NaN (inf - inf) or wrapped to INT64_MIN is a value
+    auto add_col = [&](void* data, int st, int op) { v2.push_back(dthip_col{data, st, op == DTHIP_SUM ? DTHIP_FLAG_NONA : 0}); a2.push_back(dthip_agg{op, (int32_t)v2.size() - 1}); return (int)a2.size() - 1; };
+    if (flags & ACC_SUM) { DTHIP_TRY(sci.get<unsigned long long>((size_t)np + 2, &pa.o_sum)); iSUM = add_col(pa.o_sum, isf ? DTHIP_FLOAT64 : DTHIP_INT64, DTHIP_SUM); }
+    if (flags & ACC_FSUM) { DTHIP_TRY(sci.get<double>((size_t)np + 2, &pa.o_fsum)); iFSUM = add_col(pa.o_fsum, DTHIP_FLOAT64, DTHIP_SUM); }
+    if (flags & ACC_MIN) { unsigned char* bb = nullptr; DTHIP_TRY(sci.get<unsigned char>((size_t)np * 8 + 16, &bb)); pa.o_min = bb; iMIN = add_col(bb, vst, DTHIP_MIN); }
+    if (flags & ACC_MAX) { unsigned char* bb = nullptr; DTHIP_TRY(sci.get<unsigned char>((size_t)np * 8 + 16, &bb)); pa.o_max = bb; iMAX = add_col(bb, vst, DTHIP_MAX); }
+    if (flags & ACC_VCNT) { DTHIP_TRY(sci.get<int64_t>((size_t)np + 2, &pa.o_vcnt)); iVCNT = add_col(pa.o_vcnt, DTHIP_INT64, DTHIP_SUM); }
+    if (flags & ACC_CNT) { DTHIP_TRY(sci.get<int64_t>((size_t)np + 2, &pa.o_cnt)); iCNT = add_col(pa.o_cnt, DTHIP_INT64, DTHIP_SUM); }
+    DTHIP_TRY(launch_partial_columns(ctx, pa));
 
-  // merge: the ordinary path on the partial groups (few rows), keys in their own stypes and flags
-  dthip_result* r2 = nullptr;
-  const int saved_off = ctx->agg_offsets;
-  ctx->in_merge = true; ctx->agg_offsets = 0;
-  int rc = dthip_groupby_agg(ctx, k2.data(), nkeys, v2.empty() ? nullptr : v2.data(), (int)v2.size(),
-                             a2.empty() ? nullptr : a2.data(), (int)a2.size(), np, na_pos, DTHIP_DEVICE, &r2);
-  ctx->in_merge = false; ctx->agg_offsets = saved_off;
-  if (rc != DTHIP_OK) return rc;
-  const int64_t ng = dthip_result_ngroups(r2);
-  res->nrows = n; res->ngroups = ng;
-  do {
-    for (int k = 0; k < nkeys && rc == DTHIP_OK; k++) {
-      void* kp = nullptr;
-      const size_t bytes = (size_t)ng * stype_size(kd[k].stype);
-      if ((rc = result_alloc(ctx, res, bytes, &kp)) != DTHIP_OK) break;
-      res->key[k] = kp;
-      if (bytes && hipMemcpyAsync(kp, dthip_result_key(r2, k), bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { set_error("D2D copy failed"); rc = DTHIP_EDEVICE; }
-    }
-    if (rc != DTHIP_OK) break;
-    if (need_cnt) {
-      void* off = nullptr;
-      if ((rc = result_alloc(ctx, res, sizeof(int32_t) * ((size_t)ng + 2 + (size_t)ng / 8192 + 1), &off)) != DTHIP_OK) break;
-      if ((rc = launch_narrow_i64_u32(ctx, static_cast<const long long*>(dthip_result_agg(r2, iCNT)), ng, static_cast<uint32_t*>(off))) != DTHIP_OK) break;
-      if ((rc = launch_scan_tiles(ctx, static_cast<uint32_t*>(off), (uint32_t)ng, static_cast<uint32_t*>(off) + ng)) != DTHIP_OK) break;
-      res->offsets = static_cast<int32_t*>(off);
-    }
-    for (int a = 0; a < naggs && rc == DTHIP_OK; a++) {
-      void* ap = nullptr;
-      const size_t bytes = (size_t)ng * stype_size(res->agg_stype[a]);
-      if ((rc = result_alloc(ctx, res, bytes, &ap)) != DTHIP_OK) break;
-      res->agg[a] = ap;
-      if (ng == 0) continue;
-      const void* src = nullptr;
-      switch (aggs[a].op) {
-        case DTHIP_SUM:
-          if (vst == DTHIP_FLOAT32) rc = launch_cast_f64_f32(ctx, static_cast<const double*>(dthip_result_agg(r2, iSUM)), ng, static_cast<float*>(ap));
-          else src = dthip_result_agg(r2, iSUM);
-          break;
-        case DTHIP_MEAN:
-          rc = launch_mean_div(ctx, static_cast<const double*>(dthip_result_agg(r2, isf ? iSUM : iFSUM)),
-                               static_cast<const long long*>(dthip_result_agg(r2, iVCNT)), ng, ap, vst == DTHIP_FLOAT32);
-          break;
-        case DTHIP_MIN: src = dthip_result_agg(r2, iMIN); break;
-        case DTHIP_MAX: src = dthip_result_agg(r2, iMAX); break;
-        case DTHIP_COUNT: src = dthip_result_agg(r2, iVCNT); break;
-        default: src = dthip_result_agg(r2, iCNT); break;      // COUNT0
+    // merge: the ordinary path on the partial groups (few rows), keys in their own stypes and flags
+    dthip_result* r2 = nullptr;
+    const int saved_off = ctx->agg_offsets;
+    ctx->in_merge = true; ctx->agg_offsets = 0;
+    int rc = dthip_groupby_agg(ctx, k2.data(), nkeys, v2.empty() ? nullptr : v2.data(), (int)v2.size(),
+                               a2.empty() ? nullptr : a2.data(), (int)a2.size(), np, na_pos, DTHIP_DEVICE, &r2);
+    ctx->in_merge = false; ctx->agg_offsets = saved_off;
+    if (rc != DTHIP_OK) return rc;
+    const int64_t ng = dthip_result_ngroups(r2);
+    if (ng_all >= 0 && ng != ng_all) { dthip_result_free(ctx, r2); set_error("hash combiner: columns disagree on the number of groups"); return DTHIP_EDEVICE; }
+    ng_all = ng;
+    res->nrows = n; res->ngroups = ng;
+    do {
+      if (i == 0) {
+        for (int k = 0; k < nkeys && rc == DTHIP_OK; k++) {
+          void* kp = nullptr;
+          const size_t bytes = (size_t)ng * stype_size(kd[k].stype);
+          if ((rc = result_alloc(ctx, res, bytes, &kp)) != DTHIP_OK) break;
+          res->key[k] = kp;
+          if (bytes && hipMemcpyAsync(kp, dthip_result_key(r2, k), bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { set_error("D2D copy failed"); rc = DTHIP_EDEVICE; }
+        }
+        if (rc != DTHIP_OK) break;
+        if (need_cnt) {
+          void* off = nullptr;
+          if ((rc = result_alloc(ctx, res, sizeof(int32_t) * ((size_t)ng + 2 + (size_t)ng / 8192 + 1), &off)) != DTHIP_OK) break;
+          if ((rc = launch_narrow_i64_u32(ctx, static_cast<const long long*>(dthip_result_agg(r2, iCNT)), ng, static_cast<uint32_t*>(off))) != DTHIP_OK) break;
+          if ((rc = launch_scan_tiles(ctx, static_cast<uint32_t*>(off), (uint32_t)ng, static_cast<uint32_t*>(off) + ng)) != DTHIP_OK) break;
+          res->offsets = static_cast<int32_t*>(off);
+        }
       }
-      if (rc == DTHIP_OK && src && hipMemcpyAsync(ap, src, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { set_error("D2D copy failed"); rc = DTHIP_EDEVICE; }
-    }
-  } while (0);
-  dthip_result_free(ctx, r2);
-  return rc;
+      for (int a = 0; a < naggs && rc == DTHIP_OK; a++) {
+        // this pass fills the aggregates of its own column; count() (no column) goes with the first pass
+        const bool mine = aggs[a].op == DTHIP_COUNT0 ? i == 0 : aggs[a].col == c0;
+        if (!mine) continue;
+        void* ap = nullptr;
+        const size_t bytes = (size_t)ng * stype_size(res->agg_stype[a]);
+        if ((rc = result_alloc(ctx, res, bytes, &ap)) != DTHIP_OK) break;
+        res->agg[a] = ap;
+        if (ng == 0) continue;
+        const void* src = nullptr;
+        switch (aggs[a].op) {
+          case DTHIP_SUM:
+            if (vst == DTHIP_FLOAT32) rc = launch_cast_f64_f32(ctx, static_cast<const double*>(dthip_result_agg(r2, iSUM)), ng, static_cast<float*>(ap));
+            else src = dthip_result_agg(r2, iSUM);
+            break;
+          case DTHIP_MEAN:
+            rc = launch_mean_div(ctx, static_cast<const double*>(dthip_result_agg(r2, isf ? iSUM : iFSUM)),
+                                 static_cast<const long long*>(dthip_result_agg(r2, iVCNT)), ng, ap, vst == DTHIP_FLOAT32);
+            break;
+          case DTHIP_MIN: src = dthip_result_agg(r2, iMIN); break;
+          case DTHIP_MAX: src = dthip_result_agg(r2, iMAX); break;
+          case DTHIP_COUNT: src = dthip_result_agg(r2, iVCNT); break;
+          default: src = dthip_result_agg(r2, iCNT); break;      // COUNT0
+        }
+        if (rc == DTHIP_OK && src && hipMemcpyAsync(ap, src, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { set_error("D2D copy failed"); rc = DTHIP_EDEVICE; }
+      }
+    } while (0);
+    dthip_result_free(ctx, r2);
+    if (rc != DTHIP_OK) return rc;
+  }
+  return DTHIP_OK;
 }
 
 }  // namespace dthip

@@ -114,7 +114,7 @@ def _vs_oracle(ctx, keys, vals, aggs=OPS, key_stypes=None, check_ri=True):
         assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count()" + tag)
         r.free()
     # sparse key ranges: the hash combiner (LDS hash tables -> partial groups -> merge), forced on
-    # (takes effect where the bucketed path does not apply and there is at most one value column)
+    # (takes effect where the bucketed path does not apply; several value columns: one pass of hash tables per column)
     ctx.set_option("hash_mode", 2)
     try:
         r = ctx.groupby_agg(keys, vals, alist, key_stypes=key_stypes)
