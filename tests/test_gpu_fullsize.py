@@ -93,6 +93,17 @@ def test_c3_hard_keys(ctx):
     check_fused(ctx, [k], [v], ("sum", "count"))
 
 
+def test_c3_hard_keys_two_value_columns(ctx):
+    """the hash combiner with several value columns (one partition, one pass of hash tables + merge per column)"""
+    rng = np.random.default_rng(1234 + 7)
+    n = N // 2
+    pool = rng.integers(-2**62, 2**62, 3_000_000, dtype=np.int64)
+    k = pool[rng.integers(0, len(pool), n)]
+    v = rng.standard_normal(n)
+    w = rng.integers(-1000, 1000, n).astype(np.int64)
+    check_fused(ctx, [k], [v, w], ("sum",))
+
+
 def test_c4_two_keys(ctx):
     rng = np.random.default_rng(1234 + 4)
     n = N
