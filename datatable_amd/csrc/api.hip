@@ -837,28 +837,60 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   }
   if (ctx->hash_mode != 2 && n < (1 << 22)) return DTHIP_NOT_APPLICABLE;
   const bool need_cnt = bucket_need_counts(ctx, aggs, naggs);
-  const int ncolpass = used.empty() ? 1 : (int)used.size();      // passes of hash tables (one with no value column at all)
-  std::vector<int> cflags(ncolpass);
-  std::vector<uint32_t> cC(ncolpass);
-  uint32_t Cmin = ~0u;
-  for (int i = 0; i < ncolpass; i++) {
-    const int c = used.empty() ? -1 : used[i];
-    cflags[i] = (c >= 0 ? acc_flags_for(aggs, naggs, c, vd[c].stype) : 0) | ((need_cnt && i == 0) ? ACC_CNT : 0);
-    const size_t entry = hash_agg_entry_bytes(cflags[i]);
+  const uint32_t F = 1u << (HASH_PK_BITS - HASH_R);
+  double est = 0;
+  DTHIP_TRY(estimate_distinct(ctx, kd, nkeys, n, na_pos, &est));
+  // Passes of hash tables: (payload column, accumulator set).  A column's accumulators share one pass when an entry
+  // (8-byte key + accumulators) is small enough for 2048 tables of load <= 0.75 to hold the estimated distinct keys;
+  // otherwise they are split into {sum / mean / count}, {min}, {max} passes over the same partitioned rows.
+  struct HPass { int col; int slot; int flags; uint32_t C; };
+  auto table_entries = [](int flags) {
+    const size_t entry = hash_agg_entry_bytes(flags);
     uint32_t C = (uint32_t)((158 * 1024) / entry) - 1;                // the whole LDS of a CU for one table ...
     for (;; C--) {                                                     // ... with a prime number of entries (double hashing)
       bool prime = C % 2 != 0;
       for (uint32_t q = 3; prime && q * q <= C; q += 2) prime = C % q != 0;
       if (prime) break;
     }
-    cC[i] = C;
-    Cmin = std::min(Cmin, C);
+    return C;
+  };
+  auto fits = [&](int flags) { return est * 1.05 <= 0.75 * (double)F * (double)table_entries(flags); };
+  std::vector<HPass> passes;
+  std::vector<int> agg_pass(naggs, 0);           // which pass computes aggregate a (count() rides with pass 0)
+  if (used.empty()) {
+    passes.push_back(HPass{-1, -1, need_cnt ? ACC_CNT : 0, 0});
+  } else {
+    for (size_t i = 0; i < used.size(); i++) {
+      const int c = used[i];
+      const int fl = acc_flags_for(aggs, naggs, c, vd[c].stype);
+      const int first = (need_cnt && passes.empty()) ? ACC_CNT : 0;
+      if (fits(fl | first)) {
+        for (int a = 0; a < naggs; a++) if (aggs[a].op != DTHIP_COUNT0 && aggs[a].col == c) agg_pass[a] = (int)passes.size();
+        passes.push_back(HPass{c, (int)i, fl | first, 0});
+        continue;
+      }
+      // split: {sum / mean / count}, {min}, {max}; min and max keep the valid count their NA rule needs
+      bool want[3] = {false, false, false};
+      for (int a = 0; a < naggs; a++) {
+        if (aggs[a].op == DTHIP_COUNT0 || aggs[a].col != c) continue;
+        want[aggs[a].op == DTHIP_MIN ? 1 : aggs[a].op == DTHIP_MAX ? 2 : 0] = true;
+      }
+      const int parts[3] = {fl & (ACC_SUM | ACC_FSUM | ACC_VCNT), ACC_MIN | ACC_VCNT, ACC_MAX | ACC_VCNT};
+      for (int q = 0; q < 3; q++) {
+        if (!want[q]) continue;
+        const int f2 = parts[q] | ((need_cnt && passes.empty()) ? ACC_CNT : 0);
+        if (!fits(f2)) return DTHIP_NOT_APPLICABLE;
+        for (int a = 0; a < naggs; a++) {
+          if (aggs[a].op == DTHIP_COUNT0 || aggs[a].col != c) continue;
+          if ((aggs[a].op == DTHIP_MIN ? 1 : aggs[a].op == DTHIP_MAX ? 2 : 0) == q) agg_pass[a] = (int)passes.size();
+        }
+        passes.push_back(HPass{c, (int)i, f2, 0});
+      }
+    }
   }
-  const uint32_t F = 1u << (HASH_PK_BITS - HASH_R);
-  double est = 0;
-  DTHIP_TRY(estimate_distinct(ctx, kd, nkeys, n, na_pos, &est));
-  if (est * 1.05 > 0.75 * (double)F * (double)Cmin) return DTHIP_NOT_APPLICABLE;      // expected load factor <= 0.75
-
+  for (auto& hp : passes) hp.C = table_entries(hp.flags);
+  if (!fits(passes[0].flags)) return DTHIP_NOT_APPLICABLE;
+  const int ncolpass = (int)passes.size();
   KeyXform kx;
   memset(&kx, 0, sizeof(kx));
   kx.ncols = nkeys;
@@ -909,7 +941,7 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   PayCols pc;
   memset(&pc, 0, sizeof(pc));
   pc.in[0] = xs; pc.out[0] = xs_part; pc.width[0] = 8; pc.n = 1;
-  std::vector<unsigned char*> v_part(ncolpass, nullptr);
+  std::vector<unsigned char*> v_part(std::max<size_t>(used.size(), 1), nullptr);
   for (size_t i = 0; i < used.size(); i++) {
     const int w = stype_size(vd[used[i]].stype);
     DTHIP_TRY(sc.get<unsigned char>((size_t)n * w + 64, &v_part[i]));
@@ -919,17 +951,17 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
 
   int64_t ng_all = -1;
   for (int i = 0; i < ncolpass; i++) {
-    Scratch sci(ctx);                        // this column's partial groups
-    const int c0 = used.empty() ? -1 : used[i];
+    Scratch sci(ctx);                        // this pass's partial groups
+    const int c0 = passes[i].col;
     const int vst = c0 >= 0 ? vd[c0].stype : DTHIP_INT32;
-    const int flags = cflags[i];
-    const uint32_t C = cC[i];
+    const int flags = passes[i].flags;
+    const uint32_t C = passes[i].C;
     DTHIP_CHECK_HIP(hipMemsetAsync(d_outn, 0, 2 * sizeof(uint32_t), ctx->stream));
     // partial groups
     const size_t out_cap = std::min<size_t>((size_t)n, (size_t)max_items * (C + 1));
     HashAggArgs ha;
     memset(&ha, 0, sizeof(ha));
-    ha.items = items; ha.nitems = nitems; ha.max_items = max_items; ha.xs = xs_part; ha.val = v_part[i]; ha.vstype = vst;
+    ha.items = items; ha.nitems = nitems; ha.max_items = max_items; ha.xs = xs_part; ha.val = c0 >= 0 ? v_part[passes[i].slot] : nullptr; ha.vstype = vst;
     ha.C = C; ha.flags = flags; ha.out_n = d_outn; ha.out_cap = (uint32_t)out_cap; ha.overflow = d_ovf;
     DTHIP_TRY(sci.get<unsigned long long>(out_cap, &ha.o_key));
     if (flags & ACC_CNT) DTHIP_TRY(sci.get<uint32_t>(out_cap, &ha.o_tab.cnt));
@@ -1001,8 +1033,8 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
         }
       }
       for (int a = 0; a < naggs && rc == DTHIP_OK; a++) {
-        // this pass fills the aggregates of its own column; count() (no column) goes with the first pass
-        const bool mine = aggs[a].op == DTHIP_COUNT0 ? i == 0 : aggs[a].col == c0;
+        // this pass fills the aggregates assigned to it; count() (no column) goes with the first pass
+        const bool mine = aggs[a].op == DTHIP_COUNT0 ? i == 0 : agg_pass[a] == i;
         if (!mine) continue;
         void* ap = nullptr;
         const size_t bytes = (size_t)ng * stype_size(res->agg_stype[a]);
