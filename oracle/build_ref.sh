@@ -9,7 +9,7 @@
 # copied to a scratch directory OUTSIDE the repo, built there with the reference's own driver
 # (`python ci/ext.py build`, ci/ext.py:209-330: g++ -std=c++14 -O3, 327 TUs, no third-party
 # dependencies), and only the OUTPUTS are placed under oracle/_ref/:
-#     oracle/_ref/datatable/                 the Python package of the build (src/datatable)
+#     oracle/_ref/datatable/                 the Python package of the build (src/datatable) as sourceless .pyc files
 #     oracle/_ref/datatable/lib/_datatable*.so   stripped (82 MB -> ~8 MB)
 # oracle/_ref/ is git-ignored (no reference sources enter the history) but NOT gpurun-ignored: it
 # travels to the GPU box like libdthip.so does.
@@ -44,9 +44,13 @@ fi
 SO=$(ls src/datatable/lib/_datatable*.so | head -1)
 
 rm -rf "$OUT"; mkdir -p "$OUT"
-# the package (python sources of the BUILD, incl. the generated _build_info.py) -- outputs only, git-ignored
-(cd src && find datatable -name __pycache__ -prune -o -type f \( -name '*.py' -o -name '*.h' \) -print0 | \
-   xargs -0 -I{} cp --parents {} "$OUT"/)
+# the package as BUILD OUTPUTS only: the Python modules (incl. the generated _build_info.py) are byte-compiled into
+# sourceless .pyc files (importable in place of the .py: same interpreter here and on the GPU box) and the sources are
+# removed again, so that oracle/_ref holds no reference source text at all -- just the stripped .so and bytecode
+(cd src && find datatable -name __pycache__ -prune -o -type f -name '*.py' -print0 | xargs -0 -I{} cp --parents {} "$OUT"/)
+python -m compileall -b -q "$OUT/datatable" > /dev/null
+find "$OUT/datatable" -name '*.py' -delete
+find "$OUT/datatable" -name __pycache__ -prune -exec rm -rf {} + 2>/dev/null || true
 cp "$SO" "$OUT/datatable/lib/"
 strip --strip-unneeded "$OUT/datatable/lib/$(basename "$SO")"
 # provenance: what was built from what
