@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <rccl/rccl.h>
 #include "common.hpp"
+#include "split_plan.hpp"
 
 struct dthip_comm {
   int kind = 0;                       // 0: RCCL, 1: local (one process holds every rank)
@@ -114,7 +115,6 @@ __device__ __forceinline__ u64 key_image(const void* data, int stype, uint32_t i
   }
 }
 
-struct RangeAcc { u64 lo, hi, nvalid; };   // lo starts at ~0, hi at 0
 
 // grid-stride; one set of global atomics per workgroup (every wave hitting the same three addresses cost 5 ms per 1e7 keys)
 __global__ void __launch_bounds__(256) key_image_kernel(const void* data, int stype, uint32_t n, u64 na_img, u64* img, RangeAcc* acc) {
@@ -143,7 +143,6 @@ __global__ void __launch_bounds__(256) key_image_kernel(const void* data, int st
   }
 }
 
-constexpr int SPLIT_BINS = 4096;
 
 // histogram of the valid images over [gmin, gmax] in SPLIT_BINS bins of 2^shift
 __global__ void __launch_bounds__(256) image_hist_kernel(const u64* img, uint32_t n, u64 na_img, u64 gmin, int shift, u64* hist) {
@@ -312,20 +311,10 @@ static int phase_images(Job& j, const void* key0, int stype, int64_t n, int na_p
   return DTHIP_OK;
 }
 
-struct GlobalRange { u64 gmin, gmax, nvalid; int shift; };
-
 static GlobalRange reduce_ranges(const Job& j, int world) {
-  GlobalRange g{~0ULL, 0ULL, 0ULL, 0};
-  for (int r = 0; r < world; r++) {
-    RangeAcc a;
-    memcpy(&a, j.xout.data() + (size_t)r * sizeof(RangeAcc), sizeof(RangeAcc));
-    if (a.nvalid) { g.gmin = std::min(g.gmin, a.lo); g.gmax = std::max(g.gmax, a.hi); g.nvalid += a.nvalid; }
-  }
-  if (g.nvalid == 0) { g.gmin = 1; g.gmax = 1; }
-  const u64 width = g.gmax - g.gmin;
-  int bits = 0; for (u64 w = width; w; w >>= 1) bits++;
-  g.shift = bits > 12 ? bits - 12 : 0;          // (width >> shift) < 4096
-  return g;
+  std::vector<RangeAcc> r(world);
+  memcpy(r.data(), j.xout.data(), sizeof(RangeAcc) * (size_t)world);
+  return reduce_key_ranges(r.data(), world);
 }
 
 static int phase_hist(Job& j, const GlobalRange& g) {
@@ -342,25 +331,9 @@ static int phase_hist(Job& j, const GlobalRange& g) {
   return DTHIP_OK;
 }
 
-// world-1 ascending boundary images from the summed histogram: images < bounds[j] belong to ranks <= j
+// world-1 ascending boundary images from the summed histogram (split_plan.hpp)
 static void splitters(Job& j, const GlobalRange& g, int world) {
-  std::vector<u64> h(SPLIT_BINS, 0);
-  for (int r = 0; r < world; r++) {
-    const u64* hr = reinterpret_cast<const u64*>(j.xout.data() + (size_t)r * sizeof(u64) * SPLIT_BINS);
-    for (int b = 0; b < SPLIT_BINS; b++) h[b] += hr[b];
-  }
-  u64 total = 0;
-  for (int b = 0; b < SPLIT_BINS; b++) total += h[b];
-  j.bounds.assign(world > 1 ? world - 1 : 0, ~0ULL);
-  if (total == 0) return;
-  u64 cum = 0; int b = 0;
-  for (int k = 1; k < world; k++) {
-    const u64 target = (u64)(((unsigned __int128)total * (unsigned)k) / (unsigned)world);
-    while (b < SPLIT_BINS && cum + h[b] <= target) { cum += h[b]; b++; }
-    // bins [0, b) hold <= target rows: boundary = start of bin b
-    const unsigned __int128 edge = (unsigned __int128)g.gmin + ((unsigned __int128)(u64)b << g.shift);
-    j.bounds[k - 1] = edge >= (unsigned __int128)~0ULL ? ~0ULL - 1 : (u64)edge;
-  }
+  split_bounds(reinterpret_cast<const u64*>(j.xout.data()), world, g, &j.bounds);
 }
 
 static void layout_from_counts(Job& j, int world) {

@@ -1,0 +1,104 @@
+"""Host logic of the multi-GPU key-range partition (datatable_amd/csrc/split_plan.hpp: global key range, histogram bin
+width, splitters at the world-quantiles of the summed 4096-bin histogram), compiled with g++ and driven on the CPU:
+boundaries ascend, NA images fall on rank 0 (or the last rank when NAs sort last) by themselves, no rank before the
+k-th boundary holds more than k / world of the valid keys, every rank's share stays within one histogram bin of its
+fair share, extreme ranges (full 64 bits, a single value, no valid key) are handled."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("sp") / "libsplitplan.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Werror",
+                           os.path.join(ROOT, "tests", "cpp", "split_plan_harness.cpp"), "-o", so])
+    L = C.CDLL(so)
+    L.sp_bounds.restype = C.c_int
+    return L
+
+
+def plan(lib, imgs, world, na_img=0, uneven=True, seed=0):
+    imgs = np.ascontiguousarray(imgs, np.uint64)
+    n = len(imgs)
+    rng = np.random.default_rng(seed)
+    cuts = np.array([0] + sorted(rng.integers(0, n + 1, world - 1).tolist()) + [n] if uneven else
+                    [r * n // world for r in range(world + 1)], np.int64)
+    bounds = np.zeros(max(world - 1, 1), np.uint64)
+    shift, gmin = C.c_int(0), C.c_ulonglong(0)
+    rc = lib.sp_bounds(imgs.ctypes.data_as(C.c_void_p), cuts.ctypes.data_as(C.c_void_p), world, C.c_ulonglong(na_img),
+                       bounds.ctypes.data_as(C.c_void_p), C.byref(shift), C.byref(gmin))
+    assert rc == 0
+    return bounds[:world - 1], shift.value, gmin.value
+
+
+def dest(bounds, imgs):
+    return np.searchsorted(bounds, imgs, side="right")          # number of boundaries <= image
+
+
+def image_i64(k):
+    return (k.astype(np.int64).view(np.uint64)) ^ np.uint64(1 << 63)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 127])
+@pytest.mark.parametrize("kind", ["uniform", "skew", "wide", "clustered"])
+def test_splitters_balance(lib, world, kind):
+    rng = np.random.default_rng(world * 7 + len(kind))
+    n = 200_000
+    if kind == "uniform":
+        k = rng.integers(-10**6, 10**6, n)
+    elif kind == "skew":
+        k = (rng.random(n) ** 8 * 1e12).astype(np.int64)
+    elif kind == "wide":
+        k = rng.integers(-2**62, 2**62, n)
+    else:
+        k = np.concatenate([rng.integers(0, 1000, n // 2), rng.integers(10**15, 10**15 + 1000, n - n // 2)])
+    img = image_i64(k)
+    na = rng.random(n) < 0.02
+    img[na] = 0                                                  # NA image (NA first)
+    bounds, shift, gmin = plan(lib, img, world, na_img=0, seed=world)
+    assert len(bounds) == world - 1
+    assert np.all(bounds[1:] >= bounds[:-1]), "boundaries must ascend"
+    d = dest(bounds, img)
+    assert np.all(d[na] == 0), "NA keys (smallest image) belong to rank 0"
+    valid = img[~na]
+    total = len(valid)
+    # heaviest histogram bin: the granularity the splitters cannot go below
+    bins = ((valid - np.uint64(gmin)) >> np.uint64(shift)).astype(np.int64)
+    heavy = np.bincount(bins, minlength=4096).max()
+    dv = dest(bounds, valid)
+    cum = np.cumsum(np.bincount(dv, minlength=world))
+    for kk in range(1, world):
+        assert cum[kk - 1] <= total * kk // world, "ranks < %d hold more than their share" % kk
+        assert cum[kk - 1] >= total * kk // world - heavy, "ranks < %d are short by more than one bin" % kk
+    # key-range partition: destinations are monotone in the key
+    order = np.argsort(valid, kind="stable")
+    assert np.all(np.diff(dv[order]) >= 0)
+
+
+def test_na_last_and_degenerate_ranges(lib):
+    rng = np.random.default_rng(1)
+    k = rng.integers(0, 1000, 10_000)
+    img = image_i64(k)
+    img[:100] = np.uint64(2**64 - 1)                             # NAs sort last: image ~0
+    bounds, _, _ = plan(lib, img, 4, na_img=2**64 - 1)
+    assert np.all(dest(bounds, img[:100]) == 3), "NA keys go to the last rank when NAs sort last"
+    # one single key value: everything lands on one rank, boundaries stay ordered
+    img = image_i64(np.full(5000, 42))
+    bounds, shift, gmin = plan(lib, img, 8)
+    assert shift == 0 and gmin == int(img[0]) and np.all(bounds[1:] >= bounds[:-1])
+    assert len(np.unique(dest(bounds, img))) == 1
+    # no valid key at all: every boundary is ~0, NA rows (image 0) stay on rank 0
+    img = np.zeros(1000, np.uint64)
+    bounds, _, _ = plan(lib, img, 4)
+    assert np.all(bounds == np.uint64(2**64 - 1)) and np.all(dest(bounds, img) == 0)
+    # the full 64-bit range: shift 52, no overflow of the boundary arithmetic
+    img = np.array([1, 2**63, 2**64 - 2] * 1000, np.uint64)
+    bounds, shift, _ = plan(lib, img, 3)
+    assert shift == 52 and np.all(bounds[1:] >= bounds[:-1])
+    assert sorted(np.bincount(dest(bounds, img), minlength=3).tolist()) == [1000, 1000, 1000]
