@@ -56,3 +56,17 @@ def test_match_groupwise_operators():
     assert shim.match(DT, (slice(None), [datatable.sd(f.v), datatable.cumsum(f.v)], shim.by(f.k))) is None
     assert shim.match(DT, (slice(None), datatable.nunique(f.s), shim.by(f.k))) is None
     assert shim.match(DT, (slice(None), datatable.sd(f.v + 1), shim.by(f.k))) is None
+
+
+def test_reference_thread_settings_are_safe():
+    """oracle/ref.py: sort.nthreads is stored through a uint8_t cast in the reference (sort.cc:337), so 256 would become 0
+    and group() would divide by it (SIGFPE on the 256-thread GPU box): the helper clamps it, and a groupby still works"""
+    from datatable import f, by
+    ref.set_threads(256)
+    try:
+        assert dt.options.sort.nthreads == 255 and dt.options.nthreads >= 1
+        DT = dt.Frame(k=np.arange(100_000) % 1000, v=np.ones(100_000))
+        R = DT[:, dt.sum(f.v), by(f.k)]
+        assert R.nrows == 1000 and R[:, 1].to_numpy().sum() == 100_000
+    finally:
+        ref.set_threads(min(8, __import__("os").cpu_count() or 1))
