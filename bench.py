@@ -2,6 +2,7 @@
 """bench.py -- groupby-sum throughput of the HIP path on MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 5 --warmup 2          (starts its 8 ranks itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -263,6 +264,38 @@ def host_mode_leg(ctx, rows):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the environment
+    torch.distributed.run would have set), pass rank 0's stdout -- the JSON line -- through, and take the whole group
+    down if one rank dies so nobody waits in a collective for a peer that is gone."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DTHIP_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    q.terminate()
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,6 +322,8 @@ def main():
     ap.add_argument("--agg-offsets", type=int, default=0,
                     help="1: the result also carries group sizes (not part of DT[:, sum(f.v), by(f.k)]'s result Frame)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
 
     # stdout carries exactly ONE line, the JSON: gloo and RCCL announce themselves on the C-level stdout (RCCL's banner
     # even after the line, when its buffer is flushed at exit), so fd 1 is pointed at stderr for the whole run and the
@@ -306,7 +341,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run for N>1" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_dist

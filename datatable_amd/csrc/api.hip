@@ -7,6 +7,8 @@
 //                        compute_groupby_and_sort() :249-288, evaluate_select() :497-508
 //   dthip_reduce       ~ FExpr_ReduceUnary::evaluate_n  src/core/expr/fexpr_reduce_unary.cc:32-69
 #include <cstdarg>
+#include <csignal>
+#include <unistd.h>
 #include <algorithm>
 #include "common.hpp"
 
@@ -21,8 +23,102 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- guard-page mode ----------------------------------------------------------
+// The name of the kernel in flight, for the SIGABRT handler: the ROCm runtime reports a GPU memory access fault
+// ("Memory access fault by GPU node-N ...") and aborts; with one synchronised launch at a time the kernel named
+// here is the one that touched the unmapped page.
+static char g_guard_kernel[128] = "(no kernel in flight)";
+static void guard_sigabrt(int) {
+  static const char pre[] = "\n[dthip guard] abort while kernel '";
+  static const char post[] = "' was in flight (a GPU memory access fault above means it touched memory outside its buffers)\n";
+  (void)!write(2, pre, sizeof(pre) - 1);
+  (void)!write(2, g_guard_kernel, strnlen(g_guard_kernel, sizeof(g_guard_kernel)));
+  (void)!write(2, post, sizeof(post) - 1);
+  signal(SIGABRT, SIG_DFL);
+  raise(SIGABRT);
+}
+static void guard_install_handler() {
+  static bool done = false;
+  if (!done) { signal(SIGABRT, guard_sigabrt); done = true; }
+}
+void guard_before_launch(dthip_ctx* ctx, const char* kname) {
+  snprintf(g_guard_kernel, sizeof(g_guard_kernel), "%s", kname);
+  ctx->guard_launches++;
+}
+int guard_after_launch(dthip_ctx* ctx, const char* kname) {
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { set_error("[guard] kernel %s failed: %s", kname, hipGetErrorString(e)); return DTHIP_EDEVICE; }
+  snprintf(g_guard_kernel, sizeof(g_guard_kernel), "(none; last completed: %.90s)", kname);
+  return DTHIP_OK;
+}
+
+static int guard_alloc(dthip_ctx* ctx, size_t bytes, void** out) {
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = ctx->device;
+  size_t gran = 0;
+  DTHIP_CHECK_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+  if (gran == 0) gran = 1 << 21;
+  const size_t want = (std::max<size_t>(bytes, 1) + 15) & ~(size_t)15;      // 16-byte loads are the widest access
+  dthip_ctx::GuardBlock b{};
+  b.map_bytes = (want + gran - 1) / gran * gran;
+  b.va_bytes = b.map_bytes + 2 * gran;                                       // one unmapped granule on either side
+  DTHIP_CHECK_HIP(hipMemAddressReserve(&b.va, b.va_bytes, gran, nullptr, 0));
+  hipError_t e = hipMemCreate(&b.h, b.map_bytes, &prop, 0);
+  if (e != hipSuccess) {
+    (void)hipGetLastError(); (void)hipMemAddressFree(b.va, b.va_bytes);
+    set_error("[guard] hipMemCreate(%zu bytes) failed: %s", b.map_bytes, hipGetErrorString(e));
+    return DTHIP_ENOMEM;
+  }
+  b.map = static_cast<char*>(b.va) + gran;
+  DTHIP_CHECK_HIP(hipMemMap(b.map, b.map_bytes, 0, b.h, 0));
+  hipMemAccessDesc acc{};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  DTHIP_CHECK_HIP(hipMemSetAccess(b.map, b.map_bytes, &acc, 1));
+  // poison: fresh memory is not zero (nor is hipMalloc's), and slack inside the mapping is recognisable
+  static const int poison = getenv("DTHIP_GUARD_POISON") ? atoi(getenv("DTHIP_GUARD_POISON")) : 0xA5;
+  if (poison >= 0) DTHIP_CHECK_HIP(hipMemsetAsync(b.map, poison, b.map_bytes, ctx->stream));
+  void* p = ctx->guard == 2 ? b.map : static_cast<char*>(b.map) + (b.map_bytes - want);
+  ctx->guarded[p] = b;
+  ctx->guard_allocs++;
+  *out = p;
+  return DTHIP_OK;
+}
+
+// DTHIP_GUARD_FREE: 1 (default) a released buffer is unmapped at once (use after release faults too) but its address
+// range stays reserved, so no later buffer ever appears at an address a stale pointer or a stale TLB entry still
+// knows; 2 = the range is given back as well; 0 = released buffers stay mapped until dthip_trim / dthip_destroy
+static int guard_free_mode() {
+  static const int m = getenv("DTHIP_GUARD_FREE") ? atoi(getenv("DTHIP_GUARD_FREE")) : 1;
+  return m;
+}
+static void guard_unmap(const dthip_ctx::GuardBlock& b, bool free_va) {
+  (void)hipMemUnmap(b.map, b.map_bytes);
+  (void)hipMemRelease(b.h);
+  if (free_va) (void)hipMemAddressFree(b.va, b.va_bytes);
+}
+static void guard_free(dthip_ctx* ctx, void* p, bool final = false) {
+  auto it = ctx->guarded.find(p);
+  if (it == ctx->guarded.end()) return;
+  const dthip_ctx::GuardBlock b = it->second;
+  ctx->guarded.erase(it);
+  (void)hipStreamSynchronize(ctx->stream);          // kernels queued on the block must be done before it disappears
+  if (!final && guard_free_mode() == 0) { ctx->guard_limbo.push_back(b); return; }
+  guard_unmap(b, final || guard_free_mode() == 2);
+  if (!(final || guard_free_mode() == 2)) ctx->guard_vas.push_back(b);
+}
+static void guard_trim(dthip_ctx* ctx, bool final) {
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& b : ctx->guard_limbo) { guard_unmap(b, final); if (!final) ctx->guard_vas.push_back(b); }
+  ctx->guard_limbo.clear();
+  if (final) { for (auto& b : ctx->guard_vas) (void)hipMemAddressFree(b.va, b.va_bytes); ctx->guard_vas.clear(); }
+}
+
 // ---- caching device allocator ------------------------------------------------
 int dev_alloc(dthip_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->guard == 1 || ctx->guard == 2) return guard_alloc(ctx, bytes, out);
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes == 0) bytes = 256;
   auto it = ctx->cache.lower_bound(bytes);
@@ -52,6 +148,7 @@ int dev_alloc(dthip_ctx* ctx, size_t bytes, void** out) {
 
 void dev_release(dthip_ctx* ctx, void* p) {
   if (!p) return;
+  if (!ctx->guarded.empty() && ctx->guarded.count(p)) { guard_free(ctx, p); return; }
   auto it = ctx->live.find(p);
   if (it == ctx->live.end()) return;
   ctx->cache.emplace(it->second, p);
@@ -60,6 +157,7 @@ void dev_release(dthip_ctx* ctx, void* p) {
 }
 
 int dev_trim(dthip_ctx* ctx) {
+  if (!ctx->guard_limbo.empty()) guard_trim(ctx, false);
   if (ctx->cache.empty()) return DTHIP_OK;
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->cache) (void)hipFree(kv.second);
@@ -1102,6 +1200,7 @@ int dthip_init(int device, void* stream, dthip_ctx** out) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
   if (const char* e = getenv("DTHIP_AGG_PATH")) ctx->agg_path = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;
   if (const char* e = getenv("DTHIP_BUCKET_VARIANT")) ctx->bucket_variant = atoi(e);
+  if (const char* e = getenv("DTHIP_GUARD")) { const int g = atoi(e); ctx->guard = (g >= 1 && g <= 3) ? g : 0; if (ctx->guard) guard_install_handler(); }
   (void)hipEventCreate(&ctx->t0);
   (void)hipEventCreate(&ctx->t1);
   *out = ctx;
@@ -1116,6 +1215,11 @@ int dthip_destroy(dthip_ctx* ctx) {
   prof_flush(ctx);
   dev_trim(ctx);
   for (auto& kv : ctx->live) (void)hipFree(kv.first);
+  while (!ctx->guarded.empty()) guard_free(ctx, ctx->guarded.begin()->first, true);
+  guard_trim(ctx, true);
+  if (ctx->guard)
+    fprintf(stderr, "[dthip guard] context closed: %lld guarded buffers, %lld synchronised launches, no fault\n",
+            (long long)ctx->guard_allocs, (long long)ctx->guard_launches);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
@@ -1153,6 +1257,13 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
     return DTHIP_OK;
   }
   if (!strcmp(name, "bucket_variant")) { ctx->bucket_variant = (int)value; return DTHIP_OK; }
+  if (!strcmp(name, "guard")) {
+    if (value < 0 || value > 3) { set_error("guard must be 0 (off), 1 (buffer ends on an unmapped page), 2 (buffer starts on one) or 3 (launch tracing only)"); return DTHIP_EINVAL; }
+    dev_trim(ctx);                      // cached blocks of the other flavour are not handed out again
+    ctx->guard = (int)value;
+    if (value) guard_install_handler();
+    return DTHIP_OK;
+  }
   if (!strcmp(name, "spec_min_rows")) { ctx->spec_min_rows = value; return DTHIP_OK; }
   if (!strcmp(name, "agg_offsets")) { ctx->agg_offsets = value != 0; return DTHIP_OK; }
   if (!strcmp(name, "join_table")) { ctx->join_table = value != 0; return DTHIP_OK; }

@@ -17,9 +17,16 @@
 //   * the splitters balance the destinations: a 4096-bin histogram of the order-preserving 64-bit image of the first
 //     key, min-subtracted, summed over all ranks, is cut at the world-quantiles (a plain even split of [min, max]
 //     sends skewed keys to one rank).
-// Collectives per call: 3 small all-gathers (key range 16 B, histogram 32 KB, send counts 8 B x world per rank) and
-// one grouped all-to-all-v over all columns.  xGMI is point-to-point: the grouped send/recv keeps all 7 links of a
-// GPU busy at once.
+// Collectives per call.  Aggregates: the partial groups of a rank are ASCENDING in the first key, so 1024 of them at
+// evenly spaced positions are exact local quantiles: one all-gather of those samples gives every rank the same
+// splitters (no key-image pass, no histogram over the partials), one all-gather carries the send counts, one 16-byte
+// all-gather agrees on the status before the data moves.  Rows: key range (24 B), 4096-bin histogram (32 KB), send
+// counts, status.  Then one grouped all-to-all-v over all columns: xGMI is point-to-point, the grouped send/recv keeps
+// all 7 links of a GPU busy at once.
+// Failure handling: every all-gathered blob starts with {status, query signature, rows}; a rank whose local work failed
+// keeps taking part in the all-gathers (with empty data), and after each of them ALL ranks see the failure and return
+// together -- nobody is left waiting in the next collective for a peer that bailed out (no counterpart in the
+// single-process reference; its errors are C++ exceptions on the one calling thread, sort.cc:672-673).
 //
 // A LOCAL communicator (dthip_comm_init_local) binds `world` contexts of one process -- on any devices, also all on
 // the same one -- and runs exactly the same phases with device-to-device copies as the exchange: it is how the
@@ -93,7 +100,11 @@ static int nccl_load() {
 
 // ---- kernels -------------------------------------------------------------------------------------
 // Order-preserving 64-bit image of a key column's values: ascending integers / floats keep their order, NA maps to
-// `na_img` (0 when the NA group comes first, ~0 when last).  Valid images are never 0 or ~0.
+// `na_img` (0 when the NA group comes first, ~0 when last).  A valid image is never 0 (that would be INT64_MIN, the
+// NA sentinel itself); it IS ~0 for the int64 key INT64_MAX, which therefore counts as "not valid" in the range and
+// the histogram when NAs sort last -- harmless, because the destination of a row depends on its image alone and both
+// images ~0 (INT64_MAX and NA) belong to the last rank, where the local grouping tells them apart again
+// (tests/test_gpu_sharded.py::test_int64_max_next_to_na_last).
 __device__ __forceinline__ u64 key_image(const void* data, int stype, uint32_t i, u64 na_img) {
   switch (stype) {
     case DTHIP_BOOL: case DTHIP_INT8: { const int8_t v = static_cast<const int8_t*>(data)[i]; return v == INT8_MIN ? na_img : ((u64)(long long)v ^ 0x8000000000000000ULL); }
@@ -157,14 +168,20 @@ __global__ void __launch_bounds__(256) image_hist_kernel(const u64* img, uint32_
   for (int b = threadIdx.x; b < SPLIT_BINS; b += 256) if (h[b]) atomicAdd(&hist[b], (u64)h[b]);
 }
 
-// cuts[j] = first position of the ASCENDING image sequence whose image is >= bounds[j]
-__global__ void lower_bound_kernel(const u64* img, uint32_t n, const u64* bounds, int nb, uint32_t* cuts) {
+// cuts[j] = first position of the key column (ASCENDING images) whose image is >= bounds[j]
+__global__ void lower_bound_kernel(const void* data, int stype, uint32_t n, u64 na_img, const u64* bounds, int nb, uint32_t* cuts) {
   const int j = threadIdx.x;
   if (j >= nb) return;
   const u64 b = bounds[j];
   uint32_t lo = 0, hi = n;
-  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (img[mid] < b) lo = mid + 1; else hi = mid; }
+  while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (key_image(data, stype, mid, na_img) < b) lo = mid + 1; else hi = mid; }
   cuts[j] = lo;
+}
+
+// out[i] = image of the key at position floor(i * n / q): the local q-quantiles of an ascending key column
+__global__ void __launch_bounds__(256) sample_image_kernel(const void* data, int stype, uint32_t n, uint32_t q, u64 na_img, u64* out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < q) out[i] = key_image(data, stype, (uint32_t)(((u64)i * n) / q), na_img);
 }
 
 // destination rank of every row: number of boundaries <= image (int8: world <= 127)
@@ -221,7 +238,8 @@ struct Job {
   Scratch* sc = nullptr;
   dthip_result* local = nullptr;       // the local partial result (agg) / the per-destination slabs (rows)
   dthip_result* out = nullptr;
-  int rc = DTHIP_OK;
+  int rc = DTHIP_OK;                   // status of this rank's local work so far (travels in every blob)
+  uint32_t sig = 0;                    // signature of the query this rank was called with
 };
 
 // ---- exchange primitives -------------------------------------------------------------------------
@@ -291,8 +309,42 @@ static int exchange_alltoallv(dthip_comm* comm, std::vector<Job>& jobs) {
   return DTHIP_OK;
 }
 
-// ---- shared phases --------------------------------------------------------------------------------
-// images of the first key of what will be sent + local range; the blob of the first all-gather
+// ---- blobs of the all-gathers: {status, signature, n} + payload ---------------------------------------------------
+static void blob_set(Job& j, long long n, const void* payload, size_t bytes) {
+  j.xin.assign(sizeof(ShardHdr) + bytes, 0);
+  const ShardHdr h{j.rc, j.sig, n};
+  memcpy(j.xin.data(), &h, sizeof(h));
+  if (payload && bytes) memcpy(j.xin.data() + sizeof(h), payload, bytes);
+}
+static const unsigned char* blob_of(const Job& j, int r) { return j.xout.data() + (size_t)r * j.xin.size() + sizeof(ShardHdr); }
+static ShardHdr hdr_of(const Job& j, int r) { ShardHdr h; memcpy(&h, j.xout.data() + (size_t)r * j.xin.size(), sizeof(h)); return h; }
+
+// after an all-gather: did any rank fail so far, do all ranks run the same query?  Every rank sees the same blobs and
+// takes the same decision, so either all go on or all return (the failing rank keeps its own error message).
+static int agree(dthip_comm* comm, std::vector<Job>& jobs, const char* stage) {
+  const Job& j0 = jobs[0];
+  int rank = -1; bool sig_ok = true;
+  const int rc = first_failure(j0.xout.data(), j0.xin.size(), comm->world, &rank, &sig_ok);
+  if (!sig_ok) {
+    set_error("sharded groupby: the ranks were called with different queries (key / value stypes, reducers or na_pos differ)");
+    return DTHIP_EINVAL;
+  }
+  if (rc == DTHIP_OK) return DTHIP_OK;
+  bool mine = false;
+  for (const auto& j : jobs) if (j.rank == rank) mine = true;
+  if (!mine) set_error("sharded groupby: rank %d failed during %s (code %d); every rank returns", rank, stage, rc);
+  return rc;
+}
+
+// one 16-byte all-gather that only agrees on the status (before the data moves)
+static int agree_round(dthip_comm* comm, std::vector<Job>& jobs, const char* stage) {
+  for (auto& j : jobs) blob_set(j, 0, nullptr, 0);
+  DTHIP_TRY(exchange_allgather(comm, jobs));
+  return agree(comm, jobs, stage);
+}
+
+// ---- shared phases (rows) -----------------------------------------------------------------------------
+// images of the first key of the rows + local range; the blob of the first all-gather
 static int phase_images(Job& j, const void* key0, int stype, int64_t n, int na_pos) {
   dthip_ctx* ctx = j.ctx;
   j.na_img = (na_pos == DTHIP_NA_LAST) ? ~0ULL : 0ULL;
@@ -306,48 +358,61 @@ static int phase_images(Job& j, const void* key0, int stype, int64_t n, int na_p
     DTHIP_LAUNCH(ctx, "key_image_kernel", key_image_kernel, (unsigned)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, key0, stype, (uint32_t)n, j.na_img, j.img, d_acc);
     DTHIP_TRY(read_back(ctx, &j.range, d_acc, sizeof(RangeAcc)));
   }
-  j.xin.resize(sizeof(RangeAcc));
-  memcpy(j.xin.data(), &j.range, sizeof(RangeAcc));
   return DTHIP_OK;
 }
 
 static GlobalRange reduce_ranges(const Job& j, int world) {
   std::vector<RangeAcc> r(world);
-  memcpy(r.data(), j.xout.data(), sizeof(RangeAcc) * (size_t)world);
+  for (int k = 0; k < world; k++) memcpy(&r[k], blob_of(j, k), sizeof(RangeAcc));
   return reduce_key_ranges(r.data(), world);
 }
 
-static int phase_hist(Job& j, const GlobalRange& g) {
+static int phase_hist(Job& j, const GlobalRange& g, std::vector<u64>* hist) {
   dthip_ctx* ctx = j.ctx;
-  j.xin.assign(sizeof(u64) * SPLIT_BINS, 0);
+  hist->assign(SPLIT_BINS, 0);
   if (j.nimg > 0 && g.nvalid > 0) {
     u64* d_hist = nullptr;
     DTHIP_TRY(j.sc->get<u64>(SPLIT_BINS, &d_hist));
     DTHIP_CHECK_HIP(hipMemsetAsync(d_hist, 0, sizeof(u64) * SPLIT_BINS, ctx->stream));
     const unsigned grid = (unsigned)std::min<int64_t>((j.nimg + 255) / 256, 2048);
     DTHIP_LAUNCH(ctx, "image_hist_kernel", image_hist_kernel, grid, 256, 0, j.img, (uint32_t)j.nimg, j.na_img, g.gmin, g.shift, d_hist);
-    DTHIP_TRY(read_back(ctx, j.xin.data(), d_hist, sizeof(u64) * SPLIT_BINS));
+    DTHIP_TRY(read_back(ctx, hist->data(), d_hist, sizeof(u64) * SPLIT_BINS));
   }
   return DTHIP_OK;
 }
 
 // world-1 ascending boundary images from the summed histogram (split_plan.hpp)
 static void splitters(Job& j, const GlobalRange& g, int world) {
-  split_bounds(reinterpret_cast<const u64*>(j.xout.data()), world, g, &j.bounds);
+  std::vector<u64> h((size_t)world * SPLIT_BINS);
+  for (int r = 0; r < world; r++) memcpy(&h[(size_t)r * SPLIT_BINS], blob_of(j, r), sizeof(u64) * SPLIT_BINS);
+  split_bounds(h.data(), world, g, &j.bounds);
 }
 
 static void layout_from_counts(Job& j, int world) {
-  // xout = world x world matrix of send counts (row = sender); recv counts = column `rank`
+  // blobs = world x world matrix of send counts (row = sender); recv counts = column `rank`
   j.recv_cnt.assign(world, 0); j.recv_off.assign(world, 0);
-  const int64_t* m = reinterpret_cast<const int64_t*>(j.xout.data());
   int64_t off = 0;
-  for (int s = 0; s < world; s++) { j.recv_cnt[s] = m[(size_t)s * world + j.rank]; j.recv_off[s] = off; off += j.recv_cnt[s]; }
+  for (int s = 0; s < world; s++) {
+    int64_t c = 0;
+    memcpy(&c, blob_of(j, s) + sizeof(int64_t) * (size_t)j.rank, sizeof(c));
+    j.recv_cnt[s] = c; j.recv_off[s] = off; off += c;
+  }
   j.nrecv = off;
 }
 
-static int counts_blob(Job& j, int world) {
-  j.xin.resize(sizeof(int64_t) * world);
-  memcpy(j.xin.data(), j.send_cnt.data(), sizeof(int64_t) * world);
+static void counts_blob(Job& j, int world) {
+  if (j.rc != DTHIP_OK) { j.send_cnt.assign(world, 0); j.send_off.assign(world, 0); }
+  blob_set(j, j.nsend, j.send_cnt.data(), sizeof(int64_t) * (size_t)world);
+}
+
+static int stage_dev(dthip_ctx* ctx, Scratch& sc, const dthip_col& c, int64_t n, int mem, dthip_col* out) {
+  *out = c;
+  if (mem == DTHIP_DEVICE || n == 0) return DTHIP_OK;
+  unsigned char* d = nullptr;
+  const size_t bytes = (size_t)n * stype_size(c.stype);
+  DTHIP_TRY(sc.get<unsigned char>(bytes, &d));
+  DTHIP_CHECK_HIP(hipMemcpyAsync(d, c.data, bytes, hipMemcpyHostToDevice, ctx->stream));
+  out->data = d;
   return DTHIP_OK;
 }
 
@@ -381,83 +446,128 @@ struct AggArgs {
   int64_t nrows; int na_pos; int mem;
 };
 
+// Phases (every `local` lambda may fail on one rank; the failure travels in the next blob and all ranks return together):
+//   1  local fused groupby-aggregate (the combiner) on device columns, float32 value columns widened to float64 so
+//      that partial sums cross the fabric unrounded (the single-GPU path accumulates float32 sums in float64 and
+//      rounds once; rounding every partial to float32 first would differ by more than a re-association);
+//      1024 local quantiles of the first key's image                          -> all-gather A
+//   2  splitters (same on every rank), cuts of the ascending partials          -> all-gather B (send counts)
+//   3  receive buffers                                                         -> all-gather C (status only)
+//   4  all-to-all-v of keys + partial columns, merge on the owner
 static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::vector<AggArgs>& args, const AggPlan& plan) {
   const int world = comm->world;
-  const int nkeys = args[0].nkeys;
+  const int nkeys = args[0].nkeys, nvalues = args[0].nvalues;
   const int np = (int)plan.partial.size();
   std::vector<std::vector<double*>> wsum(jobs.size());
-  // ---- local combiner + first-key images of the partial groups
+  std::vector<std::vector<dthip_col>> kd(jobs.size()), vd(jobs.size());
+  // ---- 1: local combiner + quantile samples of the partial groups' first key
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const AggArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
-    DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
-    const int saved = ctx->agg_offsets;
-    ctx->agg_offsets = 0;
-    const int rc = dthip_groupby_agg(ctx, a.keys, nkeys, a.values, a.nvalues, plan.partial.data(), np, a.nrows, a.na_pos, a.mem, &j.local);
-    ctx->agg_offsets = saved;
-    DTHIP_TRY(rc);
-    const int64_t ng = j.local->ngroups;
-    // mean partials travel as weighted sums
-    wsum[q].assign(np, nullptr);
-    for (int i = 0; i < np; i++) {
-      if (plan.partial[i].op != DTHIP_MEAN || ng == 0) continue;
-      int ci = -1;
-      for (int t = 0; t < np; t++) if (plan.partial[t].op == DTHIP_COUNT && plan.partial[t].col == plan.partial[i].col) ci = t;
-      DTHIP_TRY(j.sc->get<double>((size_t)ng, &wsum[q][i]));
-      const long long* cnt = static_cast<const long long*>(j.local->agg[ci]);
-      if (j.local->agg_stype[i] == DTHIP_FLOAT32)
-        DTHIP_LAUNCH(ctx, "mean_weight_kernel", mean_weight_kernel<float>, (unsigned)((ng + 255) / 256), 256, 0, static_cast<const float*>(j.local->agg[i]), cnt, (uint32_t)ng, wsum[q][i]);
-      else
-        DTHIP_LAUNCH(ctx, "mean_weight_kernel", mean_weight_kernel<double>, (unsigned)((ng + 255) / 256), 256, 0, static_cast<const double*>(j.local->agg[i]), cnt, (uint32_t)ng, wsum[q][i]);
-    }
-    DTHIP_TRY(phase_images(j, j.local->key[0], a.keys[0].stype, ng, a.na_pos));
+    std::vector<u64> samples(SPLIT_SAMPLES, 0);
+    j.na_img = (a.na_pos == DTHIP_NA_LAST) ? ~0ULL : 0ULL;
+    j.nimg = 0;
+    auto local = [&]() -> int {
+      DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+      kd[q].resize(nkeys); vd[q].resize(nvalues);
+      for (int k = 0; k < nkeys; k++) DTHIP_TRY(stage_dev(ctx, *j.sc, a.keys[k], a.nrows, a.mem, &kd[q][k]));
+      for (int c = 0; c < nvalues; c++) {
+        DTHIP_TRY(stage_dev(ctx, *j.sc, a.values[c], a.nrows, a.mem, &vd[q][c]));
+        if (vd[q][c].stype == DTHIP_FLOAT32 && a.nrows > 0) {
+          double* wide = nullptr;
+          DTHIP_TRY(j.sc->get<double>((size_t)a.nrows, &wide));
+          DTHIP_TRY(launch_gather_f64(ctx, vd[q][c].data, DTHIP_FLOAT32, nullptr, a.nrows, wide));
+          vd[q][c].data = wide;
+        }
+        if (vd[q][c].stype == DTHIP_FLOAT32) vd[q][c].stype = DTHIP_FLOAT64;
+      }
+      const int saved = ctx->agg_offsets;
+      ctx->agg_offsets = 0;
+      const int rc = dthip_groupby_agg(ctx, kd[q].data(), nkeys, vd[q].data(), nvalues, plan.partial.data(), np, a.nrows, a.na_pos, DTHIP_DEVICE, &j.local);
+      ctx->agg_offsets = saved;
+      DTHIP_TRY(rc);
+      const int64_t ng = j.local->ngroups;
+      // mean partials travel as weighted sums
+      wsum[q].assign(np, nullptr);
+      for (int i = 0; i < np; i++) {
+        if (plan.partial[i].op != DTHIP_MEAN || ng == 0) continue;
+        int ci = -1;
+        for (int t = 0; t < np; t++) if (plan.partial[t].op == DTHIP_COUNT && plan.partial[t].col == plan.partial[i].col) ci = t;
+        DTHIP_TRY(j.sc->get<double>((size_t)ng, &wsum[q][i]));
+        const long long* cnt = static_cast<const long long*>(j.local->agg[ci]);
+        if (j.local->agg_stype[i] == DTHIP_FLOAT32)
+          DTHIP_LAUNCH(ctx, "mean_weight_kernel", mean_weight_kernel<float>, (unsigned)((ng + 255) / 256), 256, 0, static_cast<const float*>(j.local->agg[i]), cnt, (uint32_t)ng, wsum[q][i]);
+        else
+          DTHIP_LAUNCH(ctx, "mean_weight_kernel", mean_weight_kernel<double>, (unsigned)((ng + 255) / 256), 256, 0, static_cast<const double*>(j.local->agg[i]), cnt, (uint32_t)ng, wsum[q][i]);
+      }
+      if (ng > 0) {
+        u64* d_s = nullptr;
+        DTHIP_TRY(j.sc->get<u64>(SPLIT_SAMPLES, &d_s));
+        DTHIP_LAUNCH(ctx, "sample_image_kernel", sample_image_kernel, SPLIT_SAMPLES / 256, 256, 0, j.local->key[0], a.keys[0].stype, (uint32_t)ng, (uint32_t)SPLIT_SAMPLES, j.na_img, d_s);
+        DTHIP_TRY(read_back(ctx, samples.data(), d_s, sizeof(u64) * SPLIT_SAMPLES));
+      }
+      j.nimg = ng;
+      return DTHIP_OK;
+    };
+    if (j.rc == DTHIP_OK) j.rc = local();
+    blob_set(j, j.rc == DTHIP_OK ? j.nimg : 0, samples.data(), sizeof(u64) * SPLIT_SAMPLES);
   }
   DTHIP_TRY(exchange_allgather(comm, jobs));
-  const GlobalRange g = reduce_ranges(jobs[0], world);
-  for (auto& j : jobs) { DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device)); DTHIP_TRY(phase_hist(j, g)); }
-  DTHIP_TRY(exchange_allgather(comm, jobs));
-  // ---- splitters -> contiguous slabs of the (ascending) partial groups
-  for (auto& j : jobs) {
-    dthip_ctx* ctx = j.ctx;
-    DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
-    splitters(j, g, world);
-    std::vector<uint32_t> cuts(world + 1, 0);
-    cuts[world] = (uint32_t)j.nimg;
-    if (world > 1 && j.nimg > 0) {
-      u64* d_b = nullptr; uint32_t* d_c = nullptr;
-      DTHIP_TRY(j.sc->get<u64>(world, &d_b));
-      DTHIP_TRY(j.sc->get<uint32_t>(world, &d_c));
-      DTHIP_CHECK_HIP(hipMemcpyAsync(d_b, j.bounds.data(), sizeof(u64) * (world - 1), hipMemcpyHostToDevice, ctx->stream));
-      DTHIP_LAUNCH(ctx, "lower_bound_kernel", lower_bound_kernel, 1, 128, 0, j.img, (uint32_t)j.nimg, d_b, world - 1, d_c);
-      DTHIP_TRY(read_back(ctx, cuts.data() + 1, d_c, sizeof(uint32_t) * (world - 1)));
-    } else {
-      for (int k = 1; k < world; k++) cuts[k] = 0;
-    }
+  DTHIP_TRY(agree(comm, jobs, "the local aggregation"));
+  // ---- 2: splitters -> contiguous slabs of the (ascending) partial groups
+  for (size_t q = 0; q < jobs.size(); q++) {
+    Job& j = jobs[q]; const AggArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
+    std::vector<u64> smp((size_t)world * SPLIT_SAMPLES);
+    std::vector<long long> cnt(world);
+    for (int r = 0; r < world; r++) { memcpy(&smp[(size_t)r * SPLIT_SAMPLES], blob_of(j, r), sizeof(u64) * SPLIT_SAMPLES); cnt[r] = hdr_of(j, r).n; }
+    sample_bounds(smp.data(), cnt.data(), world, &j.bounds);
     j.send_cnt.assign(world, 0); j.send_off.assign(world, 0);
-    for (int k = 0; k < world; k++) { j.send_off[k] = cuts[k]; j.send_cnt[k] = (int64_t)cuts[k + 1] - (int64_t)cuts[k]; }
+    auto local = [&]() -> int {
+      DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+      std::vector<uint32_t> cuts(world + 1, 0);
+      cuts[world] = (uint32_t)j.nimg;
+      if (world > 1 && j.nimg > 0) {
+        u64* d_b = nullptr; uint32_t* d_c = nullptr;
+        DTHIP_TRY(j.sc->get<u64>(world, &d_b));
+        DTHIP_TRY(j.sc->get<uint32_t>(world, &d_c));
+        DTHIP_CHECK_HIP(hipMemcpyAsync(d_b, j.bounds.data(), sizeof(u64) * (world - 1), hipMemcpyHostToDevice, ctx->stream));
+        DTHIP_LAUNCH(ctx, "lower_bound_kernel", lower_bound_kernel, 1, 128, 0, j.local->key[0], a.keys[0].stype, (uint32_t)j.nimg, j.na_img, d_b, world - 1, d_c);
+        DTHIP_TRY(read_back(ctx, cuts.data() + 1, d_c, sizeof(uint32_t) * (world - 1)));
+      }
+      for (int k = 0; k < world; k++) { j.send_off[k] = cuts[k]; j.send_cnt[k] = (int64_t)cuts[k + 1] - (int64_t)cuts[k]; }
+      return DTHIP_OK;
+    };
+    j.rc = local();
     j.nsend = j.nimg;
     counts_blob(j, world);
   }
   DTHIP_TRY(exchange_allgather(comm, jobs));
-  // ---- receive buffers, all-to-all-v of keys + partial columns
+  DTHIP_TRY(agree(comm, jobs, "the partition of the partial groups"));
+  // ---- 3: receive buffers
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const AggArgs& a = args[q];
-    DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device));
     layout_from_counts(j, world);
-    j.cols.clear();
-    for (int k = 0; k < nkeys; k++) {
-      XCol c; c.stype = a.keys[k].stype; c.elem = stype_size(c.stype); c.send = j.local->key[k];
-      unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r;
-      j.cols.push_back(c);
-    }
-    for (int i = 0; i < np; i++) {
-      XCol c;
-      if (plan.partial[i].op == DTHIP_MEAN) { c.stype = DTHIP_FLOAT64; c.send = wsum[q][i]; }
-      else { c.stype = j.local->agg_stype[i]; c.send = j.local->agg[i]; }
-      c.elem = stype_size(c.stype);
-      unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r;
-      j.cols.push_back(c);
-    }
+    auto local = [&]() -> int {
+      DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device));
+      j.cols.clear();
+      for (int k = 0; k < nkeys; k++) {
+        XCol c; c.stype = a.keys[k].stype; c.elem = stype_size(c.stype); c.send = j.local->key[k];
+        unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r;
+        j.cols.push_back(c);
+      }
+      for (int i = 0; i < np; i++) {
+        XCol c;
+        if (plan.partial[i].op == DTHIP_MEAN) { c.stype = DTHIP_FLOAT64; c.send = wsum[q][i]; }
+        else { c.stype = j.local->agg_stype[i]; c.send = j.local->agg[i]; }
+        c.elem = stype_size(c.stype);
+        unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r;
+        j.cols.push_back(c);
+      }
+      return DTHIP_OK;
+    };
+    j.rc = local();
   }
+  DTHIP_TRY(agree_round(comm, jobs, "the allocation of the receive buffers"));
+  // ---- 4: all-to-all-v of keys + partial columns
   DTHIP_TRY(exchange_alltoallv(comm, jobs));
   // ---- merge on the owner
   for (size_t q = 0; q < jobs.size(); q++) {
@@ -491,11 +601,18 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
       const AggPlan::Rec& r = plan.recipe[t];
       const int ost = dthip_reduce_out_stype(a.aggs[t].op, a.aggs[t].op == DTHIP_COUNT0 ? DTHIP_INT64 : a.values[a.aggs[t].col].stype);
       m->agg_stype[t] = ost;
-      if (r.kind == 0) { m->agg[t] = pa[r.a]; continue; }
+      if (r.kind == 0 && ps[r.a] == ost) { m->agg[t] = pa[r.a]; continue; }
       void* o = nullptr;
       DTHIP_TRY(result_alloc(ctx, m, (size_t)ng * stype_size(ost) + 16, &o));
       m->agg[t] = o;
-      if (ng) DTHIP_TRY(launch_mean_div(ctx, static_cast<const double*>(pa[r.a]), static_cast<const long long*>(pa[r.b]), ng, o, ost == DTHIP_FLOAT32));
+      if (!ng) continue;
+      if (r.kind == 0) {
+        // sum / min / max of a float32 column: merged in float64, rounded to the column's stype once
+        if (ps[r.a] != DTHIP_FLOAT64 || ost != DTHIP_FLOAT32) { set_error("sharded groupby: partial stype %d for output stype %d", ps[r.a], ost); return DTHIP_EDEVICE; }
+        DTHIP_TRY(launch_cast_f64_f32(ctx, static_cast<const double*>(pa[r.a]), ng, static_cast<float*>(o)));
+      } else {
+        DTHIP_TRY(launch_mean_div(ctx, static_cast<const double*>(pa[r.a]), static_cast<const long long*>(pa[r.b]), ng, o, ost == DTHIP_FLOAT32));
+      }
     }
     m->nrows = a.nrows;
   }
@@ -508,85 +625,104 @@ struct RowsArgs {
   int64_t nrows; int64_t row_offset; int na_pos; int mem;
 };
 
-static int stage_dev(dthip_ctx* ctx, Scratch& sc, const dthip_col& c, int64_t n, int mem, dthip_col* out) {
-  *out = c;
-  if (mem == DTHIP_DEVICE || n == 0) return DTHIP_OK;
-  unsigned char* d = nullptr;
-  const size_t bytes = (size_t)n * stype_size(c.stype);
-  DTHIP_TRY(sc.get<unsigned char>(bytes, &d));
-  DTHIP_CHECK_HIP(hipMemcpyAsync(d, c.data, bytes, hipMemcpyHostToDevice, ctx->stream));
-  out->data = d;
-  return DTHIP_OK;
-}
-
+// Phases: 1 key images + local range -> all-gather A;  2 4096-bin histogram over the global range -> all-gather B;
+// 3 splitters, destination of every row, stable partition by destination -> all-gather C (send counts);
+// 4 receive buffers -> all-gather D (status only);  5 all-to-all-v, one stable local grouping.
 static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std::vector<RowsArgs>& args) {
   const int world = comm->world;
   const int nkeys = args[0].nkeys, ncols = args[0].ncols;
   std::vector<std::vector<dthip_col>> kd(jobs.size()), cd(jobs.size());
   std::vector<long long*> rowid(jobs.size(), nullptr);
+  // ---- 1
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const RowsArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
-    DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
-    kd[q].resize(nkeys); cd[q].resize(ncols);
-    for (int k = 0; k < nkeys; k++) DTHIP_TRY(stage_dev(ctx, *j.sc, a.keys[k], a.nrows, a.mem, &kd[q][k]));
-    for (int c = 0; c < ncols; c++) DTHIP_TRY(stage_dev(ctx, *j.sc, a.cols[c], a.nrows, a.mem, &cd[q][c]));
-    if (a.nrows) {
-      DTHIP_TRY(j.sc->get<long long>((size_t)a.nrows, &rowid[q]));
-      DTHIP_LAUNCH(ctx, "iota64_kernel", iota64_kernel, (unsigned)((a.nrows + 255) / 256), 256, 0, rowid[q], (uint32_t)a.nrows, (long long)a.row_offset);
-    }
-    DTHIP_TRY(phase_images(j, kd[q][0].data, kd[q][0].stype, a.nrows, a.na_pos));
+    auto local = [&]() -> int {
+      DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+      kd[q].resize(nkeys); cd[q].resize(ncols);
+      for (int k = 0; k < nkeys; k++) DTHIP_TRY(stage_dev(ctx, *j.sc, a.keys[k], a.nrows, a.mem, &kd[q][k]));
+      for (int c = 0; c < ncols; c++) DTHIP_TRY(stage_dev(ctx, *j.sc, a.cols[c], a.nrows, a.mem, &cd[q][c]));
+      if (a.nrows) {
+        DTHIP_TRY(j.sc->get<long long>((size_t)a.nrows, &rowid[q]));
+        DTHIP_LAUNCH(ctx, "iota64_kernel", iota64_kernel, (unsigned)((a.nrows + 255) / 256), 256, 0, rowid[q], (uint32_t)a.nrows, (long long)a.row_offset);
+      }
+      return phase_images(j, kd[q][0].data, kd[q][0].stype, a.nrows, a.na_pos);
+    };
+    if (j.rc == DTHIP_OK) j.rc = local();
+    if (j.rc != DTHIP_OK) { j.range = RangeAcc{~0ULL, 0ULL, 0ULL}; j.nimg = 0; }
+    blob_set(j, j.nimg, &j.range, sizeof(RangeAcc));
   }
   DTHIP_TRY(exchange_allgather(comm, jobs));
+  DTHIP_TRY(agree(comm, jobs, "the key range scan"));
+  // ---- 2
   const GlobalRange g = reduce_ranges(jobs[0], world);
-  for (auto& j : jobs) { DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device)); DTHIP_TRY(phase_hist(j, g)); }
+  for (auto& j : jobs) {
+    std::vector<u64> hist;
+    auto local = [&]() -> int { DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device)); return phase_hist(j, g, &hist); };
+    j.rc = local();
+    hist.resize(SPLIT_BINS, 0);
+    blob_set(j, j.nimg, hist.data(), sizeof(u64) * SPLIT_BINS);
+  }
   DTHIP_TRY(exchange_allgather(comm, jobs));
-  // ---- destination of every row, slabs in sender row order
+  DTHIP_TRY(agree(comm, jobs, "the key histogram"));
+  // ---- 3: destination of every row, slabs in sender row order
   const int npay = nkeys + ncols + 1;                 // keys, columns, global row id
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const RowsArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
-    DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
     splitters(j, g, world);
     j.send_cnt.assign(world, 0); j.send_off.assign(world, 0);
-    j.cols.assign(npay, XCol());
-    for (int k = 0; k < nkeys; k++) { j.cols[k].stype = kd[q][k].stype; j.cols[k].send = kd[q][k].data; }
-    for (int c = 0; c < ncols; c++) { j.cols[nkeys + c].stype = cd[q][c].stype; j.cols[nkeys + c].send = cd[q][c].data; }
-    j.cols[npay - 1].stype = DTHIP_INT64; j.cols[npay - 1].send = rowid[q];
-    for (auto& c : j.cols) c.elem = stype_size(c.stype);
-    if (world > 1 && a.nrows > 0) {
-      int8_t* dest = nullptr; u64* d_b = nullptr;
-      DTHIP_TRY(j.sc->get<int8_t>((size_t)a.nrows, &dest));
-      DTHIP_TRY(j.sc->get<u64>(world, &d_b));
-      DTHIP_CHECK_HIP(hipMemcpyAsync(d_b, j.bounds.data(), sizeof(u64) * (world - 1), hipMemcpyHostToDevice, ctx->stream));
-      DTHIP_LAUNCH(ctx, "image_dest_kernel", image_dest_kernel, (unsigned)((a.nrows + 255) / 256), 256, 0, j.img, (uint32_t)a.nrows, d_b, world - 1, dest);
-      // stable partition by destination: the library's own rows-in-grouped-order on the int8 destination
-      dthip_col dk{dest, DTHIP_INT8, 0};
-      std::vector<dthip_col> pay(npay);
-      for (int c = 0; c < npay; c++) pay[c] = dthip_col{j.cols[c].send, j.cols[c].stype, 0};
-      DTHIP_TRY(dthip_groupby_rows(ctx, &dk, 1, pay.data(), npay, a.nrows, DTHIP_NA_FIRST, DTHIP_DEVICE, 0, &j.local));
-      // slabs are contiguous and in ascending destination order: their sizes are the destination counts
-      u64* d_cnt = nullptr;
-      DTHIP_TRY(j.sc->get<u64>(128, &d_cnt));
-      DTHIP_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(u64) * 128, ctx->stream));
-      DTHIP_LAUNCH(ctx, "dest_count_kernel", dest_count_kernel, (unsigned)std::min<int64_t>((a.nrows + 255) / 256, 2048), 256, 0, dest, (uint32_t)a.nrows, d_cnt);
-      u64 cnt[128];
-      DTHIP_TRY(read_back(ctx, cnt, d_cnt, sizeof(cnt)));
-      int64_t off = 0;
-      for (int d = 0; d < world; d++) { j.send_off[d] = off; j.send_cnt[d] = (int64_t)cnt[d]; off += (int64_t)cnt[d]; }
-      for (int c = 0; c < npay; c++) j.cols[c].send = j.local->col[c];
-    } else if (world == 1) {
-      j.send_cnt[0] = a.nrows;
-    }
+    auto local = [&]() -> int {
+      DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
+      j.cols.assign(npay, XCol());
+      for (int k = 0; k < nkeys; k++) { j.cols[k].stype = kd[q][k].stype; j.cols[k].send = kd[q][k].data; }
+      for (int c = 0; c < ncols; c++) { j.cols[nkeys + c].stype = cd[q][c].stype; j.cols[nkeys + c].send = cd[q][c].data; }
+      j.cols[npay - 1].stype = DTHIP_INT64; j.cols[npay - 1].send = rowid[q];
+      for (auto& c : j.cols) c.elem = stype_size(c.stype);
+      if (world > 1 && a.nrows > 0) {
+        int8_t* dest = nullptr; u64* d_b = nullptr;
+        DTHIP_TRY(j.sc->get<int8_t>((size_t)a.nrows, &dest));
+        DTHIP_TRY(j.sc->get<u64>(world, &d_b));
+        DTHIP_CHECK_HIP(hipMemcpyAsync(d_b, j.bounds.data(), sizeof(u64) * (world - 1), hipMemcpyHostToDevice, ctx->stream));
+        DTHIP_LAUNCH(ctx, "image_dest_kernel", image_dest_kernel, (unsigned)((a.nrows + 255) / 256), 256, 0, j.img, (uint32_t)a.nrows, d_b, world - 1, dest);
+        // stable partition by destination: the library's own rows-in-grouped-order on the int8 destination
+        dthip_col dk{dest, DTHIP_INT8, 0};
+        std::vector<dthip_col> pay(npay);
+        for (int c = 0; c < npay; c++) pay[c] = dthip_col{j.cols[c].send, j.cols[c].stype, 0};
+        DTHIP_TRY(dthip_groupby_rows(ctx, &dk, 1, pay.data(), npay, a.nrows, DTHIP_NA_FIRST, DTHIP_DEVICE, 0, &j.local));
+        // slabs are contiguous and in ascending destination order: their sizes are the destination counts
+        u64* d_cnt = nullptr;
+        DTHIP_TRY(j.sc->get<u64>(128, &d_cnt));
+        DTHIP_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(u64) * 128, ctx->stream));
+        DTHIP_LAUNCH(ctx, "dest_count_kernel", dest_count_kernel, (unsigned)std::min<int64_t>((a.nrows + 255) / 256, 2048), 256, 0, dest, (uint32_t)a.nrows, d_cnt);
+        u64 cnt[128];
+        DTHIP_TRY(read_back(ctx, cnt, d_cnt, sizeof(cnt)));
+        int64_t off = 0;
+        for (int d = 0; d < world; d++) { j.send_off[d] = off; j.send_cnt[d] = (int64_t)cnt[d]; off += (int64_t)cnt[d]; }
+        for (int c = 0; c < npay; c++) j.cols[c].send = j.local->col[c];
+      } else if (world == 1) {
+        j.send_cnt[0] = a.nrows;
+      }
+      return DTHIP_OK;
+    };
+    j.rc = local();
     j.nsend = a.nrows;
     counts_blob(j, world);
   }
   DTHIP_TRY(exchange_allgather(comm, jobs));
+  DTHIP_TRY(agree(comm, jobs, "the partition of the rows"));
+  // ---- 4
   for (auto& j : jobs) {
-    DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device));
     layout_from_counts(j, world);
-    for (auto& c : j.cols) { unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r; }
+    auto local = [&]() -> int {
+      DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device));
+      for (auto& c : j.cols) { unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r; }
+      return DTHIP_OK;
+    };
+    j.rc = local();
   }
+  DTHIP_TRY(agree_round(comm, jobs, "the allocation of the receive buffers"));
+  // ---- 5
   DTHIP_TRY(exchange_alltoallv(comm, jobs));
-  // ---- one stable local grouping of what arrived (source-rank order = global row order)
+  // one stable local grouping of what arrived (source-rank order = global row order)
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const RowsArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
     DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
@@ -668,21 +804,50 @@ int dthip_comm_destroy(dthip_ctx* ctx) {
 int dthip_comm_rank(const dthip_ctx* ctx) { return (ctx && ctx->comm) ? ctx->comm_rank : -1; }
 int dthip_comm_world(const dthip_ctx* ctx) { return (ctx && ctx->comm) ? ctx->comm->world : 0; }
 
+// query signature: ranks of an RCCL communicator are separate processes, nothing else tells them they were handed
+// the same query
+static uint32_t query_sig(const dthip_col* keys, int nkeys, const dthip_col* vals, int nvals, const dthip_agg* aggs, int naggs, int na_pos, int kind) {
+  uint32_t h = 2166136261u;
+  const int head[5] = {kind, nkeys, nvals, naggs, na_pos};
+  h = fnv1a(h, head, sizeof(head));
+  for (int k = 0; keys && k < nkeys && k < MAX_KEYCOLS; k++) { const int v[2] = {keys[k].stype, keys[k].flags}; h = fnv1a(h, v, sizeof(v)); }
+  for (int c = 0; vals && c < nvals && c < 64; c++) { const int v[2] = {vals[c].stype, vals[c].flags}; h = fnv1a(h, v, sizeof(v)); }
+  for (int a = 0; aggs && a < naggs && a < 256; a++) { const int v[2] = {aggs[a].op, aggs[a].col}; h = fnv1a(h, v, sizeof(v)); }
+  return h;
+}
+
 static int sharded_agg_impl(dthip_ctx* const* ctxs, int n, const std::vector<AggArgs>& args, dthip_result** outs) {
   if (!ctxs || !outs || n < 1) { set_error("null argument"); return DTHIP_EINVAL; }
   dthip_comm* comm = ctxs[0] ? ctxs[0]->comm : nullptr;
   DTHIP_TRY(check_jobs(comm, ctxs, n));
-  for (int i = 0; i < n; i++) {
-    const AggArgs& a = args[i];
-    if (!a.keys || a.nkeys < 1 || a.nkeys > MAX_KEYCOLS || (a.naggs > 0 && !a.aggs) || a.nrows < 0 || a.nrows > (int64_t)INT32_MAX) { set_error("bad argument"); return DTHIP_EINVAL; }
-    if (a.keys[0].flags & DTHIP_FLAG_DESCENDING) { set_error("sharded groupby: the first key must be ascending (range partition)"); return DTHIP_ENOTIMPL; }
-    if (a.nkeys != args[0].nkeys || a.naggs != args[0].naggs) { set_error("ranks disagree on the query"); return DTHIP_EINVAL; }
-  }
+  for (int i = 0; i < n; i++) outs[i] = nullptr;
   AggPlan plan;
-  DTHIP_TRY(plan_partials(args[0].aggs, args[0].naggs, &plan));
+  // argument errors of ONE rank of an RCCL communicator must not make it return alone (its peers would wait for it
+  // in the first all-gather): they become the rank's status and every rank returns after that all-gather
+  auto validate = [&](const AggArgs& a) -> int {
+    if (!a.keys || a.nkeys < 1 || a.nkeys > MAX_KEYCOLS || (a.naggs > 0 && !a.aggs) || (a.nvalues > 0 && !a.values) || a.nvalues < 0 ||
+        a.nrows < 0 || a.nrows > (int64_t)INT32_MAX) { set_error("bad argument"); return DTHIP_EINVAL; }
+    if (a.na_pos != DTHIP_NA_FIRST && a.na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", a.na_pos); return DTHIP_ENOTIMPL; }
+    for (int t = 0; t < a.naggs; t++)
+      if (a.aggs[t].op != DTHIP_COUNT0 && (a.aggs[t].col < 0 || a.aggs[t].col >= a.nvalues)) { set_error("agg %d refers to value column %d of %d", t, a.aggs[t].col, a.nvalues); return DTHIP_EINVAL; }
+    if (a.keys[0].flags & DTHIP_FLAG_DESCENDING) { set_error("sharded groupby: the first key must be ascending (range partition)"); return DTHIP_ENOTIMPL; }
+    if (a.nkeys != args[0].nkeys || a.naggs != args[0].naggs || a.nvalues != args[0].nvalues) { set_error("ranks disagree on the query"); return DTHIP_EINVAL; }
+    return DTHIP_OK;
+  };
+  std::vector<int> pre(n, DTHIP_OK);
+  for (int i = 0; i < n; i++) {
+    pre[i] = validate(args[i]);
+    if (pre[i] != DTHIP_OK && comm->kind == 1) return pre[i];          // one process holds every rank: nobody waits
+  }
+  int prc = pre[0] == DTHIP_OK ? plan_partials(args[0].aggs, args[0].naggs, &plan) : DTHIP_OK;
+  if (prc != DTHIP_OK) { if (comm->kind == 1) return prc; pre[0] = prc; plan = AggPlan(); }
   std::vector<Job> jobs(n);
   std::vector<Scratch*> scs;
-  for (int i = 0; i < n; i++) { jobs[i].ctx = ctxs[i]; jobs[i].rank = ctxs[i]->comm_rank; scs.push_back(new Scratch(ctxs[i])); jobs[i].sc = scs.back(); }
+  for (int i = 0; i < n; i++) {
+    jobs[i].ctx = ctxs[i]; jobs[i].rank = ctxs[i]->comm_rank; scs.push_back(new Scratch(ctxs[i])); jobs[i].sc = scs.back();
+    jobs[i].rc = pre[i];
+    jobs[i].sig = query_sig(args[i].keys, args[i].nkeys, args[i].values, args[i].nvalues, args[i].aggs, args[i].naggs, args[i].na_pos, 1);
+  }
   std::sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return a.rank < b.rank; });
   std::vector<AggArgs> sorted_args(n);
   for (int i = 0; i < n; i++) for (int q = 0; q < n; q++) if (jobs[q].ctx == ctxs[i]) sorted_args[q] = args[i];
@@ -717,16 +882,28 @@ static int sharded_rows_impl(dthip_ctx* const* ctxs, int n, const std::vector<Ro
   if (!ctxs || !outs || n < 1) { set_error("null argument"); return DTHIP_EINVAL; }
   dthip_comm* comm = ctxs[0] ? ctxs[0]->comm : nullptr;
   DTHIP_TRY(check_jobs(comm, ctxs, n));
-  for (int i = 0; i < n; i++) {
-    const RowsArgs& a = args[i];
+  for (int i = 0; i < n; i++) outs[i] = nullptr;
+  auto validate = [&](const RowsArgs& a) -> int {
     if (!a.keys || a.nkeys < 1 || a.nkeys > MAX_KEYCOLS || a.ncols < 0 || (a.ncols > 0 && !a.cols) || a.nrows < 0 || a.nrows > (int64_t)INT32_MAX) {
       set_error("bad argument"); return DTHIP_EINVAL;
     }
+    if (a.na_pos != DTHIP_NA_FIRST && a.na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", a.na_pos); return DTHIP_ENOTIMPL; }
     if (a.keys[0].flags & DTHIP_FLAG_DESCENDING) { set_error("sharded groupby: the first key must be ascending (range partition)"); return DTHIP_ENOTIMPL; }
+    if (a.nkeys != args[0].nkeys || a.ncols != args[0].ncols) { set_error("ranks disagree on the query"); return DTHIP_EINVAL; }
+    return DTHIP_OK;
+  };
+  std::vector<int> pre(n, DTHIP_OK);
+  for (int i = 0; i < n; i++) {
+    pre[i] = validate(args[i]);
+    if (pre[i] != DTHIP_OK && comm->kind == 1) return pre[i];
   }
   std::vector<Job> jobs(n);
   std::vector<Scratch*> scs;
-  for (int i = 0; i < n; i++) { jobs[i].ctx = ctxs[i]; jobs[i].rank = ctxs[i]->comm_rank; scs.push_back(new Scratch(ctxs[i])); jobs[i].sc = scs.back(); }
+  for (int i = 0; i < n; i++) {
+    jobs[i].ctx = ctxs[i]; jobs[i].rank = ctxs[i]->comm_rank; scs.push_back(new Scratch(ctxs[i])); jobs[i].sc = scs.back();
+    jobs[i].rc = pre[i];
+    jobs[i].sig = query_sig(args[i].keys, args[i].nkeys, args[i].cols, args[i].ncols, nullptr, 0, args[i].na_pos, 2);
+  }
   std::sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return a.rank < b.rank; });
   std::vector<RowsArgs> sorted_args(n);
   for (int i = 0; i < n; i++) for (int q = 0; q < n; q++) if (jobs[q].ctx == ctxs[i]) sorted_args[q] = args[i];

@@ -80,6 +80,15 @@ struct dthip_ctx {
   // multi-GPU (comm.hip): the communicator this context is a rank of
   struct dthip_comm* comm = nullptr;
   int comm_rank = 0;
+  // guard-page mode (env DTHIP_GUARD / option "guard"; a debugging flavour like the reference's ASan build,
+  // ci/ext.py:318-327): every device buffer is its own virtual-memory mapping with unmapped pages on both sides and
+  // its END (1) or START (2) flush against them, nothing is cached, every launch is synchronised, so a kernel that
+  // reads or writes one 16-byte piece outside a buffer faults at once and the SIGABRT handler names it
+  int guard = 0;
+  struct GuardBlock { void* va; size_t va_bytes; void* map; size_t map_bytes; hipMemGenericAllocationHandle_t h; };
+  std::unordered_map<void*, GuardBlock> guarded;
+  std::vector<GuardBlock> guard_limbo, guard_vas;    // released but still mapped / unmapped but still reserved
+  int64_t guard_allocs = 0, guard_launches = 0;
 };
 
 // device-resident result of a groupby (dthip.h: dthip_result); every buffer in `owned` goes back to the context's
@@ -109,6 +118,8 @@ void dev_release(dthip_ctx* ctx, void* p);   // back to the cache
 int dev_trim(dthip_ctx* ctx);                // cache -> hipFree
 int prof_flush(dthip_ctx* ctx);
 hipEvent_t prof_event(dthip_ctx* ctx);
+void guard_before_launch(dthip_ctx* ctx, const char* kname);
+int guard_after_launch(dthip_ctx* ctx, const char* kname);
 
 // Scoped set of temporary device buffers returned to the cache on exit.
 struct Scratch {
@@ -135,6 +146,7 @@ struct Scratch {
 #define DTHIP_LAUNCH(ctx, kname, kernel, grid, block, shmem, ...)                           \
   do {                                                                                      \
     hipEvent_t _ea = nullptr, _eb = nullptr;                                                \
+    if ((ctx)->guard) ::dthip::guard_before_launch(ctx, kname);                             \
     if ((ctx)->prof) { _ea = ::dthip::prof_event(ctx); _eb = ::dthip::prof_event(ctx);      \
                        (void)hipEventRecord(_ea, (ctx)->stream); }                                \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (shmem), (ctx)->stream, __VA_ARGS__); \
@@ -146,6 +158,8 @@ struct Scratch {
       ::dthip::set_error("launch of %s failed: %s", kname, hipGetErrorString(_le));         \
       return DTHIP_EDEVICE;                                                                 \
     }                                                                                       \
+    if ((ctx)->guard) { int _grc = ::dthip::guard_after_launch(ctx, kname);                 \
+                        if (_grc != DTHIP_OK) return _grc; }                                \
   } while (0)
 
 // small synchronous device->host read-back through pinned memory

@@ -2,8 +2,10 @@
 // order-preserving 64-bit key images, histogram bin width, and the world-1 splitters cut from the summed histogram.
 // Plain C++ (no HIP): included by comm.hip and compiled on its own by tests/test_split_plan.py.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace dthip {
@@ -50,6 +52,58 @@ inline void split_bounds(const unsigned long long* hist, int world, const Global
     const unsigned __int128 edge = (unsigned __int128)g.gmin + ((unsigned __int128)(unsigned long long)b << g.shift);
     (*bounds)[k - 1] = edge >= (unsigned __int128)~0ULL ? ~0ULL - 1 : (unsigned long long)edge;
   }
+}
+
+// ---- splitters from local quantiles (aggregates: every rank's partial groups ascend in the first key) --------------
+constexpr int SPLIT_SAMPLES = 1024;
+
+// samples[r * SPLIT_SAMPLES + i] = image at position floor(i * n[r] / SPLIT_SAMPLES) of rank r's ascending sequence
+// (ignored when n[r] == 0).  Every sample stands for n[r] / SPLIT_SAMPLES elements; the boundary of rank k is the
+// smallest sample image below which at least k / world of the total weight lies.  All ranks hold the same samples and
+// get the same boundaries.  Rank k's share exceeds its fair share by at most sum_r n[r] / SPLIT_SAMPLES elements plus
+// the elements that share the boundary image (one key is never cut).
+inline void sample_bounds(const unsigned long long* samples, const long long* n, int world, std::vector<unsigned long long>* bounds) {
+  bounds->assign(world > 1 ? world - 1 : 0, ~0ULL);
+  std::vector<std::pair<unsigned long long, double>> pts;
+  double total = 0;
+  for (int r = 0; r < world; r++) {
+    if (n[r] <= 0) continue;
+    const double w = (double)n[r] / SPLIT_SAMPLES;
+    for (int i = 0; i < SPLIT_SAMPLES; i++) pts.emplace_back(samples[(size_t)r * SPLIT_SAMPLES + i], w);
+    total += (double)n[r];
+  }
+  if (pts.empty()) return;
+  std::sort(pts.begin(), pts.end(), [](const std::pair<unsigned long long, double>& a, const std::pair<unsigned long long, double>& b) { return a.first < b.first; });
+  double cum = 0;
+  size_t i = 0;
+  for (int k = 1; k < world; k++) {
+    const double target = total * k / world;
+    while (i < pts.size() && cum + pts[i].second <= target) { cum += pts[i].second; i++; }
+    // samples [0, i) weigh <= target: the boundary is the next sample's image (everything below it goes to ranks < k)
+    (*bounds)[k - 1] = i < pts.size() ? pts[i].first : ~0ULL;
+  }
+  for (int k = 1; k < world - 1; k++) if ((*bounds)[k] < (*bounds)[k - 1]) (*bounds)[k] = (*bounds)[k - 1];
+}
+
+// ---- what every all-gathered blob starts with: status agreement -------------------------------------------------------
+struct ShardHdr { int32_t rc; uint32_t sig; long long n; };     // status of the rank so far, query signature, rows / partials
+
+inline uint32_t fnv1a(uint32_t h, const void* p, size_t bytes) {
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  for (size_t i = 0; i < bytes; i++) { h ^= b[i]; h *= 16777619u; }
+  return h;
+}
+
+// the first failing rank and its code (0 when none); *sig_ok = every rank sent the same query signature
+inline int first_failure(const unsigned char* blobs, size_t stride, int world, int* rank, bool* sig_ok) {
+  int rc = 0; *rank = -1; *sig_ok = true;
+  ShardHdr h0; memcpy(&h0, blobs, sizeof(h0));
+  for (int r = 0; r < world; r++) {
+    ShardHdr h; memcpy(&h, blobs + (size_t)r * stride, sizeof(h));
+    if (h.rc != 0 && rc == 0) { rc = h.rc; *rank = r; }
+    if (h.sig != h0.sig) *sig_ok = false;
+  }
+  return rc;
 }
 
 }  // namespace dthip

@@ -170,6 +170,12 @@ int  dthip_trim(dthip_ctx* ctx);
  *   "cluster_mode"   0 (default): a sample of neighbouring rows decides whether the bucketed aggregation
  *                    runs its variants for sorted / clustered / constant keys (a wave that addresses one
  *                    bucket or slot is counted / reduced in registers first); 1 = never, 2 = always
+ *   "guard"          debugging flavour (also env DTHIP_GUARD=1|2 at dthip_init; the counterpart of the reference's ASan build,
+ *                    ci/ext.py:318-327): every device buffer the library allocates (scratch, results, staged host
+ *                    columns, dthip_malloc) becomes its own virtual-memory mapping between two unmapped pages, with its
+ *                    END (1) or START (2) flush against them, nothing is cached and every kernel launch is synchronised:
+ *                    a kernel that touches even one 16-byte piece outside a buffer faults at once and is named on stderr;
+ *                    3 = only the synchronised, named launches (ordinary allocator), e.g. under a profiler
  *   "spec_min_rows"  from this many rows on, integer key ranges are first guessed from a sample
  *                    and verified by the bucketed aggregation (default 2^23) */
 int  dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value);

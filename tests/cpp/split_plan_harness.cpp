@@ -33,3 +33,32 @@ extern "C" int sp_bounds(const unsigned long long* imgs, const long long* cuts, 
   *shift = g.shift; *gmin = g.gmin;
   return 0;
 }
+
+// the aggregate path's splitters: every rank's slice imgs[cuts[r] .. cuts[r+1]) is ASCENDING; samples at the positions
+// sample_image_kernel reads (floor(i * n / SPLIT_SAMPLES)), then the library's sample_bounds
+extern "C" int sp_sample_bounds(const unsigned long long* imgs, const long long* cuts, int world, unsigned long long* bounds) {
+  using namespace dthip;
+  std::vector<unsigned long long> smp((size_t)world * SPLIT_SAMPLES, 0);
+  std::vector<long long> n(world);
+  for (int r = 0; r < world; r++) {
+    n[r] = cuts[r + 1] - cuts[r];
+    for (int i = 0; i < SPLIT_SAMPLES && n[r] > 0; i++)
+      smp[(size_t)r * SPLIT_SAMPLES + i] = imgs[cuts[r] + (long long)(((unsigned long long)i * (unsigned long long)n[r]) / SPLIT_SAMPLES)];
+  }
+  std::vector<unsigned long long> b;
+  sample_bounds(smp.data(), n.data(), world, &b);
+  for (size_t k = 0; k < b.size(); k++) bounds[k] = b[k];
+  return 0;
+}
+
+// status agreement over `world` blobs of `stride` bytes, each starting with a ShardHdr
+extern "C" int sp_first_failure(const int* rcs, const unsigned* sigs, int world, int* rank, int* sig_ok) {
+  using namespace dthip;
+  const size_t stride = sizeof(ShardHdr) + 24;
+  std::vector<unsigned char> blobs(stride * (size_t)world, 0xEE);
+  for (int r = 0; r < world; r++) { const ShardHdr h{rcs[r], sigs[r], (long long)r}; memcpy(blobs.data() + stride * (size_t)r, &h, sizeof(h)); }
+  bool ok = true;
+  const int rc = first_failure(blobs.data(), stride, world, rank, &ok);
+  *sig_ok = ok ? 1 : 0;
+  return rc;
+}

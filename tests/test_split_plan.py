@@ -102,3 +102,71 @@ def test_na_last_and_degenerate_ranges(lib):
     bounds, shift, _ = plan(lib, img, 3)
     assert shift == 52 and np.all(bounds[1:] >= bounds[:-1])
     assert sorted(np.bincount(dest(bounds, img), minlength=3).tolist()) == [1000, 1000, 1000]
+
+
+# ---- the aggregate path: splitters from every rank's 1024 local quantiles (sample_bounds) --------------------------
+def sample_plan(lib, slices):
+    """slices: one ASCENDING uint64 image array per rank"""
+    world = len(slices)
+    imgs = np.ascontiguousarray(np.concatenate(slices) if slices else np.zeros(0, np.uint64), np.uint64)
+    cuts = np.array([0] + list(np.cumsum([len(s) for s in slices])), np.int64)
+    bounds = np.zeros(max(world - 1, 1), np.uint64)
+    assert lib.sp_sample_bounds(imgs.ctypes.data_as(C.c_void_p), cuts.ctypes.data_as(C.c_void_p), world,
+                                bounds.ctypes.data_as(C.c_void_p)) == 0
+    return bounds[:world - 1]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8, 64])
+@pytest.mark.parametrize("kind", ["uniform", "skew", "wide", "uneven", "disjoint"])
+def test_sample_splitters_balance(lib, world, kind):
+    rng = np.random.default_rng(world * 13 + len(kind))
+    n = 400_000
+    if kind == "skew":
+        k = (rng.random(n) ** 8 * 1e12).astype(np.int64)
+    elif kind == "wide":
+        k = rng.integers(-2**62, 2**62, n)
+    else:
+        k = rng.integers(0, 10**7, n)
+    if kind == "uneven":
+        cuts = [0] + sorted(rng.integers(0, n + 1, world - 1).tolist()) + [n]
+    else:
+        cuts = [r * n // world for r in range(world + 1)]
+    if kind == "disjoint":       # every rank holds its own key range (already partitioned input)
+        k = np.sort(k)
+    slices = [np.unique(image_i64(k[cuts[r]:cuts[r + 1]])) for r in range(world)]     # partial groups: distinct, ascending
+    b = sample_plan(lib, slices)
+    assert np.all(b[1:] >= b[:-1])
+    total = sum(len(s) for s in slices)
+    got = np.zeros(world, np.int64)
+    for s in slices:
+        got += np.bincount(dest(b, s), minlength=world)
+    assert got.sum() == total
+    # every prefix of ranks holds its fair share to within one sample step per source (+ rounding)
+    slack = sum(len(s) / 1024 + 1 for s in slices) + 2
+    for kk in range(1, world):
+        assert abs(int(got[:kk].sum()) - total * kk / world) <= slack, (kk, got, slack)
+
+
+def test_sample_splitters_edge_cases(lib):
+    # no partial groups anywhere; one rank only; a single distinct key; the NA image (0) next to valid ones
+    assert list(sample_plan(lib, [np.zeros(0, np.uint64)] * 4)) == [2**64 - 1] * 3
+    b = sample_plan(lib, [np.zeros(0, np.uint64), np.arange(1, 5001, dtype=np.uint64), np.zeros(0, np.uint64)])
+    assert np.all(b[1:] >= b[:-1])
+    assert np.bincount(dest(b, np.arange(1, 5001, dtype=np.uint64)), minlength=3).max() <= 5000 // 3 + 8
+    one = [np.array([77], np.uint64)] * 5
+    b = sample_plan(lib, one)
+    assert len(set(dest(b, np.array([77], np.uint64)).tolist())) == 1          # one key -> one owner, never cut
+    na_first = [np.concatenate([[0], np.arange(10, 2000)]).astype(np.uint64)] * 2
+    b = sample_plan(lib, na_first)
+    assert dest(b, np.array([0], np.uint64))[0] == 0                           # NA image with the first rank
+
+
+def test_status_agreement(lib):
+    def ff(rcs, sigs):
+        rank, ok = C.c_int(0), C.c_int(0)
+        rc = lib.sp_first_failure((C.c_int * len(rcs))(*rcs), (C.c_uint * len(sigs))(*sigs), len(rcs), C.byref(rank), C.byref(ok))
+        return rc, rank.value, bool(ok.value)
+    assert ff([0, 0, 0], [5, 5, 5]) == (0, -1, True)
+    assert ff([0, -3, -1], [5, 5, 5]) == (-3, 1, True)            # first failing rank and ITS code, seen by every rank
+    assert ff([0, 0, 0, 0], [5, 5, 6, 5]) == (0, -1, False)       # ranks called with different queries
+    assert ff([-2], [1]) == (-2, 0, True)
