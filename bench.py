@@ -150,12 +150,113 @@ def port_leg(ctx, keys, vals, last_gpu, threads):
     return port, parity
 
 
-# ---- the other BASELINE configs: driver-visible timings -----------------------------------------------------
-def run_configs(ctx, dev, which, steps, scale):
+# ---- the other BASELINE configs: timed, then VERIFIED at full size, then the reference timed on a sample -----------
+class Budget:
+    """wall-clock budget of the optional legs (verification, CPU samples): a leg that would start after the budget is
+    spent is skipped and says so in the line -- the one JSON line must come out whatever the host's speed"""
+
+    def __init__(self, seconds):
+        self.t0, self.seconds = time.perf_counter(), seconds
+
+    def left(self):
+        return self.seconds - (time.perf_counter() - self.t0)
+
+    def ok(self, need=0.0):
+        return self.left() > need
+
+
+def _cmp_exact(got, exp):
+    import numpy as np
+    return bool(got.dtype == exp.dtype and got.shape == exp.shape and np.array_equal(got, exp, equal_nan=(exp.dtype.kind == "f")))
+
+
+def verify_agg(ctx, name, keys_t, vals_t, aggs, threads):
+    """GPU result of DT[:, aggs, by(keys)] on ALL rows of the config vs the OpenMP oracle (oracle/dt_oracle.c): group
+    keys, counts, min / max bit-exact, float64 sums / means within RTOL (+ATOL); raises on mismatch"""
+    import numpy as np
+    from oracle import oracle as o
+    from datatable_amd.torch_bridge import devcol
+    t0 = time.perf_counter()
+    r = ctx.groupby_agg([devcol(k) for k in keys_t], [devcol(v) for v in vals_t], aggs, nrows=keys_t[0].numel())
+    gk = [r.key(i) for i in range(len(keys_t))]
+    ga = [r.agg(a) for a in range(len(aggs))]
+    r.free()
+    hk = [to_host(k) for k in keys_t]
+    hv = [to_host(v) for v in vals_t]
+    o.lib(); o.set_threads(threads)
+    try:
+        ri, off = o.group(hk)
+        first = ri[off[:-1]]
+        keys_ok = all(_cmp_exact(gk[i], hk[i][first]) for i in range(len(hk)))
+        out = {"against": "oracle/dt_oracle.c, %d OpenMP threads" % threads, "rows": int(len(ri)), "groups": int(len(off) - 1),
+               "keys_bit_exact": keys_ok}
+        worst_abs, worst_rel, ok_all = 0.0, 0.0, keys_ok
+        for a, (op, c) in enumerate(aggs):
+            if not keys_ok:
+                break
+            exp = np.diff(off).astype(np.int64) if c is None else o.reduce(op, hv[c], ri, off)
+            if exp.dtype.kind == "f" and op in ("sum", "mean"):
+                ok, ma, mr = sums_close(ga[a], exp)
+                worst_abs, worst_rel = max(worst_abs, ma), max(worst_rel, mr)
+            else:
+                ok = _cmp_exact(ga[a], exp)
+            out["%s(%s)" % (op, "" if c is None else "v%d" % c)] = bool(ok)
+            ok_all = ok_all and ok
+    finally:
+        o.set_threads(1)
+    out.update({"ok": bool(ok_all), "sum_max_abs_err": worst_abs, "sum_max_rel_err": worst_rel, "rtol": RTOL, "atol": ATOL,
+                "seconds": time.perf_counter() - t0})
+    return out, (hk, hv)
+
+
+def verify_c5(ctx, k_t, x_t, threads):
+    """config 5 on ALL rows: the filter's RowIndex, the rows in grouped order (key, x, the composed RowIndex riding
+    through the sort) and the offsets, all bit-exact against the oracle's filter -> gather -> group"""
+    import numpy as np
+    import torch
+    from oracle import oracle as o
+    from datatable_amd.torch_bridge import devcol
+    t0 = time.perf_counter()
+    n = k_t.numel()
+    dev = k_t.device
+    ri_t = torch.empty(n, dtype=torch.int32, device=dev)
+    kb = torch.empty(n, dtype=torch.int64, device=dev)
+    xb = torch.empty(n, dtype=torch.float64, device=dev)
+    npass = ctx.filter_take_dev(devcol(x_t), ">", 0.0, [devcol(k_t), devcol(x_t)], n, ri_t.data_ptr(), [kb.data_ptr(), xb.data_ptr()])
+    r = ctx.groupby_rows([devcol(kb[:npass])], [devcol(kb[:npass]), devcol(xb[:npass]), devcol(ri_t[:npass])], nrows=npass, want_rowindex=False)
+    g_off = r.offsets()
+    g_k, g_x, g_ri = r.col(0), r.col(1), r.col(2)
+    r.free()
+    g_filter = to_host(ri_t[:npass])
+    del ri_t, kb, xb
+    torch.cuda.empty_cache()
+    hk, hx = to_host(k_t), to_host(x_t)
+    o.lib(); o.set_threads(threads)
+    try:
+        fri = o.filter_cmp(hx, ">", 0.0)
+        filter_ok = _cmp_exact(g_filter, fri)
+        kv = hk[fri]
+        p, off = o.group([kv])
+        comp = fri[p]                                  # RowIndex composition ab*bc (rowindex_array.cc:258-269)
+        res = {"against": "oracle/dt_oracle.c, %d OpenMP threads" % threads, "rows": int(n), "rows_passing": int(len(fri)),
+               "groups": int(len(off) - 1), "filter_rowindex_bit_exact": filter_ok,
+               "offsets_bit_exact": _cmp_exact(g_off, off), "composed_rowindex_bit_exact": _cmp_exact(g_ri, comp),
+               "key_column_bit_exact": _cmp_exact(g_k, hk[comp]), "x_column_bit_exact": _cmp_exact(g_x, hx[comp])}
+    finally:
+        o.set_threads(1)
+    res["ok"] = all(v for k, v in res.items() if k.endswith("bit_exact"))
+    res["seconds"] = time.perf_counter() - t0
+    return res, (hk, hx)
+
+
+def run_configs(ctx, dev, which, steps, scale, verify, cpu_sample, ref_threads, port_threads, budget):
+    import numpy as np
     import torch
     from datatable_amd.torch_bridge import devcol
+    from oracle import ref
     g = torch.Generator(device=dev)
     out = {}
+    dt_ref = ref.load() if cpu_sample else None
 
     def measure(name, n, alg_bytes, run, desc):
         run(); torch.cuda.synchronize()                      # warm-up: allocator, first touch
@@ -173,6 +274,32 @@ def run_configs(ctx, dev, which, steps, scale):
                      "kernel_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]}}
         torch.cuda.empty_cache(); ctx.trim()
 
+    def check(name, fn):
+        """full-size verification outside the timed loop; a mismatch aborts the bench"""
+        if not verify:
+            return None
+        if not budget.ok(30):
+            out[name]["parity"] = {"skipped": "time budget (%.0f s) spent" % budget.seconds}
+            return None
+        par, host = fn()
+        out[name]["parity"] = par
+        assert par["ok"], (name, par)
+        return host
+
+    def cpu(name, rows, fn):
+        """the reference's own CPU path on the first `rows` rows of this config's tensors"""
+        if dt_ref is None or not budget.ok(40):
+            if dt_ref is not None:
+                out[name]["cpu_reference"] = {"skipped": "time budget (%.0f s) spent" % budget.seconds}
+            return
+        try:
+            sec = fn()
+            out[name]["cpu_reference"] = {"rows": rows, "seconds": sec, "cpu_rows_s": rows / sec, "threads": ref_threads,
+                                          "gpu_over_cpu": out[name]["rows_s"] / (rows / sec),
+                                          "what": "unmodified reference (oracle/_ref), dt.options.nthreads=%d, fresh Frame, first %d rows" % (ref_threads, rows)}
+        except Exception as e:
+            out[name]["cpu_reference"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
     for c in which:
         if c == "C1":
             n = int(1e6 * scale); g.manual_seed(1235)
@@ -181,7 +308,10 @@ def run_configs(ctx, dev, which, steps, scale):
             def run():
                 r = ctx.groupby_agg([devcol(k)], [devcol(v)], [("sum", 0)], nrows=n); ng = r.ngroups; r.free(); return ng
             measure(c, n, n * 12 + 100 * 12, run, "DT[:, sum(f.v), by(f.k)], int32 key in [0,100), float64")
-            del k, v
+            host = check(c, lambda: verify_agg(ctx, c, [k], [v], [("sum", 0), ("count0", None)], port_threads))
+            if host:
+                cpu(c, n, lambda: ref.groupby_agg({"k": host[0][0], "v": host[1][0]}, ["k"], [("sum", "v")], nthreads=ref_threads)[1])
+            del k, v, host
         elif c == "C2":
             n = int(1e8 * scale); g.manual_seed(1236)
             k = torch.randint(0, 100_000, (n,), dtype=torch.int64, device=dev, generator=g)
@@ -190,7 +320,13 @@ def run_configs(ctx, dev, which, steps, scale):
             def run():
                 r = ctx.groupby_agg([devcol(k)], [devcol(x) for x in vs], aggs, nrows=n); ng = r.ngroups; r.free(); return ng
             measure(c, n, n * 40 + 100_000 * 136, run, "DT[:, [sum,mean,min,max](f[1:]), by(f.k)], int64 key in [0,1e5), 4 x float64")
-            del k, vs
+            host = check(c, lambda: verify_agg(ctx, c, [k], vs, aggs + [("count0", None)], port_threads))
+            if host:
+                S = min(n, cpu_sample)
+                cols = {"k": host[0][0][:S]}
+                cols.update({"v%d" % i: host[1][i][:S] for i in range(4)})
+                cpu(c, S, lambda: ref.groupby_agg(cols, ["k"], [(op, "v%d" % i) for op, i in aggs], nthreads=ref_threads)[1])
+            del k, vs, host
         elif c in ("C3_hard",):
             n = int(1e9 * scale); g.manual_seed(1240)
             pool = torch.randint(-2**62, 2**62, (10_000_000,), dtype=torch.int64, device=dev, generator=g)
@@ -200,7 +336,11 @@ def run_configs(ctx, dev, which, steps, scale):
             def run():
                 r = ctx.groupby_agg([devcol(k)], [devcol(v)], [("sum", 0)], nrows=n); ng = r.ngroups; r.free(); return ng
             measure(c, n, n * 16 + 10_000_000 * 16, run, "C3 with 63-bit keys drawn from a pool of 1e7 values (SURVEY 8(d) hard keys)")
-            del k, v
+            host = check(c, lambda: verify_agg(ctx, c, [k], [v], [("sum", 0), ("count0", None)], port_threads))
+            if host:
+                S = min(n, cpu_sample)
+                cpu(c, S, lambda: ref.groupby_agg({"k": host[0][0][:S], "v": host[1][0][:S]}, ["k"], [("sum", "v")], nthreads=ref_threads)[1])
+            del k, v, host
         elif c == "C4":
             n = int(1e9 * scale); g.manual_seed(1238)
             a = torch.randint(0, 3163, (n,), dtype=torch.int32, device=dev, generator=g)
@@ -210,7 +350,12 @@ def run_configs(ctx, dev, which, steps, scale):
                 r = ctx.groupby_agg([devcol(a), devcol(b)], [devcol(v)], [("count0", None), ("sum", 0)], nrows=n)
                 ng = r.ngroups; r.free(); return ng
             measure(c, n, n * 16 + 10_004_569 * 24, run, "DT[:, [count(), sum(f.v)], by(f.a, f.b)], 2 x int32 keys in [0,3163), float64")
-            del a, b, v
+            host = check(c, lambda: verify_agg(ctx, c, [a, b], [v], [("count0", None), ("sum", 0)], port_threads))
+            if host:
+                S = min(n, cpu_sample)
+                cpu(c, S, lambda: ref.groupby_agg({"a": host[0][0][:S], "b": host[0][1][:S], "v": host[1][0][:S]}, ["a", "b"],
+                                                  [("count", None), ("sum", "v")], nthreads=ref_threads)[1])
+            del a, b, v, host
         elif c == "C5":
             n = int(1e9 * scale); g.manual_seed(1239)
             k = torch.randint(0, 100_000_000, (n,), dtype=torch.int64, device=dev, generator=g)
@@ -227,9 +372,46 @@ def run_configs(ctx, dev, which, steps, scale):
                 r = ctx.groupby_rows([devcol(kv)], [devcol(kv), devcol(xv), devcol(ri[:npass])], nrows=npass, want_rowindex=False)
                 ng = r.ngroups; r.free(); return ng
             measure(c, n, int(n * 30.4), run, "V = DT[f.x > 0, :]; V[:, :, by(f.k)], int64 key in [0,1e8), float64 x, ~50% pass")
-            del k, x, ri, kbuf, xbuf
-        torch.cuda.empty_cache()
+            del ri, kbuf, xbuf
+            torch.cuda.empty_cache(); ctx.trim()
+            host = check(c, lambda: verify_c5(ctx, k, x, port_threads))
+            if host:
+                S = min(n, cpu_sample)
+                cpu(c, S, lambda: ref.filter_group_rows({"k": host[0][:S], "x": host[1][:S]}, "x", "k", nthreads=ref_threads)[1])
+            del k, x, host
+        torch.cuda.empty_cache(); ctx.trim()
     return out
+
+
+def dist_one_rank_leg(ctx, keys, vals, steps, local_ms):
+    """the sharded code path (RCCL all-gathers, all-to-all-v to self, merge) with ONE rank: its fixed cost over the
+    plain local call, per kernel -- what every rank of an N-GPU run pays on top of its 1/N of the rows"""
+    import torch
+    from datatable_amd.torch_bridge import devcol
+    from datatable_amd.engine import comm_unique_id
+    ctx.comm_init(0, 1, comm_unique_id())
+    try:
+        kc, vc = devcol(keys), devcol(vals)
+        n = keys.numel()
+        for _ in range(2):
+            ctx.sharded_groupby_agg([kc], [vc], [("sum", 0)], nrows=n).free()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.sharded_groupby_agg([kc], [vc], [("sum", 0)], nrows=n).free()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        ctx.profile_reset(); ctx.profile(True)
+        ctx.sharded_groupby_agg([kc], [vc], [("sum", 0)], nrows=n).free()
+        torch.cuda.synchronize(); ctx.profile(False)
+        prof = {nm: ctx.profile_get(nm) for nm in ctx.profile_names()}
+        return {"ms_per_step": ms, "local_ms_per_step": local_ms, "overhead_ms": ms - local_ms, "rows": n,
+                "what": "dthip_sharded_groupby_agg on a 1-rank RCCL communicator: 3 all-gathers (samples, send counts, status), "
+                        "all-to-all-v to self, merge of the partial groups",
+                "kernel_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},
+                "kernel_launches": int(sum(v[1] for v in prof.values()))}
+    finally:
+        ctx.comm_destroy()
 
 
 def host_mode_leg(ctx, rows):
@@ -312,6 +494,12 @@ def main():
     ap.add_argument("--configs", default="C1,C2,C4,C5,C3_hard", help="other BASELINE configs to time after C3 ('' = none)")
     ap.add_argument("--config-steps", type=int, default=3)
     ap.add_argument("--config-scale", type=float, default=1.0)
+    ap.add_argument("--no-verify-configs", action="store_true", help="time the other configs only (no full-size oracle check, no CPU sample)")
+    ap.add_argument("--time-budget", type=float, default=600.0,
+                    help="seconds after which the remaining OPTIONAL legs (full-size checks of the other configs, CPU samples, "
+                         "the all-rows reference run, the 1-rank sharded leg) are skipped and reported as skipped")
+    ap.add_argument("--no-ref-full", action="store_true", help="skip the reference's run over ALL rows of C3 (~1 min of CPU)")
+    ap.add_argument("--no-dist-1rank", action="store_true", help="skip the 1-rank run of the sharded (RCCL) code path")
     ap.add_argument("--host-rows", type=int, default=100_000_000, help="rows of the host-pointer (PCIe-inclusive) leg, 0 = skip")
     ap.add_argument("--no-check", action="store_true", help="skip the result sanity check (kernel timing experiments)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
@@ -319,11 +507,14 @@ def main():
     ap.add_argument("--bucket-variant", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (RCCL collectives, merge) even with one rank")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher contract only (CPU): ranks meet over gloo, the communicator id travels, one JSON line; no GPU work")
     ap.add_argument("--agg-offsets", type=int, default=0,
                     help="1: the result also carries group sizes (not part of DT[:, sum(f.v), by(f.k)]'s result Frame)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
+    budget = Budget(args.time_budget)
 
     # stdout carries exactly ONE line, the JSON: gloo and RCCL announce themselves on the C-level stdout (RCCL's banner
     # even after the line, when its buffer is flushed at exit), so fd 1 is pointed at stderr for the whole run and the
@@ -334,14 +525,36 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from datatable_amd.torch_bridge import context_for_current_stream, devcol
-    from datatable_amd.engine import comm_unique_id
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        # the control plane of a sharded run and nothing else: rendezvous, id hand-off, barrier, max over ranks
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        box = [os.urandom(128) if rank == 0 else None]          # stands for dthip_comm_unique_id() (needs librccl + a GPU)
+        dist.broadcast_object_list(box, src=0)
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, len(box[0])))
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.barrier()
+        tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "dry run: launcher contract only", "value": 0.0, "unit": "rows/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(tmax.item()) * 1e3,
+                              "dry_run": True, "ranks_seen": sorted(r for r, _ in seen), "id_bytes": min(n for _, n in seen)}),
+                  file=json_out, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    from datatable_amd.torch_bridge import context_for_current_stream, devcol
+    from datatable_amd.engine import comm_unique_id
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_dist
@@ -532,14 +745,51 @@ def main():
                 else:
                     line["cpu_baseline"]["port"] = port
         line["parity"] = parity or None
+    threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
+    if rank == 0 and world == 1 and not sharded and not args.no_dist_1rank and not args.no_check:
+        # the fixed cost of the sharded call, driver-visible (one rank: local work + collectives + merge)
+        if budget.ok(20):
+            try:
+                line["dist_1rank"] = dist_one_rank_leg(ctx, keys, vals, args.steps, ms_per_step)
+            except Exception as e:
+                line["dist_1rank"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        else:
+            line["dist_1rank"] = {"skipped": "time budget"}
+    ref_full_inputs = None
+    if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline and not args.no_ref_full and line.get("cpu_baseline") \
+            and line["cpu_baseline"].get("kind") == "reference":
+        ref_full_inputs = (to_host(keys), to_host(vals))
     del keys, vals, kcol, vcol
     torch.cuda.empty_cache(); ctx.trim()
     if rank == 0 and world == 1 and not sharded:
         which = [c for c in args.configs.split(",") if c]
         if which:
-            line["configs"] = run_configs(ctx, dev, which, args.config_steps, args.config_scale)
+            best_threads = int(line["cpu_baseline"]["cores"]) if line.get("cpu_baseline") and line["cpu_baseline"].get("kind") == "reference" else 16
+            cfg = run_configs(ctx, dev, which, args.config_steps, args.config_scale,
+                              verify=not (args.no_verify_configs or args.no_check),
+                              cpu_sample=0 if args.no_cpu_baseline else args.cpu_sample,
+                              ref_threads=best_threads, port_threads=threads, budget=budget)
+            line["configs"] = cfg
+            line["parity"] = line.get("parity") or {}
+            line["parity"]["configs"] = {c: (v["parity"].get("ok", v["parity"].get("skipped")) if "parity" in v else None) for c, v in cfg.items()}
+        if ref_full_inputs is not None:
+            # the reference's CPU path on the WHOLE workload, once, at the thread count the sample leg found best
+            # (sort.cc:1243-1282: past ~1e7 groups it pays a thread-team wake-up per tiny radix bucket -- the "cliff")
+            if budget.ok(150):
+                from oracle import ref
+                nt = int(line["cpu_baseline"]["cores"])
+                try:
+                    _, sec = ref.groupby_agg({"k": ref_full_inputs[0], "v": ref_full_inputs[1]}, ["k"], [("sum", "v")], nthreads=nt, reps=1)
+                    line["cpu_baseline"]["all_rows"] = {"rows": n_total, "seconds": sec, "rows_per_s": n_total / sec, "threads": nt,
+                                                        "gpu_over_cpu": value / (n_total / sec)}
+                except Exception as e:
+                    line["cpu_baseline"]["all_rows"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            else:
+                line["cpu_baseline"]["all_rows"] = {"skipped": "time budget"}
+            ref_full_inputs = None
         if args.host_rows:
             line["host_mode"] = host_mode_leg(ctx, args.host_rows)
+        line["seconds_total"] = time.perf_counter() - budget.t0
     if rank == 0:
         print(json.dumps(line), file=json_out, flush=True)
     if sharded:

@@ -10,8 +10,10 @@ source, and forwards every other form of `DT[...]` to the reference unchanged:
     from datatable import f, sum, mean, count
     from integration.datatable_hip_shim import Frame, by        # the shim's Frame and by()
     DT = Frame(dt.fread("data.jay"))                             # or Frame(k=..., v=...)
-    DT[:, [sum(f.v), count()], by(f.k)]                          # -> libdthip (MI355X)
-    DT[f.v > 0, :]                                               # -> the reference, as before
+    DT[:, [sum(f.v), count()], by(f.k)]                          # -> libdthip (MI355X): dthip_groupby_agg
+    V = DT[f.x > 0, :]; V[:, :, by(f.k)]                         # -> dthip_filter_take, dthip_groupby_rows (BASELINE config 5)
+    DT[:, [f.a, f.b], by(f.k)];  DT[:, :, sort(f.k)];  DT.sort("k")   # -> dthip_groupby_rows / dthip_groupby
+    DT[f.s == "a", :]                                            # -> the reference, as before
 
 How data crosses the boundary (all borrowed, zero-copy on the host side):
   * column buffers: `dt.internal.frame_column_data_r(frame, i)` -> `ctypes.c_void_p`
@@ -27,8 +29,18 @@ How data crosses the boundary (all borrowed, zero-copy on the host side):
   * errors: negative DTHIP_E* codes -> the Python exception the reference would raise
     (`datatable_amd._lib.check`, mirroring api.cc:34-38).
 
-`by()` must be the shim's: the reference's `datatable.by` object is opaque from Python
-(src/core/expr/py_by.cc:71-78), so the shim cannot read the grouping columns out of it.
+`by()` and `sort()` must be the shim's: the reference's `datatable.by` / `datatable.sort` objects are opaque from
+Python (src/core/expr/py_by.cc:71-78, py_sort.cc:33-100), so the shim cannot read the columns out of them.
+
+Row filters `DT[f.col <cmp> scalar, cols]`: an FExpr cannot be taken apart from Python either and its repr prints
+float scalars with six decimals only (`FExpr<f.v >= 1.500000>`), so the column and the operator come from the repr
+and the EXACT threshold is recovered by asking the reference itself: the predicate is evaluated on small probe frames
+of candidate values (a bisection over the column's value domain, ~6 evaluations of <= 1024 rows), which yields the
+smallest / largest element value that passes.  Whatever promotion rules the reference applies (an int column against
+2.5, a float32 column against a float64 scalar) are thereby reproduced rather than re-implemented.  The result of a
+row filter, of `DT[:, cols, by()]` and of a sort is a shim Frame (still a `datatable.Frame`) with materialised columns,
+so the second step of the two-step form of config 5 stays on the GPU; aggregations return the base class like the
+reference does.
 """
 import re
 import warnings
@@ -62,6 +74,23 @@ class by:
 
     def native(self):
         return dt.by(*self.cols)
+
+
+class sort:
+    """sort(f.k, ..., reverse=False, na_position="first") understood by the shim (py_sort.cc:33-100)"""
+
+    def __init__(self, *cols, reverse=False, na_position="first"):
+        self.cols = list(cols[0]) if len(cols) == 1 and isinstance(cols[0], (list, tuple)) else list(cols)
+        self.reverse, self.na_position = reverse, na_position
+
+    def native(self):
+        return dt.sort(*self.cols, reverse=self.reverse, na_position=self.na_position)
+
+
+_FILTER = re.compile(r"^FExpr<(%s) (>=|<=|==|!=|>|<) (.+)>$" % _CREF)
+_INT = re.compile(r"^-?\d+$")
+_FLOAT = re.compile(r"^-?(\d+\.\d+|inf)$")
+_ALLCOLS = "FExpr<f[:]>"
 
 
 def _colindex(frame, spec):
@@ -270,14 +299,311 @@ def run(frame, keys, aggs, ctx=None):
     return _finish(frame, keys, cols, names, bool_cols)
 
 
+# ---- row-returning routes: DT[f.x <cmp> c, cols], DT[:, cols, by(keys)], DT[:, cols, sort(...)] ---------------------
+def _is_all(x):
+    return x is None or x is Ellipsis or (isinstance(x, slice) and x == slice(None))
+
+
+def _jcols(frame, j, exclude=()):
+    """j = : | f[:] | column | [columns] -> column indices (`:` / f[:] leave out `exclude`: the by-columns), or None"""
+    if _is_all(j) or (not isinstance(j, (str, int, list, tuple, dict)) and repr(j) == _ALLCOLS):
+        return [c for c in range(frame.ncols) if c not in exclude]
+    if isinstance(j, dict):
+        return None
+    out = []
+    for x in (j if isinstance(j, (list, tuple)) else [j]):
+        if isinstance(x, bool):
+            return None
+        c = _colindex(frame, x)
+        if c is None:
+            return None
+        out.append(c)
+    return out
+
+
+def _accel(frame, cols):
+    return frame.nrows <= 2**31 - 1 and all(frame.stypes[c].value in _ACCEL_STYPES for c in cols)
+
+
+def _ord(a):
+    """order-preserving integer image of a float array (-0.0 just below +0.0); integers are their own image"""
+    if a.dtype.kind != "f":
+        return a.astype(object)
+    it = np.int64 if a.dtype == np.float64 else np.int32
+    b = a.view(it).astype(object)
+    top = int(np.iinfo(it).max)
+    return np.array([int(x) if x >= 0 else int(x) ^ top for x in b], dtype=object)
+
+
+def _unord(o, dtype):
+    if dtype.kind != "f":
+        return np.array([int(x) for x in o], dtype=dtype)
+    it = np.int64 if dtype == np.float64 else np.int32
+    top = int(np.iinfo(it).max)
+    return np.array([x if x >= 0 else x ^ top for x in o], dtype=it).view(dtype)
+
+
+def _threshold(frame, expr, ci, op, text):
+    """The exact meaning of `f.col <op> scalar` on column ci's stype, recovered from the reference's own evaluation of
+    `expr` on probe frames: ("ge" | "le", smallest / largest passing element value), ("eq" | "ne", value),
+    ("isna",) / ("notna",) / ("none",) -- or None when the predicate is not one the library evaluates."""
+    if text == "None":
+        return ("isna",) if op == "==" else ("notna",) if op == "!=" else None
+    st = frame.stypes[ci].value
+    if st == L.BOOL:
+        return None
+    dtype = ST2NP[st]
+    if text in ("True", "False"):
+        approx = 1.0 if text == "True" else 0.0
+    elif _INT.match(text):
+        approx = int(text)
+    elif _FLOAT.match(text):
+        approx = float(text)
+    else:
+        return None
+    name = frame.names[ci]
+    if dtype.kind == "f":
+        with np.errstate(over="ignore"):
+            approx = float(dtype.type(approx)) if dtype == np.float64 or abs(float(approx)) <= 3.4e38 else (np.inf if approx > 0 else -np.inf)
+
+    def count(vals):
+        """rows of a probe frame (same names and stypes as `frame`; column ci = vals) passing the predicate"""
+        m = len(vals)
+        parts = []
+        for c in range(frame.ncols):
+            stc = frame.stypes[c]
+            if c == ci:
+                parts.append(dt.Frame({frame.names[c]: vals}))
+            elif stc.value in ST2NP:
+                parts.append(dt.Frame({frame.names[c]: np.zeros(m, np.bool_ if stc.value == L.BOOL else ST2NP[stc.value])}))
+            else:
+                parts.append(dt.Frame({frame.names[c]: [None] * m}, stype=stc))
+        P = dt.cbind(*parts) if len(parts) > 1 else parts[0]
+        return dt.Frame.__getitem__(P, (expr, name)).nrows
+
+    isf = dtype.kind == "f"
+    if isf:
+        lo_d, hi_d = (-np.inf, np.inf)
+        dom = _ord(np.array([lo_d, hi_d], dtype))
+    else:
+        info = np.iinfo(dtype)
+        dom = np.array([int(info.min) + 1, int(info.max)], dtype=object)        # the minimum is the NA sentinel
+    if op in ("==", "!="):
+        if isf:
+            c0 = dtype.type(approx)
+            if not np.isfinite(c0) and not np.isinf(c0):
+                return None
+            probe = np.array([np.nextafter(c0, dtype.type(-np.inf)), c0, np.nextafter(c0, dtype.type(np.inf))], dtype)
+        else:
+            if isinstance(approx, float):
+                if approx != int(approx):
+                    return ("none",) if op == "==" else ("all",)               # never equal / always unequal (NA included)
+                approx = int(approx)
+            if approx < dom[0] or approx > dom[1]:
+                return ("none",) if op == "==" else ("all",)
+            probe = np.array([v for v in (approx - 1, approx, approx + 1) if dom[0] <= v <= dom[1]], dtype)
+            c0 = dtype.type(approx)
+        hits = [count(probe[i:i + 1]) for i in range(len(probe))]
+        want = [int((v == c0) == (op == "==")) for v in probe]
+        return (("eq" if op == "==" else "ne"), c0.item()) if hits == want else None
+    # orderings: a step function over the ordered domain; find the step
+    up = op in (">", ">=")                                                        # passing values are the large ones
+    if isf:
+        c0 = dtype.type(approx)
+        if np.isinf(c0):
+            lo = hi = int(_ord(np.array([c0], dtype))[0])
+        else:
+            w = dtype.type(4e-6) + abs(c0) * dtype.type(1e-6 if dtype == np.float32 else 1e-15)
+            with np.errstate(over="ignore"):
+                lo, hi = _ord(np.array([c0 - w, c0 + w], dtype))
+            lo, hi = int(lo) - 8, int(hi) + 8
+    else:
+        lo, hi = int(np.floor(approx)) - 2, int(np.ceil(approx)) + 2
+    lo, hi = min(max(lo, int(dom[0])), int(dom[1])), min(max(hi, int(dom[0])), int(dom[1]))
+    ends = _unord([lo, hi], dtype)
+    f_lo, f_hi = count(ends[:1]), count(ends[1:])
+    if f_lo == f_hi:                                       # no step inside the window: look at the whole domain
+        lo, hi = int(dom[0]), int(dom[1])
+        ends = _unord([lo, hi], dtype)
+        f_lo, f_hi = count(ends[:1]), count(ends[1:])
+        if f_lo == f_hi:
+            return ("notna",) if f_lo else ("none",)
+    if (f_hi == 1) != up:
+        return None                                         # not monotone the way the operator says: leave it alone
+    while hi - lo > 1:
+        m = min(1024, hi - lo + 1)
+        cand = sorted({lo + (hi - lo) * i // (m - 1) for i in range(m)})
+        npass = count(_unord(cand, dtype))
+        # passing candidates are the top npass (up) or the bottom npass (down)
+        if up:
+            lo, hi = cand[len(cand) - npass - 1], cand[len(cand) - npass]
+        else:
+            lo, hi = cand[npass - 1], cand[npass]
+    t = _unord([hi if up else lo], dtype)[0]
+    return ("ge" if up else "le", t.item())
+
+
+def match_filter(frame, item):
+    """DT[f.col <cmp> scalar, cols] -> (predicate column, ("ge"|"le"|"eq"|..., value), selected columns) or None"""
+    if not (isinstance(item, tuple) and len(item) == 2):
+        return None
+    i, j = item
+    if isinstance(i, (int, slice, list, tuple, str, type(None), np.ndarray)) or i is Ellipsis or isinstance(i, dt.Frame):
+        return None
+    m = _FILTER.match(repr(i))
+    if not m:
+        return None
+    ci = _colspec(frame, "FExpr<%s>" % m.group(1))
+    cols = _jcols(frame, j)
+    if ci is None or cols is None or not cols or not _accel(frame, cols + [ci]) or frame.nrows == 0:
+        return None
+    try:
+        th = _threshold(frame, i, ci, m.group(2), m.group(3))
+    except Exception:
+        return None
+    return None if th is None else (ci, th, cols)
+
+
+def _wrap(frame, cols, names, bool_cols):
+    return Frame(_finish(frame, [], cols, names, bool_cols))
+
+
+def run_filter(frame, ci, th, cols, ctx=None):
+    """the passing rows of `cols`, materialised in one sweep next to the predicate column (dthip_filter_take)"""
+    import ctypes as C
+    ctx = ctx or default_context()
+    lib = ctx._lib
+    n = frame.nrows
+    kind = th[0]
+    if kind in ("none", "all"):
+        sel = slice(0, 0) if kind == "none" else slice(None)
+        return Frame(dt.Frame.__getitem__(frame, (sel, [frame.names[c] for c in cols])))
+    st = frame.stypes[ci].value
+    isf = st in (L.FLOAT32, L.FLOAT64)
+    code = {"ge": L.GE, "le": L.LE, "eq": L.EQ, "ne": L.NE, "isna": L.ISNA, "notna": L.NOTNA}[kind]
+    cf = float(th[1]) if len(th) > 1 and isf else 0.0
+    cint = int(th[1]) if len(th) > 1 and not isf else 0
+    pcol = _col(frame, ci)
+    outs, names, bool_cols = [], [], []
+    npass = None
+    for lo in range(0, len(cols), 8):                       # dthip_filter_take takes up to 8 columns per sweep
+        part = cols[lo:lo + 8]
+        carr = (L.Col * len(part))(*[_col(frame, c) for c in part])
+        bufs = [np.empty(n, ST2NP[frame.stypes[c].value]) for c in part]
+        optr = (C.c_void_p * len(part))(*[b.ctypes.data for b in bufs])
+        k = C.c_int64(0)
+        L.check(lib.dthip_filter_take(ctx._h, C.byref(pcol), code, cf, cint, carr, len(part), n, L.HOST, None, optr, C.byref(k)))
+        npass = k.value
+        for c, b in zip(part, bufs):
+            if frame.stypes[c].value == L.BOOL:
+                bool_cols.append(len(outs))
+            outs.append(b[:npass]); names.append(frame.names[c])
+    return _wrap(frame, outs, names, bool_cols)
+
+
+def match_rows(frame, item):
+    """DT[:, cols, by(keys)] with plain columns in j -> (key indices, column indices) or None"""
+    if not (isinstance(item, tuple) and len(item) == 3 and isinstance(item[2], by) and _is_all(item[0])):
+        return None
+    keys = [_colindex(frame, c) for c in item[2].cols]
+    if not keys or any(k is None for k in keys) or len(set(keys)) != len(keys):
+        return None
+    cols = _jcols(frame, item[1], exclude=keys)
+    if cols is None or not _accel(frame, keys + cols) or frame.nrows == 0:
+        return None
+    return keys, cols
+
+
+def _rows_call(frame, keys, desc, cols, na_pos, ctx):
+    """dthip_groupby_rows (or, for na_position='remove', dthip_groupby + dthip_gather per column): `cols` in key order"""
+    import ctypes as C
+    lib = ctx._lib
+    n = frame.nrows
+    karr = (L.Col * len(keys))(*[L.Col(dt.internal.frame_column_data_r(frame, k).value, frame.stypes[k].value,
+                                       L.FLAG_DESCENDING if d else 0) for k, d in zip(keys, desc)])
+    h = C.c_void_p()
+    outs = []
+    if na_pos == L.NA_REMOVE:
+        L.check(lib.dthip_groupby(ctx._h, karr, len(keys), n, na_pos, L.HOST, 1, C.byref(h)))
+        try:
+            m = lib.dthip_result_nrows(h)
+            ri = np.empty(m, np.int32)
+            L.check(lib.dthip_result_copy_rowindex(ctx._h, h, ri.ctypes.data, L.HOST))
+        finally:
+            lib.dthip_result_free(ctx._h, h)
+        for c in cols:
+            out = np.empty(m, ST2NP[frame.stypes[c].value])
+            cc = _col(frame, c)
+            if m:
+                L.check(lib.dthip_gather(ctx._h, C.byref(cc), ri.ctypes.data, m, L.HOST, out.ctypes.data))
+            outs.append(out)
+        return outs
+    carr = (L.Col * max(len(cols), 1))(*[_col(frame, c) for c in cols])
+    L.check(lib.dthip_groupby_rows(ctx._h, karr, len(keys), carr, len(cols), n, na_pos, L.HOST, 0, C.byref(h)))
+    try:
+        for i, c in enumerate(cols):
+            out = np.empty(n, ST2NP[frame.stypes[c].value])
+            L.check(lib.dthip_result_copy_col(ctx._h, h, i, out.ctypes.data, L.HOST))
+            outs.append(out)
+    finally:
+        lib.dthip_result_free(ctx._h, h)
+    return outs
+
+
+def run_rows(frame, keys, cols, ctx=None):
+    """DT[:, cols, by(keys)]: the by-columns, then `cols`, every row, in grouped order (evaluate_select,
+    eval_context.cc:497-508): the columns ride through the sort on the device"""
+    ctx = ctx or default_context()
+    allc = list(keys) + list(cols)
+    outs = _rows_call(frame, keys, [False] * len(keys), allc, L.NA_FIRST, ctx)
+    bools = [i for i, c in enumerate(allc) if frame.stypes[c].value == L.BOOL]
+    return _wrap(frame, outs, [frame.names[c] for c in allc], bools)
+
+
+def match_sort(frame, item):
+    """DT[:, cols, sort(...)] -> (key indices, descending flags, na_pos, column indices) or None"""
+    if not (isinstance(item, tuple) and len(item) == 3 and isinstance(item[2], sort) and _is_all(item[0])):
+        return None
+    srt = item[2]
+    keys = [_colindex(frame, c) for c in srt.cols]
+    if not keys or any(k is None for k in keys):
+        return None
+    rev = srt.reverse
+    desc = [bool(rev)] * len(keys) if not isinstance(rev, (list, tuple)) else [bool(x) for x in rev]
+    if len(desc) != len(keys) or srt.na_position not in ("first", "last", "remove"):
+        return None                                              # the reference raises its own error
+    cols = _jcols(frame, item[1])
+    if cols is None or not cols or not _accel(frame, keys + cols) or frame.nrows == 0:
+        return None
+    return keys, desc, {"first": L.NA_FIRST, "last": L.NA_LAST, "remove": L.NA_REMOVE}[srt.na_position], cols
+
+
+def run_sort(frame, keys, desc, na_pos, cols, ctx=None):
+    ctx = ctx or default_context()
+    outs = _rows_call(frame, keys, desc, cols, na_pos, ctx)
+    bools = [i for i, c in enumerate(cols) if frame.stypes[c].value == L.BOOL]
+    return _wrap(frame, outs, [frame.names[c] for c in cols], bools)
+
+
 class Frame(dt.Frame):
-    """datatable.Frame whose __getitem__ sends the groupby-aggregate hot path to the GPU.
-    Everything else -- and every Frame it returns -- is the reference's."""
+    """datatable.Frame whose __getitem__ sends the group-by hot path to the GPU: aggregations, the row filter and the
+    rows-in-grouped-order / sort forms.  Everything else is the reference's."""
 
     def __getitem__(self, item):
         plan = match(self, item)
         if plan is not None:
             return run(self, *plan)
+        for matcher, runner in ((match_filter, run_filter), (match_rows, run_rows), (match_sort, run_sort)):
+            plan = matcher(self, item)
+            if plan is not None:
+                return runner(self, *plan)
         if isinstance(item, tuple):
-            item = tuple(x.native() if isinstance(x, by) else x for x in item)
+            item = tuple(x.native() if isinstance(x, (by, sort)) else x for x in item)
         return super().__getitem__(item)
+
+    def sort(self, *cols):
+        """Frame.sort(cols): ascending, NA first (src/core/sort.cc:539-558) == DT[:, :, sort(cols)]"""
+        plan = match_sort(self, (slice(None), slice(None), sort(*cols)))
+        if plan is not None:
+            return run_sort(self, *plan)
+        return super().sort(*cols)

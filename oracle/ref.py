@@ -96,3 +96,19 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def filter_group_rows(cols, xname, keyname, nthreads=None):
+    """BASELINE config 5 in the only form the reference supports: V = DT[f.x > 0, :]; V[:, :, by(f.k)],
+    the result materialised (the GPU path returns materialised columns; the reference's result columns are views until
+    someone reads them).  Returns (result Frame, seconds)."""
+    dt = load()
+    from datatable import f, by
+    if nthreads is not None:
+        set_threads(nthreads)
+    DT = dt.Frame(cols)
+    t0 = time.perf_counter()
+    V = DT[f[xname] > 0, :]
+    R = V[:, :, by(f[keyname])]
+    R.materialize()
+    return R, time.perf_counter() - t0

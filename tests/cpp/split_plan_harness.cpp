@@ -62,3 +62,31 @@ extern "C" int sp_first_failure(const int* rcs, const unsigned* sigs, int world,
   *sig_ok = ok ? 1 : 0;
   return rc;
 }
+
+// sample_bounds on raw all-gathered samples (world x SPLIT_SAMPLES) -- what every rank of comm.hip computes after all-gather A
+extern "C" int sp_bounds_from_samples(const unsigned long long* samples, const long long* n, int world, unsigned long long* bounds) {
+  std::vector<unsigned long long> b;
+  dthip::sample_bounds(samples, n, world, &b);
+  for (size_t k = 0; k < b.size(); k++) bounds[k] = b[k];
+  return dthip::SPLIT_SAMPLES;
+}
+
+// reduce_key_ranges + split_bounds on raw all-gathered ranges / histograms (the rows path after all-gathers A and B)
+extern "C" int sp_range(const unsigned long long* ranges3, int world, unsigned long long* gmin, int* shift, unsigned long long* nvalid) {
+  using namespace dthip;
+  std::vector<RangeAcc> r(world);
+  for (int k = 0; k < world; k++) r[k] = RangeAcc{ranges3[3 * k], ranges3[3 * k + 1], ranges3[3 * k + 2]};
+  const GlobalRange g = reduce_key_ranges(r.data(), world);
+  *gmin = g.gmin; *shift = g.shift; *nvalid = g.nvalid;
+  return SPLIT_BINS;
+}
+extern "C" int sp_bounds_from_hist(const unsigned long long* ranges3, const unsigned long long* hist, int world, unsigned long long* bounds) {
+  using namespace dthip;
+  std::vector<RangeAcc> r(world);
+  for (int k = 0; k < world; k++) r[k] = RangeAcc{ranges3[3 * k], ranges3[3 * k + 1], ranges3[3 * k + 2]};
+  const GlobalRange g = reduce_key_ranges(r.data(), world);
+  std::vector<unsigned long long> b;
+  split_bounds(hist, world, g, &b);
+  for (size_t k = 0; k < b.size(); k++) bounds[k] = b[k];
+  return 0;
+}

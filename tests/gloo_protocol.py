@@ -1,0 +1,181 @@
+"""TEST INFRASTRUCTURE: the multi-GPU protocol of datatable_amd/csrc/comm.hip re-enacted over gloo on CPU tensors, one
+process per rank, with the CPU oracle standing in for the per-rank HIP kernels.  What it shares with the product is the
+host-side planning code itself -- csrc/split_plan.hpp compiled by g++ (tests/cpp/split_plan_harness.cpp): quantile
+splitters (sample_bounds), histogram splitters (reduce_key_ranges / split_bounds), the {status, signature, n} header of
+every all-gathered blob and first_failure -- and the phase order: all-gather A (samples | range), [B histogram], send
+counts, status, all-to-all-v, merge.  Used by tests/test_dist_gloo.py (world_size 2)."""
+import ctypes as C
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Q = 1024
+BINS = 4096
+_H = None
+
+
+def harness():
+    global _H
+    if _H is None:
+        so = os.path.join(tempfile.mkdtemp(prefix="splitplan"), "libsplitplan.so")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC",
+                               os.path.join(ROOT, "tests", "cpp", "split_plan_harness.cpp"), "-o", so])
+        _H = C.CDLL(so)
+    return _H
+
+
+def image(k, na_last=False):
+    """order-preserving uint64 image of an integer key column (comm.hip key_image); NA -> 0 / ~0"""
+    k64 = k.astype(np.int64)
+    img = k64.view(np.uint64) ^ np.uint64(1 << 63)
+    na = k == np.iinfo(k.dtype).min
+    img[na] = np.uint64(2**64 - 1) if na_last else np.uint64(0)
+    return img
+
+
+def allgather_blob(rc, sig, n, payload):
+    """every rank's {rc, sig, n} + payload bytes -> list of (rc, sig, n, payload) in rank order"""
+    blob = struct.pack("<iIq", rc, sig, n) + payload
+    t = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    res = []
+    for o in outs:
+        b = o.numpy().tobytes()
+        res.append(struct.unpack("<iIq", b[:16]) + (b[16:],))
+    return res
+
+
+def agree(blobs):
+    """first_failure of split_plan.hpp on the gathered headers: (rc, failing rank, signatures equal)"""
+    world = len(blobs)
+    rank, ok = C.c_int(0), C.c_int(0)
+    rc = harness().sp_first_failure((C.c_int * world)(*[b[0] for b in blobs]), (C.c_uint * world)(*[b[1] for b in blobs]),
+                                    world, C.byref(rank), C.byref(ok))
+    return rc, rank.value, bool(ok.value)
+
+
+class Disagreement(Exception):
+    pass
+
+
+def _check(blobs):
+    rc, rank, ok = agree(blobs)
+    if not ok:
+        raise Disagreement("ranks were called with different queries")
+    if rc:
+        raise Disagreement("rank %d failed with code %d" % (rank, rc))
+
+
+def _a2av(t, send_counts, recv_counts):
+    out = t.new_empty((int(sum(recv_counts)),) + tuple(t.shape[1:]))
+    dist.all_to_all_single(out, t.contiguous(), list(map(int, recv_counts)), list(map(int, send_counts)))
+    return out
+
+
+def _exchange_counts(send_cnt, sig, rc=0):
+    blobs = allgather_blob(rc, sig, int(sum(send_cnt)), np.asarray(send_cnt, np.int64).tobytes())
+    _check(blobs)
+    me = dist.get_rank()
+    return [int(np.frombuffer(b[3], np.int64)[me]) for b in blobs]
+
+
+def partial_plan(aggs):
+    """comm.hip plan_partials: mean -> (weighted sum, count); duplicates shared"""
+    partial, recipe = [], []
+
+    def need(op, col):
+        if (op, col) not in partial:
+            partial.append((op, col))
+        return partial.index((op, col))
+    for op, col in aggs:
+        if op == "mean":
+            recipe.append((1, need("mean", col), need("count", col)))
+        elif op == "count0":
+            recipe.append((0, need("count0", None), -1))
+        else:
+            recipe.append((0, need(op, col), -1))
+    return partial, recipe
+
+
+def sharded_groupby_agg(local_agg, keys, values, aggs, sig=1, fail=False, na_last=False):
+    """keys / values: this rank's numpy columns.  local_agg(keys, values, aggs) -> (group key columns, agg columns) in key
+    order (the oracle).  Returns (group keys, aggregates) of this rank's key range."""
+    world = dist.get_world_size()
+    partial, recipe = partial_plan(aggs)
+    rc = -3 if fail else 0
+    gk, cols, smp, ng = [], [], np.zeros(Q, np.uint64), 0
+    if rc == 0:
+        gk, cols = local_agg(keys, values, partial)
+        ng = len(gk[0])
+        for i, (op, col) in enumerate(partial):          # mean partials travel as weighted sums
+            if op == "mean":
+                cnt = cols[partial.index(("count", col))]
+                cols[i] = np.where(cnt > 0, cols[i].astype(np.float64) * cnt, 0.0)
+        img = image(gk[0], na_last)
+        if ng:
+            smp = img[(np.arange(Q, dtype=np.uint64) * np.uint64(ng)) // np.uint64(Q)]
+    blobs = allgather_blob(rc, sig, ng, smp.tobytes())                                  # all-gather A
+    _check(blobs)
+    allsmp = np.concatenate([np.frombuffer(b[3], np.uint64) for b in blobs])
+    counts = np.array([b[2] for b in blobs], np.int64)
+    bounds = np.zeros(max(world - 1, 1), np.uint64)
+    harness().sp_bounds_from_samples(allsmp.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), world,
+                                     bounds.ctypes.data_as(C.c_void_p))
+    cuts = [0] + [int(np.searchsorted(img, b, side="left")) for b in bounds[:world - 1]] + [ng]    # lower_bound_kernel
+    send_cnt = np.diff(cuts)
+    recv_cnt = _exchange_counts(send_cnt, sig)                                          # all-gather B
+    _check(allgather_blob(0, sig, 0, b""))                                              # all-gather C (status)
+    rk = [_a2av(torch.from_numpy(np.ascontiguousarray(k)), send_cnt, recv_cnt).numpy() for k in gk]
+    rp = [_a2av(torch.from_numpy(np.ascontiguousarray(c)), send_cnt, recv_cnt).numpy() for c in cols]
+    # merge on the owner: sums of sums / counts, min of mins, max of maxs
+    mops = [("sum" if op in ("sum", "mean", "count", "count0") else op, i) for i, (op, _) in enumerate(partial)]
+    mk, mc = local_agg(rk, rp, mops, nona=[op in ("sum", "mean", "count", "count0") for op, _ in partial])
+    out = []
+    for (kind, a, b), (op, col) in zip(recipe, aggs):
+        if kind == 0:
+            out.append(mc[a])
+        else:
+            with np.errstate(invalid="ignore", divide="ignore"):
+                out.append(np.where(mc[b] > 0, mc[a] / np.maximum(mc[b], 1), np.nan))
+    return mk, out
+
+
+def sharded_groupby_rows(local_rows, keys, cols, row_offset, sig=2, na_last=False):
+    """rows in grouped order: range (A), histogram (B), counts (C), status (D), all-to-all-v, one stable local grouping.
+    local_rows(keys, cols) -> (offsets, cols in grouped order)."""
+    world = dist.get_world_size()
+    n = len(keys[0])
+    img = image(keys[0], na_last)
+    na_img = np.uint64(2**64 - 1) if na_last else np.uint64(0)
+    valid = img != na_img
+    rng = np.array([img[valid].min() if valid.any() else 2**64 - 1, img[valid].max() if valid.any() else 0, int(valid.sum())], np.uint64)
+    blobs = allgather_blob(0, sig, n, rng.tobytes())                                     # A
+    _check(blobs)
+    ranges = np.concatenate([np.frombuffer(b[3], np.uint64) for b in blobs])
+    gmin, shift, nvalid = C.c_ulonglong(0), C.c_int(0), C.c_ulonglong(0)
+    assert harness().sp_range(ranges.ctypes.data_as(C.c_void_p), world, C.byref(gmin), C.byref(shift), C.byref(nvalid)) == BINS
+    hist = np.zeros(BINS, np.uint64)
+    if nvalid.value and valid.any():
+        hist = np.bincount(((img[valid] - np.uint64(gmin.value)) >> np.uint64(shift.value)).astype(np.int64), minlength=BINS).astype(np.uint64)
+    blobs = allgather_blob(0, sig, n, hist.tobytes())                                    # B
+    _check(blobs)
+    allhist = np.concatenate([np.frombuffer(b[3], np.uint64) for b in blobs])
+    bounds = np.zeros(max(world - 1, 1), np.uint64)
+    harness().sp_bounds_from_hist(ranges.ctypes.data_as(C.c_void_p), allhist.ctypes.data_as(C.c_void_p), world,
+                                  bounds.ctypes.data_as(C.c_void_p))
+    dest = np.searchsorted(bounds[:world - 1], img, side="right")                         # image_dest_kernel
+    order = np.argsort(dest, kind="stable")                                               # stable partition by destination
+    send_cnt = np.bincount(dest, minlength=world)
+    recv_cnt = _exchange_counts(send_cnt, sig)                                            # C
+    _check(allgather_blob(0, sig, 0, b""))                                                # D
+    rowid = np.arange(row_offset, row_offset + n, dtype=np.int64)
+    rk = [_a2av(torch.from_numpy(np.ascontiguousarray(k[order])), send_cnt, recv_cnt).numpy() for k in keys]
+    rc = [_a2av(torch.from_numpy(np.ascontiguousarray(c[order])), send_cnt, recv_cnt).numpy() for c in list(cols) + [rowid]]
+    return local_rows(rk, rc, na_last)

@@ -1,12 +1,16 @@
-"""CPU, world_size 2, gloo: the exchange logic of datatable_amd.dist (range partition of
-partials, all-to-all-v, merge) with the CPU oracle standing in for the per-rank HIP
-groupby.  The concatenation of the ranks' outputs must equal a single-process run."""
+"""CPU, world_size 2, gloo, one process per rank: the multi-GPU protocol of datatable_amd/csrc/comm.hip (tests/
+gloo_protocol.py re-enacts its phases around the library's own host planning code, csrc/split_plan.hpp) with the CPU
+oracle standing in for the per-rank HIP kernels.  The concatenation of the ranks' outputs must equal the oracle's
+single-process result; a failing rank / a rank with another query must make EVERY rank return (nobody hangs); and
+`python bench.py --gpus 2` must bring its own ranks up (launcher contract, --dry-run: no GPU work)."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -15,44 +19,34 @@ from conftest import ROOT
 OPS = [("sum", 0), ("mean", 0), ("min", 0), ("max", 0), ("count", 0), ("count0", None), ("sum", 1), ("mean", 1)]
 
 
-class OracleBackend:
-    """local groupby_agg computed by oracle/ (test infrastructure) on CPU tensors"""
+def oracle_agg(keys, values, aggs, nona=None):
+    """local groupby-aggregate by oracle/ (test infrastructure); nona[i]: value column i holds partial sums, every bit
+    pattern is a value (DTHIP_FLAG_NONA) -- summed with numpy instead of the NA-skipping reducer"""
+    from oracle import oracle as o
+    ri, off = o.group(keys)
+    gk = [k[ri[off[:-1]]] for k in keys]
+    out = []
+    for op, col in aggs:
+        if op == "count0":
+            out.append(o.reduce("count0", None, None, off))
+        elif nona is not None and nona[col]:
+            out.append(np.add.reduceat(values[col][ri], off[:-1]) if len(ri) else values[col][:0].copy())
+        else:
+            out.append(o.reduce(op, values[col], ri, off))
+    return gk, out
 
-    def groupby_agg(self, keys, values, aggs):
-        from oracle import oracle as o
-        kn = [k.numpy() for k in keys]
-        vn = [v.numpy() for v in values]
-        ri, off = o.group(kn)
-        gk = [torch.from_numpy(k[ri[off[:-1]]].copy()) for k in kn]
-        out = []
-        for op, col in aggs:
-            if op == "count0":
-                out.append(torch.from_numpy(o.reduce("count0", None, None, off)))
-            else:
-                out.append(torch.from_numpy(o.reduce(op, vn[col], ri, off)))
-        return gk, out
 
-
-    def groupby_rows(self, keys, cols):
-        from oracle import oracle as o
-        kn = [k.numpy() for k in keys]
-        if len(kn[0]) == 0:
-            return torch.zeros(1, dtype=torch.int32), [c.clone() for c in cols]
-        ri, off = o.group(kn)
-        return torch.from_numpy(off.copy()), [torch.from_numpy(c.numpy()[ri].copy()) for c in cols]
-
-    def range_bucket(self, key, bounds):
-        k = key.numpy()
-        valid = k != np.iinfo(k.dtype).min
-        d = np.zeros(len(k), np.int8)
-        for b in bounds:
-            d += (valid & (k.astype(np.int64) >= b)).astype(np.int8)
-        return torch.from_numpy(d)
+def oracle_rows(keys, cols, na_last=False):
+    from oracle import oracle as o
+    if len(keys[0]) == 0:
+        return np.zeros(1, np.int32), [c.copy() for c in cols]
+    ri, off = o.group(keys, na_last=na_last)
+    return off, [c[ri] for c in cols]
 
 
 def make_data(seed, n, nkeys):
     rng = np.random.default_rng(seed)
-    keys = [rng.integers(-40, 40, n).astype(np.int64 if i == 0 else np.int32) for i in range(nkeys)]
+    keys = [rng.integers(-4000, 4000, n).astype(np.int64 if i == 0 else np.int32) for i in range(nkeys)]
     keys[0][rng.random(n) < 0.05] = np.iinfo(np.int64).min
     v0 = rng.standard_normal(n)
     v0[rng.random(n) < 0.1] = np.nan
@@ -61,65 +55,54 @@ def make_data(seed, n, nkeys):
     return keys, [v0, v1]
 
 
-def worker(rank, world, port, nkeys, outdir):
+def _init(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from datatable_amd.dist import sharded_groupby_agg
-    keys, vals = make_data(77, 20_000, nkeys)
+
+
+def worker(rank, world, port, nkeys, outdir):
+    _init(rank, world, port)
+    import gloo_protocol as gp
+    keys, vals = make_data(77, 40_000, nkeys)
     n = len(keys[0])
     lo, hi = rank * n // world, (rank + 1) * n // world
     if rank == 1 and nkeys == 1:
         hi = lo            # one rank with an empty shard
-    k = [torch.from_numpy(a[lo:hi].copy()) for a in keys]
-    v = [torch.from_numpy(a[lo:hi].copy()) for a in vals]
-    gk, out = sharded_groupby_agg(OracleBackend(), k, v, OPS)
-    np.savez(os.path.join(outdir, "r%d.npz" % rank), *[t.numpy() for t in gk + out])
+    gk, out = gp.sharded_groupby_agg(oracle_agg, [a[lo:hi] for a in keys], [a[lo:hi] for a in vals], OPS)
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), *(gk + out))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def rows_worker(rank, world, port, nkeys, outdir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import sys
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from datatable_amd.dist import sharded_groupby_rows
-    keys, vals = make_data(78, 20_000, nkeys)
+    _init(rank, world, port)
+    import gloo_protocol as gp
+    keys, vals = make_data(78, 40_000, nkeys)
     n = len(keys[0])
     lo, hi = rank * n // world, (rank + 1) * n // world
-    k = [torch.from_numpy(a[lo:hi].copy()) for a in keys]
-    v = [torch.from_numpy(a[lo:hi].copy()) for a in vals]
-    off, rowid, cols = sharded_groupby_rows(OracleBackend(), k, v, row_offset=lo)
-    np.savez(os.path.join(outdir, "rows%d.npz" % rank), off.numpy(), rowid.numpy(), *[t.numpy() for t in cols])
+    off, cols = gp.sharded_groupby_rows(oracle_rows, [a[lo:hi] for a in keys], [a[lo:hi] for a in vals], row_offset=lo)
+    np.savez(os.path.join(outdir, "rows%d.npz" % rank), off, *cols)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nkeys", [1, 2])
-def test_sharded_groupby_rows_world2(tmp_path, nkeys):
-    """rows in grouped order across 2 ranks == one process: global RowIndex, group offsets, columns"""
-    from oracle import oracle as o
-    world = 2
-    mp.spawn(rows_worker, args=(world, free_port(), nkeys, str(tmp_path)), nprocs=world, join=True)
-    keys, vals = make_data(78, 20_000, nkeys)
-    ri, off = o.group(keys)
-    parts = [np.load(os.path.join(str(tmp_path), "rows%d.npz" % r)) for r in range(world)]
-    rowid = np.concatenate([p["arr_1"] for p in parts])
-    assert np.array_equal(rowid, ri.astype(np.int64)), "global RowIndex differs"
-    offs, base = [np.zeros(1, np.int64)], 0
-    for p in parts:
-        o_ = p["arr_0"].astype(np.int64)
-        offs.append(o_[1:] + base)
-        base += int(o_[-1])
-    assert np.array_equal(np.concatenate(offs), off.astype(np.int64)), "group offsets differ"
-    for c, v in enumerate(vals):
-        got = np.concatenate([p["arr_%d" % (2 + c)] for p in parts])
-        assert np.array_equal(got, v[ri], equal_nan=(v.dtype.kind == "f")), "column %d differs" % c
-    assert all(len(p["arr_1"]) > 0 for p in parts)
+def failing_worker(rank, world, port, mode, outdir):
+    """mode 'fail': rank 1's local aggregation fails; mode 'sig': rank 1 runs another query.  Every rank must come back
+    with the same verdict after the FIRST all-gather -- none may go on to a collective its peer never enters."""
+    _init(rank, world, port)
+    import gloo_protocol as gp
+    keys, vals = make_data(5, 2000, 1)
+    try:
+        gp.sharded_groupby_agg(oracle_agg, keys, vals, OPS, sig=(9 if mode == "sig" and rank == 1 else 1),
+                               fail=(mode == "fail" and rank == 1))
+        verdict = "completed"
+    except gp.Disagreement as e:
+        verdict = str(e)
+    open(os.path.join(outdir, "v%d.txt" % rank), "w").write(verdict)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def free_port():
@@ -131,14 +114,38 @@ def free_port():
 
 
 @pytest.mark.parametrize("nkeys", [1, 2])
+def test_sharded_groupby_rows_world2(tmp_path, nkeys):
+    """rows in grouped order across 2 ranks == one process: global RowIndex, group offsets, columns"""
+    from oracle import oracle as o
+    world = 2
+    mp.spawn(rows_worker, args=(world, free_port(), nkeys, str(tmp_path)), nprocs=world, join=True)
+    keys, vals = make_data(78, 40_000, nkeys)
+    ri, off = o.group(keys)
+    parts = [np.load(os.path.join(str(tmp_path), "rows%d.npz" % r)) for r in range(world)]
+    rowid = np.concatenate([p["arr_3"] for p in parts])
+    assert np.array_equal(rowid, ri.astype(np.int64)), "global RowIndex differs"
+    offs, base = [np.zeros(1, np.int64)], 0
+    for p in parts:
+        o_ = p["arr_0"].astype(np.int64)
+        offs.append(o_[1:] + base)
+        base += int(o_[-1])
+    assert np.array_equal(np.concatenate(offs), off.astype(np.int64)), "group offsets differ"
+    for c, v in enumerate(vals):
+        got = np.concatenate([p["arr_%d" % (1 + c)] for p in parts])
+        assert np.array_equal(got, v[ri], equal_nan=(v.dtype.kind == "f")), "column %d differs" % c
+    sizes = [len(p["arr_3"]) for p in parts]
+    assert min(sizes) > 0.4 * sum(sizes) / world, sizes          # histogram splitters: both ranks own a fair key range
+
+
+@pytest.mark.parametrize("nkeys", [1, 2])
 def test_sharded_groupby_world2(tmp_path, nkeys):
     from oracle import oracle as o
     world = 2
     mp.spawn(worker, args=(world, free_port(), nkeys, str(tmp_path)), nprocs=world, join=True)
-    keys, vals = make_data(77, 20_000, nkeys)
+    keys, vals = make_data(77, 40_000, nkeys)
     if nkeys == 1:     # rank 1 had an empty shard
-        keys = [a[:10_000] for a in keys]
-        vals = [a[:10_000] for a in vals]
+        keys = [a[:20_000] for a in keys]
+        vals = [a[:20_000] for a in vals]
     ri, off = o.group(keys)
     exp = [k[ri[off[:-1]]] for k in keys]
     for op, col in OPS:
@@ -146,18 +153,44 @@ def test_sharded_groupby_world2(tmp_path, nkeys):
     parts = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
     for i, e in enumerate(exp):
         got = np.concatenate([p["arr_%d" % i] for p in parts])
-        assert got.dtype == e.dtype, (i, got.dtype, e.dtype)
         if e.dtype.kind == "f":
             assert np.array_equal(np.isnan(got), np.isnan(e))
             np.testing.assert_allclose(got, e, rtol=1e-9, atol=1e-9, equal_nan=True)
         else:
-            assert np.array_equal(got, e), "column %d differs" % i
-    # both ranks own a non-trivial key range
-    assert all(len(p["arr_0"]) > 0 for p in parts)
+            assert np.array_equal(got.astype(e.dtype), e), "column %d differs" % i
+    sizes = [len(p["arr_0"]) for p in parts]
+    assert min(sizes) > 0.4 * sum(sizes) / world, sizes          # quantile splitters: both ranks own about half the groups
 
 
-def test_range_boundaries():
-    from datatable_amd.dist import range_boundaries
-    assert range_boundaries(0, 99, 4) == [25, 50, 75]
-    b = range_boundaries(-2**63 + 1, 2**63 - 1, 8)
-    assert len(b) == 7 and all(b[i] < b[i + 1] for i in range(6))
+@pytest.mark.parametrize("mode", ["fail", "sig"])
+def test_every_rank_returns_when_one_fails(tmp_path, mode):
+    world = 2
+    mp.spawn(failing_worker, args=(world, free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    v = [open(os.path.join(str(tmp_path), "v%d.txt" % r)).read() for r in range(world)]
+    assert v[0] == v[1] != "completed", v
+    assert ("rank 1 failed with code -3" in v[0]) if mode == "fail" else ("different queries" in v[0])
+
+
+def _bench_line(cmd, env=None):
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                 # stdout carries exactly the JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (the shape of the driver's N=1 command): bench.py spawns rank 0 and
+    rank 1 itself, they meet over gloo, hand the 128-byte communicator id from rank 0 to rank 1, agree on the timing --
+    --dry-run stops before any GPU work"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    line = _bench_line([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"], env)
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["ranks_seen"] == [0, 1] and line["id_bytes"] == 128
+
+
+def test_bench_under_torch_distributed_run():
+    """the launcher form the driver uses for N > 1"""
+    line = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--dry-run"])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["ranks_seen"] == [0, 1]

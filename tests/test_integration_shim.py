@@ -70,3 +70,95 @@ def test_reference_thread_settings_are_safe():
         assert R.nrows == 1000 and R[:, 1].to_numpy().sum() == 100_000
     finally:
         ref.set_threads(min(8, __import__("os").cpu_count() or 1))
+
+
+def _canonical_mask(vals, na, th):
+    """rows a canonical predicate of shim._threshold selects (what dthip_filter_take evaluates): NA rows never pass,
+    except for != (and the degenerate 'all')"""
+    kind = th[0]
+    if kind == "none":
+        return np.zeros(len(vals), bool)
+    if kind == "all":
+        return np.ones(len(vals), bool)
+    if kind == "isna":
+        return na.copy()
+    if kind == "notna":
+        return ~na
+    t = th[1]
+    with np.errstate(invalid="ignore"):
+        m = {"ge": vals >= t, "le": vals <= t, "eq": vals == t, "ne": vals != t}[kind]
+    return (m | na) if kind == "ne" else (m & ~na)
+
+
+@pytest.mark.parametrize("stype", ["int8", "int32", "int64", "float32", "float64"])
+def test_filter_thresholds_recovered_exactly(stype):
+    """`f.col <cmp> scalar`: an FExpr prints float scalars with six decimals, so the shim recovers the exact threshold by
+    probing the reference's own evaluation of the expression; the canonical predicate it hands to dthip_filter_take must
+    select exactly the rows the reference selects -- for scalars the repr cannot carry, int columns against fractions,
+    float32 columns against float64 scalars, out-of-range and infinite scalars, None"""
+    import operator
+    from datatable import f
+    from integration import datatable_hip_shim as shim
+    rng = np.random.default_rng(len(stype))
+    npdt = np.dtype(stype)
+    n = 400
+    if npdt.kind == "f":
+        vals = np.concatenate([rng.standard_normal(n - 8) * 3, [0.0, -0.0, 1.5, 1.5000001, np.inf, -np.inf, 1e-300 if stype == "float64" else 1e-30, 2.0]]).astype(npdt)
+        na = rng.random(n) < 0.1
+        vals[na] = np.nan
+        scalars = [0, 1.5, 1.5000001, 1.4999999999, -0.0, 2, 1e-300, -1e308, 1e308, float("inf"), float("-inf"), 0.1, 1 / 3, 1e-7, None, True]
+    else:
+        info = np.iinfo(npdt)
+        vals = rng.integers(max(info.min + 1, -50), min(info.max, 50), n).astype(npdt)
+        vals[:4] = [info.max, info.min + 1, 0, -1]
+        na = rng.random(n) < 0.1
+        vals[na] = info.min
+        scalars = [0, 3, -7, 2.5, -0.5, 3.0, 1e12, -1e12, info.max, info.min + 1, 2**40, 1e300, float("inf"), None, False]
+    DT = shim.Frame(a=np.arange(n, dtype=np.int32), x=vals, b=rng.standard_normal(n))
+    cmp = {">": operator.gt, ">=": operator.ge, "<": operator.lt, "<=": operator.le, "==": operator.eq, "!=": operator.ne}
+    routed = 0
+    for sc in scalars:
+        for op, fn in cmp.items():
+            if sc is None and op not in ("==", "!="):
+                continue
+            for col in (f.x, f["x"], f[1]):
+                expr = fn(col, sc)
+                exp = dt.Frame.__getitem__(DT, (expr, "a")).to_numpy().ravel()         # the reference's own answer
+                plan = shim.match_filter(DT, (expr, slice(None)))
+                if plan is None:
+                    continue
+                ci, th, cols = plan
+                assert ci == 1 and cols == [0, 1, 2]
+                got = np.nonzero(_canonical_mask(vals, na, th))[0]
+                assert np.array_equal(got, exp), (stype, op, sc, th, len(got), len(exp))
+                routed += 1
+    # nearly every predicate is taken (== / != against a float scalar that the six-decimal repr cannot carry goes to the reference)
+    assert routed >= (0.8 if stype.startswith("float") else 0.9) * 3 * (6 * (len(scalars) - 1) + 2), routed
+
+
+def test_match_rows_sort_and_filter_forms():
+    from datatable import f, sum
+    from integration import datatable_hip_shim as shim
+    DT = shim.Frame(k=np.array([3, 1, 3], np.int64), v=np.array([1.0, 2.0, 4.0]), w=np.array([1, 2, 3], np.int32))
+    S = shim.Frame(k=np.array([3, 1, 3], np.int64), s=["a", "b", "c"])
+    assert shim.match_rows(DT, (slice(None), slice(None), shim.by(f.k))) == ([0], [1, 2])       # `:` leaves the by-column out
+    assert shim.match_rows(DT, (slice(None), f[:], shim.by("k"))) == ([0], [1, 2])
+    assert shim.match_rows(DT, (slice(None), [f.k, "w"], shim.by(f.k))) == ([0], [0, 2])          # listed explicitly: kept
+    assert shim.match_rows(DT, (slice(None), f.v, shim.by(f.k, f.w))) == ([0, 2], [1])
+    assert shim.match_rows(DT, (slice(None), sum(f.v), shim.by(f.k))) is None                     # a reducer: match()'s
+    assert shim.match_rows(DT, (f.v > 1, slice(None), shim.by(f.k))) is None                      # i + by: the reference refuses it
+    assert shim.match_rows(S, (slice(None), slice(None), shim.by(f.k))) is None                   # a string column rides along
+    assert shim.match_sort(DT, (slice(None), slice(None), shim.sort(f.k))) == ([0], [False], 0, [0, 1, 2])
+    assert shim.match_sort(DT, (slice(None), [f.v], shim.sort(f.k, f.w, reverse=[True, False], na_position="last"))) == \
+        ([0, 2], [True, False], 1, [1])
+    assert shim.match_sort(DT, (slice(None), slice(None), shim.sort(f.k, na_position="remove")))[2] == 2
+    assert shim.match_sort(DT, (slice(None), slice(None), shim.sort(f.k + 1))) is None            # computed sort key
+    assert shim.match_filter(DT, (f.v > 1, slice(None)))[:2] == (1, ("ge", float(np.nextafter(1.0, 2.0))))
+    assert shim.match_filter(DT, (f.v > 1, [f.k, f.w]))[2] == [0, 2]
+    assert shim.match_filter(DT, ((f.v > 1) & (f.k > 1), slice(None))) is None                    # a compound predicate
+    assert shim.match_filter(DT, (f.v > f.w, slice(None))) is None                                # column against column
+    assert shim.match_filter(S, (f.k > 1, slice(None))) is None                                   # string column selected
+    assert shim.match_filter(S, (f.k > 1, "k"))[2] == [0]
+    # the native objects still reach the reference for everything else
+    R = S[:, :, shim.sort(f.s)]
+    assert R.to_list() == [[3, 1, 3], ["a", "b", "c"]]

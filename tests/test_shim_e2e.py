@@ -173,3 +173,89 @@ def test_fallthrough_and_views(env):
     assert got.names == ("k", "v", "v.0", "v.1", "v.2", "v.3", "count")
     assert got.to_list() == [[None, 1, 2, 3], [10.0, 0.0, 16.0, math.inf], [5.0, None, 16.0, math.inf],
                              [2.0, None, 16.0, 1.5], [8.0, None, 16.0, math.inf], [2, 0, 1, 3], [2, 2, 1, 3]]
+
+
+# ---- row-returning routes: the filter, rows in grouped order, sort (VERDICT r02 "missing" #1) ------------------------
+def assert_rows_equal(dt, got, exp):
+    """row-returning results are shim Frames (a datatable.Frame subclass, so that chains stay on the GPU): everything
+    else -- shape, names, stypes, every value, bit for bit (these routes move rows, they compute nothing)"""
+    assert isinstance(got, dt.Frame) and type(exp) is dt.Frame
+    assert got.shape == exp.shape, (got.shape, exp.shape)
+    assert got.names == exp.names, (got.names, exp.names)
+    assert got.stypes == exp.stypes, (got.stypes, exp.stypes)
+    for i in range(exp.ncols):
+        a, b = got[:, i].to_numpy(), exp[:, i].to_numpy()
+        assert np.array_equal(np.ma.getmaskarray(a), np.ma.getmaskarray(b)), "column %d %r: NA pattern" % (i, exp.names[i])
+        assert np.array_equal(np.ma.filled(a, 0), np.ma.filled(b, 0), equal_nan=(np.asarray(a).dtype.kind == "f")), \
+            "column %d %r differs" % (i, exp.names[i])
+
+
+@pytest.mark.parametrize("n", [1, 37, 5000, 300_000])
+def test_filter_route(env, n):
+    dt, shim = env
+    from datatable import f
+    DT = make_frame(shim, n, seed=300 + n)
+    preds = [f.f8 > 0, f.f8 >= 0.25000001, f.f8 <= -1.5, f.i4 < 2.5, f.i8 != 0, f.i2 == 7, f.f4 > 0.1, f.i1 >= -3,
+             f.f8 == None, f.i4 != None, f.f8 < math.inf, f.i8 > 1e30]
+    for p in preds:
+        assert shim.match_filter(DT, (p, slice(None))) is not None, repr(p)
+        got = DT[p, :]
+        exp = dt.Frame.__getitem__(DT, (p, slice(None)))
+        assert type(got) is shim.Frame
+        assert_rows_equal(dt, got, exp)
+    got = DT[f.f8 > 0, [f.k, "i4", f[3]]]
+    assert_rows_equal(dt, got, dt.Frame.__getitem__(DT, (f.f8 > 0, [f.k, "i4", f[3]])))
+
+
+@pytest.mark.parametrize("key", ["int64", "int32", "float64", "bool"])
+@pytest.mark.parametrize("n", [1, 37, 5000, 300_000])
+def test_rows_in_grouped_order_route(env, key, n):
+    dt, shim = env
+    from datatable import f
+    DT = make_frame(shim, n, seed=400 + n + len(key), key=key)
+    for j, bycols in ((slice(None), [f.k]), (f[:], [f.k, f.k2]), ([f.f8, f.k, "i1"], ["k"]), (f.b, [f.k2])):
+        assert shim.match_rows(DT, (slice(None), j, shim.by(*bycols))) is not None
+        got = DT[:, j, shim.by(*bycols)]
+        exp = dt.Frame.__getitem__(DT, (slice(None), j, dt.by(*bycols)))
+        assert_rows_equal(dt, got, exp)
+
+
+@pytest.mark.parametrize("n", [1, 37, 5000, 300_000])
+def test_sort_route(env, n):
+    dt, shim = env
+    from datatable import f
+    DT = make_frame(shim, n, seed=500 + n, key="float64")
+    cases = [dict(cols=[f.k]), dict(cols=[f.k], reverse=True), dict(cols=[f.k], na_position="last"),
+             dict(cols=[f.k], reverse=True, na_position="last"), dict(cols=[f.i4, f.f8], reverse=[True, False]),
+             dict(cols=[f.i1], na_position="remove"), dict(cols=["k2", f.i2], na_position="remove"), dict(cols=[f.b, f.f4])]
+    for c in cases:
+        cols = c.pop("cols")
+        assert shim.match_sort(DT, (slice(None), slice(None), shim.sort(*cols, **c))) is not None
+        got = DT[:, :, shim.sort(*cols, **c)]
+        exp = dt.Frame.__getitem__(DT, (slice(None), slice(None), dt.sort(*cols, **c)))
+        assert_rows_equal(dt, got, exp)
+    assert_rows_equal(dt, DT.sort("k"), dt.Frame.sort(DT, "k"))
+    assert_rows_equal(dt, DT.sort(f.k2, f.i8), dt.Frame.sort(DT, f.k2, f.i8))
+    assert_rows_equal(dt, DT[:, [f.f8, f.k], shim.sort(f.k)], dt.Frame.__getitem__(DT, (slice(None), [f.f8, f.k], dt.sort(f.k))))
+
+
+def test_config5_two_step_form_at_scale(env):
+    """BASELINE config 5 the only way the reference spells it: V = DT[f.x > 0, :]; V[:, :, by(f.k)] --
+    1e7 rows, ~1e6 groups, both steps on the GPU (dthip_filter_take, dthip_groupby_rows), compared with the reference
+    evaluating the same two expressions; then an aggregation of the filtered frame"""
+    dt, shim = env
+    from datatable import f, sum, count
+    rng = np.random.default_rng(1239)
+    n = 10_000_000
+    DT = shim.Frame(k=rng.integers(0, 1_000_000, n, dtype=np.int64), x=rng.standard_normal(n))
+    V = DT[f.x > 0, :]
+    assert type(V) is shim.Frame and abs(V.nrows - n / 2) < 1e-2 * n
+    R = V[:, :, shim.by(f.k)]
+    Vr = dt.Frame.__getitem__(DT, (f.x > 0, slice(None)))
+    Rr = Vr[:, :, dt.by(f.k)]
+    assert_rows_equal(dt, V, Vr)
+    assert_rows_equal(dt, R, Rr)
+    A = V[:, [sum(f.x), count()], shim.by(f.k)]
+    Ar = Vr[:, [sum(f.x), count()], dt.by(f.k)]
+    assert np.array_equal(A[:, 0].to_numpy(), Ar[:, 0].to_numpy()) and np.array_equal(A[:, 2].to_numpy(), Ar[:, 2].to_numpy())
+    assert np.allclose(A[:, 1].to_numpy(), Ar[:, 1].to_numpy(), rtol=1e-6, atol=1e-9)
