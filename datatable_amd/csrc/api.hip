@@ -244,6 +244,7 @@ struct KeyPlan {
 };
 
 constexpr uint32_t SPEC_SAMPLES = 1u << 17;
+constexpr int DTHIP_RETRY_EXACT = 1;              // internal: a guessed key range was wrong, redo with the exact one
 
 static void stype_int_limits(int st, long long* lo, long long* hi) {
   switch (st) {
@@ -257,8 +258,10 @@ static void stype_int_limits(int st, long long* lo, long long* hi) {
 // min/max of integer keys -> transform parameters (sort.cc:728-776), packing layout.
 // speculative: the range of big integer columns is GUESSED from a sample and widened; only the
 // bucketed aggregation may use such a plan, because its histogram pass verifies every row.
+// tight (sort path): a guess whose 1/64 margin adds a significant bit to a key could cost a whole radix pass, which is
+// more than the exact range scan it saves -- such a plan is made again with the exact range at once.
 static int plan_keys(dthip_ctx* ctx, Scratch& sc, const dthip_col* keys_dev, int nkeys, int64_t n, int na_pos,
-                     KeyPlan* plan, bool speculative = false) {
+                     KeyPlan* plan, bool speculative = false, bool tight = false) {
   if (nkeys < 1 || nkeys > MAX_KEYCOLS) { set_error("number of key columns must be 1..%d", MAX_KEYCOLS); return DTHIP_EINVAL; }
   plan->nkeys = nkeys;
   plan->speculative = false;
@@ -301,10 +304,13 @@ static int plan_keys(dthip_ctx* ctx, Scratch& sc, const dthip_col* keys_dev, int
         long long tlo, thi;
         stype_int_limits(st, &tlo, &thi);
         const unsigned long long width = (unsigned long long)mx - (unsigned long long)mn;
+        const int nb_sample = nbits_u64(width + 1ULL);
         const unsigned long long margin = width / 64 + 64;
         mn = ((unsigned long long)mn - (unsigned long long)tlo > margin) ? (long long)((unsigned long long)mn - margin) : tlo;
         mx = ((unsigned long long)thi - (unsigned long long)mx > margin) ? (long long)((unsigned long long)mx + margin) : thi;
         plan->speculative = true;
+        if (tight && nbits_u64((unsigned long long)mx - (unsigned long long)mn + 1ULL) != nb_sample)
+          return plan_keys(ctx, sc, keys_dev, nkeys, n, na_pos, plan, false, false);
       }
       const unsigned long long range1 = (unsigned long long)mx - (unsigned long long)mn + 1ULL;
       c.edge = c.desc ? (unsigned long long)mx : (unsigned long long)mn;
@@ -385,10 +391,15 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
   DTHIP_CHECK_HIP(hipMemsetAsync(hist, 0, sizeof(uint32_t) * MAX_PASSES * HIST_STRIDE, ctx->stream));
   xa.out = kA;
   xa.hist = hist;
+  // a plan made from a GUESSED key range (plan_keys: sampled min / max) is verified by this very pass: the word after
+  // the last histogram row comes back non-zero when some key fell outside, and the caller plans again (exact range)
+  static_assert(MAX_PASSES * 8 >= 64 + 8, "a histogram row stays free for the range check");
+  xa.bad = plan.speculative ? hist + (size_t)npass * HIST_STRIDE : nullptr;
   DTHIP_TRY(launch_xform_hist(ctx, xa));
   // which passes actually permute anything?
-  std::vector<uint32_t> hh((size_t)npass * HIST_STRIDE);
+  std::vector<uint32_t> hh((size_t)npass * HIST_STRIDE + 1);
   DTHIP_TRY(read_back(ctx, hh.data(), hist, hh.size() * sizeof(uint32_t)));
+  if (plan.speculative && hh[(size_t)npass * HIST_STRIDE]) return DTHIP_RETRY_EXACT;
   int active[MAX_PASSES], nactive = 0;
   for (int p = 0; p < npass; p++) {
     bool constant = false;
@@ -520,15 +531,26 @@ static int heads_to_offsets(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
 // full group(): ordering + offsets (+ head bitmap) for any number of keys
 static int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthip_col* keys_dev, int nkeys,
                       int64_t n, int na_pos, KeyPlan* plan, Grouping* g) {
-  DTHIP_TRY(plan_keys(ctx, sc, keys_dev, nkeys, n, na_pos, plan));
+  // integer key ranges of big columns are guessed from a sample first (saves the exact min / max scan: 0.8 ms per 1e9-row
+  // int64 column); the key-transform pass of every stage verifies the guess, a wrong one costs one more round
   const int32_t* order = nullptr;
   SortOut so;
-  for (int s = plan->nstages - 1; s >= 0; s--) {
-    PaySpec ps;
-    ps.n = 1; ps.width[0] = 4;
-    if (order) { ps.in[0] = order; ps.iota = false; } else { ps.in[0] = nullptr; ps.iota = true; }
-    DTHIP_TRY(sort_stage(ctx, sc, *plan, s, n, order, ps, &so));
-    order = static_cast<const int32_t*>(so.pay[0]);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    DTHIP_TRY(plan_keys(ctx, sc, keys_dev, nkeys, n, na_pos, plan, attempt == 0, true));
+    order = nullptr;
+    int rc = DTHIP_OK;
+    for (int s = plan->nstages - 1; s >= 0; s--) {
+      PaySpec ps;
+      ps.n = 1; ps.width[0] = 4;
+      if (order) { ps.in[0] = order; ps.iota = false; } else { ps.in[0] = nullptr; ps.iota = true; }
+      rc = sort_stage(ctx, sc, *plan, s, n, order, ps, &so);
+      if (rc != DTHIP_OK) break;
+      order = static_cast<const int32_t*>(so.pay[0]);
+    }
+    if (rc == DTHIP_RETRY_EXACT && attempt == 0) continue;
+    if (rc == DTHIP_RETRY_EXACT) { set_error("group: exact key range violated"); return DTHIP_EDEVICE; }
+    DTHIP_TRY(rc);
+    break;
   }
   g->rowindex = const_cast<int32_t*>(order);
   g->sorted_keys = so.keys; g->key64 = so.key64;
@@ -627,7 +649,6 @@ static int floor_log2_sz(size_t v) { int b = -1; while (v) { b++; v >>= 1; } ret
 constexpr size_t BUCKET_LDS_TABLE = 144 * 1024;   // LDS bytes one aggregation table may take
 constexpr int BUCKET_MAX_R = 14;                  // slot keys are uint16
 constexpr int BUCKET_MAX_D = 11;                  // <= 2048 buckets in one partition pass
-constexpr int DTHIP_RETRY_EXACT = 1;              // internal: a guessed key range was wrong, redo with the exact one
 
 static bool bucket_need_counts(const dthip_ctx* ctx, const dthip_agg* aggs, int naggs) {
   if (ctx->agg_offsets) return true;
@@ -705,7 +726,10 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   {
     const uint64_t denom = std::max<uint64_t>(g.F, (uint64_t)ctx->num_cus * 4);
     uint64_t m = (2 * (uint64_t)n + denom - 1) / denom;
-    if (m < 65536) m = 65536;
+    // a part must amortise the set-up and the flush of its LDS table (S slots): small tables allow small parts, so a
+    // 1e6-row frame with 100 groups (BASELINE C1) still spreads over a few hundred workgroups instead of 16
+    const uint64_t m_min = std::min<uint64_t>(65536, std::max<uint64_t>(4096, 16ull * g.S));
+    if (m < m_min) m = m_min;
     m = (m + 7) & ~7ULL;
     M = (uint32_t)std::min<uint64_t>(m, 0x7FFFFFF8ULL);
   }
@@ -885,6 +909,16 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
 }
 
 
+// a path gave up after it had started to fill `res` (the hash combiner's pass i > 0 on a table overflow): its buffers go
+// back to the cache AND every pointer into them is cleared, so the path that takes over cannot hand out a dangling one
+static void drop_partial_result(dthip_ctx* ctx, dthip_result* res) {
+  for (void* p : res->owned) dev_release(ctx, p);
+  res->owned.clear();
+  res->offsets = nullptr; res->rowindex = nullptr; res->ngroups = 0;
+  for (auto& k : res->key) k = nullptr;
+  for (auto& a : res->agg) a = nullptr;
+}
+
 // ---- hash combiner for sparse keys (bucket.hip): partial groups + merge ------------------------
 constexpr int HASH_PK_BITS = 24, HASH_R = 13;          // pseudo key: 2048 buckets by hash
 
@@ -993,10 +1027,19 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   memset(&kx, 0, sizeof(kx));
   kx.ncols = nkeys;
   for (int k = 0; k < nkeys; k++) kx.cols[k] = plan.col[k];
+  // one int64 key: the raw key IS a usable 64-bit image (round 3): no packed-key array is written (8 of the 20 bytes
+  // per row hash_xform moved), the key column itself is payload 0 of the partition, and the partial groups' keys come
+  // out typed already
+  static const bool raw_ok = !(getenv("DTHIP_HASH_RAW") && atoi(getenv("DTHIP_HASH_RAW")) == 0);
+  const bool raw_key = raw_ok && nkeys == 1 && kd[0].stype == DTHIP_INT64;
   unsigned long long* xs = nullptr; int32_t* pk = nullptr;
-  DTHIP_TRY(sc.get<unsigned long long>((size_t)n + 2, &xs));
   DTHIP_TRY(sc.get<int32_t>((size_t)n + 4, &pk));
-  DTHIP_TRY(launch_hash_xform(ctx, kx, n, xs, pk));
+  if (raw_key) {
+    DTHIP_TRY(launch_hash_pk_raw(ctx, kd[0].data, n, pk));
+  } else {
+    DTHIP_TRY(sc.get<unsigned long long>((size_t)n + 2, &xs));
+    DTHIP_TRY(launch_hash_xform(ctx, kx, n, xs, pk));
+  }
   // the bucket machinery, driven by the pseudo key pk in [0, 2^24)
   KeyXform pkx;
   memset(&pkx, 0, sizeof(pkx));
@@ -1005,6 +1048,7 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   pkx.cols[0].na_repl = 0; pkx.cols[0].inc = 0; pkx.cols[0].xmax = ~0ULL; pkx.cols[0].shift = 0;
   int km = 2;
   for (int c : used) if (reinterpret_cast<uintptr_t>(vd[c].data) & 15) km = 0;
+  if (raw_key && (reinterpret_cast<uintptr_t>(kd[0].data) & 15)) km = 0;
   BucketGeom g;
   bucket_geometry(ctx, n, HASH_PK_BITS, HASH_R, km, &g);
   uint32_t* bbase = nullptr;
@@ -1018,7 +1062,10 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   {
     const uint64_t denom = std::max<uint64_t>(g.F, (uint64_t)ctx->num_cus * 4);
     uint64_t m = (2 * (uint64_t)n + denom - 1) / denom;
-    if (m < 65536) m = 65536;
+    // a part must amortise the set-up and the flush of its LDS table (S slots): small tables allow small parts, so a
+    // 1e6-row frame with 100 groups (BASELINE C1) still spreads over a few hundred workgroups instead of 16
+    const uint64_t m_min = std::min<uint64_t>(65536, std::max<uint64_t>(4096, 16ull * g.S));
+    if (m < m_min) m = m_min;
     m = (m + 7) & ~7ULL;
     M = (uint32_t)std::min<uint64_t>(m, 0x7FFFFFF8ULL);
   }
@@ -1038,7 +1085,7 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   DTHIP_TRY(sc.get<unsigned long long>((size_t)n + 8, &xs_part));
   PayCols pc;
   memset(&pc, 0, sizeof(pc));
-  pc.in[0] = xs; pc.out[0] = xs_part; pc.width[0] = 8; pc.n = 1;
+  pc.in[0] = raw_key ? kd[0].data : static_cast<const void*>(xs); pc.out[0] = xs_part; pc.width[0] = 8; pc.n = 1;
   std::vector<unsigned char*> v_part(std::max<size_t>(used.size(), 1), nullptr);
   for (size_t i = 0; i < used.size(); i++) {
     const int w = stype_size(vd[used[i]].stype);
@@ -1077,10 +1124,11 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
     // typed columns of the partial groups
     std::vector<dthip_col> k2(nkeys);
     for (int k = 0; k < nkeys; k++) {
+      k2[k] = kd[k];
+      if (raw_key) { k2[k].data = ha.o_key; continue; }
       unsigned char* bb = nullptr;
       DTHIP_TRY(sci.get<unsigned char>((size_t)np * stype_size(kd[k].stype) + 16, &bb));
       DTHIP_TRY(launch_untransform_keys(ctx, ha.o_key, 1, nullptr, np, plan.col[k], plan.nsig[k], bb));
-      k2[k] = kd[k];
       k2[k].data = bb;
     }
     const bool isf = stype_is_float(vst);
@@ -1445,7 +1493,7 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
     if ((rc = stage_cols(ctx, sc, cols, ncols, nrows, mem, &cd)) != DTHIP_OK) break;
     if (nrows == 0) { rc = empty_result(ctx, res); break; }
     KeyPlan plan; Grouping g;
-    if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan)) != DTHIP_OK) break;
+    if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan, true, true)) != DTHIP_OK) break;   // guessed key range: verified below
     bool ride = plan.nstages == 1 && ncols + (want_rowindex ? 1 : 0) <= MAX_PAYCOLS && ncols > 0;
     for (int c = 0; c < ncols; c++) if (stype_size(cd[c].stype) < 4) ride = false;
     if (ride) {
@@ -1465,7 +1513,12 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
         ps.in[ps.n] = cd[c].data; ps.width[ps.n] = stype_size(cd[c].stype); ps.n++;
       }
       SortOut so;
-      if ((rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so)) != DTHIP_OK) break;
+      rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so);
+      if (rc == DTHIP_RETRY_EXACT) {          // the sampled key range did not hold: the exact one (narrower: still one stage)
+        if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan)) != DTHIP_OK) break;
+        rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so);
+      }
+      if (rc != DTHIP_OK) break;
       if ((rc = heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, nrows, &g)) != DTHIP_OK) break;
       if (want_rowindex) { result_adopt(sc, res, so.pay[0]); res->rowindex = static_cast<int32_t*>(so.pay[0]); }
       for (int c = 0; c < ncols && rc == DTHIP_OK; c++) {
@@ -1565,8 +1618,7 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
           if (rc == DTHIP_OK) { done = true; break; }
           if (rc != DTHIP_NOT_APPLICABLE) break;
           rc = DTHIP_OK;
-          for (void* p : res->owned) dev_release(ctx, p);
-          res->owned.clear();
+          drop_partial_result(ctx, res);
           continue;
         }
         if (bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &slot_bits)) {
@@ -1583,8 +1635,7 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
       if (rc == DTHIP_OK) break;
       if (rc != DTHIP_NOT_APPLICABLE) break;
       rc = DTHIP_OK;
-      for (void* p : res->owned) dev_release(ctx, p);      // nothing of a half-built attempt survives
-      res->owned.clear();
+      drop_partial_result(ctx, res);                       // nothing of a half-built attempt survives
       if (plan.nstages != 1) fused = false;
     }
     if (fused) {

@@ -1242,6 +1242,22 @@ int launch_hash_xform(dthip_ctx* ctx, const KeyXform& kx, int64_t n, unsigned lo
   return DTHIP_OK;
 }
 
+// the same pseudo key for ONE int64 key column taken as it is: the hash tables then hold the raw key (any injective
+// 64-bit image of the key works -- the merge of the partial groups orders and types them), so the 8-byte packed key
+// need not be written at all: the key column itself rides through the partition as payload 0
+__global__ void __launch_bounds__(256) hash_pk_raw_kernel(const u64* __restrict__ key, uint32_t n, int32_t* __restrict__ pk) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) pk[i] = (int32_t)(mix64(key[i]) >> 40);
+}
+
+int launch_hash_pk_raw(dthip_ctx* ctx, const void* key, int64_t n, int32_t* pk) {
+  if (n == 0) return DTHIP_OK;
+  long long blocks = (n + 2047) / 2048;
+  if (blocks > ctx->num_cus * 16) blocks = ctx->num_cus * 16;
+  DTHIP_LAUNCH(ctx, "hash_xform_kernel", hash_pk_raw_kernel, (unsigned)blocks, 256, 0, static_cast<const u64*>(key), (uint32_t)n, pk);
+  return DTHIP_OK;
+}
+
 constexpr u64 HASH_EMPTY = ~0ULL;
 
 struct HashAggDev {

@@ -196,6 +196,7 @@ struct XformArgs {
   void* out;             // uint32_t[n] or uint64_t[n]
   int out64;
   uint32_t* hist;        // [npass][HIST_STRIDE], zeroed by the caller
+  uint32_t* bad;         // nullable: set when a transformed key exceeds its column's xmax (the key range was a guess)
   int npass;
   int pshift[MAX_PASSES];
   int pbits[MAX_PASSES];
@@ -317,6 +318,7 @@ int launch_table_finalize(dthip_ctx* ctx, const TableFinArgs& a);
 
 // hash combiner (bucket.hip): partial groups of sparse keys
 int launch_hash_xform(dthip_ctx* ctx, const KeyXform& kx, int64_t n, unsigned long long* xs, int32_t* pk);
+int launch_hash_pk_raw(dthip_ctx* ctx, const void* key, int64_t n, int32_t* pk);
 struct HashAggArgs {
   const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
   const unsigned long long* xs;      // packed transformed keys of the partitioned rows

@@ -29,10 +29,15 @@ __global__ void __launch_bounds__(XH_BLOCK) xform_hist_kernel(XformArgs a) {
   for (int i = threadIdx.x; i < a.npass * HIST_STRIDE; i += XH_BLOCK) lhist[i] = 0;
   __syncthreads();
   const uint32_t stride = gridDim.x * XH_BLOCK;
+  bool oob = false;            // a key outside the (guessed) range of its column: the caller plans again with the exact one
   for (uint32_t row = blockIdx.x * XH_BLOCK + threadIdx.x; row < a.n; row += stride) {
     const uint32_t src = a.order ? (uint32_t)a.order[row] : row;
     unsigned long long k = 0;
-    for (int j = 0; j < a.ncols; j++) k |= xform_key(a.cols[j], src) << a.cols[j].shift;
+    for (int j = 0; j < a.ncols; j++) {
+      const unsigned long long x = xform_key(a.cols[j], src);
+      if (x > a.cols[j].xmax) oob = true;
+      k |= x << a.cols[j].shift;
+    }
     if (a.out64) static_cast<unsigned long long*>(a.out)[row] = k;
     else static_cast<uint32_t*>(a.out)[row] = (uint32_t)k;
     for (int p = 0; p < a.npass; p++) {
@@ -48,6 +53,7 @@ __global__ void __launch_bounds__(XH_BLOCK) xform_hist_kernel(XformArgs a) {
       }
     }
   }
+  if (oob && a.bad) atomicOr(a.bad, 1u);
   __syncthreads();
   for (int i = threadIdx.x; i < a.npass * HIST_STRIDE; i += XH_BLOCK) {
     const uint32_t c = lhist[i];
@@ -70,6 +76,7 @@ __global__ void __launch_bounds__(XH_BLOCK) xform_hist_int_kernel(XformArgs a) {
   const T na = (T)((u64)1 << (8 * sizeof(T) - 1));
   const uint32_t ngrp = (a.n + 3) / 4;
   const uint32_t stride = gridDim.x * XH_BLOCK;
+  bool oob = false;
   for (uint32_t g = blockIdx.x * XH_BLOCK + threadIdx.x; g < ngrp; g += stride) {
     const uint32_t r0 = g * 4;
     const uint32_t nv = a.n - r0 < 4u ? a.n - r0 : 4u;
@@ -92,6 +99,7 @@ __global__ void __launch_bounds__(XH_BLOCK) xform_hist_int_kernel(XformArgs a) {
     for (int j = 0; j < 4; j++) {
       const u64 u = (u64)(long long)v[j];
       k[j] = (v[j] == na) ? c.na_repl : (c.desc ? c.edge - u + c.inc : u - c.edge + c.inc);
+      if ((uint32_t)j < nv && k[j] > c.xmax) oob = true;
     }
     if (nv == 4) {
       if (OUT64) {
@@ -120,6 +128,7 @@ __global__ void __launch_bounds__(XH_BLOCK) xform_hist_int_kernel(XformArgs a) {
       }
     }
   }
+  if (oob && a.bad) atomicOr(a.bad, 1u);
   __syncthreads();
   for (int i = threadIdx.x; i < a.npass * HIST_STRIDE; i += XH_BLOCK) {
     const uint32_t cnt = lhist[i];
@@ -174,7 +183,10 @@ int launch_hist_scan(dthip_ctx* ctx, const uint32_t* hist, uint32_t* base, int n
 // order (one extra 4/8-byte read per row and pass) and bucket_gscan_kernel turns the counts into
 // positions -- so the pass needs no inter-workgroup communication: no decoupled look-back, no
 // tickets, no spinning (measured at 1e9 rows: 7.2 ms per pass with look-back, 5.6 + 0.8 ms without).
-constexpr int RP_BLOCK = 512, RP_ITEMS = 16, RP_TILE = RP_BLOCK * RP_ITEMS;
+#ifndef DTHIP_RP_BLOCK
+#define DTHIP_RP_BLOCK 512
+#endif
+constexpr int RP_BLOCK = DTHIP_RP_BLOCK, RP_ITEMS = 16, RP_TILE = RP_BLOCK * RP_ITEMS;
 
 template <typename KeyT>
 struct PassArgsT {
@@ -196,7 +208,7 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_tile_hist_kernel(const KeyT* _
   const int tid = threadIdx.x;
   const uint32_t bins = 1u << bits, dmask = bins - 1u;
   uint32_t run = 0;
-  cnt[tid] = 0;
+  if (tid < HIST_STRIDE) cnt[tid] = 0;
   __syncthreads();
   const uint32_t t0 = blockIdx.x * tpg, t1 = (t0 + tpg < ntiles) ? t0 + tpg : ntiles;
   typedef uint32_t hu32x4 __attribute__((ext_vector_type(4)));

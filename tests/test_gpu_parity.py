@@ -482,6 +482,43 @@ def test_speculative_key_range(ctx):
         ctx.set_option("spec_min_rows", 1 << 23)
 
 
+def test_speculative_key_range_on_the_sort_path(ctx):
+    """dthip_groupby / dthip_groupby_rows with the key range guessed from a sample (round 3; default from 2^23 rows on):
+    a guess that holds; outliers at rows the sample does not visit (the key-transform pass reports them, the call
+    plans again with the exact range); two keys (both guessed, one broken); NA-last; descending"""
+    from oracle import oracle as o
+    rng = np.random.default_rng(78)
+    n = 3_000_000
+    k = rng.integers(1000, 300_000, n).astype(np.int64)
+    x = rng.standard_normal(n)
+    ctx.set_option("spec_min_rows", 1)
+    try:
+        cases = [k]
+        for hi, lo in ((600_000, -100_000), (2**40, -2**41), (300_001, 999)):
+            k2 = k.copy()
+            k2[1_234_567] = hi
+            k2[2_000_001] = lo
+            cases.append(k2)
+        for kk in cases:
+            for na_last in (False, True):
+                ri, off = o.group([kk], na_last=na_last)
+                g = ctx.groupby([kk], na_last=na_last)
+                assert_same(g.rowindex(), ri, "rowindex"); assert_same(g.offsets(), off, "offsets")
+                g.free()
+            ri, off = o.group([kk])
+            r = ctx.groupby_rows([kk], [kk, x], want_rowindex=True)
+            assert_same(r.rowindex(), ri, "rowindex (rows)"); assert_same(r.col(0), kk[ri], "key column"); assert_same(r.col(1), x[ri], "x")
+            r.free()
+        a = rng.integers(0, 500, n).astype(np.int32)
+        a[777_777] = 10_000_000                      # breaks the guess of the FIRST key only
+        ri, off = o.group([a, cases[0]], desc=[True, False])
+        g = ctx.groupby([a, cases[0]], desc=[True, False])
+        assert_same(g.rowindex(), ri, "two keys, first descending"); assert_same(g.offsets(), off, "offsets")
+        g.free()
+    finally:
+        ctx.set_option("spec_min_rows", 1 << 23)
+
+
 # ---- full-size properties (no oracle: size-independent invariants) ----------------------------
 
 def test_full_size_properties_1e8(ctx):
