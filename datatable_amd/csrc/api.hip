@@ -724,7 +724,12 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   DTHIP_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
   uint32_t M;
   {
-    const uint64_t denom = std::max<uint64_t>(g.F, (uint64_t)ctx->num_cus * 4);
+    // with fewer buckets than CUs (BASELINE C2: 32) the aggregation is bound by its DS atomics, one 1024-thread workgroup
+    // per CU: many small parts even out the tail (measured on 1e8 rows x 4 columns: 512 parts 0.29 ms per column,
+    // 1500 parts 0.26; C2 3.07 -> 2.89 ms); with >= 1024 buckets the parts are whole buckets anyway
+    static const int part_div_env = getenv("DTHIP_PART_DIV") ? atoi(getenv("DTHIP_PART_DIV")) : 0;
+    const int part_div = part_div_env > 0 ? part_div_env : (g.F < (uint32_t)ctx->num_cus ? 16 : 4);
+    const uint64_t denom = std::max<uint64_t>(g.F, (uint64_t)ctx->num_cus * part_div);
     uint64_t m = (2 * (uint64_t)n + denom - 1) / denom;
     // a part must amortise the set-up and the flush of its LDS table (S slots): small tables allow small parts, so a
     // 1e6-row frame with 100 groups (BASELINE C1) still spreads over a few hundred workgroups instead of 16
