@@ -1319,6 +1319,7 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
   }
   if (!strcmp(name, "spec_min_rows")) { ctx->spec_min_rows = value; return DTHIP_OK; }
   if (!strcmp(name, "agg_offsets")) { ctx->agg_offsets = value != 0; return DTHIP_OK; }
+  if (!strcmp(name, "f32_sum")) { ctx->f32_sum_ref = value != 0; return DTHIP_OK; }
   if (!strcmp(name, "join_table")) { ctx->join_table = value != 0; return DTHIP_OK; }
   if (!strcmp(name, "median_pairs")) { ctx->pairs_always = value != 0; return DTHIP_OK; }
   if (!strcmp(name, "hash_mode")) {
@@ -1596,6 +1597,9 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
     bool fused = (int)used.size() <= MAX_PAYCOLS;
     for (int c : used) if (stype_size(vd[c].stype) < 4) fused = false;
     for (int a = 0; a < naggs; a++) if (aggs[a].op == DTHIP_FIRST || aggs[a].op == DTHIP_LAST) fused = false;   // need the row order
+    bool f32_seq = false;       // option "f32_sum": the reference's float32 accumulation needs the rows of a group in order
+    for (int a = 0; a < naggs; a++)
+      if (ctx->f32_sum_ref && aggs[a].op == DTHIP_SUM && vd[aggs[a].col].stype == DTHIP_FLOAT32) { f32_seq = true; fused = false; }
     KeyPlan plan; Grouping g;
     std::vector<const void*> sorted_val(nvalues, nullptr);
     const int32_t* gather_ri = nullptr;
@@ -1715,6 +1719,11 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
     for (int a = 0; a < naggs; a++) {
       if (aggs[a].op != DTHIP_COUNT0) continue;
       if ((rc = launch_count0(ctx, g.offsets, ng, static_cast<int64_t*>(res->agg[a]))) != DTHIP_OK) break;
+    }
+    if (rc != DTHIP_OK) break;
+    for (int a = 0; a < naggs && f32_seq; a++) {
+      if (aggs[a].op != DTHIP_SUM || vd[aggs[a].col].stype != DTHIP_FLOAT32) continue;
+      if ((rc = launch_sum_f32_seq(ctx, vd[aggs[a].col].data, gather_ri, g.offsets, ng, res->agg[a])) != DTHIP_OK) break;
     }
   } while (0);
   if (rc != DTHIP_OK) { result_destroy(ctx, res); return rc; }
@@ -1920,7 +1929,10 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
       } else {
         ReduceOuts ro;
         DTHIP_TRY(reduce_outs_for(op, d_out, &ro));
-        DTHIP_TRY(launch_reduce(ctx, d_val, value->stype, ri32, reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, ro));
+        if (op == DTHIP_SUM && value->stype == DTHIP_FLOAT32 && ctx->f32_sum_ref)
+          DTHIP_TRY(launch_sum_f32_seq(ctx, d_val, ri32, off32, ngroups, d_out));
+        else
+          DTHIP_TRY(launch_reduce(ctx, d_val, value->stype, ri32, reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, ro));
       }
     }
   }

@@ -77,6 +77,7 @@ struct dthip_ctx {
   bool in_merge = false;     // internal: the merge of partial groups must not take the hash path again
   int cluster_mode = 0;      // clustered-key kernel variants: 0 decide from a sample, 1 never, 2 always
   int agg_offsets = 1;       // dthip_groupby_agg results carry group offsets (= sizes) even when no count() asks for them
+  int f32_sum_ref = 0;       // 1: sum(float32) accumulates in float32, row by row, like the reference (slow path)
   // multi-GPU (comm.hip): the communicator this context is a rank of
   struct dthip_comm* comm = nullptr;
   int comm_rank = 0;
@@ -350,6 +351,7 @@ int launch_reduce(dthip_ctx* ctx, const void* values, int stype, const int32_t* 
                   const uint8_t* bitmap, const uint32_t* tile_first_head, int64_t nrows,
                   const ReduceOuts& outs, int nona = 0);
 int launch_count0(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t* out);
+int launch_sum_f32_seq(dthip_ctx* ctx, const void* values, const int32_t* ri, const int32_t* offsets, int64_t ngroups, void* out);
 
 constexpr int DTHIP_NOT_APPLICABLE = 2;     // internal: this path does not fit, take the next one
 

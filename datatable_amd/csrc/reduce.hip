@@ -392,4 +392,30 @@ int launch_count0(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64
   return DTHIP_OK;
 }
 
+// sum(float32 column) EXACTLY as the reference computes it (option "f32_sum" = 1): one float accumulator per group,
+// the valid rows added one by one in grouped row order (SumProd_ColumnImpl<float>::get_element, column/sumprod.h:48-55).
+// One thread per group: sequential by definition, so a single huge group is slow -- it is a reproduction switch, the
+// default accumulates in float64 (include/dthip.h, DTHIP_SUM).
+__global__ void __launch_bounds__(256) sum_f32_seq_kernel(const float* __restrict__ v, const int32_t* __restrict__ ri,
+                                                          const int32_t* __restrict__ offsets, uint32_t ngroups, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  float s = 0.0f;
+  for (int32_t p = offsets[g]; p < offsets[g + 1]; p++) {
+    const int32_t j = ri ? ri[p] : p;
+    if (j < 0) continue;
+    const float x = v[j];
+    if (x == x) s += x;
+  }
+  out[g] = s;
+}
+
+int launch_sum_f32_seq(dthip_ctx* ctx, const void* values, const int32_t* ri, const int32_t* offsets, int64_t ngroups, void* out) {
+  if (ngroups == 0) return DTHIP_OK;
+  DTHIP_LAUNCH(ctx, "sum_f32_seq_kernel", sum_f32_seq_kernel, (unsigned)((ngroups + 255) / 256), 256, 0,
+               static_cast<const float*>(values), ri, offsets, (uint32_t)ngroups, static_cast<float*>(out));
+  return DTHIP_OK;
+}
+
 }  // namespace dthip

@@ -75,7 +75,8 @@ enum dthip_op {
                         DEVIATION (documented): float32 sums are ACCUMULATED IN float64 and rounded to
                         float32 once; the reference accumulates in float32 row by row (column/sumprod.h:48-55), so
                         its result carries its own rounding (~1e-7 x sum|v| per group) that this one does not:
-                        the two agree to ~1e-4 relative on long groups, exactly on short ones */
+                        the two agree to ~1e-4 relative on long groups, exactly on short ones.  Option "f32_sum" = 1
+                        reproduces the reference's float32 accumulation bit for bit (dthip_set_option) */
   DTHIP_MEAN = 1, DTHIP_MIN = 2, DTHIP_MAX = 3,
   DTHIP_COUNT = 4,   /* count(col): non-NA rows per group   (count.h:35-58) */
   DTHIP_COUNT0 = 5,  /* count():    rows per group          (count.h:61-88) */
@@ -159,6 +160,10 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    0: only when a count() aggregate asks for group sizes -- the reference's result
  *                    Frame of DT[:, sum(f.v), by(f.k)] holds keys and sums only, and not counting rows
  *                    lets the bucketed aggregation use twice as many table slots per bucket
+ *   "f32_sum"        0 (default): sum(float32 column) accumulates in float64 and rounds once (the documented deviation at
+ *                    DTHIP_SUM); 1: it accumulates in float32, the valid rows of a group added one by one in grouped row
+ *                    order -- bit for bit the reference's SumProd_ColumnImpl<float> (column/sumprod.h:48-55); one thread
+ *                    per group through the RowIndex, a reproduction switch, not a fast path
  *   "median_pairs"   0 (default): median / nunique of FLOAT columns order the rows by (group, value); integer
  *                    columns go through the distinct (group, value) pairs of a fused count() aggregation,
  *                    which is sort-free for categorical data; 1 = floats too

@@ -117,7 +117,7 @@ def match(frame, item):
     if frame.nrows > 2**31 - 1:
         return None
     keys = [_colindex(frame, c) for c in b.cols]
-    if not keys or any(k is None for k in keys):
+    if not keys or any(k is None for k in keys) or not _uniform(b.cols):
         return None
     aggs = []
     for expr in (j if isinstance(j, (list, tuple)) else [j]):
@@ -300,6 +300,11 @@ def run(frame, keys, aggs, ctx=None):
 
 
 # ---- row-returning routes: DT[f.x <cmp> c, cols], DT[:, cols, by(keys)], DT[:, cols, sort(...)] ---------------------
+def _uniform(items):
+    """the reference refuses lists that mix names, indices and expressions ("Mixed selector types are not allowed")"""
+    return len({("s" if isinstance(x, str) else "i" if isinstance(x, int) else "e") for x in items}) <= 1
+
+
 def _is_all(x):
     return x is None or x is Ellipsis or (isinstance(x, slice) and x == slice(None))
 
@@ -311,7 +316,10 @@ def _jcols(frame, j, exclude=()):
     if isinstance(j, dict):
         return None
     out = []
-    for x in (j if isinstance(j, (list, tuple)) else [j]):
+    items = j if isinstance(j, (list, tuple)) else [j]
+    if not _uniform(items):
+        return None            # the reference raises that itself
+    for x in items:
         if isinstance(x, bool):
             return None
         c = _colindex(frame, x)
@@ -506,7 +514,7 @@ def match_rows(frame, item):
     if not (isinstance(item, tuple) and len(item) == 3 and isinstance(item[2], by) and _is_all(item[0])):
         return None
     keys = [_colindex(frame, c) for c in item[2].cols]
-    if not keys or any(k is None for k in keys) or len(set(keys)) != len(keys):
+    if not keys or any(k is None for k in keys) or len(set(keys)) != len(keys) or not _uniform(item[2].cols):
         return None
     cols = _jcols(frame, item[1], exclude=keys)
     if cols is None or not _accel(frame, keys + cols) or frame.nrows == 0:
@@ -566,7 +574,7 @@ def match_sort(frame, item):
         return None
     srt = item[2]
     keys = [_colindex(frame, c) for c in srt.cols]
-    if not keys or any(k is None for k in keys):
+    if not keys or any(k is None for k in keys) or not _uniform(srt.cols):
         return None
     rev = srt.reverse
     desc = [bool(rev)] * len(keys) if not isinstance(rev, (list, tuple)) else [bool(x) for x in rev]

@@ -688,3 +688,33 @@ def test_partial_sums_that_look_like_na_on_the_hash_path(ctx):
                     assert got.dtype == exp.dtype and np.array_equal(got, exp, equal_nan=True), (opn, col, hm, got, exp)
                 else:
                     assert_same(got, exp, "%s(v%d) hash_mode=%d" % (opn, col, hm))
+
+
+def test_float32_sum_reference_order_switch(ctx):
+    """option "f32_sum" = 1: sum(float32) accumulated in float32, row by row in grouped order -- BIT-EXACT against the
+    oracle (= the reference's column/sumprod.h:48-55), on the fused entry point and on dthip_reduce; the default
+    (float64 accumulation, one rounding) stays within the documented 1e-4"""
+    from oracle import oracle as o
+    rng = np.random.default_rng(21)
+    n = 400_000
+    k = rng.integers(0, 3000, n).astype(np.int64)
+    k[rng.random(n) < 0.02] = np.iinfo(np.int64).min
+    v = (rng.standard_normal(n) * 1e3).astype(np.float32)
+    v[rng.random(n) < 0.05] = np.nan
+    w = rng.standard_normal(n)
+    ri, off = o.group([k])
+    exp = o.reduce("sum", v, ri, off)
+    assert exp.dtype == np.float32
+    ctx.set_option("f32_sum", 1)
+    try:
+        r = ctx.groupby_agg([k], [v, w], [("sum", 0), ("mean", 0), ("sum", 1), ("count0", None)])
+        assert_same(r.agg(0), exp, "sum(float32), reference order")
+        assert_close(r.agg(2), o.reduce("sum", w, ri, off), what="sum(float64) next to it")
+        r.free()
+        assert_same(ctx.reduce("sum", v, ri, off), exp, "dthip_reduce sum(float32), reference order")
+    finally:
+        ctx.set_option("f32_sum", 0)
+    r = ctx.groupby_agg([k], [v], [("sum", 0)])
+    got = r.agg(0); r.free()
+    scale = np.add.reduceat(np.abs(np.nan_to_num(v[ri].astype(np.float64))), off[:-1])
+    assert np.all(np.abs(got.astype(np.float64) - exp.astype(np.float64)) <= 1e-4 * np.abs(exp) + 4e-7 * scale + 1e-30)

@@ -143,7 +143,8 @@ def test_match_rows_sort_and_filter_forms():
     S = shim.Frame(k=np.array([3, 1, 3], np.int64), s=["a", "b", "c"])
     assert shim.match_rows(DT, (slice(None), slice(None), shim.by(f.k))) == ([0], [1, 2])       # `:` leaves the by-column out
     assert shim.match_rows(DT, (slice(None), f[:], shim.by("k"))) == ([0], [1, 2])
-    assert shim.match_rows(DT, (slice(None), [f.k, "w"], shim.by(f.k))) == ([0], [0, 2])          # listed explicitly: kept
+    assert shim.match_rows(DT, (slice(None), [f.k, f.w], shim.by(f.k))) == ([0], [0, 2])          # listed explicitly: kept
+    assert shim.match_rows(DT, (slice(None), [f.k, "w"], shim.by(f.k))) is None                   # mixed selector types
     assert shim.match_rows(DT, (slice(None), f.v, shim.by(f.k, f.w))) == ([0, 2], [1])
     assert shim.match_rows(DT, (slice(None), sum(f.v), shim.by(f.k))) is None                     # a reducer: match()'s
     assert shim.match_rows(DT, (f.v > 1, slice(None), shim.by(f.k))) is None                      # i + by: the reference refuses it

@@ -203,8 +203,11 @@ def test_filter_route(env, n):
         exp = dt.Frame.__getitem__(DT, (p, slice(None)))
         assert type(got) is shim.Frame
         assert_rows_equal(dt, got, exp)
-    got = DT[f.f8 > 0, [f.k, "i4", f[3]]]
-    assert_rows_equal(dt, got, dt.Frame.__getitem__(DT, (f.f8 > 0, [f.k, "i4", f[3]])))
+    got = DT[f.f8 > 0, [f.k, f["i4"], f[3]]]
+    assert_rows_equal(dt, got, dt.Frame.__getitem__(DT, (f.f8 > 0, [f.k, f["i4"], f[3]])))
+    assert_rows_equal(dt, DT[f.i4 <= 0, ["i8", "k"]], dt.Frame.__getitem__(DT, (f.i4 <= 0, ["i8", "k"])))
+    with pytest.raises(TypeError):           # mixed selector types: not matched, the reference raises its own error
+        DT[f.f8 > 0, [f.k, "i4"]]
 
 
 @pytest.mark.parametrize("key", ["int64", "int32", "float64", "bool"])
@@ -213,7 +216,7 @@ def test_rows_in_grouped_order_route(env, key, n):
     dt, shim = env
     from datatable import f
     DT = make_frame(shim, n, seed=400 + n + len(key), key=key)
-    for j, bycols in ((slice(None), [f.k]), (f[:], [f.k, f.k2]), ([f.f8, f.k, "i1"], ["k"]), (f.b, [f.k2])):
+    for j, bycols in ((slice(None), [f.k]), (f[:], [f.k, f.k2]), ([f.f8, f.k, f["i1"]], ["k"]), (f.b, [f.k2])):
         assert shim.match_rows(DT, (slice(None), j, shim.by(*bycols))) is not None
         got = DT[:, j, shim.by(*bycols)]
         exp = dt.Frame.__getitem__(DT, (slice(None), j, dt.by(*bycols)))
@@ -227,7 +230,7 @@ def test_sort_route(env, n):
     DT = make_frame(shim, n, seed=500 + n, key="float64")
     cases = [dict(cols=[f.k]), dict(cols=[f.k], reverse=True), dict(cols=[f.k], na_position="last"),
              dict(cols=[f.k], reverse=True, na_position="last"), dict(cols=[f.i4, f.f8], reverse=[True, False]),
-             dict(cols=[f.i1], na_position="remove"), dict(cols=["k2", f.i2], na_position="remove"), dict(cols=[f.b, f.f4])]
+             dict(cols=[f.i1], na_position="remove"), dict(cols=[f.k2, f.i2], na_position="remove"), dict(cols=[f.b, f.f4])]
     for c in cases:
         cols = c.pop("cols")
         assert shim.match_sort(DT, (slice(None), slice(None), shim.sort(*cols, **c))) is not None
