@@ -14,6 +14,7 @@
 //                 from a per-tile digit count taken before the pass (no look-back);
 //                 keys and payloads are re-ordered through LDS so that global
 //                 stores are runs of consecutive addresses per digit.
+#include <cstdlib>
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "keyxform.hpp"
@@ -514,8 +515,11 @@ static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
 
 template <typename KeyT>
 static int launch_pass_k(dthip_ctx* ctx, const RadixPass& p) {
-  const int p0w = (p.pay.n > 0 && !p.iota) ? p.pay.width[0] : 0;
-  const int p1w = (p0w == 8 && p.pay.n > 1) ? p.pay.width[1] : 0;
+  static const int prefetch = getenv("DTHIP_RP_PREFETCH") ? atoi(getenv("DTHIP_RP_PREFETCH")) : 2;   // payload columns loaded with the keys
+  int p0w = (p.pay.n > 0 && !p.iota) ? p.pay.width[0] : 0;
+  int p1w = (p0w == 8 && p.pay.n > 1) ? p.pay.width[1] : 0;
+  if (prefetch < 2) p1w = 0;
+  if (prefetch < 1) p0w = 0;
   if (p.bits > 8) {
     if (p0w == 8 && p1w == 8) return launch_pass_t<KeyT, 9, 8, 8>(ctx, p);
     if (p0w == 8 && p1w == 4) return launch_pass_t<KeyT, 9, 8, 4>(ctx, p);
