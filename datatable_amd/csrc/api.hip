@@ -28,12 +28,25 @@ void set_error(const char* fmt, ...) {
 // ("Memory access fault by GPU node-N ...") and aborts; with one synchronised launch at a time the kernel named
 // here is the one that touched the unmapped page.
 static char g_guard_kernel[128] = "(no kernel in flight)";
+// the most recent guarded buffers {first mapped byte, mapped bytes, user pointer, requested bytes, 1 = released}: printed by
+// the handler so that the address the runtime reports can be placed next to (before / after / inside) a buffer
+struct GuardLog { unsigned long long map, map_bytes, ptr, bytes, freed; };
+static GuardLog g_guard_log[96];
+static unsigned g_guard_logn = 0;
 static void guard_sigabrt(int) {
   static const char pre[] = "\n[dthip guard] abort while kernel '";
   static const char post[] = "' was in flight (a GPU memory access fault above means it touched memory outside its buffers)\n";
   (void)!write(2, pre, sizeof(pre) - 1);
   (void)!write(2, g_guard_kernel, strnlen(g_guard_kernel, sizeof(g_guard_kernel)));
   (void)!write(2, post, sizeof(post) - 1);
+  char line[160];
+  const unsigned nlog = g_guard_logn < 96 ? g_guard_logn : 96;
+  for (unsigned i = 0; i < nlog; i++) {
+    const GuardLog& g = g_guard_log[(g_guard_logn - 1 - i) % 96];
+    const int m = snprintf(line, sizeof(line), "[dthip guard]   buffer %u back: mapped [0x%llx, 0x%llx) user 0x%llx + %llu bytes%s\n", i,
+                           g.map, g.map + g.map_bytes, g.ptr, g.bytes, g.freed ? " (released)" : "");
+    if (m > 0) (void)!write(2, line, (size_t)m);
+  }
   signal(SIGABRT, SIG_DFL);
   raise(SIGABRT);
 }
@@ -79,10 +92,18 @@ static int guard_alloc(dthip_ctx* ctx, size_t bytes, void** out) {
   DTHIP_CHECK_HIP(hipMemSetAccess(b.map, b.map_bytes, &acc, 1));
   // poison: fresh memory is not zero (nor is hipMalloc's), and slack inside the mapping is recognisable
   static const int poison = getenv("DTHIP_GUARD_POISON") ? atoi(getenv("DTHIP_GUARD_POISON")) : 0xA5;
-  if (poison >= 0) DTHIP_CHECK_HIP(hipMemsetAsync(b.map, poison, b.map_bytes, ctx->stream));
+  if (poison >= 0) {
+    // synchronous: the next guarded allocation edits the page tables (hipMemMap / hipMemSetAccess), and doing that while
+    // the fill of a multi-GB mapping was still running was seen to fault INSIDE the freshly mapped range
+    DTHIP_CHECK_HIP(hipMemsetAsync(b.map, poison, b.map_bytes, ctx->stream));
+    DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  }
   void* p = ctx->guard == 2 ? b.map : static_cast<char*>(b.map) + (b.map_bytes - want);
   ctx->guarded[p] = b;
   ctx->guard_allocs++;
+  g_guard_log[g_guard_logn % 96] = GuardLog{(unsigned long long)(uintptr_t)b.map, (unsigned long long)b.map_bytes,
+                                            (unsigned long long)(uintptr_t)p, (unsigned long long)bytes, 0ULL};
+  g_guard_logn++;
   *out = p;
   return DTHIP_OK;
 }
@@ -104,6 +125,7 @@ static void guard_free(dthip_ctx* ctx, void* p, bool final = false) {
   if (it == ctx->guarded.end()) return;
   const dthip_ctx::GuardBlock b = it->second;
   ctx->guarded.erase(it);
+  for (unsigned i = 0; i < 96 && i < g_guard_logn; i++) if (g_guard_log[i].ptr == (unsigned long long)(uintptr_t)p) g_guard_log[i].freed = 1;
   (void)hipStreamSynchronize(ctx->stream);          // kernels queued on the block must be done before it disappears
   if (!final && guard_free_mode() == 0) { ctx->guard_limbo.push_back(b); return; }
   guard_unmap(b, final || guard_free_mode() == 2);
