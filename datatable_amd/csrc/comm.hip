@@ -70,7 +70,13 @@ static int nccl_load() {
   if (g_nccl.handle) return DTHIP_OK;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void* h = nullptr;
-  for (const char* nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+  // DTHIP_RCCL_LIB: another library with RCCL's entry points (tests/cpp/fake_rccl.cpp lets several PROCESSES share one
+  // GPU, which RCCL refuses, so that the multi-rank branch below can run on a single-GPU box)
+  if (const char* alt = getenv("DTHIP_RCCL_LIB")) {
+    h = dlopen(alt, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { set_error("DTHIP_RCCL_LIB=%s could not be loaded: %s", alt, dlerror()); return DTHIP_EDEVICE; }
+  }
+  for (const char* nm : names) { if (h) break; h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); }
   if (!h) { set_error("librccl.so could not be loaded: %s", dlerror()); return DTHIP_EDEVICE; }
 #define NCCL_SYM(field, sym)                                                                  \
   g_nccl.field = reinterpret_cast<decltype(g_nccl.field)>(dlsym(h, #sym));                    \
