@@ -75,14 +75,14 @@ def main():
                 res["%s/c%d" % (name, i)] = r.col(i)
             res["%s/off" % name] = r.offsets()
         r.free()
-    # failures must reach EVERY rank: (1) rank 1 alone asks for a reducer the distributed path refuses, (2) rank 1 alone
-    # runs another query, (3) the communicator still works afterwards
+    # failures must reach EVERY rank: (1) rank 1 alone fails locally (a bad row count: the same query, so only its status
+    # word tells the others), (2) rank 1 alone runs another query, (3) the communicator still works afterwards
     k = np.arange(1000, dtype=np.int64) % 7
     v = np.ones(1000)
     verdicts = []
-    for bad in ([("first", 0)], [("sum", 0), ("count0", None)]):
+    for aggs, nrows in (([("sum", 0)], -1 if rank == 1 else None), ([("sum", 0), ("count0", None)] if rank == 1 else [("sum", 0)], None)):
         try:
-            r = ctx.sharded_groupby_agg([k], [v], bad if rank == 1 else [("sum", 0)])
+            r = ctx.sharded_groupby_agg([k], [v], aggs, nrows=nrows)
             r.free()
             verdicts.append("completed")
         except Exception as e:
