@@ -555,6 +555,8 @@ def main():
         return
     from datatable_amd.torch_bridge import context_for_current_stream, devcol
     from datatable_amd.engine import comm_unique_id
+    if os.environ.get("DTHIP_BENCH_ONE_GPU"):
+        local_rank = 0      # tests only: every rank on GPU 0 (with DTHIP_RCCL_LIB = the shared-memory stand-in; RCCL refuses that)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_dist

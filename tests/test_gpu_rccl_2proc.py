@@ -90,3 +90,24 @@ def test_ranks_as_processes(world, fake_rccl, tmp_path):
         assert ("rank 1 failed" in v[0]) if r != 1 else ("bad argument" in v[0]), (r, v)
     assert_same(cat("after_errors/k0"), np.arange(7, dtype=np.int64), "keys after the error rounds")
     assert np.array_equal(cat("after_errors/a0"), np.array([143 * world if i < 6 else 142 * world for i in range(7)], np.float64))
+
+
+def test_bench_two_ranks_end_to_end(fake_rccl):
+    """`python bench.py --gpus 2` exactly as the driver starts it for N > 1 -- no launcher: bench.py spawns its ranks, gloo
+    carries the communicator id and the timing barrier, libdthip runs the sharded groupby -- on this box's ONE GPU (both
+    ranks on device 0, the shared-memory stand-in for RCCL): the JSON line must come out with the sharded properties
+    checked (key ranges of the ranks ascending and disjoint, sum of the group sums == sum of the values)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DTHIP_RCCL_LIB=fake_rccl, DTHIP_BENCH_ONE_GPU="1", FAKE_RCCL_DIR=os.path.dirname(fake_rccl))
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rows", "20000000", "--groups", "200000", "--steps", "2",
+                          "--warmup", "1"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["rows"] == 20_000_000 and line["config"]["rows_per_gpu"] == 10_000_000
+    p = line["parity"]["properties"]
+    assert p["groups"] == 200_000 and p["keys_strictly_ascending_within_and_across_ranks"] and p["sum_of_group_sums_equals_sum_of_values"]
+    assert line["roofline"]["kernel"] and line["cpu_baseline"] is None
