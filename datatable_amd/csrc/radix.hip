@@ -187,7 +187,13 @@ int launch_hist_scan(dthip_ctx* ctx, const uint32_t* hist, uint32_t* base, int n
 #ifndef DTHIP_RP_BLOCK
 #define DTHIP_RP_BLOCK 512
 #endif
-constexpr int RP_BLOCK = DTHIP_RP_BLOCK, RP_ITEMS = 16, RP_TILE = RP_BLOCK * RP_ITEMS;
+#ifndef DTHIP_RP_ITEMS
+#define DTHIP_RP_ITEMS 16
+#endif
+#ifndef DTHIP_RP_WAVES
+#define DTHIP_RP_WAVES 4
+#endif
+constexpr int RP_BLOCK = DTHIP_RP_BLOCK, RP_ITEMS = DTHIP_RP_ITEMS, RP_TILE = RP_BLOCK * RP_ITEMS;
 
 template <typename KeyT>
 struct PassArgsT {
@@ -273,7 +279,7 @@ __device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t
 // P0W  = byte width of payload column 0 when it is prefetched with the keys (0: none / iota)
 // P1W  = the same for payload column 1 (only with P0W == 8): both columns' loads are in flight before the ranking
 template <typename KeyT, int RB, int P0W, int P1W = 0>
-__global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) radix_pass_kernel(PassArgsT<KeyT> a) {
+__global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) radix_pass_kernel(PassArgsT<KeyT> a) {
   constexpr int BLOCK = RP_BLOCK, ITEMS = RP_ITEMS;
   constexpr int WAVES = BLOCK / 64, TILE = BLOCK * ITEMS;
   constexpr int GROUPS = ITEMS / 4;     // each thread owns GROUPS groups of 4 consecutive tile-sorted slots
