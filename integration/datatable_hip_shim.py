@@ -8,7 +8,7 @@ source, and forwards every other form of `DT[...]` to the reference unchanged:
 
     import datatable as dt
     from datatable import f, sum, mean, count
-    from integration.datatable_hip_shim import Frame, by        # the shim's Frame and by()
+    from integration.datatable_hip_shim import Frame, by, sort  # the shim's Frame, by() and sort()
     DT = Frame(dt.fread("data.jay"))                             # or Frame(k=..., v=...)
     DT[:, [sum(f.v), count()], by(f.k)]                          # -> libdthip (MI355X): dthip_groupby_agg
     V = DT[f.x > 0, :]; V[:, :, by(f.k)]                         # -> dthip_filter_take, dthip_groupby_rows (BASELINE config 5)
