@@ -302,6 +302,15 @@ static int plan_keys(dthip_ctx* ctx, Scratch& sc, const dthip_col* keys_dev, int
   }
   MinMax mm[MAX_KEYCOLS];
   if (any_int) DTHIP_TRY(read_back(ctx, mm, d_mm, sizeof(MinMax) * nkeys));
+  if (speculative) {
+    // a sample that met nothing but NAs (a sparse, mostly-NA key column) says nothing about the valid keys in the rows
+    // it skipped: such a column gets its exact range (a plan that is not speculative is never verified)
+    for (int k = 0; k < nkeys; k++) {
+      const int st = keys_dev[k].stype;
+      if (st >= DTHIP_INT8 && st <= DTHIP_INT64 && mm[k].nvalid == 0)
+        return plan_keys(ctx, sc, keys_dev, nkeys, n, na_pos, plan, false, false);
+    }
+  }
   for (int k = 0; k < nkeys; k++) {
     KeyColDev& c = plan->col[k];
     const int st = keys_dev[k].stype;
@@ -338,7 +347,7 @@ static int plan_keys(dthip_ctx* ctx, Scratch& sc, const dthip_col* keys_dev, int
       c.edge = c.desc ? (unsigned long long)mx : (unsigned long long)mn;
       c.inc = (na_pos == DTHIP_NA_LAST) ? 0 : 1;
       c.na_repl = (na_pos == DTHIP_NA_LAST) ? range1 : 0;
-      c.xmax = range1 ? range1 : ~0ULL;    // range1 == 0: the range covers all 2^64 values
+      c.xmax = range1 - 1ULL;              // valid keys: [inc, inc + range1 - 1] (range1 == 0: all 2^64 values, wraps to ~0)
       const int nb = nbits_u64(range1);
       plan->nsig[k] = nb ? nb : 64;
     }
@@ -1524,15 +1533,16 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
     if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan, true, true)) != DTHIP_OK) break;   // guessed key range: verified below
     bool ride = plan.nstages == 1 && ncols + (want_rowindex ? 1 : 0) <= MAX_PAYCOLS && ncols > 0;
     for (int c = 0; c < ncols; c++) if (stype_size(cd[c].stype) < 4) ride = false;
+    PaySpec ps;
+    SortOut so;
+    std::vector<int> slot(ncols, -1), is_key(ncols, -1);
     if (ride) {
       // the columns (and the row ids) ride through the radix passes: streaming reads and run-wise
       // writes instead of one random gather per column through the finished RowIndex
-      PaySpec ps;
       ps.n = 0;
       if (want_rowindex) { ps.in[0] = nullptr; ps.width[0] = 4; ps.iota = true; ps.n = 1; }
       // a requested column that IS a key column does not ride along: the sorted packed keys are
       // turned back into it afterwards (streaming), which saves its bytes in every pass
-      std::vector<int> slot(ncols, -1), is_key(ncols, -1);
       for (int c = 0; c < ncols; c++) {
         for (int k = 0; k < nkeys; k++)
           if (cols[c].data == keys[k].data && cols[c].stype == keys[k].stype) is_key[c] = k;
@@ -1540,13 +1550,17 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
         slot[c] = ps.n;
         ps.in[ps.n] = cd[c].data; ps.width[ps.n] = stype_size(cd[c].stype); ps.n++;
       }
-      SortOut so;
       rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so);
-      if (rc == DTHIP_RETRY_EXACT) {          // the sampled key range did not hold: the exact one (narrower: still one stage)
+      if (rc == DTHIP_RETRY_EXACT) {
+        // the sampled key range did not hold, so real keys lie OUTSIDE it: the exact range is usually WIDER, and with
+        // several keys the packed width may now exceed 64 bits (two stages) -- then the columns cannot ride
         if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan)) != DTHIP_OK) break;
-        rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so);
+        if (plan.nstages != 1) { ride = false; rc = DTHIP_OK; }
+        else rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so);
       }
       if (rc != DTHIP_OK) break;
+    }
+    if (ride) {
       if ((rc = heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, nrows, &g)) != DTHIP_OK) break;
       if (want_rowindex) { result_adopt(sc, res, so.pay[0]); res->rowindex = static_cast<int32_t*>(so.pay[0]); }
       for (int c = 0; c < ncols && rc == DTHIP_OK; c++) {

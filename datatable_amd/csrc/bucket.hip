@@ -52,9 +52,9 @@ __device__ __forceinline__ uint32_t item_row(int j, int tid) {
 // integer key transform (sort.cc:728-776) without branches: ascending u - edge, descending edge - u
 __device__ __forceinline__ uint32_t xf_int(const KeyColDev& c, long long v, long long na, bool& bad) {
   const u64 m = 0ULL - (u64)c.desc;              // all-ones when descending
-  const u64 d = ((((u64)v - c.edge) ^ m) - m) + c.inc;
-  const u64 t = (v == na) ? c.na_repl : d;
-  const bool b = t > c.xmax;                     // only possible when the key range was guessed from a sample
+  const u64 d0 = (((u64)v - c.edge) ^ m) - m;    // distance from the range's edge: [0, xmax] for a key inside the range
+  const u64 t = (v == na) ? c.na_repl : d0 + c.inc;
+  const bool b = v != na && d0 > c.xmax;         // only possible when the key range was guessed from a sample
   bad |= b;
   return b ? 0u : (uint32_t)t;
 }
@@ -612,12 +612,7 @@ int launch_bucket_plan(dthip_ctx* ctx, const uint32_t* tot, uint32_t F, uint32_t
 template <int BLOCK, int ITEMS, int KM, bool CL, bool PF>
 static int part_launch(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds) {
   auto kfn = bucket_partition_kernel<BLOCK, ITEMS, KM, CL, PF>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    attr_set = true;
-  }
+  DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 256));
   DTHIP_LAUNCH(ctx, "bucket_partition_kernel", kfn, ntiles, BLOCK, lds, a);
   return DTHIP_OK;
 }
@@ -916,12 +911,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
 template <typename VT, int SRC, bool UNI>
 static int table_agg_t(dthip_ctx* ctx, const TableAggDev& d, uint32_t grid, size_t lds) {
   auto kfn = table_agg_kernel<VT, SRC, UNI>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    attr_set = true;
-  }
+  DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 256));
   DTHIP_LAUNCH(ctx, "table_agg_kernel", kfn, grid, TA_BLOCK, lds, d);
   return DTHIP_OK;
 }
@@ -1067,12 +1057,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_seg_kernel(TableAggSegDev 
 template <typename VT>
 static int table_agg_seg_t(dthip_ctx* ctx, const TableAggSegDev& d, uint32_t grid, size_t lds) {
   auto kfn = table_agg_seg_kernel<VT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    attr_set = true;
-  }
+  DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 256));
   DTHIP_LAUNCH(ctx, "table_agg_seg_kernel", kfn, grid, TA_BLOCK, lds, d);
   return DTHIP_OK;
 }
@@ -1441,12 +1426,7 @@ size_t hash_agg_entry_bytes(int flags) { return 8 + table_agg_slot_bytes(flags);
 template <typename VT, int CFLAGS>
 static int hash_agg_t(dthip_ctx* ctx, const HashAggDev& d, uint32_t grid, size_t lds) {
   auto kfn = hash_agg_kernel<VT, CFLAGS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-    attr_set = true;
-  }
+  DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 256));
   DTHIP_LAUNCH(ctx, "hash_agg_kernel", kfn, grid, TA_BLOCK, lds, d);
   return DTHIP_OK;
 }

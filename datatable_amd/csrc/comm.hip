@@ -45,6 +45,11 @@ struct dthip_comm {
   ncclComm_t nccl = nullptr;
   std::vector<dthip_ctx*> ranks;      // local: context of every rank
   int refs = 0;
+  // RCCL: device staging of the small all-gathers, allocated ONCE at dthip_comm_init -- a rank must never fail between
+  // deciding to all-gather and entering the collective (its peers would wait in it forever)
+  unsigned char* ag_send = nullptr;
+  unsigned char* ag_recv = nullptr;
+  size_t ag_cap = 0;                  // bytes per rank
 };
 
 namespace dthip {
@@ -261,16 +266,17 @@ static int exchange_allgather(dthip_comm* comm, std::vector<Job>& jobs) {
   }
   Job& j = jobs[0];
   dthip_ctx* ctx = j.ctx;
-  Scratch sc(ctx);
-  unsigned char* ds = nullptr; unsigned char* dr = nullptr;
-  DTHIP_TRY(sc.get<unsigned char>(bytes, &ds));
-  DTHIP_TRY(sc.get<unsigned char>(bytes * comm->world, &dr));
-  DTHIP_CHECK_HIP(hipMemcpyAsync(ds, j.xin.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-  DTHIP_CHECK_NCCL(g_nccl.AllGather(ds, dr, bytes, ncclInt8, comm->nccl, ctx->stream));
+  // the blob size is the same on every rank (a property of the protocol stage), so this refusal is taken by all ranks alike
+  if (bytes > comm->ag_cap) { set_error("all-gather blob of %zu bytes exceeds the staging buffer (%zu)", bytes, comm->ag_cap); return DTHIP_EINVAL; }
+  // from here on the collective is entered whatever happens locally: a failed copy is reported AFTER it
+  int rc = DTHIP_OK;
+  hipError_t he = hipMemcpyAsync(comm->ag_send, j.xin.data(), bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (he != hipSuccess) { set_error("all-gather staging copy failed: %s", hipGetErrorString(he)); rc = DTHIP_EDEVICE; }
+  DTHIP_CHECK_NCCL(g_nccl.AllGather(comm->ag_send, comm->ag_recv, bytes, ncclInt8, comm->nccl, ctx->stream));
   j.xout.resize(bytes * comm->world);
-  DTHIP_CHECK_HIP(hipMemcpyAsync(j.xout.data(), dr, bytes * comm->world, hipMemcpyDeviceToHost, ctx->stream));
+  DTHIP_CHECK_HIP(hipMemcpyAsync(j.xout.data(), comm->ag_recv, bytes * comm->world, hipMemcpyDeviceToHost, ctx->stream));
   DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-  return DTHIP_OK;
+  return rc;
 }
 
 // all-to-all-v of every column of every job (send_off / send_cnt / recv_off / recv_cnt in rows)
@@ -298,20 +304,24 @@ static int exchange_alltoallv(dthip_comm* comm, std::vector<Job>& jobs) {
   }
   Job& j = jobs[0];
   DTHIP_CHECK_NCCL(g_nccl.GroupStart());
-  for (size_t c = 0; c < j.cols.size(); c++) {
+  // an error inside the group must not leave it open: remember the first one, always reach GroupEnd
+  ncclResult_t first = ncclSuccess;
+  for (size_t c = 0; c < j.cols.size() && first == ncclSuccess; c++) {
     const int e = j.cols[c].elem;
-    for (int p = 0; p < comm->world; p++) {
+    for (int p = 0; p < comm->world && first == ncclSuccess; p++) {
       if (j.send_cnt[p]) {
         const unsigned char* src = static_cast<const unsigned char*>(j.cols[c].send) + (size_t)j.send_off[p] * e;
-        DTHIP_CHECK_NCCL(g_nccl.Send(src, (size_t)j.send_cnt[p] * e, ncclInt8, p, comm->nccl, j.ctx->stream));
+        first = g_nccl.Send(src, (size_t)j.send_cnt[p] * e, ncclInt8, p, comm->nccl, j.ctx->stream);
       }
-      if (j.recv_cnt[p]) {
+      if (j.recv_cnt[p] && first == ncclSuccess) {
         unsigned char* dst = static_cast<unsigned char*>(j.cols[c].recv) + (size_t)j.recv_off[p] * e;
-        DTHIP_CHECK_NCCL(g_nccl.Recv(dst, (size_t)j.recv_cnt[p] * e, ncclInt8, p, comm->nccl, j.ctx->stream));
+        first = g_nccl.Recv(dst, (size_t)j.recv_cnt[p] * e, ncclInt8, p, comm->nccl, j.ctx->stream);
       }
     }
   }
-  DTHIP_CHECK_NCCL(g_nccl.GroupEnd());
+  const ncclResult_t ge = g_nccl.GroupEnd();
+  if (first != ncclSuccess) { set_error("ncclSend / ncclRecv failed inside the all-to-all-v group: %s", g_nccl.GetErrorString(first)); return DTHIP_EDEVICE; }
+  if (ge != ncclSuccess) { set_error("ncclGroupEnd failed: %s", g_nccl.GetErrorString(ge)); return DTHIP_EDEVICE; }
   return DTHIP_OK;
 }
 
@@ -475,6 +485,15 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
     auto local = [&]() -> int {
       DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
       kd[q].resize(nkeys); vd[q].resize(nvalues);
+      if (ctx->f32_sum_ref) {
+        // option "f32_sum" = 1 promises the reference's float32 accumulation in grouped ROW order; partial sums of row
+        // shards merged across ranks cannot reproduce that order, so the sharded call says so instead of ignoring it
+        for (int i = 0; i < a.naggs; i++)
+          if (a.aggs[i].op == DTHIP_SUM && a.aggs[i].col >= 0 && a.aggs[i].col < nvalues && a.values[a.aggs[i].col].stype == DTHIP_FLOAT32) {
+            set_error("sharded groupby: option f32_sum = 1 (float32 sums accumulated row by row) applies to single-GPU calls only");
+            return DTHIP_ENOTIMPL;
+          }
+      }
       for (int k = 0; k < nkeys; k++) DTHIP_TRY(stage_dev(ctx, *j.sc, a.keys[k], a.nrows, a.mem, &kd[q][k]));
       for (int c = 0; c < nvalues; c++) {
         DTHIP_TRY(stage_dev(ctx, *j.sc, a.values[c], a.nrows, a.mem, &vd[q][c]));
@@ -776,6 +795,16 @@ int dthip_comm_init(dthip_ctx* ctx, int rank, int world, const void* id) {
   c->kind = 0; c->world = world; c->refs = 1;
   ncclResult_t r = g_nccl.CommInitRank(&c->nccl, world, uid, rank);
   if (r != ncclSuccess) { set_error("ncclCommInitRank failed: %s", g_nccl.GetErrorString(r)); delete c; return DTHIP_EDEVICE; }
+  // staging of the all-gathers (largest blob: 4096 histogram bins of 8 bytes + header; 64 KB per rank leaves room)
+  c->ag_cap = 64 * 1024;
+  if (hipMalloc(reinterpret_cast<void**>(&c->ag_send), c->ag_cap) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->ag_recv), c->ag_cap * (size_t)world) != hipSuccess) {
+    set_error("dthip_comm_init: out of device memory for the all-gather staging buffers");
+    if (c->ag_send) (void)hipFree(c->ag_send);
+    (void)g_nccl.CommDestroy(c->nccl);
+    delete c;
+    return DTHIP_ENOMEM;
+  }
   ctx->comm = c; ctx->comm_rank = rank;
   return DTHIP_OK;
 }
@@ -802,6 +831,8 @@ int dthip_comm_destroy(dthip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)g_nccl.CommDestroy(c->nccl);
+    if (c->ag_send) (void)hipFree(c->ag_send);
+    if (c->ag_recv) (void)hipFree(c->ag_recv);
   }
   delete c;
   return DTHIP_OK;

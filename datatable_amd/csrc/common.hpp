@@ -8,6 +8,7 @@
 #include <map>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/dthip.h"
@@ -68,6 +69,9 @@ struct dthip_ctx {
   std::vector<hipEvent_t> event_pool;
   std::map<std::string, dthip::ProfAcc> acc;
   int num_cus = 256;
+  // kernels whose dynamic-LDS limit was raised on THIS context's device (hipFuncSetAttribute is per device: a
+  // process-wide flag would leave the devices 1..7 of a local communicator at the 64 KB default)
+  std::unordered_set<const void*> lds_raised;
   int agg_path = 0;          // 0 auto, 1 sort path, 2 bucket path whenever eligible
   int bucket_variant = 0;    // partition tile geometry (experiments)
   int64_t spec_min_rows = 1 << 23;   // key ranges are guessed from a sample only at or above this many rows
@@ -163,6 +167,14 @@ struct Scratch {
                         if (_grc != DTHIP_OK) return _grc; }                                \
   } while (0)
 
+// raise a kernel's dynamic-LDS limit once per (context = device, kernel)
+inline int ensure_dyn_lds(dthip_ctx* ctx, const void* kfn, int bytes) {
+  if (ctx->lds_raised.count(kfn)) return DTHIP_OK;
+  DTHIP_CHECK_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  ctx->lds_raised.insert(kfn);
+  return DTHIP_OK;
+}
+
 // small synchronous device->host read-back through pinned memory
 int read_back(dthip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
 
@@ -186,7 +198,7 @@ struct KeyColDev {
   unsigned long long edge;     // min (ascending) or max (descending), as the column's unsigned image
   unsigned long long na_repl;  // transformed value of NA
   unsigned long long inc;      // 1 when NA is first, else 0
-  unsigned long long xmax;     // largest legal transformed value (rows beyond it: the key range was a guess and is wrong)
+  unsigned long long xmax;     // valid (non-NA) keys transform to [inc, inc + xmax]; a non-NA key outside: the key range was a guess and is wrong
   int shift;                   // bit position of this key inside the packed key
 };
 struct XformArgs {

@@ -35,8 +35,9 @@ __global__ void __launch_bounds__(XH_BLOCK) xform_hist_kernel(XformArgs a) {
     const uint32_t src = a.order ? (uint32_t)a.order[row] : row;
     unsigned long long k = 0;
     for (int j = 0; j < a.ncols; j++) {
-      const unsigned long long x = xform_key(a.cols[j], src);
-      if (x > a.cols[j].xmax) oob = true;
+      bool na;
+      const unsigned long long x = xform_key_na(a.cols[j], src, na);
+      if (!na && !xform_in_range(a.cols[j], x)) oob = true;
       k |= x << a.cols[j].shift;
     }
     if (a.out64) static_cast<unsigned long long*>(a.out)[row] = k;
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(XH_BLOCK) xform_hist_int_kernel(XformArgs a) {
     for (int j = 0; j < 4; j++) {
       const u64 u = (u64)(long long)v[j];
       k[j] = (v[j] == na) ? c.na_repl : (c.desc ? c.edge - u + c.inc : u - c.edge + c.inc);
-      if ((uint32_t)j < nv && k[j] > c.xmax) oob = true;
+      if ((uint32_t)j < nv && v[j] != na && !xform_in_range(c, k[j])) oob = true;
     }
     if (nv == 4) {
       if (OUT64) {
@@ -203,6 +204,7 @@ struct PassArgsT {
   const uint32_t* gpre;     // [G][bins]      global position of group g's first row of digit d
   uint32_t tpg;             // tiles per group
   int iota;
+  int seq;                  // -DDTHIP_RP_EXPERIMENT builds only (timing experiments, WRONG results): tile-local output positions
   PayCols pay;
 };
 
@@ -278,7 +280,14 @@ __device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t
 // RB   = number of ballot rounds (>= bits of every pass run with this instance)
 // P0W  = byte width of payload column 0 when it is prefetched with the keys (0: none / iota)
 // P1W  = the same for payload column 1 (only with P0W == 8): both columns' loads are in flight before the ranking
-template <typename KeyT, int RB, int P0W, int P1W = 0>
+// RK   = how a key finds the lanes of its wave that hold the same digit (the stable "match any"):
+//        0  RB ballot rounds, one per digit bit (6 VALU instructions per bit and key: 154 per key at 9 bits, which kept
+//           every SIMD busy 37 % of the pass -- profiles/r03_sq_tcc_counters.txt);
+//        1  through LDS: every lane ORs its lane bit into a wave-private 64-bit word per digit (ds_or_b64), reads the
+//           word back -- the wave's DS instructions execute in order, so the word then holds exactly the lanes of this
+//           item with this digit -- and the lowest of them clears it for the next item.  popcount below the lane = the
+//           stable rank inside the item.  Three DS instructions and ~10 VALU per key, whatever the digit width.
+template <typename KeyT, int RB, int P0W, int P1W = 0, int RK = 0>
 __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) radix_pass_kernel(PassArgsT<KeyT> a) {
   constexpr int BLOCK = RP_BLOCK, ITEMS = RP_ITEMS;
   constexpr int WAVES = BLOCK / 64, TILE = BLOCK * ITEMS;
@@ -354,25 +363,73 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
   }
 
   // ---- stable rank of every key among equal digits of its wave --------------
-  volatile uint16_t* mywh = wh + wave * bins;
+  // (the cross-lane traffic below goes through wavefront-scope relaxed atomics, not `volatile`: volatile accesses lose
+  // the LDS address space and become flat_load / flat_store ... sc0 sc1 with a full vmcnt(0) wait each -- rounds 1-3
+  // paid that for the 16-bit counters, 32 flat accesses per lane and tile)
+  uint16_t* mywh = wh + wave * bins;
   uint32_t pos[ITEMS];
+  if (RK == 1) {
+    // the wave's own slice of `exch` (its transposed keys, all read by now: DS instructions of a wave run in order)
+    // becomes its table of lane masks, one 64-bit word per digit
+    constexpr uint32_t SLICE = 64u * ITEMS * (uint32_t)sizeof(KeyT);
+    if (SLICE < (8u << RB)) __syncthreads();        // narrow slices: the table spills into the neighbours' keys
+    const uint32_t stride = SLICE < (8u << RB) ? (8u << RB) : SLICE;
+    unsigned long long* mk = reinterpret_cast<unsigned long long*>(exch + (size_t)wave * stride);
+    for (int b = lane; b < bins; b += 64) mk[b] = 0ULL;
+    const unsigned long long mybit = 1ULL << lane;
 #pragma unroll
-  for (int i = 0; i < ITEMS; i++) {
-    const bool valid = (wbase + 64u * i) < nvalid;
-    const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
-    unsigned long long m = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < RB; b++) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long bal = __ballot(bit);
-      m &= bit ? bal : ~bal;
+    for (int i = 0; i < ITEMS; i++) {
+      const bool valid = (wbase + 64u * i) < nvalid;
+      const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
+      pos[i] = 0;
+      __builtin_amdgcn_wave_barrier();
+      if (valid) {
+        __hip_atomic_fetch_or(&mk[d], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const unsigned long long m = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t prev = __hip_atomic_load(&mywh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t below = mbcnt64(m);
+        pos[i] = prev + below;
+        if (below == 0) {
+          __hip_atomic_store(&mk[d], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          __hip_atomic_store(&mywh[d], (uint16_t)(prev + (uint32_t)__popcll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
     }
-    const uint32_t below = mbcnt64(m);
-    const uint32_t cnt = (uint32_t)__popcll(m);
-    uint32_t prev = 0;
-    if (valid) prev = mywh[d];
-    pos[i] = prev + below;
-    if (valid && below == 0) mywh[d] = (uint16_t)(prev + cnt);
+#ifdef DTHIP_RP_EXPERIMENT
+  } else if (RK == 2) {
+    // TIMING EXPERIMENT ONLY (unstable, so the sort is wrong): arrival ranks from one DS atomic per key -- what an
+    // unordered partition would pay for its ranks
+    constexpr uint32_t SLICE = 64u * ITEMS * (uint32_t)sizeof(KeyT);
+    uint32_t* c32 = reinterpret_cast<uint32_t*>(exch + (size_t)wave * SLICE);
+    for (int b = lane; b < bins; b += 64) c32[b] = 0u;
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const bool valid = (wbase + 64u * i) < nvalid;
+      const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
+      pos[i] = valid ? atomicAdd(&c32[d], 1u) : 0u;
+    }
+    for (int b = lane; b < bins; b += 64) mywh[b] = (uint16_t)c32[b];
+#endif
+  } else {
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const bool valid = (wbase + 64u * i) < nvalid;
+      const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
+      unsigned long long m = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < RB; b++) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+      }
+      const uint32_t below = mbcnt64(m);
+      const uint32_t cnt = (uint32_t)__popcll(m);
+      uint32_t prev = 0;
+      __builtin_amdgcn_wave_barrier();
+      if (valid) prev = __hip_atomic_load(&mywh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      pos[i] = prev + below;
+      if (valid && below == 0) __hip_atomic_store(&mywh[d], (uint16_t)(prev + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
   }
   __syncthreads();
 
@@ -392,6 +449,9 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
   if (tid < bins) {
     bin_excl[tid] = excl;
     bin_delta[tid] = a.gpre[(size_t)(tile / a.tpg) * bins + tid] + a.P[(size_t)tile * bins + tid] - excl;
+#ifdef DTHIP_RP_EXPERIMENT
+    if (a.seq) bin_delta[tid] = tile_base;      // TIMING EXPERIMENT ONLY: every tile writes its own row range
+#endif
   }
   __syncthreads();
 
@@ -497,26 +557,36 @@ int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t
   return DTHIP_OK;
 }
 
-template <typename KeyT, int RB, int P0W, int P1W = 0>
-static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
+template <typename KeyT, int RB, int P0W, int P1W, int RK>
+static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
   PassArgsT<KeyT> a;
   a.kin = static_cast<const KeyT*>(p.kin); a.kout = static_cast<KeyT*>(p.kout);
   a.n = p.n; a.shift = p.shift; a.bits = p.bits; a.P = p.P; a.gpre = p.gpre; a.tpg = p.tpg;
   a.iota = p.iota; a.pay = p.pay;
+  a.seq = 0;
+#ifdef DTHIP_RP_EXPERIMENT
+  a.seq = getenv("DTHIP_RP_SEQ") ? atoi(getenv("DTHIP_RP_SEQ")) : 0;
+#endif
   int maxw = (int)sizeof(KeyT);
   for (int c = 0; c < p.pay.n; c++) maxw = p.pay.width[c] > maxw ? p.pay.width[c] : maxw;
   const int bins = 1 << p.bits;
   const size_t lds = (size_t)(RP_BLOCK / 64) * bins * 2 + (size_t)(2 * bins + 16) * 4 + (size_t)RP_TILE * maxw;
-  auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    DTHIP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-    attr_set = true;
-  }
+  auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W, RK>;
+  DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
   const uint32_t ntiles = (p.n + RP_TILE - 1) / RP_TILE;
   DTHIP_LAUNCH(ctx, "radix_pass_kernel", kfn, ntiles, RP_BLOCK, lds, a);
   return DTHIP_OK;
+}
+
+// DTHIP_RP_RANK = 0: the ballot ranking of rounds 1-3 (kept selectable for A/B runs); default: the LDS lane masks
+template <typename KeyT, int RB, int P0W, int P1W = 0>
+static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
+  static const int rank = getenv("DTHIP_RP_RANK") ? atoi(getenv("DTHIP_RP_RANK")) : 1;
+  if (rank == 0) return launch_pass_r<KeyT, RB, P0W, P1W, 0>(ctx, p);
+#ifdef DTHIP_RP_EXPERIMENT
+  if (rank == 2) return launch_pass_r<KeyT, RB, P0W, P1W, 2>(ctx, p);
+#endif
+  return launch_pass_r<KeyT, RB, P0W, P1W, 1>(ctx, p);
 }
 
 template <typename KeyT>

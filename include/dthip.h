@@ -163,7 +163,9 @@ int  dthip_trim(dthip_ctx* ctx);
  *   "f32_sum"        0 (default): sum(float32 column) accumulates in float64 and rounds once (the documented deviation at
  *                    DTHIP_SUM); 1: it accumulates in float32, the valid rows of a group added one by one in grouped row
  *                    order -- bit for bit the reference's SumProd_ColumnImpl<float> (column/sumprod.h:48-55); one thread
- *                    per group through the RowIndex, a reproduction switch, not a fast path
+ *                    per group through the RowIndex, a reproduction switch, not a fast path.  Single-GPU calls only:
+ *                    dthip_sharded_groupby_agg* return DTHIP_ENOTIMPL for sum(float32) while it is set (partial sums of
+ *                    row shards cannot reproduce the row order)
  *   "median_pairs"   0 (default): median / nunique of FLOAT columns order the rows by (group, value); integer
  *                    columns go through the distinct (group, value) pairs of a fused count() aggregation,
  *                    which is sort-free for categorical data; 1 = floats too

@@ -519,6 +519,107 @@ def test_speculative_key_range_on_the_sort_path(ctx):
         ctx.set_option("spec_min_rows", 1 << 23)
 
 
+def _unsampled_rows(n, elem_bytes, want, nsamp=1 << 17):
+    """rows that stats.hip::minmax_sample_kernel does NOT read (nsamp evenly spaced 16-byte pieces + the last piece)"""
+    e = 16 // elem_bytes
+    gid = np.arange(nsamp, dtype=np.uint64)
+    r0 = (gid * np.uint64(n)) // np.uint64(nsamp)
+    r0[-1] = n - e if n > e else 0
+    seen = np.zeros(n, dtype=bool)
+    for j in range(e):
+        seen[np.minimum(r0 + j, n - 1).astype(np.int64)] = True
+    free = np.flatnonzero(~seen)
+    assert len(free) >= want
+    return free[np.linspace(0, len(free) - 1, want).astype(np.int64)]
+
+
+def test_speculative_range_edges_do_not_merge_into_na(ctx):
+    """a VALID key one below the guessed minimum transforms to 0 (the NA-first code), one above the guessed
+    maximum to na_repl (NA last); the range check must flag them (NA rows excluded), never group them with the NAs"""
+    rng = np.random.default_rng(79)
+    n = 3_000_000
+    k = rng.integers(1000, 300_000, n).astype(np.int64)
+    k[0], k[-1] = 1000, 299_999                      # first / last rows are always sampled: the sampled range is exact
+    k[rng.random(n) < 0.001] = -2**63
+    k[0], k[-1] = 1000, 299_999
+    v = rng.standard_normal(n)
+    margin = (299_999 - 1000) // 64 + 64             # plan_keys: width / 64 + 64 on both sides
+    rows = _unsampled_rows(n, 8, 2)
+    ctx.set_option("spec_min_rows", 1)
+    try:
+        for d in (-2, -1, 0, 1, 2):
+            for val in (1000 - margin - 1 + d, 299_999 + margin + 1 + d):
+                k2 = k.copy()
+                k2[rows[0]] = val
+                for na_last in (False, True):
+                    ri, off = o.group([k2], na_last=na_last)
+                    g = ctx.groupby([k2], na_last=na_last)
+                    assert_same(g.offsets(), off, "offsets (edge %d, na_last=%s)" % (val, na_last))
+                    assert_same(g.rowindex(), ri, "rowindex (edge %d, na_last=%s)" % (val, na_last))
+                    g.free()
+                    for path in (0, 1, 2):
+                        ctx.set_option("agg_path", path)
+                        try:
+                            r = ctx.groupby_agg([k2], [v], [("count0", None)], na_last=na_last)
+                        finally:
+                            ctx.set_option("agg_path", 0)
+                        assert_same(r.offsets(), off, "fused offsets (edge %d, na_last=%s, path %d)" % (val, na_last, path))
+                        assert_same(r.key(0), k2[ri[off[:-1]]], "fused keys (edge %d, na_last=%s, path %d)" % (val, na_last, path))
+                        r.free()
+    finally:
+        ctx.set_option("spec_min_rows", 1 << 23)
+
+
+def test_speculative_sample_of_nothing_but_na(ctx):
+    """a mostly-NA key column whose valid keys all sit in rows the sample skips: the sample has nvalid == 0,
+    which must not be taken for 'range [0, 0], exact'"""
+    n = 3_000_000
+    rows = _unsampled_rows(n, 8, 5000)
+    rng = np.random.default_rng(80)
+    k = np.full(n, -2**63, dtype=np.int64)
+    k[rows] = rng.integers(-50, 7000, len(rows))
+    v = rng.standard_normal(n)
+    ctx.set_option("spec_min_rows", 1)
+    try:
+        for na_last in (False, True):
+            ri, off = o.group([k], na_last=na_last)
+            g = ctx.groupby([k], na_last=na_last)
+            assert_same(g.offsets(), off, "offsets"); assert_same(g.rowindex(), ri, "rowindex")
+            g.free()
+            r = ctx.groupby_rows([k], [k, v], want_rowindex=True, na_last=na_last)
+            assert_same(r.rowindex(), ri, "rowindex (rows)"); assert_same(r.col(1), v[ri], "v")
+            r.free()
+        _vs_oracle(ctx, [k], [v], aggs=("sum", "count"), check_ri=False)
+        k32 = k.astype(np.int32); k32[k == -2**63] = -2**31
+        _vs_oracle(ctx, [k32, k], [v], aggs=("sum",), check_ri=True)
+    finally:
+        ctx.set_option("spec_min_rows", 1 << 23)
+
+
+def test_rows_ride_path_replanned_into_two_stages(ctx):
+    """dthip_groupby_rows' ride path with a guessed range that an unsampled outlier breaks so badly that
+    the exact plan needs TWO stages (21 + 21 guessed bits -> 51 + 21 = 72 exact bits): must leave the ride path"""
+    rng = np.random.default_rng(81)
+    n = 3_000_000
+    a = rng.integers(0, 2**20, n).astype(np.int64)
+    b = rng.integers(0, 2**20, n).astype(np.int64)
+    x = rng.standard_normal(n)
+    rows = _unsampled_rows(n, 8, 3)
+    a[rows[1]] = 2**50
+    ctx.set_option("spec_min_rows", 1)
+    try:
+        ri, off = o.group([a, b])
+        for want_ri in (True, False):
+            r = ctx.groupby_rows([a, b], [a, b, x], want_rowindex=want_ri)
+            assert_same(r.offsets(), off, "offsets")
+            if want_ri:
+                assert_same(r.rowindex(), ri, "rowindex")
+            assert_same(r.col(0), a[ri], "a"); assert_same(r.col(1), b[ri], "b"); assert_same(r.col(2), x[ri], "x")
+            r.free()
+    finally:
+        ctx.set_option("spec_min_rows", 1 << 23)
+
+
 # ---- full-size properties (no oracle: size-independent invariants) ----------------------------
 
 def test_full_size_properties_1e8(ctx):
