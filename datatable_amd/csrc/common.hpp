@@ -82,6 +82,12 @@ struct dthip_ctx {
   int cluster_mode = 0;      // clustered-key kernel variants: 0 decide from a sample, 1 never, 2 always
   int agg_offsets = 1;       // dthip_groupby_agg results carry group offsets (= sizes) even when no count() asks for them
   int f32_sum_ref = 0;       // 1: sum(float32) accumulates in float32, row by row, like the reference (slow path)
+  int filter_path = 1;       // row filters: 1 count pass + write pass (default: 1.3 + 5.8 ms per 1e9 float64 rows with two 8-byte columns
+                             // taken); 0 ONE pass, tile offsets by decoupled look-back (measured 8.6-9.2 ms: the look-back chain costs
+                             // more than the second read of the predicate column; kept selectable)
+  int sort_path = 0;         // 0 / 1: LSD passes; 2: MSD levels (two scatter levels + final buckets ordered in LDS) whenever their preconditions hold
+  int64_t msd_min_rows = 1 << 26;    // below this the LSD passes are quick enough (and the final buckets would be tiny)
+  int msd_bucket_rows = 2048;        // target size of a final bucket (sorted in LDS: at most one radix tile)
   // multi-GPU (comm.hip): the communicator this context is a rank of
   struct dthip_comm* comm = nullptr;
   int comm_rank = 0;
@@ -232,10 +238,20 @@ struct RadixPass {
   uint32_t tpg;
   int iota;                      // payload column 0 is the row number (not loaded)
   PayCols pay;
+  // MSD levels: ragged tiles {first row, rows, group, -} of a level inside the buckets of the level above, or the
+  // final level's buckets as boundaries (tile t = rows [bounds[t], bounds[t+1]), sorted in LDS, written in place)
+  uint32_t ntiles;               // 0: regular tiles over n rows
+  const uint32_t* tdesc;
+  const uint32_t* bounds;
+  const char* label;             // nullable: name of this launch in the per-kernel accounting (dthip_profile_*)
+  int block;                     // 0 / 256: workgroup size of the final MSD level (256: buckets of <= 4096 rows)
 };
 uint32_t radix_tile_items(int key64, int maxpaywidth);
 int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t n, int shift, int bits,
-                           uint32_t ntiles, uint32_t tpg, uint32_t G, uint32_t* P, uint32_t* gtot);
+                           uint32_t ntiles, uint32_t tpg, uint32_t G, uint32_t* P, uint32_t* gtot,
+                           const uint32_t* tdesc = nullptr, const uint32_t* gdesc = nullptr);
+int launch_msd_scan(dthip_ctx* ctx, uint32_t* gtot, const uint32_t* gfirst, const uint32_t* pstart, int bits, uint32_t nb,
+                    uint32_t n, uint32_t* fstart, uint32_t* maxsize);
 int launch_radix_pass(dthip_ctx* ctx, const RadixPass& p);
 
 // group.hip: run heads of a sorted key sequence -> offsets, head bitmap, tile head counts

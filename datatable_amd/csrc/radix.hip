@@ -204,28 +204,38 @@ struct PassArgsT {
   const uint32_t* gpre;     // [G][bins]      global position of group g's first row of digit d
   uint32_t tpg;             // tiles per group
   int iota;
-  int seq;                  // -DDTHIP_RP_EXPERIMENT builds only (timing experiments, WRONG results): tile-local output positions
+  // MSD levels (sort_stage_msd in api.hip).  A level below the first works INSIDE the buckets of the level above, so its
+  // tiles are ragged: tdesc[t] = {first row, rows, histogram group, -} never spans two parent buckets.  The final
+  // level sorts every bucket of the last scatter level in LDS: tile t = rows [bounds[t], bounds[t+1]) and the tile's
+  // rows, ordered by the remaining digit, go back to the tile's own row range (seq): sequential writes, no histogram.
+  const uint32_t* tdesc;
+  const uint32_t* bounds;
+  int seq;
   PayCols pay;
 };
 
-// per-tile digit counts of a key array: P and group totals (same scheme as bucket_hist_kernel)
+// per-tile digit counts of a key array: P and group totals (same scheme as bucket_hist_kernel).
+// tdesc / gdesc (nullable): ragged tiles {first row, rows, group, -} and groups {first tile, tiles} of an MSD level
 template <typename KeyT>
 __global__ void __launch_bounds__(RP_BLOCK) radix_tile_hist_kernel(const KeyT* __restrict__ keys, uint32_t n, int shift, int bits,
                                                                  uint32_t ntiles, uint32_t tpg, uint32_t* __restrict__ P,
-                                                                 uint32_t* __restrict__ gtot) {
+                                                                 uint32_t* __restrict__ gtot, const uint32_t* __restrict__ tdesc,
+                                                                 const uint32_t* __restrict__ gdesc) {
   __shared__ uint32_t cnt[HIST_STRIDE];
   const int tid = threadIdx.x;
   const uint32_t bins = 1u << bits, dmask = bins - 1u;
   uint32_t run = 0;
   if (tid < HIST_STRIDE) cnt[tid] = 0;
   __syncthreads();
-  const uint32_t t0 = blockIdx.x * tpg, t1 = (t0 + tpg < ntiles) ? t0 + tpg : ntiles;
-  typedef uint32_t hu32x4 __attribute__((ext_vector_type(4)));
+  uint32_t t0 = blockIdx.x * tpg, t1 = (t0 + tpg < ntiles) ? t0 + tpg : ntiles;
+  if (gdesc) { t0 = gdesc[2 * blockIdx.x]; t1 = t0 + gdesc[2 * blockIdx.x + 1]; }
+  typedef uint32_t hu32x4 __attribute__((ext_vector_type(4), aligned(4)));      // ragged tiles start at any row
   constexpr int KPV = 16 / (int)sizeof(KeyT);          // keys per 16-byte load
   constexpr int NV = RP_ITEMS / KPV;
   for (uint32_t t = t0; t < t1; t++) {
-    const uint32_t tile_base = t * (uint32_t)RP_TILE;
-    const uint32_t nvalid = (n - tile_base < (uint32_t)RP_TILE) ? (n - tile_base) : (uint32_t)RP_TILE;
+    uint32_t tile_base = t * (uint32_t)RP_TILE;
+    uint32_t nvalid = (n - tile_base < (uint32_t)RP_TILE) ? (n - tile_base) : (uint32_t)RP_TILE;
+    if (tdesc) { tile_base = tdesc[4 * t]; nvalid = tdesc[4 * t + 1]; }
     if (nvalid == (uint32_t)RP_TILE) {
       const hu32x4* src = reinterpret_cast<const hu32x4*>(keys + tile_base);
       hu32x4 w[NV];
@@ -249,8 +259,56 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_tile_hist_kernel(const KeyT* _
   if ((uint32_t)tid < bins) gtot[(size_t)blockIdx.x * bins + tid] = run;
 }
 
+// MSD level below the first: the groups of parent bucket b are [gfirst[b], gfirst[b+1]).  One workgroup per parent
+// bucket, thread = digit: gtot[g][d] (rows of digit d in group g) -> the global position of group g's first row of digit
+// d; fstart[b * bins + d] = first row of the child bucket (b, d) (and fstart[nb * bins] = n); *maxsize = largest child.
+__global__ void __launch_bounds__(HIST_STRIDE) msd_scan_kernel(uint32_t* __restrict__ gtot, const uint32_t* __restrict__ gfirst,
+                                                               const uint32_t* __restrict__ pstart, int bits, uint32_t nb, uint32_t n,
+                                                               uint32_t* __restrict__ fstart, uint32_t* __restrict__ maxsize) {
+  __shared__ uint32_t scratch[HIST_STRIDE / 64];
+  const uint32_t bins = 1u << bits, b = blockIdx.x, d = threadIdx.x;
+  const uint32_t g0 = gfirst[b], g1 = gfirst[b + 1];
+  uint32_t run = 0;
+  if (d < bins) {
+    for (uint32_t g = g0; g < g1; g++) {
+      const uint32_t c = gtot[(size_t)g * bins + d];
+      gtot[(size_t)g * bins + d] = run;
+      run += c;
+    }
+  }
+  const uint32_t excl = block_excl_scan_u32<HIST_STRIDE>(run, scratch, nullptr);
+  if (d < bins) {
+    const uint32_t fs = pstart[b] + excl;
+    fstart[(size_t)b * bins + d] = fs;
+    for (uint32_t g = g0; g < g1; g++) gtot[(size_t)g * bins + d] += fs;
+    uint32_t m = run;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)m, o, 64); m = x > m ? x : m; }
+    if ((d & 63u) == 0 && m) atomicMax(maxsize, m);
+  }
+  if (b + 1 == nb && d == 0) fstart[(size_t)nb * bins] = n;
+}
+
+int launch_msd_scan(dthip_ctx* ctx, uint32_t* gtot, const uint32_t* gfirst, const uint32_t* pstart, int bits, uint32_t nb,
+                    uint32_t n, uint32_t* fstart, uint32_t* maxsize) {
+  DTHIP_LAUNCH(ctx, "msd_scan_kernel", msd_scan_kernel, nb, HIST_STRIDE, 0, gtot, gfirst, pstart, bits, nb, n, fstart, maxsize);
+  return DTHIP_OK;
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-B access
+
+// build-time experiments (A/B through DTHIP_LIB): streaming hints on the pass' loads / stores
+#ifdef DTHIP_RP_NT
+#define RP_LD(p) __builtin_nontemporal_load(p)
+#else
+#define RP_LD(p) (*(p))
+#endif
+#ifdef DTHIP_RP_NTS
+#define RP_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define RP_ST(p, v) (*(p) = (v))
+#endif
 
 // store 4 values of tile-sorted slots s0..s0+3 to their global positions: one 16-B
 // (or two, for 8-byte elements) store when the four land on consecutive addresses
@@ -261,7 +319,7 @@ __device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t
     if (sizeof(T) == 4) {
       u32x4 w;
       w.x = (uint32_t)v[0]; w.y = (uint32_t)v[1]; w.z = (uint32_t)v[2]; w.w = (uint32_t)v[3];
-      *reinterpret_cast<u32x4_u*>(out + gp[0]) = w;
+      RP_ST(reinterpret_cast<u32x4_u*>(out + gp[0]), w);
     } else {
       u32x4 w0, w1;
       w0.x = (uint32_t)v[0]; w0.y = (uint32_t)((unsigned long long)v[0] >> 32);
@@ -269,11 +327,11 @@ __device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t
       w1.x = (uint32_t)v[2]; w1.y = (uint32_t)((unsigned long long)v[2] >> 32);
       w1.z = (uint32_t)v[3]; w1.w = (uint32_t)((unsigned long long)v[3] >> 32);
       u32x4_u* o = reinterpret_cast<u32x4_u*>(out + gp[0]);
-      o[0] = w0; o[1] = w1;
+      RP_ST(&o[0], w0); RP_ST(&o[1], w1);
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; j++) if ((uint32_t)j < nv) out[gp[j]] = v[j];
+    for (int j = 0; j < 4; j++) if ((uint32_t)j < nv) RP_ST(&out[gp[j]], v[j]);
   }
 }
 
@@ -287,9 +345,12 @@ __device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t
 //           word back -- the wave's DS instructions execute in order, so the word then holds exactly the lanes of this
 //           item with this digit -- and the lowest of them clears it for the next item.  popcount below the lane = the
 //           stable rank inside the item.  Three DS instructions and ~10 VALU per key, whatever the digit width.
-template <typename KeyT, int RB, int P0W, int P1W = 0, int RK = 0>
-__global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) radix_pass_kernel(PassArgsT<KeyT> a) {
-  constexpr int BLOCK = RP_BLOCK, ITEMS = RP_ITEMS;
+// BLK  = threads per workgroup: RP_BLOCK, or 256 for the final MSD level over small buckets (a bucket of ~2000 rows gives
+//        a 512-thread workgroup four items per wave: too few bytes in flight per CU to cover the HBM latency of its
+//        load -> rank -> store chain; four 256-thread workgroups per CU hold twice as many)
+template <typename KeyT, int RB, int P0W, int P1W = 0, int RK = 0, int BLK = RP_BLOCK>
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) radix_pass_kernel(PassArgsT<KeyT> a) {
+  constexpr int BLOCK = BLK, ITEMS = RP_ITEMS;
   constexpr int WAVES = BLOCK / 64, TILE = BLOCK * ITEMS;
   constexpr int GROUPS = ITEMS / 4;     // each thread owns GROUPS groups of 4 consecutive tile-sorted slots
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -305,17 +366,30 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-  for (int i = tid; i < WAVES * bins / 2; i += BLOCK) reinterpret_cast<uint32_t*>(wh)[i] = 0;
-  __syncthreads();
   // tiles are dealt to XCDs (block b runs on XCD b % 8: speed only) in contiguous ranges, so the
   // neighbouring runs of a digit are completed in one XCD's L2
   const uint32_t nt = gridDim.x, bi = blockIdx.x;
   const uint32_t xq = nt / 8, xr = nt % 8, xc = bi % 8;
   const uint32_t tile = xc * xq + (xc < xr ? xc : xr) + bi / 8;
-  const uint32_t tile_base = tile * (uint32_t)TILE;
-  const uint32_t nvalid = (a.n - tile_base < (uint32_t)TILE) ? (a.n - tile_base) : (uint32_t)TILE;
+  uint32_t tile_base = tile * (uint32_t)TILE;
+  uint32_t nvalid = (a.n - tile_base < (uint32_t)TILE) ? (a.n - tile_base) : (uint32_t)TILE;
+  uint32_t grp = tile / a.tpg;
+  if (a.bounds) {
+    tile_base = a.bounds[tile];
+    nvalid = a.bounds[tile + 1] - tile_base;
+    if (nvalid > (uint32_t)TILE) nvalid = (uint32_t)TILE;     // the host never launches this level over a bigger bucket
+    if (nvalid == 0) return;                                   // (uniform: before the first barrier)
+  } else if (a.tdesc) {
+    tile_base = a.tdesc[4 * tile]; nvalid = a.tdesc[4 * tile + 1]; grp = a.tdesc[4 * tile + 2];
+  }
+  for (int i = tid; i < WAVES * bins / 2; i += BLOCK) reinterpret_cast<uint32_t*>(wh)[i] = 0;
+  __syncthreads();
   const bool full = nvalid == (uint32_t)TILE;
-  const uint32_t wbase = (uint32_t)wave * 64u * ITEMS + (uint32_t)lane;   // wave-striped: item i at wbase + 64*i
+  // wave w owns the `chunk` consecutive rows from w * chunk on (wave-striped: item i at wbase + 64 * i); a short tile
+  // (the last one, a ragged one, a final bucket) is shared out evenly, so that all waves rank and move rows
+  const uint32_t chunk = full ? 64u * ITEMS : ((((nvalid + WAVES - 1) / WAVES) + 63u) & ~63u);
+  const uint32_t wbase = (uint32_t)wave * chunk + (uint32_t)lane;
+#define RP_VALID(i) (64u * (uint32_t)(i) < chunk && wbase + 64u * (uint32_t)(i) < nvalid)
 
   // ---- load keys (and payload column 0) -----------------------------------
   // Full tiles: 16-byte coalesced loads of the wave's 1024 consecutive keys, transposed
@@ -328,7 +402,7 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
       const uint32_t loc = wbase + 64u * i;
-      pay0[i] = (loc < nvalid) ? pin[tile_base + loc] : P0T(0);
+      pay0[i] = RP_VALID(i) ? RP_LD(&pin[tile_base + loc]) : P0T(0);
     }
   }
   typedef typename std::conditional<P1W == 8, unsigned long long, uint32_t>::type P1T;
@@ -338,16 +412,16 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
       const uint32_t loc = wbase + 64u * i;
-      pay1[i] = (loc < nvalid) ? pin[tile_base + loc] : P1T(0);
+      pay1[i] = RP_VALID(i) ? RP_LD(&pin[tile_base + loc]) : P1T(0);
     }
   }
   if (full) {
     constexpr int NV = ITEMS * (int)sizeof(KeyT) / 16;
-    const u32x4* gsrc = reinterpret_cast<const u32x4*>(a.kin + tile_base + (uint32_t)wave * 64u * ITEMS);
+    const u32x4_u* gsrc = reinterpret_cast<const u32x4_u*>(a.kin + tile_base + (uint32_t)wave * 64u * ITEMS);   // ragged tiles start at any row
     u32x4* wl = reinterpret_cast<u32x4*>(exch) + (size_t)wave * 64 * NV;
     u32x4 tmp[NV];
 #pragma unroll
-    for (int j = 0; j < NV; j++) tmp[j] = gsrc[j * 64 + lane];
+    for (int j = 0; j < NV; j++) tmp[j] = RP_LD(&gsrc[j * 64 + lane]);
 #pragma unroll
     for (int j = 0; j < NV; j++) wl[j * 64 + lane] = tmp[j];
     __syncthreads();
@@ -358,7 +432,7 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
       const uint32_t loc = wbase + 64u * i;
-      key[i] = (loc < nvalid) ? a.kin[tile_base + loc] : KeyT(0);
+      key[i] = RP_VALID(i) ? RP_LD(&a.kin[tile_base + loc]) : KeyT(0);
     }
   }
 
@@ -379,7 +453,7 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
     const unsigned long long mybit = 1ULL << lane;
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-      const bool valid = (wbase + 64u * i) < nvalid;
+      const bool valid = RP_VALID(i);
       const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
       pos[i] = 0;
       __builtin_amdgcn_wave_barrier();
@@ -404,7 +478,7 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
     for (int b = lane; b < bins; b += 64) c32[b] = 0u;
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-      const bool valid = (wbase + 64u * i) < nvalid;
+      const bool valid = RP_VALID(i);
       const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
       pos[i] = valid ? atomicAdd(&c32[d], 1u) : 0u;
     }
@@ -413,7 +487,7 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
   } else {
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-      const bool valid = (wbase + 64u * i) < nvalid;
+      const bool valid = RP_VALID(i);
       const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
       unsigned long long m = __ballot(valid);
 #pragma unroll
@@ -434,24 +508,34 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
   __syncthreads();
 
   // ---- per-digit: wave offsets, tile count, global position of the run ----------
-  uint32_t tcount = 0;
-  if (tid < bins) {
-    uint32_t s = 0;
+  // (KB consecutive digits per thread: 1 unless the workgroup has fewer threads than bins)
+  constexpr int KB = (1 << RB) > BLOCK ? (1 << RB) / BLOCK : 1;
+  uint32_t tc[KB], tsum = 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; w++) {
-      const uint32_t c = wh[w * bins + tid];
-      wh[w * bins + tid] = (uint16_t)s;
-      s += c;
+  for (int k = 0; k < KB; k++) {
+    const int b = tid * KB + k;
+    tc[k] = 0;
+    if (b < bins) {
+      uint32_t s = 0;
+#pragma unroll
+      for (int w = 0; w < WAVES; w++) {
+        const uint32_t c = wh[w * bins + b];
+        wh[w * bins + b] = (uint16_t)s;
+        s += c;
+      }
+      tc[k] = s;
     }
-    tcount = s;
+    tsum += tc[k];
   }
-  const uint32_t excl = block_excl_scan_u32<BLOCK>(tcount, misc, nullptr);
-  if (tid < bins) {
-    bin_excl[tid] = excl;
-    bin_delta[tid] = a.gpre[(size_t)(tile / a.tpg) * bins + tid] + a.P[(size_t)tile * bins + tid] - excl;
-#ifdef DTHIP_RP_EXPERIMENT
-    if (a.seq) bin_delta[tid] = tile_base;      // TIMING EXPERIMENT ONLY: every tile writes its own row range
-#endif
+  uint32_t excl = block_excl_scan_u32<BLOCK>(tsum, misc, nullptr);
+#pragma unroll
+  for (int k = 0; k < KB; k++) {
+    const int b = tid * KB + k;
+    if (b < bins) {
+      bin_excl[b] = excl;
+      bin_delta[b] = a.seq ? tile_base : a.gpre[(size_t)grp * bins + b] + a.P[(size_t)tile * bins + b] - excl;
+      excl += tc[k];
+    }
   }
   __syncthreads();
 
@@ -459,7 +543,7 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
   KeyT* ek = reinterpret_cast<KeyT*>(exch);
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
-    if ((wbase + 64u * i) < nvalid) {
+    if (RP_VALID(i)) {
       const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
       pos[i] += bin_excl[d] + wh[wave * bins + d];
       ek[pos[i]] = key[i];
@@ -494,12 +578,12 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
 #pragma unroll
       for (int i = 0; i < ITEMS; i++) {
         const uint32_t loc = wbase + 64u * i;
-        if (loc < nvalid) {
+        if (RP_VALID(i)) {
           uint32_t v;
           if (c == 0 && a.iota) v = tile_base + loc;
           else if (c == 0 && P0W == 4) v = (uint32_t)pay0[i];
           else if (c == 1 && P1W == 4) v = (uint32_t)pay1[i];
-          else v = pin[tile_base + loc];
+          else v = RP_LD(&pin[tile_base + loc]);
           e4[pos[i]] = v;
         }
       }
@@ -520,11 +604,11 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
 #pragma unroll
       for (int i = 0; i < ITEMS; i++) {
         const uint32_t loc = wbase + 64u * i;
-        if (loc < nvalid) {
+        if (RP_VALID(i)) {
           unsigned long long v;
           if (c == 0 && P0W == 8) v = (unsigned long long)pay0[i];
           else if (c == 1 && P1W == 8) v = (unsigned long long)pay1[i];
-          else v = pin[tile_base + loc];
+          else v = RP_LD(&pin[tile_base + loc]);
           e8[pos[i]] = v;
         }
       }
@@ -543,38 +627,41 @@ __global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(D
   }
 }
 
+#undef RP_VALID
+
 uint32_t radix_tile_items(int, int) { return (uint32_t)RP_TILE; }
 
 int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t n, int shift, int bits,
-                           uint32_t ntiles, uint32_t tpg, uint32_t G, uint32_t* P, uint32_t* gtot) {
+                           uint32_t ntiles, uint32_t tpg, uint32_t G, uint32_t* P, uint32_t* gtot, const uint32_t* tdesc,
+                           const uint32_t* gdesc) {
   if (key64) {
     DTHIP_LAUNCH(ctx, "radix_tile_hist_kernel", radix_tile_hist_kernel<unsigned long long>, G, RP_BLOCK, 0,
-                 static_cast<const unsigned long long*>(keys), n, shift, bits, ntiles, tpg, P, gtot);
+                 static_cast<const unsigned long long*>(keys), n, shift, bits, ntiles, tpg, P, gtot, tdesc, gdesc);
   } else {
     DTHIP_LAUNCH(ctx, "radix_tile_hist_kernel", radix_tile_hist_kernel<uint32_t>, G, RP_BLOCK, 0,
-                 static_cast<const uint32_t*>(keys), n, shift, bits, ntiles, tpg, P, gtot);
+                 static_cast<const uint32_t*>(keys), n, shift, bits, ntiles, tpg, P, gtot, tdesc, gdesc);
   }
   return DTHIP_OK;
 }
 
-template <typename KeyT, int RB, int P0W, int P1W, int RK>
+template <typename KeyT, int RB, int P0W, int P1W, int RK, int BLK = RP_BLOCK>
 static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
   PassArgsT<KeyT> a;
   a.kin = static_cast<const KeyT*>(p.kin); a.kout = static_cast<KeyT*>(p.kout);
   a.n = p.n; a.shift = p.shift; a.bits = p.bits; a.P = p.P; a.gpre = p.gpre; a.tpg = p.tpg;
   a.iota = p.iota; a.pay = p.pay;
-  a.seq = 0;
+  a.tdesc = p.tdesc; a.bounds = p.bounds; a.seq = p.bounds ? 1 : 0;
 #ifdef DTHIP_RP_EXPERIMENT
-  a.seq = getenv("DTHIP_RP_SEQ") ? atoi(getenv("DTHIP_RP_SEQ")) : 0;
+  if (getenv("DTHIP_RP_SEQ") && atoi(getenv("DTHIP_RP_SEQ"))) a.seq = 1;      // timing experiment: wrong results
 #endif
   int maxw = (int)sizeof(KeyT);
   for (int c = 0; c < p.pay.n; c++) maxw = p.pay.width[c] > maxw ? p.pay.width[c] : maxw;
   const int bins = 1 << p.bits;
-  const size_t lds = (size_t)(RP_BLOCK / 64) * bins * 2 + (size_t)(2 * bins + 16) * 4 + (size_t)RP_TILE * maxw;
-  auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W, RK>;
+  const size_t lds = (size_t)(BLK / 64) * bins * 2 + (size_t)(2 * bins + 16) * 4 + (size_t)(BLK * RP_ITEMS) * maxw;
+  auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W, RK, BLK>;
   DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
-  const uint32_t ntiles = (p.n + RP_TILE - 1) / RP_TILE;
-  DTHIP_LAUNCH(ctx, "radix_pass_kernel", kfn, ntiles, RP_BLOCK, lds, a);
+  const uint32_t ntiles = p.ntiles ? p.ntiles : (p.n + RP_TILE - 1) / RP_TILE;
+  DTHIP_LAUNCH(ctx, (p.label ? p.label : "radix_pass_kernel"), kfn, ntiles, BLK, lds, a);
   return DTHIP_OK;
 }
 
@@ -582,6 +669,7 @@ static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
 template <typename KeyT, int RB, int P0W, int P1W = 0>
 static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
   static const int rank = getenv("DTHIP_RP_RANK") ? atoi(getenv("DTHIP_RP_RANK")) : 1;
+  if (p.block == 256 && sizeof(KeyT) == 4) return launch_pass_r<uint32_t, RB, P0W, P1W, 1, 256>(ctx, p);   // final MSD level, small buckets
   if (rank == 0) return launch_pass_r<KeyT, RB, P0W, P1W, 0>(ctx, p);
 #ifdef DTHIP_RP_EXPERIMENT
   if (rank == 2) return launch_pass_r<KeyT, RB, P0W, P1W, 2>(ctx, p);
@@ -596,6 +684,15 @@ static int launch_pass_k(dthip_ctx* ctx, const RadixPass& p) {
   int p1w = (p0w == 8 && p.pay.n > 1) ? p.pay.width[1] : 0;
   if (prefetch < 2) p1w = 0;
   if (prefetch < 1) p0w = 0;
+  if (p.bits > 9) {
+    // final MSD level over 10 bits: 1024 bins rule the per-wave mask tables out (8 KB each), the ballot ranking needs none
+    if (sizeof(KeyT) != 4 || !p.bounds) { set_error("radix pass: a 10-bit digit is for the final MSD level only"); return DTHIP_EINVAL; }
+    if (p0w == 8 && p1w == 8) return launch_pass_r<uint32_t, 10, 8, 8, 0>(ctx, p);
+    if (p0w == 8 && p1w == 4) return launch_pass_r<uint32_t, 10, 8, 4, 0>(ctx, p);
+    if (p0w == 8) return launch_pass_r<uint32_t, 10, 8, 0, 0>(ctx, p);
+    if (p0w == 4) return launch_pass_r<uint32_t, 10, 4, 0, 0>(ctx, p);
+    return launch_pass_r<uint32_t, 10, 0, 0, 0>(ctx, p);
+  }
   if (p.bits > 8) {
     if (p0w == 8 && p1w == 8) return launch_pass_t<KeyT, 9, 8, 8>(ctx, p);
     if (p0w == 8 && p1w == 4) return launch_pass_t<KeyT, 9, 8, 4>(ctx, p);
@@ -612,7 +709,7 @@ static int launch_pass_k(dthip_ctx* ctx, const RadixPass& p) {
 
 int launch_radix_pass(dthip_ctx* ctx, const RadixPass& p) {
   if (p.n == 0) return DTHIP_OK;
-  if (p.bits < 1 || p.bits > 9) { set_error("radix pass: bad digit width %d", p.bits); return DTHIP_EINVAL; }
+  if (p.bits < 1 || p.bits > 10) { set_error("radix pass: bad digit width %d", p.bits); return DTHIP_EINVAL; }
   if (p.key64) return launch_pass_k<unsigned long long>(ctx, p);
   return launch_pass_k<uint32_t>(ctx, p);
 }

@@ -146,9 +146,12 @@ __global__ void __launch_bounds__(CP_BLOCK) compact_write_kernel(PredArgs p, uin
   }
 }
 
+static int launch_compact1(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out_ri, const TakeCols& tc, int64_t* nout_host);
+
 int launch_compact(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out, int64_t* nout_host) {
   *nout_host = 0;
   if (n == 0) return DTHIP_OK;
+  if (ctx->filter_path != 1) { TakeCols none; none.n = 0; return launch_compact1(ctx, p, n, out, none, nout_host); }
   const uint32_t nt = (uint32_t)((n + CP_TILE - 1) / CP_TILE);
   Scratch sc(ctx);
   uint32_t* tile_counts = nullptr;
@@ -200,6 +203,7 @@ __global__ void __launch_bounds__(CP_BLOCK) compact_take_kernel(PredArgs p, uint
 int launch_compact_take(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out_ri, const TakeCols& tc, int64_t* nout_host) {
   *nout_host = 0;
   if (n == 0) return DTHIP_OK;
+  if (ctx->filter_path != 1) return launch_compact1(ctx, p, n, out_ri, tc, nout_host);
   const uint32_t nt = (uint32_t)((n + CP_TILE - 1) / CP_TILE);
   Scratch sc(ctx);
   uint32_t* tile_counts = nullptr;
@@ -209,6 +213,115 @@ int launch_compact_take(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* o
   DTHIP_LAUNCH(ctx, "compact_take_kernel", compact_take_kernel, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts, out_ri, tc);
   uint32_t total = 0;
   DTHIP_TRY(read_back(ctx, &total, tile_counts + nt, sizeof(total)));
+  *nout_host = total;
+  return DTHIP_OK;
+}
+
+// ---- single pass (round 4): the tile offsets come from a decoupled look-back instead of a count pass -----------------
+// MEASURED SLOWER than the two-pass form on MI355X (C5's filter: 8.6-9.2 ms against 1.3 + 5.8) and therefore not the default
+// (option filter_path = 0 / DTHIP_FILTER_PATH=0 selects it).
+// The two-pass form reads the predicate column twice (count, then write: 1.3 + 5.7 ms per 1e9 float64 rows).  Here every
+// workgroup takes a TICKET (its tile number: tiles are numbered in the order workgroups start, so every lower tile
+// belongs to a workgroup that is already running and will publish without waiting for anyone behind it -- no assumption
+// about dispatch order or co-residency), counts its tile's passing rows, publishes {flag, count} as ONE 64-bit word and
+// looks back over the words of the tiles before it: an "aggregate" word adds its count and the walk goes on, an
+// "inclusive" word ends it.  Wave 0 inspects 64 predecessors per step.  state[] must be zero when the kernel starts.
+constexpr int C1_BLOCK = 256, C1_ITEMS = 16, C1_TILE = C1_BLOCK * C1_ITEMS;
+constexpr unsigned long long C1_AGG = 1ULL << 62, C1_INC = 2ULL << 62, C1_VAL = (1ULL << 62) - 1ULL;
+
+__device__ __forceinline__ unsigned long long c1_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void c1_store(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(C1_BLOCK) compact_take1_kernel(PredArgs p, uint32_t n, unsigned long long* __restrict__ state,
+                                                                 uint32_t* __restrict__ ticket, int32_t* __restrict__ out_ri,
+                                                                 TakeCols tc, uint32_t* __restrict__ total) {
+  __shared__ uint32_t wc[C1_BLOCK / 64];
+  __shared__ uint32_t s_tile, s_excl;
+  const int lane = lane_id(), wave = wave_id();
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint32_t wave_base = tile * C1_TILE + wave * (64 * C1_ITEMS);
+  // predicate bits of the lane's 16 rows (wave-striped: row = wave_base + 64 k + lane)
+  uint32_t bits = 0, cnt = 0;
+#pragma unroll
+  for (int k = 0; k < C1_ITEMS; k++) {
+    const uint32_t idx = wave_base + 64u * k + lane;
+    const bool f = idx < n && pred_at(p, idx);
+    bits |= (uint32_t)f << k;
+    cnt += (uint32_t)__popcll(__ballot(f));
+  }
+  if (lane == 0) wc[wave] = cnt;
+  __syncthreads();
+  uint32_t agg = 0;
+#pragma unroll
+  for (int w = 0; w < C1_BLOCK / 64; w++) agg += wc[w];
+  if (wave == 0) {
+    uint32_t excl = 0;
+    if (tile == 0) {
+      if (lane == 0) c1_store(&state[0], C1_INC | agg);
+    } else {
+      if (lane == 0) c1_store(&state[tile], C1_AGG | agg);
+      int32_t look = (int32_t)tile - 1;                  // the nearest predecessor not yet accounted for
+      while (true) {
+        const int32_t idx = look - lane;
+        unsigned long long w = C1_INC;                   // tiles before tile 0: an empty inclusive prefix
+        if (idx >= 0) w = c1_load(&state[idx]);
+        const unsigned long long inc = __ballot((w >> 62) == 2ULL);
+        const unsigned long long inv = __ballot((w >> 62) == 0ULL);
+        // lanes up to (and including) the first inclusive word must all be published
+        const int first_inc = inc ? __ffsll((long long)inc) - 1 : 64;
+        const unsigned long long need = first_inc >= 63 ? ~0ULL : ((2ULL << first_inc) - 1ULL);
+        if (inv & need) { __builtin_amdgcn_s_sleep(1); continue; }       // somebody in the window is still counting
+        uint32_t v = (lane <= first_inc) ? (uint32_t)(w & C1_VAL) : 0u;
+        excl += wave_reduce_sum_u32(v);
+        if (first_inc < 64) break;
+        look -= 64;
+      }
+      if (lane == 0) c1_store(&state[tile], C1_INC | (unsigned long long)(excl + agg));
+    }
+    if (lane == 0) {
+      s_excl = excl;
+      if ((uint64_t)(tile + 1) * C1_TILE >= n) *total = excl + agg;      // the last tile knows the number of passing rows
+    }
+  }
+  __syncthreads();
+  uint32_t running = s_excl;
+  for (int w = 0; w < wave; w++) running += wc[w];
+#pragma unroll
+  for (int k = 0; k < C1_ITEMS; k++) {
+    const bool f = (bits >> k) & 1u;
+    const unsigned long long bal = __ballot(f);
+    if (f) {
+      const uint32_t src = wave_base + 64u * k + lane, dst = running + mbcnt64(bal);
+      if (out_ri) out_ri[dst] = (int32_t)src;
+      for (int c = 0; c < tc.n; c++) {
+        switch (tc.width[c]) {
+          case 8: static_cast<unsigned long long*>(tc.out[c])[dst] = static_cast<const unsigned long long*>(tc.in[c])[src]; break;
+          case 4: static_cast<uint32_t*>(tc.out[c])[dst] = static_cast<const uint32_t*>(tc.in[c])[src]; break;
+          case 2: static_cast<uint16_t*>(tc.out[c])[dst] = static_cast<const uint16_t*>(tc.in[c])[src]; break;
+          default: static_cast<uint8_t*>(tc.out[c])[dst] = static_cast<const uint8_t*>(tc.in[c])[src]; break;
+        }
+      }
+    }
+    running += (uint32_t)__popcll(bal);
+  }
+}
+
+static int launch_compact1(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out_ri, const TakeCols& tc, int64_t* nout_host) {
+  const uint32_t nt = (uint32_t)((n + C1_TILE - 1) / C1_TILE);
+  Scratch sc(ctx);
+  unsigned long long* state = nullptr;
+  DTHIP_TRY(sc.get<unsigned long long>((size_t)nt + 2, &state));
+  uint32_t* ticket = reinterpret_cast<uint32_t*>(state + nt);       // {ticket, total} in the words after the tile states
+  DTHIP_CHECK_HIP(hipMemsetAsync(state, 0, sizeof(unsigned long long) * ((size_t)nt + 2), ctx->stream));
+  DTHIP_LAUNCH(ctx, "compact_take1_kernel", compact_take1_kernel, nt, C1_BLOCK, 0, p, (uint32_t)n, state, ticket, out_ri, tc, ticket + 1);
+  uint32_t total = 0;
+  DTHIP_TRY(read_back(ctx, &total, ticket + 1, sizeof(total)));
   *nout_host = total;
   return DTHIP_OK;
 }

@@ -42,6 +42,7 @@ row filter, of `DT[:, cols, by()]` and of a sort is a shim Frame (still a `datat
 so the second step of the two-step form of config 5 stays on the GPU; aggregations return the base class like the
 reference does.
 """
+import os
 import re
 import warnings
 
@@ -50,7 +51,107 @@ import numpy as np
 import datatable as dt
 
 from datatable_amd import _lib as L
-from datatable_amd.engine import ST2NP, default_context
+from datatable_amd.engine import ST2NP, _DevBuf, default_context
+
+
+class _Options:
+    """shim.options
+    residency  "auto" (default): the columns an accelerated query touches are uploaded to HBM ONCE and kept per Frame
+                  (cache entry = column index -> device buffer, valid while the column's host buffer pointer
+                  `frame_column_data_r`, the row count and the stype are unchanged; every mutating Frame call drops the
+                  cache); every route then passes DTHIP_DEVICE pointers.  Results are downloaded at once and are plain
+                  reference objects, exactly as before.
+               "lazy": "auto" + results STAY in HBM: `DT[...]` returns a DeviceFrame (names / stypes / shape answered
+                  from metadata, the next accelerated `DT[...]` on it runs on the device columns, anything else
+                  downloads once and hands over to a real Frame).  The two statements of BASELINE config 5 never leave
+                  the GPU this way.
+               "off": host pointers in, host buffers out on every call (rounds 1-3; PCIe-bound).
+               Environment: DTHIP_SHIM_RESIDENCY.
+    f32_sum    True: sum(float32 column) accumulates in float32 row by row like the reference (dthip option f32_sum = 1,
+               column/sumprod.h:48-55); default False: float64 accumulation, rounded once.  Environment: DTHIP_SHIM_F32_SUM=1."""
+    residency = os.environ.get("DTHIP_SHIM_RESIDENCY", "auto")
+    f32_sum = os.environ.get("DTHIP_SHIM_F32_SUM", "0") not in ("", "0")
+
+
+options = _Options()
+
+
+def _context(ctx=None):
+    ctx = ctx or default_context()
+    want = 1 if options.f32_sum else 0
+    if getattr(ctx, "_shim_f32", None) != want:
+        ctx.set_option("f32_sum", want)
+        ctx._shim_f32 = want
+    return ctx
+
+
+class _DevColumn:
+    """one column in HBM: pointer, bytes, what it mirrors (host pointer / rows / stype) and the owner of the memory
+    (a dthip_malloc buffer, or the dthip_result a pointer was borrowed from)"""
+    __slots__ = ("ptr", "nbytes", "host_ptr", "nrows", "stype", "keep")
+
+    def __init__(self, ptr, nbytes, host_ptr, nrows, stype, keep):
+        self.ptr, self.nbytes, self.host_ptr, self.nrows, self.stype, self.keep = int(ptr or 0), nbytes, host_ptr, nrows, stype, keep
+
+
+def _dev_alloc(ctx, nbytes):
+    import ctypes as C
+    p = C.c_void_p()
+    L.check(ctx._lib.dthip_malloc(ctx._h, max(int(nbytes), 1), C.byref(p)))
+    return _DevBuf(ctx, p.value)
+
+
+def _upload_column(ctx, frame, c):
+    import ctypes as C
+    st = frame.stypes[c].value
+    n = frame.nrows
+    hp = dt.internal.frame_column_data_r(frame, c).value or 0
+    nbytes = n * ST2NP[st].itemsize
+    buf = _dev_alloc(ctx, nbytes)
+    if nbytes:
+        L.check(ctx._lib.dthip_memcpy_h2d(ctx._h, C.c_void_p(buf.ptr), C.c_void_p(hp), nbytes))
+    return _DevColumn(buf.ptr, nbytes, hp, n, st, buf)
+
+
+def _resident(frame, cols, ctx):
+    """device columns of `cols` of a host Frame (uploading what the cache lacks or what went stale), or None when
+    residency is off / the frame is not the shim's"""
+    if options.residency == "off" or not isinstance(frame, Frame):
+        return None
+    cache = frame.__dict__.setdefault("_dthip_dev", {})
+    if frame.__dict__.get("_dthip_ctx") not in (None, ctx):
+        cache.clear()
+    frame.__dict__["_dthip_ctx"] = ctx
+    out = []
+    for c in cols:
+        e = cache.get(c)
+        st = frame.stypes[c].value
+        if e is not None and e.host_ptr is not None:
+            hp = dt.internal.frame_column_data_r(frame, c).value or 0
+            if hp != e.host_ptr:
+                e = None
+        if e is not None and (e.nrows != frame.nrows or e.stype != st):
+            e = None
+        if e is None:
+            e = cache[c] = _upload_column(ctx, frame, c)
+        out.append(e)
+    return out
+
+
+def _columns(frame, cols, ctx, flags=None):
+    """(list of L.Col, memory space) for one library call: device pointers when the frame is a DeviceFrame or its columns
+    are resident, else the reference's borrowed host pointers (src/datatable/include/datatable.h:80-99)"""
+    flags = flags or [0] * len(cols)
+    if isinstance(frame, DeviceFrame):
+        return [L.Col(frame._cols[c].ptr, frame.stypes[c].value, fl) for c, fl in zip(cols, flags)], L.DEVICE
+    dev = _resident(frame, cols, ctx)
+    if dev is not None:
+        return [L.Col(e.ptr, frame.stypes[c].value, fl) for e, c, fl in zip(dev, cols, flags)], L.DEVICE
+    return [L.Col(dt.internal.frame_column_data_r(frame, c).value, frame.stypes[c].value, fl) for c, fl in zip(cols, flags)], L.HOST
+
+
+def _lazy():
+    return options.residency == "lazy"
 
 # min()/max() print their argument as a one-element list: FExpr<min([f.v])>
 _REDUCER = re.compile(r"^FExpr<(sum|mean|min|max|count)\(\[?(?:f\.(\w+)|f\['([^']+)'\]|f\[(\d+)\])?\]?\)>$")
@@ -183,120 +284,214 @@ def _colspec(frame, text):
     return _colindex(frame, m.group(1) or m.group(2))
 
 
-def _col(frame, c):
-    return L.Col(dt.internal.frame_column_data_r(frame, c).value, frame.stypes[c].value, 0)
+def _mangled(names):
+    """result names as the reference would make them: duplicates mangled (names.cc:232-266), "" auto-named"""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", dt.exceptions.DatatableWarning)
+        return list(dt.Frame([[]] * len(names), names=list(names)).names) if names else []
 
 
-def _finish(frame, keys, cols, names, bool_cols=()):
+class _Out:
+    """output columns of one query, in the memory space of the call: numpy buffers (DTHIP_HOST) or HBM (DTHIP_DEVICE)"""
+
+    def __init__(self, ctx, mem):
+        self.ctx, self.mem = ctx, mem
+        self.cols, self.names, self.stypes, self.nrows = [], [], [], None
+
+    def alloc(self, n, st):
+        """-> (pointer for the library call, holder)"""
+        if self.mem == L.HOST:
+            a = np.empty(n, ST2NP[st])
+            return a.ctypes.data, a
+        buf = _dev_alloc(self.ctx, n * ST2NP[st].itemsize)
+        return buf.ptr, _DevColumn(buf.ptr, n * ST2NP[st].itemsize, None, n, st, buf)
+
+    def add(self, holder, name, st, nrows=None):
+        if nrows is not None:
+            if isinstance(holder, _DevColumn):
+                holder.nrows, holder.nbytes = nrows, nrows * ST2NP[st].itemsize
+            else:
+                holder = holder[:nrows]
+        self.cols.append(holder); self.names.append(name); self.stypes.append(st)
+
+    def borrowed(self, ptr, n, st, keep, name):
+        """a column that lives inside a dthip_result (kept alive by `keep`)"""
+        self.add(_DevColumn(ptr, n * ST2NP[st].itemsize, None, n, st, keep), name, st)
+
+    def _host(self, holder, st):
+        import ctypes as C
+        if not isinstance(holder, _DevColumn):
+            return holder
+        a = np.empty(holder.nrows, ST2NP[st])
+        if a.nbytes:
+            L.check(self.ctx._lib.dthip_memcpy_d2h(self.ctx._h, C.c_void_p(a.ctypes.data), C.c_void_p(holder.ptr), a.nbytes))
+        return a
+
+    def finish(self, frame, nkeys_bool=(), wrap=False):
+        """the result object: a DeviceFrame (lazy residency, device call) or the reference's Frame built from host buffers"""
+        bool_cols = [i for i, st in enumerate(self.stypes) if st == L.BOOL]
+        if _lazy() and self.mem == L.DEVICE:
+            n = self.cols[0].nrows if self.cols else 0
+            return DeviceFrame(self.ctx, _mangled(self.names), [dt.stype(st) for st in self.stypes], n, self.cols, wrap)
+        host = [self._host(h, st) for h, st in zip(self.cols, self.stypes)]
+        res = _finish(host, self.names, bool_cols)
+        return Frame(res) if wrap else res
+
+
+class _ResultKeep:
+    """owner of a dthip_result whose buffers are borrowed by DeviceFrame columns"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def free(self):
+        if self.h is not None and self.ctx._h is not None:
+            self.ctx._lib.dthip_result_free(self.ctx._h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _finish(cols, names, bool_cols=()):
     """numpy result buffers -> the result Frame.  bool8 columns (keys, and min/max/first/last/cummin/cummax of a
     bool8 column: the reference keeps the stype, fexpr_minmax.cc:47-68) travel as int8 with NA = -128 and are
     cast back here (int8 -> bool8 keeps NA)."""
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", dt.exceptions.DatatableWarning)     # duplicate names are mangled, as in the reference
         res = dt.Frame(cols, names=names)                                   # "" -> auto-named C<k> by the reference
-    bools = set(bool_cols) | {i for i, k in enumerate(keys) if frame.stypes[k] == dt.stype.bool8}
-    for i in sorted(bools):
+    for i in sorted(set(bool_cols)):
         res[:, i] = dt.as_type(dt.f[i], dt.bool8)
     return res
 
 
+def _carr(cols):
+    return (L.Col * max(len(cols), 1))(*cols)
+
+
 def run_sred(frame, keys, aggs, ctx=None):
     """the S-red route: dthip_groupby once, then dthip_reduce / dthip_reduce2 (one row per group) or
-    dthip_cumulate (one row per input row, grouped order) per j item -- host pointers throughout"""
+    dthip_cumulate (one row per input row, grouped order) per j item -- in the memory space of the frame's columns"""
     import ctypes as C
     from datatable_amd.engine import OPS, OPS2, CUMOPS
-    ctx = ctx or default_context()
+    ctx = _context(ctx)
     lib = ctx._lib
     n = frame.nrows
-    karr = (L.Col * len(keys))(*[_col(frame, k) for k in keys])
+    used = list(keys)
+    for a in aggs:
+        c = a[1]
+        used += list(c) if isinstance(c, tuple) else ([] if c is None else [c])
+    used = list(dict.fromkeys(used))
+    lcols, mem = _columns(frame, used, ctx)
+    col = dict(zip(used, lcols))
+    out = _Out(ctx, mem)
     h = C.c_void_p()
-    L.check(lib.dthip_groupby(ctx._h, karr, len(keys), n, L.NA_FIRST, L.HOST, 1, C.byref(h)))
+    L.check(lib.dthip_groupby(ctx._h, _carr([col[k] for k in keys]), len(keys), n, L.NA_FIRST, mem, 1, C.byref(h)))
+    keep = _ResultKeep(ctx, h)
     try:
         ng = lib.dthip_result_ngroups(h)
-        ri, off = np.empty(n, np.int32), np.empty(ng + 1, np.int32)
-        L.check(lib.dthip_result_copy_rowindex(ctx._h, h, ri.ctypes.data, L.HOST))
-        L.check(lib.dthip_result_copy_offsets(ctx._h, h, off.ctypes.data, L.HOST))
-    finally:
-        lib.dthip_result_free(ctx._h, h)
-    rowwise = bool(aggs) and len(aggs[0]) == 3
-    cols, names, bool_cols = [], [], []
-    sel = ri if rowwise else ri[off[:-1]]              # the by-columns: every row / first row of each group
-    for k in keys:
-        out = np.empty(len(sel), ST2NP[frame.stypes[k].value])
-        kc = _col(frame, k)
-        L.check(lib.dthip_gather(ctx._h, C.byref(kc), sel.ctypes.data, len(sel), L.HOST, out.ctypes.data))
-        cols.append(out); names.append(frame.names[k])
-    for a in aggs:
-        op, c = a[0], a[1]
-        if rowwise:
-            st = lib.dthip_cumulate_out_stype(CUMOPS[op], L.INT64 if c is None else frame.stypes[c].value)
-            out = np.empty(n, ST2NP[st])
-            if st == L.BOOL:
-                bool_cols.append(len(cols))
-            vc = _col(frame, c) if c is not None else None
-            if n:
-                L.check(lib.dthip_cumulate(ctx._h, CUMOPS[op], C.byref(vc) if vc is not None else None,
-                                           ri.ctypes.data if c is not None else None, off.ctypes.data, ng, n,
-                                           1 if a[2] else 0, L.HOST, out.ctypes.data))
-            names.append("" if c is None else frame.names[c])
-        elif isinstance(c, tuple):
-            ca, cb = _col(frame, c[0]), _col(frame, c[1])
-            out = np.empty(ng, ST2NP[lib.dthip_reduce2_out_stype(ca.stype, cb.stype)])
-            if ng:
-                L.check(lib.dthip_reduce2(ctx._h, OPS2[op], C.byref(ca), C.byref(cb), ri.ctypes.data, off.ctypes.data, ng, n,
-                                          L.HOST, out.ctypes.data))
-            names.append("")
-        elif c is None:
-            out = np.empty(ng, np.int64)
-            if ng:
-                L.check(lib.dthip_reduce(ctx._h, L.COUNT0, None, None, off.ctypes.data, ng, n, L.HOST, out.ctypes.data))
-            names.append("count")
+        if mem == L.HOST:
+            ri, off = np.empty(n, np.int32), np.empty(ng + 1, np.int32)
+            L.check(lib.dthip_result_copy_rowindex(ctx._h, h, ri.ctypes.data, L.HOST))
+            L.check(lib.dthip_result_copy_offsets(ctx._h, h, off.ctypes.data, L.HOST))
+            ri_p, off_p = ri.ctypes.data, off.ctypes.data
         else:
-            vc = _col(frame, c)
-            st = lib.dthip_reduce_out_stype(OPS[op], vc.stype)
-            out = np.empty(ng, ST2NP[st])
-            if st == L.BOOL:
-                bool_cols.append(len(cols))
-            if ng:
-                L.check(lib.dthip_reduce(ctx._h, OPS[op], C.byref(vc), ri.ctypes.data, off.ctypes.data, ng, n, L.HOST,
-                                         out.ctypes.data))
-            names.append(frame.names[c])
-        cols.append(out)
-    return _finish(frame, keys, cols, names, bool_cols)
+            ri_p, off_p = lib.dthip_result_rowindex(h), lib.dthip_result_offsets(h)
+        rowwise = bool(aggs) and len(aggs[0]) == 3
+        for k in keys:                                     # the by-columns: every row / first row of each group
+            st = frame.stypes[k].value
+            ptr, holder = out.alloc(n if rowwise else ng, st)
+            kc = col[k]
+            if rowwise:
+                if n:
+                    L.check(lib.dthip_gather(ctx._h, C.byref(kc), C.c_void_p(ri_p), n, mem, C.c_void_p(ptr)))
+            else:
+                L.check(lib.dthip_result_group_keys(ctx._h, h, C.byref(kc), mem, C.c_void_p(ptr)))
+            out.add(holder, frame.names[k], st)
+        for a in aggs:
+            op, c = a[0], a[1]
+            if rowwise:
+                st = lib.dthip_cumulate_out_stype(CUMOPS[op], L.INT64 if c is None else frame.stypes[c].value)
+                ptr, holder = out.alloc(n, st)
+                vc = col[c] if c is not None else None
+                if n:
+                    L.check(lib.dthip_cumulate(ctx._h, CUMOPS[op], C.byref(vc) if vc is not None else None,
+                                               C.c_void_p(ri_p) if c is not None else None, C.c_void_p(off_p), ng, n,
+                                               1 if a[2] else 0, mem, C.c_void_p(ptr)))
+                out.add(holder, "" if c is None else frame.names[c], st)
+            elif isinstance(c, tuple):
+                ca, cb = col[c[0]], col[c[1]]
+                st = lib.dthip_reduce2_out_stype(ca.stype, cb.stype)
+                ptr, holder = out.alloc(ng, st)
+                if ng:
+                    L.check(lib.dthip_reduce2(ctx._h, OPS2[op], C.byref(ca), C.byref(cb), C.c_void_p(ri_p), C.c_void_p(off_p), ng, n,
+                                              mem, C.c_void_p(ptr)))
+                out.add(holder, "", st)
+            elif c is None:
+                ptr, holder = out.alloc(ng, L.INT64)
+                if ng:
+                    L.check(lib.dthip_reduce(ctx._h, L.COUNT0, None, None, C.c_void_p(off_p), ng, n, mem, C.c_void_p(ptr)))
+                out.add(holder, "count", L.INT64)
+            else:
+                vc = col[c]
+                st = lib.dthip_reduce_out_stype(OPS[op], vc.stype)
+                ptr, holder = out.alloc(ng, st)
+                if ng:
+                    L.check(lib.dthip_reduce(ctx._h, OPS[op], C.byref(vc), C.c_void_p(ri_p), C.c_void_p(off_p), ng, n, mem,
+                                             C.c_void_p(ptr)))
+                out.add(holder, frame.names[c], st)
+        return out.finish(frame)
+    finally:
+        keep.free()
 
 
 def run(frame, keys, aggs, ctx=None):
-    """evaluate the matched query through the C ABI (dthip_groupby_agg, host pointers)"""
+    """evaluate the matched query through the C ABI (dthip_groupby_agg)"""
     import ctypes as C
     if not all(len(a) == 2 and a[0] in _FUSED for a in aggs):
         return run_sred(frame, keys, aggs, ctx)
-    ctx = ctx or default_context()
+    ctx = _context(ctx)
     lib = ctx._lib
     vcols = sorted({c for _, c in aggs if c is not None})
-    karr = (L.Col * len(keys))(*[L.Col(dt.internal.frame_column_data_r(frame, k).value, frame.stypes[k].value, 0) for k in keys])
-    varr = (L.Col * max(len(vcols), 1))(*[L.Col(dt.internal.frame_column_data_r(frame, c).value, frame.stypes[c].value, 0) for c in vcols])
+    lcols, mem = _columns(frame, list(keys) + vcols, ctx)
+    karr, varr = _carr(lcols[:len(keys)]), _carr(lcols[len(keys):])
     aarr = (L.Agg * len(aggs))(*[L.Agg({"sum": L.SUM, "mean": L.MEAN, "min": L.MIN, "max": L.MAX, "count": L.COUNT,
                                         "count0": L.COUNT0}[op], -1 if c is None else vcols.index(c)) for op, c in aggs])
     h = C.c_void_p()
     L.check(lib.dthip_groupby_agg(ctx._h, karr, len(keys), varr, len(vcols), aarr, len(aggs), frame.nrows,
-                                  L.NA_FIRST, L.HOST, C.byref(h)))
+                                  L.NA_FIRST, mem, C.byref(h)))
+    keep = _ResultKeep(ctx, h)
+    out = _Out(ctx, mem)
+    lazy = _lazy() and mem == L.DEVICE
     try:
         ng = lib.dthip_result_ngroups(h)
-        cols, names, bool_cols = [], [], []
         for i, k in enumerate(keys):
-            out = np.empty(ng, ST2NP[frame.stypes[k].value])
-            L.check(lib.dthip_result_copy_key(ctx._h, h, i, out.ctypes.data, L.HOST))
-            cols.append(out); names.append(frame.names[k])
-        for a, (op, c) in enumerate(aggs):
-            st = lib.dthip_result_agg_stype(h, a)
-            out = np.empty(ng, ST2NP[st])
-            if st == L.BOOL:
-                bool_cols.append(len(cols))
-            L.check(lib.dthip_result_copy_agg(ctx._h, h, a, out.ctypes.data, L.HOST))
-            cols.append(out); names.append("count" if c is None else frame.names[c])
+            st = frame.stypes[k].value
+            if lazy:
+                out.borrowed(lib.dthip_result_key(h, i), ng, st, keep, frame.names[k])
+            else:
+                a = np.empty(ng, ST2NP[st])
+                L.check(lib.dthip_result_copy_key(ctx._h, h, i, a.ctypes.data, L.HOST))
+                out.add(a, frame.names[k], st)
+        for a_i, (op, c) in enumerate(aggs):
+            st = lib.dthip_result_agg_stype(h, a_i)
+            name = "count" if c is None else frame.names[c]
+            if lazy:
+                out.borrowed(lib.dthip_result_agg(h, a_i), ng, st, keep, name)
+            else:
+                a = np.empty(ng, ST2NP[st])
+                L.check(lib.dthip_result_copy_agg(ctx._h, h, a_i, a.ctypes.data, L.HOST))
+                out.add(a, name, st)
+        if lazy:
+            return out.finish(frame)
+        out.mem = L.HOST                 # the copies above already landed in host buffers
+        return out.finish(frame)
     finally:
-        lib.dthip_result_free(ctx._h, h)
-    return _finish(frame, keys, cols, names, bool_cols)
+        if not lazy:
+            keep.free()
 
 
 # ---- row-returning routes: DT[f.x <cmp> c, cols], DT[:, cols, by(keys)], DT[:, cols, sort(...)] ---------------------
@@ -472,41 +667,35 @@ def match_filter(frame, item):
     return None if th is None else (ci, th, cols)
 
 
-def _wrap(frame, cols, names, bool_cols):
-    return Frame(_finish(frame, [], cols, names, bool_cols))
-
-
 def run_filter(frame, ci, th, cols, ctx=None):
     """the passing rows of `cols`, materialised in one sweep next to the predicate column (dthip_filter_take)"""
     import ctypes as C
-    ctx = ctx or default_context()
+    ctx = _context(ctx)
     lib = ctx._lib
     n = frame.nrows
     kind = th[0]
     if kind in ("none", "all"):
         sel = slice(0, 0) if kind == "none" else slice(None)
-        return Frame(dt.Frame.__getitem__(frame, (sel, [frame.names[c] for c in cols])))
+        base = frame.to_frame() if isinstance(frame, DeviceFrame) else frame
+        return Frame(dt.Frame.__getitem__(base, (sel, [frame.names[c] for c in cols])))
     st = frame.stypes[ci].value
     isf = st in (L.FLOAT32, L.FLOAT64)
     code = {"ge": L.GE, "le": L.LE, "eq": L.EQ, "ne": L.NE, "isna": L.ISNA, "notna": L.NOTNA}[kind]
     cf = float(th[1]) if len(th) > 1 and isf else 0.0
     cint = int(th[1]) if len(th) > 1 and not isf else 0
-    pcol = _col(frame, ci)
-    outs, names, bool_cols = [], [], []
-    npass = None
+    lcols, mem = _columns(frame, [ci] + list(cols), ctx)
+    pcol = lcols[0]
+    out = _Out(ctx, mem)
     for lo in range(0, len(cols), 8):                       # dthip_filter_take takes up to 8 columns per sweep
         part = cols[lo:lo + 8]
-        carr = (L.Col * len(part))(*[_col(frame, c) for c in part])
-        bufs = [np.empty(n, ST2NP[frame.stypes[c].value]) for c in part]
-        optr = (C.c_void_p * len(part))(*[b.ctypes.data for b in bufs])
+        carr = _carr(lcols[1 + lo:1 + lo + len(part)])
+        bufs = [out.alloc(n, frame.stypes[c].value) for c in part]
+        optr = (C.c_void_p * len(part))(*[b[0] for b in bufs])
         k = C.c_int64(0)
-        L.check(lib.dthip_filter_take(ctx._h, C.byref(pcol), code, cf, cint, carr, len(part), n, L.HOST, None, optr, C.byref(k)))
-        npass = k.value
+        L.check(lib.dthip_filter_take(ctx._h, C.byref(pcol), code, cf, cint, carr, len(part), n, mem, None, optr, C.byref(k)))
         for c, b in zip(part, bufs):
-            if frame.stypes[c].value == L.BOOL:
-                bool_cols.append(len(outs))
-            outs.append(b[:npass]); names.append(frame.names[c])
-    return _wrap(frame, outs, names, bool_cols)
+            out.add(b[1], frame.names[c], frame.stypes[c].value, nrows=k.value)
+    return out.finish(frame, wrap=True)
 
 
 def match_rows(frame, item):
@@ -527,45 +716,59 @@ def _rows_call(frame, keys, desc, cols, na_pos, ctx):
     import ctypes as C
     lib = ctx._lib
     n = frame.nrows
-    karr = (L.Col * len(keys))(*[L.Col(dt.internal.frame_column_data_r(frame, k).value, frame.stypes[k].value,
-                                       L.FLAG_DESCENDING if d else 0) for k, d in zip(keys, desc)])
+    used = list(dict.fromkeys(list(keys) + list(cols)))
+    flags = {k: (L.FLAG_DESCENDING if d else 0) for k, d in zip(keys, desc)}
+    lcols, mem = _columns(frame, used, ctx)
+    col = dict(zip(used, lcols))
+    karr = _carr([L.Col(col[k].data, col[k].stype, flags[k]) for k in keys])
+    out = _Out(ctx, mem)
     h = C.c_void_p()
-    outs = []
     if na_pos == L.NA_REMOVE:
-        L.check(lib.dthip_groupby(ctx._h, karr, len(keys), n, na_pos, L.HOST, 1, C.byref(h)))
+        L.check(lib.dthip_groupby(ctx._h, karr, len(keys), n, na_pos, mem, 1, C.byref(h)))
+        keep = _ResultKeep(ctx, h)
         try:
             m = lib.dthip_result_nrows(h)
-            ri = np.empty(m, np.int32)
-            L.check(lib.dthip_result_copy_rowindex(ctx._h, h, ri.ctypes.data, L.HOST))
+            if mem == L.HOST:
+                ri = np.empty(m, np.int32)
+                L.check(lib.dthip_result_copy_rowindex(ctx._h, h, ri.ctypes.data, L.HOST))
+                ri_p = ri.ctypes.data
+            else:
+                ri_p = lib.dthip_result_rowindex(h)
+            for c in cols:
+                st = frame.stypes[c].value
+                ptr, holder = out.alloc(m, st)
+                if m:
+                    L.check(lib.dthip_gather(ctx._h, C.byref(col[c]), C.c_void_p(ri_p), m, mem, C.c_void_p(ptr)))
+                out.add(holder, frame.names[c], st)
         finally:
-            lib.dthip_result_free(ctx._h, h)
-        for c in cols:
-            out = np.empty(m, ST2NP[frame.stypes[c].value])
-            cc = _col(frame, c)
-            if m:
-                L.check(lib.dthip_gather(ctx._h, C.byref(cc), ri.ctypes.data, m, L.HOST, out.ctypes.data))
-            outs.append(out)
-        return outs
-    carr = (L.Col * max(len(cols), 1))(*[_col(frame, c) for c in cols])
-    L.check(lib.dthip_groupby_rows(ctx._h, karr, len(keys), carr, len(cols), n, na_pos, L.HOST, 0, C.byref(h)))
+            keep.free()
+        return out
+    carr = _carr([col[c] for c in cols])
+    L.check(lib.dthip_groupby_rows(ctx._h, karr, len(keys), carr, len(cols), n, na_pos, mem, 0, C.byref(h)))
+    keep = _ResultKeep(ctx, h)
+    lazy = _lazy() and mem == L.DEVICE
     try:
         for i, c in enumerate(cols):
-            out = np.empty(n, ST2NP[frame.stypes[c].value])
-            L.check(lib.dthip_result_copy_col(ctx._h, h, i, out.ctypes.data, L.HOST))
-            outs.append(out)
+            st = frame.stypes[c].value
+            if lazy:
+                out.borrowed(lib.dthip_result_col(h, i), n, st, keep, frame.names[c])
+            else:
+                a = np.empty(n, ST2NP[st])
+                L.check(lib.dthip_result_copy_col(ctx._h, h, i, a.ctypes.data, L.HOST))
+                out.add(a, frame.names[c], st)
     finally:
-        lib.dthip_result_free(ctx._h, h)
-    return outs
+        if not lazy:
+            keep.free()
+            out.mem = L.HOST
+    return out
 
 
 def run_rows(frame, keys, cols, ctx=None):
     """DT[:, cols, by(keys)]: the by-columns, then `cols`, every row, in grouped order (evaluate_select,
     eval_context.cc:497-508): the columns ride through the sort on the device"""
-    ctx = ctx or default_context()
+    ctx = _context(ctx)
     allc = list(keys) + list(cols)
-    outs = _rows_call(frame, keys, [False] * len(keys), allc, L.NA_FIRST, ctx)
-    bools = [i for i, c in enumerate(allc) if frame.stypes[c].value == L.BOOL]
-    return _wrap(frame, outs, [frame.names[c] for c in allc], bools)
+    return _rows_call(frame, keys, [False] * len(keys), allc, L.NA_FIRST, ctx).finish(frame, wrap=True)
 
 
 def match_sort(frame, item):
@@ -587,27 +790,103 @@ def match_sort(frame, item):
 
 
 def run_sort(frame, keys, desc, na_pos, cols, ctx=None):
-    ctx = ctx or default_context()
-    outs = _rows_call(frame, keys, desc, cols, na_pos, ctx)
-    bools = [i for i, c in enumerate(cols) if frame.stypes[c].value == L.BOOL]
-    return _wrap(frame, outs, [frame.names[c] for c in cols], bools)
+    ctx = _context(ctx)
+    return _rows_call(frame, keys, desc, cols, na_pos, ctx).finish(frame, wrap=True)
+
+
+def _route(frame, item):
+    """the accelerated evaluation of frame[item], or NotImplemented"""
+    plan = match(frame, item)
+    if plan is not None:
+        return run(frame, *plan)
+    for matcher, runner in ((match_filter, run_filter), (match_rows, run_rows), (match_sort, run_sort)):
+        plan = matcher(frame, item)
+        if plan is not None:
+            return runner(frame, *plan)
+    return NotImplemented
+
+
+def _native(item):
+    return tuple(x.native() if isinstance(x, (by, sort)) else x for x in item) if isinstance(item, tuple) else item
+
+
+class DeviceFrame:
+    """Result of an accelerated `DT[...]` under `options.residency = "lazy"`: the columns live in HBM (inside the
+    dthip_result they came from, or in dthip_malloc buffers), the metadata answers like a Frame's, the next accelerated
+    `DT[...]` runs on the device columns, and ANY other use downloads the columns once (`to_frame()`) and hands over to
+    the real Frame -- whose resident cache then adopts the device buffers, so nothing is uploaded again.
+    Not a `datatable.Frame` subclass on purpose: the base type's C-level buffer protocol cannot be intercepted from
+    Python, and it must never export memory that has not been downloaded yet."""
+
+    def __init__(self, ctx, names, stypes, nrows, cols, wrap):
+        self._ctx, self._names, self._stypes, self._nrows, self._cols, self._wrap = ctx, tuple(names), tuple(stypes), int(nrows), list(cols), wrap
+        self._frame = None
+
+    names = property(lambda self: self._names)
+    stypes = property(lambda self: self._stypes)
+    nrows = property(lambda self: self._nrows)
+    ncols = property(lambda self: len(self._names))
+    shape = property(lambda self: (self._nrows, len(self._names)))
+    is_resident = property(lambda self: True)
+
+    def to_frame(self):
+        import ctypes as C
+        if self._frame is None:
+            host = []
+            for e, st in zip(self._cols, self._stypes):
+                a = np.empty(self._nrows, ST2NP[st.value])
+                if a.nbytes:
+                    L.check(self._ctx._lib.dthip_memcpy_d2h(self._ctx._h, C.c_void_p(a.ctypes.data), C.c_void_p(e.ptr), a.nbytes))
+                host.append(a)
+            res = _finish(host, list(self._names), [i for i, st in enumerate(self._stypes) if st == dt.stype.bool8])
+            if self._wrap:
+                res = Frame(res)
+                # the device copies stay valid for the new Frame: adopt them as its resident cache
+                cache = {}
+                for c, e in enumerate(self._cols):
+                    hp = dt.internal.frame_column_data_r(res, c).value or 0
+                    cache[c] = _DevColumn(e.ptr, e.nbytes, hp, self._nrows, self._stypes[c].value, e.keep)
+                res.__dict__["_dthip_dev"] = cache
+                res.__dict__["_dthip_ctx"] = self._ctx
+            self._frame = res
+        return self._frame
+
+    def __getitem__(self, item):
+        if self._frame is None:
+            r = _route(self, item)
+            if r is not NotImplemented:
+                return r
+        return self.to_frame()[item]
+
+    def __getattr__(self, name):                      # anything else a Frame can do: on the downloaded Frame
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.to_frame(), name)
+
+    def __array__(self, *a, **k):
+        return np.asarray(self.to_frame().to_numpy(), *a, **k)
+
+    def __len__(self):
+        return self._nrows
+
+    def __repr__(self):
+        return "<DeviceFrame [%d rows x %d cols] in HBM%s>" % (self._nrows, len(self._names), "" if self._frame is None else " (downloaded)")
 
 
 class Frame(dt.Frame):
     """datatable.Frame whose __getitem__ sends the group-by hot path to the GPU: aggregations, the row filter and the
-    rows-in-grouped-order / sort forms.  Everything else is the reference's."""
+    rows-in-grouped-order / sort forms.  Everything else is the reference's.  With `options.residency` "auto" / "lazy"
+    the columns those queries touch stay in HBM between queries (see _Options); the reference's own contract for borrowed
+    column pointers applies -- valid until the next mutating call (src/datatable/include/datatable.h:80-99,113-114) -- and
+    every mutating Frame method below drops the device copies."""
 
     def __getitem__(self, item):
-        plan = match(self, item)
-        if plan is not None:
-            return run(self, *plan)
-        for matcher, runner in ((match_filter, run_filter), (match_rows, run_rows), (match_sort, run_sort)):
-            plan = matcher(self, item)
-            if plan is not None:
-                return runner(self, *plan)
-        if isinstance(item, tuple):
-            item = tuple(x.native() if isinstance(x, (by, sort)) else x for x in item)
-        return super().__getitem__(item)
+        r = _route(self, item)
+        if r is not NotImplemented:
+            return r
+        if isinstance(item, tuple) and any(isinstance(x, dt.update) for x in item):
+            self.release_device()                                # DT[:, update(...)] assigns in place
+        return super().__getitem__(_native(item))
 
     def sort(self, *cols):
         """Frame.sort(cols): ascending, NA first (src/core/sort.cc:539-558) == DT[:, :, sort(cols)]"""
@@ -615,3 +894,66 @@ class Frame(dt.Frame):
         if plan is not None:
             return run_sort(self, *plan)
         return super().sort(*cols)
+
+    # ---- residency ---------------------------------------------------------------------------------------------------
+    def to_device(self, ctx=None):
+        """upload every fixed-width column now (otherwise columns are uploaded by the first query that touches them)"""
+        if options.residency == "off":
+            raise ValueError("shim.options.residency is 'off'")
+        cols = [c for c in range(self.ncols) if self.stypes[c].value in _ACCEL_STYPES]
+        _resident(self, cols, _context(ctx))
+        return self
+
+    def release_device(self):
+        """drop the device copies (they are dropped automatically by every mutating call)"""
+        self.__dict__.pop("_dthip_dev", None)
+
+    @property
+    def is_resident(self):
+        return bool(self.__dict__.get("_dthip_dev"))
+
+    # ---- every mutating entry point of the reference's Frame drops the device copies ------------------------------------
+    def __setitem__(self, key, value):
+        self.release_device()
+        return super().__setitem__(key, value)
+
+    def __delitem__(self, key):
+        self.release_device()
+        return super().__delitem__(key)
+
+    def cbind(self, *a, **k):
+        self.release_device()
+        return super().cbind(*a, **k)
+
+    def rbind(self, *a, **k):
+        self.release_device()
+        return super().rbind(*a, **k)
+
+    def replace(self, *a, **k):
+        self.release_device()
+        return super().replace(*a, **k)
+
+    def materialize(self, *a, **k):
+        self.release_device()
+        return super().materialize(*a, **k)
+
+    def _drop_then_set(prop):                                    # noqa: N805 -- builds the hooked property setters below
+        base = getattr(dt.Frame, prop)
+
+        def getter(self):
+            return base.__get__(self)
+
+        def setter(self, value):
+            self.release_device()
+            base.__set__(self, value)
+
+        def deleter(self):
+            self.release_device()
+            base.__delete__(self)
+
+        return property(getter, setter, deleter, base.__doc__)
+
+    nrows = _drop_then_set("nrows")       # resizes the columns
+    key = _drop_then_set("key")           # re-orders the rows
+    names = _drop_then_set("names")
+    del _drop_then_set

@@ -163,3 +163,126 @@ def test_match_rows_sort_and_filter_forms():
     # the native objects still reach the reference for everything else
     R = S[:, :, shim.sort(f.s)]
     assert R.to_list() == [[3, 1, 3], ["a", "b", "c"]]
+
+
+# ---- residency layer (round 4): cache validation, invalidation by every mutating call, DeviceFrame -- with a stand-in
+# for the library's memory entry points (host memory plays HBM), so the host logic runs without a GPU
+class _FakeLib:
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.live = {}
+        self.uploads = 0
+
+    def dthip_malloc(self, h, nbytes, pp):
+        buf = self.C.create_string_buffer(int(nbytes))
+        p = self.C.addressof(buf)
+        self.live[p] = buf
+        pp._obj.value = p
+        return 0
+
+    def dthip_free(self, h, p):
+        self.live.pop(p.value, None)
+        return 0
+
+    def dthip_memcpy_h2d(self, h, dst, src, n):
+        self.uploads += 1
+        self.C.memmove(dst.value, src.value, n)
+        return 0
+
+    def dthip_memcpy_d2h(self, h, dst, src, n):
+        self.C.memmove(dst.value, src.value, n)
+        return 0
+
+    def dthip_set_option(self, h, name, v):
+        return 0
+
+
+class _FakeCtx:
+    def __init__(self):
+        self._lib, self._h = _FakeLib(), 1
+
+    def set_option(self, name, value):
+        pass
+
+
+def test_resident_cache_is_validated_and_dropped_by_mutations():
+    from datatable import f, update
+    from integration import datatable_hip_shim as shim
+    ctx = _FakeCtx()
+    old = shim.options.residency
+    shim.options.residency = "auto"
+    try:
+        DT = shim.Frame(k=np.array([3, 1, 3, 2], np.int64), v=np.array([1.0, 2.0, 4.0, 8.0]), s=["a", "b", "c", "d"])
+        e = shim._resident(DT, [0, 1], ctx)
+        assert ctx._lib.uploads == 2 and DT.is_resident and [x.nrows for x in e] == [4, 4]
+        assert shim._resident(DT, [1, 0], ctx)[0] is e[1] and ctx._lib.uploads == 2          # served from the cache
+        cols, mem = shim._columns(DT, [1], ctx)
+        assert mem == shim.L.DEVICE and cols[0].data == e[1].ptr and cols[0].stype == 7
+        got = np.frombuffer(ctx._lib.live[e[1].ptr], dtype=np.float64, count=4)
+        assert got.tolist() == [1.0, 2.0, 4.0, 8.0]
+        mutations = [
+            lambda D: D.__setitem__((0, "v"), 5.0),
+            lambda D: D.__delitem__((slice(None), "s")),
+            lambda D: D.cbind(dt.Frame(z=[1, 2, 3, 4])),
+            lambda D: D.rbind(dt.Frame(k=[9], v=[9.0], s=["z"])),
+            lambda D: D.replace(1.0, 7.0),
+            lambda D: D.materialize(),
+            lambda D: setattr(D, "nrows", 2),
+            lambda D: setattr(D, "key", "k"),
+            lambda D: setattr(D, "names", ("k", "w", "s")),
+            lambda D: D[:, update(v=f.v * 2)],
+        ]
+        for m in mutations:
+            D = shim.Frame(k=np.array([3, 1, 4, 2], np.int64), v=np.array([1.0, 2.0, 4.0, 8.0]), s=["a", "b", "c", "d"])
+            shim._resident(D, [0, 1], ctx)
+            assert D.is_resident
+            m(D)
+            assert not D.is_resident, "a mutating call kept the device copies"
+        # second line of defence: a column whose host buffer moved, or whose row count / stype changed, is uploaded again
+        D = shim.Frame(k=np.arange(6, dtype=np.int64), v=np.arange(6.0))
+        shim._resident(D, [0], ctx)
+        n0 = ctx._lib.uploads
+        D.__dict__["_dthip_dev"][0].host_ptr += 8                   # pretend the buffer was reallocated behind our back
+        shim._resident(D, [0], ctx)
+        assert ctx._lib.uploads == n0 + 1
+        shim.options.residency = "off"
+        assert shim._resident(D, [0], ctx) is None
+        assert shim._columns(D, [0], ctx)[1] == shim.L.HOST
+        # a plain reference Frame is never cached
+        shim.options.residency = "auto"
+        assert shim._resident(dt.Frame(k=[1, 2]), [0], ctx) is None
+        D.to_device(ctx)
+        assert sorted(D.__dict__["_dthip_dev"]) == [0, 1]
+        D.release_device()
+        assert not D.is_resident
+    finally:
+        shim.options.residency = old
+
+
+def test_device_frame_metadata_download_and_adoption():
+    from integration import datatable_hip_shim as shim
+    ctx = _FakeCtx()
+    src = shim.Frame(a=np.array([5, 6, 7], np.int32), b=np.array([True, False, True]), c=np.array([0.5, np.nan, 2.0]))
+    dev = [shim._upload_column(ctx, src, c) for c in range(3)]
+    for e in dev:
+        e.host_ptr = None
+    V = shim.DeviceFrame(ctx, shim._mangled(["a", "a", ""]), [dt.stype.int32, dt.stype.bool8, dt.stype.float64], 3, dev, True)
+    assert V.names == ("a", "a.0", "C0") and V.shape == (3, 3) and V.nrows == 3 and V.ncols == 3 and len(V) == 3
+    assert V.stypes == (dt.stype.int32, dt.stype.bool8, dt.stype.float64)
+    assert "HBM" in repr(V) and V._frame is None                       # nothing downloaded so far
+    assert V.to_list() == [[5, 6, 7], [True, False, True], [0.5, None, 2.0]]      # any Frame method: download once
+    F = V.to_frame()
+    assert type(F) is shim.Frame and F.stypes == V.stypes and F is V.to_frame()
+    assert F.is_resident and sorted(F.__dict__["_dthip_dev"]) == [0, 1, 2]          # the device copies were adopted
+    n0 = ctx._lib.uploads
+    old = shim.options.residency
+    shim.options.residency = "auto"
+    try:
+        assert shim._resident(F, [0, 2], ctx)[0].ptr == dev[0].ptr and ctx._lib.uploads == n0     # nothing uploaded again
+    finally:
+        shim.options.residency = old
+    assert np.asarray(V).shape == (3, 3)
+    assert V[1, "a"] == 6                                              # other forms of [] go to the Frame
+    W = shim.DeviceFrame(ctx, ["x"], [dt.stype.int64], 0, [shim._DevColumn(0, 0, None, 0, 5, None)], False)
+    assert type(W.to_frame()) is dt.Frame and W.to_frame().shape == (0, 1)
