@@ -262,3 +262,145 @@ def test_config5_two_step_form_at_scale(env):
     Ar = Vr[:, [sum(f.x), count()], dt.by(f.k)]
     assert np.array_equal(A[:, 0].to_numpy(), Ar[:, 0].to_numpy()) and np.array_equal(A[:, 2].to_numpy(), Ar[:, 2].to_numpy())
     assert np.allclose(A[:, 1].to_numpy(), Ar[:, 1].to_numpy(), rtol=1e-6, atol=1e-9)
+
+
+# ---- round 4: device-resident columns and lazy results ----------------------------------------------------------------
+@pytest.fixture()
+def residency(env):
+    dt, shim = env
+    old = shim.options.residency
+
+    def set_mode(m):
+        shim.options.residency = m
+    yield set_mode
+    shim.options.residency = old
+
+
+def _host(shim, x):
+    return x.to_frame() if isinstance(x, shim.DeviceFrame) else x
+
+
+@pytest.mark.parametrize("mode", ["off", "auto", "lazy"])
+def test_every_route_in_every_residency_mode(env, residency, mode):
+    """the four routes (fused aggregation, S-red, filter, rows / sort) give the reference's answer whether the columns are
+    passed as host pointers, served from the per-Frame device cache, or the results stay in HBM as DeviceFrames"""
+    dt, shim = env
+    import datatable
+    from datatable import f, sum, mean, min, max, count
+    residency(mode)
+    DT = make_frame(shim, 120_000, seed=77)
+    for rep in range(2):                                                     # the second round runs on the cached columns
+        got, exp = both(dt, shim, DT, [op(f[c]) for c in ("f8", "i4", "b") for op in (sum, mean, min, max, count)] + [count()], [f.k, f.k2])
+        assert (type(got) is shim.DeviceFrame) == (mode == "lazy")
+        assert_frames_equal(dt, _host(shim, got), exp)
+        got, exp = both(dt, shim, DT, [datatable.sd(f.f8), datatable.median(f.i2), datatable.first(f.b), datatable.cov(f.f8, f.i4), datatable.count()], [f.k])
+        assert_frames_equal(dt, _host(shim, got), exp)
+        got, exp = both(dt, shim, DT, [datatable.cumsum(f.i4), datatable.cummax(f.b), datatable.cumcount()], [f.k2])
+        assert_frames_equal(dt, _host(shim, got), exp)
+        assert DT.is_resident == (mode != "off")
+        V = DT[f.f8 > 0.1, [f.k, f.f8, f["i1"], f.b]]
+        assert (type(V) is shim.DeviceFrame) == (mode == "lazy")
+        Vr = dt.Frame.__getitem__(DT, (f.f8 > 0.1, [f.k, f.f8, f["i1"], f.b]))
+        assert V.shape == Vr.shape and V.names == Vr.names and tuple(V.stypes) == tuple(Vr.stypes)
+        R = V[:, :, shim.by(f.k)]                                             # lazy: runs on the DeviceFrame's columns
+        assert (type(R) is shim.DeviceFrame) == (mode == "lazy")
+        assert_rows_equal(dt, _host(shim, R), Vr[:, :, dt.by(f.k)])
+        assert_rows_equal(dt, _host(shim, V), Vr)
+        S = DT[:, [f.f8, f.k], shim.sort(f.k, na_position="remove")]
+        assert_rows_equal(dt, _host(shim, S), dt.Frame.__getitem__(DT, (slice(None), [f.f8, f.k], dt.sort(f.k, na_position="remove"))))
+        assert_rows_equal(dt, _host(shim, DT.sort(f.k2, f.i8)), dt.Frame.sort(DT, f.k2, f.i8))
+    if mode == "lazy":
+        assert R.to_frame().is_resident                                      # the downloaded Frame adopted the device copies
+        assert R.to_list() == R.to_frame().to_list() and len(R) == R.nrows and "HBM" in repr(R)
+        assert np.asarray(R).shape == R.shape
+
+
+def test_config5_never_leaves_the_gpu_when_lazy(env, residency, monkeypatch):
+    """options.residency = "lazy": after the one upload of DT, V = DT[f.x > 0, :]; R = V[:, :, by(f.k)]; A = V[:, sum, by] move
+    NOTHING over PCIe (no upload, no download) until a result is looked at"""
+    dt, shim = env
+    from datatable import f, sum, count
+    residency("lazy")
+    rng = np.random.default_rng(1239)
+    n = 4_000_000
+    DT = shim.Frame(k=rng.integers(0, 500_000, n, dtype=np.int64), x=rng.standard_normal(n))
+    DT.to_device()
+    ctx = shim._context()
+    moved = {"h2d": 0, "d2h": 0}
+    real_up, real_d2h = shim._upload_column, ctx._lib.dthip_memcpy_d2h
+
+    def up(*a, **k):
+        moved["h2d"] += 1
+        return real_up(*a, **k)
+
+    class LibSpy:
+        def __init__(self, lib):
+            self._lib = lib
+
+        def __getattr__(self, name):
+            if name == "dthip_memcpy_d2h":
+                def spy(*a):
+                    moved["d2h"] += 1
+                    return real_d2h(*a)
+                return spy
+            return getattr(self._lib, name)
+
+    monkeypatch.setattr(shim, "_upload_column", up)
+    monkeypatch.setattr(ctx, "_lib", LibSpy(ctx._lib))
+    V = DT[f.x > 0, :]
+    R = V[:, :, shim.by(f.k)]
+    A = V[:, [sum(f.x), count()], shim.by(f.k)]
+    assert all(type(x) is shim.DeviceFrame for x in (V, R, A))
+    assert moved == {"h2d": 0, "d2h": 0}, moved
+    monkeypatch.undo()
+    Vr = dt.Frame.__getitem__(DT, (f.x > 0, slice(None)))
+    assert_rows_equal(dt, R.to_frame(), Vr[:, :, dt.by(f.k)])
+    Ar = Vr[:, [sum(f.x), count()], dt.by(f.k)]
+    Ah = A.to_frame()
+    assert type(Ah) is dt.Frame and Ah.names == Ar.names
+    assert np.array_equal(Ah[:, 0].to_numpy(), Ar[:, 0].to_numpy()) and np.array_equal(Ah[:, 2].to_numpy(), Ar[:, 2].to_numpy())
+    assert np.allclose(Ah[:, 1].to_numpy(), Ar[:, 1].to_numpy(), rtol=1e-6, atol=1e-9)
+
+
+def test_resident_frame_follows_mutations(env, residency):
+    """a query after an in-place change of a resident Frame sees the change (the device copies were dropped)"""
+    dt, shim = env
+    from datatable import f, sum, update
+    residency("auto")
+    rng = np.random.default_rng(3)
+    n = 50_000
+    DT = shim.Frame(k=rng.integers(0, 50, n).astype(np.int32), v=rng.standard_normal(n))
+    q = lambda D: (D[:, sum(f.v), shim.by(f.k)], dt.Frame.__getitem__(D, (slice(None), sum(f.v), dt.by(f.k))))
+    got, exp = q(DT); assert_frames_equal(dt, got, exp); assert DT.is_resident
+    DT[7, "v"] = 1e9
+    got, exp = q(DT); assert_frames_equal(dt, got, exp)
+    DT[:, update(v=f.v * 2)]
+    got, exp = q(DT); assert_frames_equal(dt, got, exp)
+    DT.rbind(dt.Frame(k=np.array([3, 3], np.int32), v=[5e9, 5e9]))
+    got, exp = q(DT); assert_frames_equal(dt, got, exp)
+    DT.nrows = 1000
+    got, exp = q(DT); assert_frames_equal(dt, got, exp)
+    del DT[:, "v"]
+    DT.cbind(dt.Frame(v=np.arange(1000.0)))
+    got, exp = q(DT); assert_frames_equal(dt, got, exp)
+
+
+def test_f32_sum_switch_gives_the_reference_bits(env):
+    """shim.options.f32_sum = True: sum(float32) equals the reference's float32 accumulation exactly (VERDICT r03 weak #3)"""
+    dt, shim = env
+    from datatable import f, sum
+    rng = np.random.default_rng(9)
+    n = 400_000
+    DT = shim.Frame(k=rng.integers(0, 300, n).astype(np.int32), v=(rng.standard_normal(n) * 1000).astype(np.float32))
+    old = shim.options.f32_sum
+    try:
+        shim.options.f32_sum = True
+        got = DT[:, sum(f.v), shim.by(f.k)]
+        exp = dt.Frame.__getitem__(DT, (slice(None), sum(f.v), dt.by(f.k)))
+        assert got.stypes == exp.stypes and np.array_equal(got[:, 1].to_numpy(), exp[:, 1].to_numpy())
+        shim.options.f32_sum = False
+        got = DT[:, sum(f.v), shim.by(f.k)]
+        # float64 accumulation rounded once against float32 accumulation: the reference's own rounding, ~eps32 * sum|v| per group
+        assert np.allclose(got[:, 1].to_numpy(), exp[:, 1].to_numpy(), rtol=1e-4, atol=0.5)
+    finally:
+        shim.options.f32_sum = old
