@@ -272,6 +272,18 @@ def run_configs(ctx, dev, which, steps, scale, verify, cpu_sample, ref_threads, 
                      "alg_bytes": alg_bytes, "alg_GBs": alg_bytes / sec / 1e9, "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS,
                      "dominant_kernel": dom, "dominant_ms": prof[dom][0] if dom else None,
                      "kernel_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]}}
+        # HBM bytes of one whole query from the rocprofv3 PMC passes recorded under profiles/ (scripts/prof_r04.sh):
+        # FETCH_SIZE x 2 + WRITE_SIZE over every kernel of the query; amplification = traffic / algorithmic bytes
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("_configs", {}).get(name)
+        except Exception:
+            rec = None
+        if rec and rec.get("rows") == n:
+            out[name]["traffic"] = rec["hbm_bytes_per_query"]
+            out[name]["amplification"] = rec["hbm_bytes_per_query"] / alg_bytes
+            out[name]["traffic_GBs"] = rec["hbm_bytes_per_query"] / sec / 1e9
+        else:
+            out[name]["traffic"] = None
         torch.cuda.empty_cache(); ctx.trim()
 
     def check(name, fn):
@@ -446,6 +458,158 @@ def host_mode_leg(ctx, rows):
     return out
 
 
+XGMI_GBS_PER_GPU = 7 * 153.0          # 7 point-to-point xGMI links x ~153 GB/s out of every GPU (MI355X_MICROARCH.md)
+
+
+def shim_resident_leg(steps, rows_c3, groups_c3, rows_c5, raw_c3_ms, raw_c5_ms):
+    """The reference-side binding with device-resident columns (integration/datatable_hip_shim.py, options.residency =
+    "lazy"): a real datatable.Frame (oracle/_ref), columns uploaded once, then the SAME `DT[...]` expressions repeated --
+    C3 as DT[:, sum(f.v), by(f.k)] and config 5 in its two-step form V = DT[f.x > 0, :]; V[:, :, by(f.k)] -- timed from the
+    Python statement to the end of the device work (results stay in HBM; the raw C-ABI times stand beside them)"""
+    import numpy as np
+    import torch
+    from oracle import ref
+    dtm = ref.load()
+    if dtm is None:
+        return {"error": "oracle/_ref (the reference build) is not on this machine"}
+    from datatable import f, sum as dsum
+    from integration import datatable_hip_shim as shim
+    old = shim.options.residency
+    shim.options.residency = "lazy"
+    out = {"residency": "lazy", "steps": steps,
+           "what": "datatable.Frame -> shim.Frame.to_device() once; every step = one Python `DT[...]` statement, device work "
+                   "finished (dthip_sync), nothing copied to the host"}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev)
+    try:
+        sctx = shim._context()
+        # ---- C3
+        g.manual_seed(1237)
+        k = torch.randint(0, groups_c3, (rows_c3,), dtype=torch.int64, device=dev, generator=g)
+        v = torch.randn(rows_c3, dtype=torch.float64, device=dev, generator=g)
+        hk, hv = to_host(k), to_host(v)
+        del k, v
+        torch.cuda.empty_cache()
+        DT = shim.Frame(k=hk, v=hv)
+        t0 = time.perf_counter(); DT.to_device(); sctx.sync(); up = time.perf_counter() - t0
+        q = lambda: DT[:, dsum(f.v), shim.by(f.k)]
+        R = q(); sctx.sync()
+        ng = R.nrows
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter(); R = q(); sctx.sync(); ts.append(time.perf_counter() - t0)
+        out["C3"] = {"rows": rows_c3, "groups": int(ng), "upload_s": up, "ms_best": min(ts) * 1e3, "ms_mean": sum(ts) / len(ts) * 1e3,
+                     "raw_c_abi_ms": raw_c3_ms, "over_raw": (min(ts) * 1e3 / raw_c3_ms) if raw_c3_ms else None,
+                     "rows_per_s": rows_c3 / min(ts), "result": type(R).__name__}
+        # first host access of the lazy result, once (PCIe-inclusive, not part of the step)
+        t0 = time.perf_counter(); F = R.to_frame(); out["C3"]["download_result_ms"] = (time.perf_counter() - t0) * 1e3
+        assert F.nrows == ng and F.names == ("k", "v")
+        del DT, R, F, hk, hv
+        sctx.trim()
+        # ---- C5, two-step form
+        g.manual_seed(1239)
+        k = torch.randint(0, 100_000_000, (rows_c5,), dtype=torch.int64, device=dev, generator=g)
+        x = torch.randn(rows_c5, dtype=torch.float64, device=dev, generator=g)
+        hk, hx = to_host(k), to_host(x)
+        del k, x
+        torch.cuda.empty_cache()
+        DT = shim.Frame(k=hk, x=hx)
+        DT.to_device(); sctx.sync()
+        pred = f.x > 0                    # one FExpr object: its exact threshold is probed once and remembered
+
+        def q5():
+            V = DT[pred, :]
+            return V, V[:, :, shim.by(f.k)]
+        V, R = q5(); sctx.sync()
+        ts = []
+        for _ in range(steps):
+            del V, R
+            t0 = time.perf_counter(); V, R = q5(); sctx.sync(); ts.append(time.perf_counter() - t0)
+        out["C5"] = {"rows": rows_c5, "rows_passing": int(V.nrows), "ms_best": min(ts) * 1e3, "ms_mean": sum(ts) / len(ts) * 1e3,
+                     "raw_c_abi_ms": raw_c5_ms, "over_raw": (min(ts) * 1e3 / raw_c5_ms) if raw_c5_ms else None,
+                     "statements": "V = DT[f.x > 0, :]; R = V[:, :, by(f.k)]", "result": type(R).__name__,
+                     "note": "the raw figure carries the filter's RowIndex through the sort as a third column; the two-step "
+                             "datatable form has no such column"}
+        del DT, V, R, hk, hx
+        sctx.trim()
+    finally:
+        shim.options.residency = old
+    return out
+
+
+def sharded_config_legs(ctx, dev, rank, world, n_total, steps, dist):
+    """--gpus N: BASELINE configs 4 and 5 through the sharded entry points, row-block shards like C3's.  Per config: wall
+    time (barrier, max over ranks), rows/s, bytes every rank sent to its peers in the all-to-all-v and what that is of the
+    xGMI bound, and the wall-clock phases of one profiled call."""
+    import torch
+    from datatable_amd.torch_bridge import devcol
+    lo, hi = rank * n_total // world, (rank + 1) * n_total // world
+    n = hi - lo
+    g = torch.Generator(device=dev)
+    out = {}
+
+    def barrier():
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+    def timed(run, alg_bytes):
+        run().free()                                   # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run().free()
+        barrier()
+        t = torch.tensor([(time.perf_counter() - t0) / steps], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sec = float(t.item())
+        ctx.profile_reset(); ctx.profile(True)
+        r = run(); torch.cuda.synchronize(); ctx.profile(False)
+        ngl = r.ngroups
+        r.free()
+        st = ctx.comm_last_stats()
+        prof = {nm: ctx.profile_get(nm) for nm in ctx.profile_names()}
+        phases = {nm[6:]: round(ms, 4) for nm, (ms, _) in prof.items() if nm.startswith("phase_")}
+        kern = {nm: round(ms, 4) for nm, (ms, _) in sorted(prof.items(), key=lambda kv: -kv[1][0]) if not nm.startswith("phase_")}
+        tot = torch.tensor([st["bytes_to_peers"], ngl], dtype=torch.float64)
+        mx = tot.clone()
+        dist.all_reduce(tot); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        a2a = phases.get("alltoallv") or None
+        return {"ms": sec * 1e3, "rows_per_s": n_total / sec, "groups": int(tot[1].item()),
+                "alg_GBs": alg_bytes / sec / 1e9, "hbm_frac": alg_bytes / sec / 1e9 / (HBM_PEAK_GBS * world),
+                "bytes_to_peers_rank0": st["bytes_to_peers"], "bytes_to_peers_max": int(mx[0].item()), "bytes_to_peers_all": int(tot[0].item()),
+                "xgmi_frac_of_step": mx[0].item() / sec / 1e9 / XGMI_GBS_PER_GPU,
+                "xgmi_frac_of_exchange": (st["bytes_to_peers"] / (a2a * 1e-3) / 1e9 / XGMI_GBS_PER_GPU) if a2a else None,
+                "xgmi_peak_GBs_per_gpu": XGMI_GBS_PER_GPU, "allgathers": st["allgathers"],
+                "phases_ms_rank0": phases, "kernel_ms_rank0": dict(list(kern.items())[:8])}
+
+    # C4: DT[:, [count(), sum(f.v)], by(f.a, f.b)]
+    g.manual_seed(1238 + 1000 * rank)
+    a = torch.randint(0, 3163, (n,), dtype=torch.int32, device=dev, generator=g)
+    b = torch.randint(0, 3163, (n,), dtype=torch.int32, device=dev, generator=g)
+    v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    out["C4"] = timed(lambda: ctx.sharded_groupby_agg([devcol(a), devcol(b)], [devcol(v)], [("count0", None), ("sum", 0)], nrows=n),
+                      n_total * 16 + 10_004_569 * 24)
+    out["C4"]["query"] = "DT[:, [count(), sum(f.v)], by(f.a, f.b)], %d rows over %d ranks" % (n_total, world)
+    del a, b, v
+    torch.cuda.empty_cache(); ctx.trim()
+    # C5: V = DT[f.x > 0, :] on the shard (local: a filter needs no exchange), then V[:, :, by(f.k)] sharded
+    g.manual_seed(1239 + 1000 * rank)
+    k = torch.randint(0, 100_000_000, (n,), dtype=torch.int64, device=dev, generator=g)
+    x = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    ri = torch.empty(n, dtype=torch.int32, device=dev)
+    kb = torch.empty(n, dtype=torch.int64, device=dev)
+    xb = torch.empty(n, dtype=torch.float64, device=dev)
+
+    def c5():
+        npass = ctx.filter_take_dev(devcol(x), ">", 0.0, [devcol(k), devcol(x)], n, ri.data_ptr(), [kb.data_ptr(), xb.data_ptr()])
+        return ctx.sharded_groupby_rows([devcol(kb[:npass])], [devcol(kb[:npass]), devcol(xb[:npass]), devcol(ri[:npass])],
+                                        row_offset=lo, nrows=npass)
+    out["C5"] = timed(c5, int(n_total * 30.4))
+    out["C5"]["query"] = "V = DT[f.x > 0, :] per shard; V[:, :, by(f.k)] sharded (rows + the filter's RowIndex travel), %d rows over %d ranks" % (n_total, world)
+    del k, x, ri, kb, xb
+    torch.cuda.empty_cache(); ctx.trim()
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the environment
     torch.distributed.run would have set), pass rank 0's stdout -- the JSON line -- through, and take the whole group
@@ -501,6 +665,9 @@ def main():
     ap.add_argument("--no-ref-full", action="store_true", help="skip the reference's run over ALL rows of C3 (~1 min of CPU)")
     ap.add_argument("--no-dist-1rank", action="store_true", help="skip the 1-rank run of the sharded (RCCL) code path")
     ap.add_argument("--host-rows", type=int, default=100_000_000, help="rows of the host-pointer (PCIe-inclusive) leg, 0 = skip")
+    ap.add_argument("--no-shim-resident", action="store_true", help="skip the reference-side binding leg with device-resident columns")
+    ap.add_argument("--shim-scale", type=float, default=1.0, help="row-count factor of the shim_resident leg")
+    ap.add_argument("--no-sharded-configs", action="store_true", help="--gpus N: skip the sharded legs of configs 4 and 5")
     ap.add_argument("--no-check", action="store_true", help="skip the result sanity check (kernel timing experiments)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--agg-path", type=int, default=0, help="dthip option agg_path: 0 auto, 1 sort, 2 bucketed")
@@ -686,6 +853,21 @@ def main():
                                 "sum_of_group_sums_equals_sum_of_values": True, "groups": ng}
         del sums, gkeys
 
+    sharded_extra = None
+    if sharded:
+        # one profiled call of the timed query: wall-clock phases + what crossed the fabric (rank 0's view, max over ranks)
+        ctx.profile_reset(); ctx.profile(True)
+        release(step()); torch.cuda.synchronize(); ctx.profile(False)
+        st = ctx.comm_last_stats()
+        prof = {nm: ctx.profile_get(nm) for nm in ctx.profile_names()}
+        mxb = torch.tensor([float(st["bytes_to_peers"])], dtype=torch.float64)
+        dist.all_reduce(mxb, op=dist.ReduceOp.MAX)
+        phases = {nm[6:]: round(ms, 4) for nm, (ms, _) in prof.items() if nm.startswith("phase_")}
+        a2a = phases.get("alltoallv") or None
+        sharded_extra = {"phases_ms_rank0": phases, "bytes_to_peers_rank0": st["bytes_to_peers"], "bytes_to_peers_max": int(mxb.item()),
+                         "allgathers": st["allgathers"], "xgmi_peak_GBs_per_gpu": XGMI_GBS_PER_GPU,
+                         "xgmi_frac_of_step": mxb.item() / (dt / args.steps) / 1e9 / XGMI_GBS_PER_GPU,
+                         "xgmi_frac_of_exchange": (st["bytes_to_peers"] / (a2a * 1e-3) / 1e9 / XGMI_GBS_PER_GPU) if a2a else None}
     line = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -747,6 +929,10 @@ def main():
                 else:
                     line["cpu_baseline"]["port"] = port
         line["parity"] = parity or None
+        if sharded_extra:
+            line["exchange"] = sharded_extra
+            if line.get("roofline"):
+                line["roofline"]["xgmi"] = {k: sharded_extra[k] for k in ("xgmi_peak_GBs_per_gpu", "xgmi_frac_of_step", "xgmi_frac_of_exchange", "bytes_to_peers_max")}
     threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
     if rank == 0 and world == 1 and not sharded and not args.no_dist_1rank and not args.no_check:
         # the fixed cost of the sharded call, driver-visible (one rank: local work + collectives + merge)
@@ -761,8 +947,16 @@ def main():
     if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline and not args.no_ref_full and line.get("cpu_baseline") \
             and line["cpu_baseline"].get("kind") == "reference":
         ref_full_inputs = (to_host(keys), to_host(vals))
+    raw_c3_ms = dt / args.steps * 1e3
     del keys, vals, kcol, vcol
     torch.cuda.empty_cache(); ctx.trim()
+    if sharded and world > 1 and not args.no_sharded_configs:
+        try:
+            cfgs = sharded_config_legs(ctx, dev, rank, world, int(n_total * args.config_scale), max(1, min(args.steps, 5)), dist)
+        except Exception as e:
+            cfgs = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if rank == 0:
+            line["configs"] = cfgs
     if rank == 0 and world == 1 and not sharded:
         which = [c for c in args.configs.split(",") if c]
         if which:
@@ -791,6 +985,16 @@ def main():
             ref_full_inputs = None
         if args.host_rows:
             line["host_mode"] = host_mode_leg(ctx, args.host_rows)
+        if not args.no_shim_resident:
+            if budget.ok(90):
+                try:
+                    c5 = (line.get("configs") or {}).get("C5") or {}
+                    line["shim_resident"] = shim_resident_leg(max(3, min(args.steps, 10)), int(n_total * args.shim_scale), args.groups,
+                                                              int(1e9 * args.config_scale * args.shim_scale), raw_c3_ms, c5.get("ms"))
+                except Exception as e:
+                    line["shim_resident"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            else:
+                line["shim_resident"] = {"skipped": "time budget"}
         line["seconds_total"] = time.perf_counter() - budget.t0
     if rank == 0:
         print(json.dumps(line), file=json_out, flush=True)

@@ -62,6 +62,7 @@ SIGNATURES = {
                                     C.POINTER(Agg), C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "dthip_groupby_rows": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int, C.POINTER(Col), C.c_int, C.c_int64, C.c_int,
                                      C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dthip_comm_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "dthip_result_col": (C.c_void_p, [C.c_void_p, C.c_int]),
     "dthip_result_copy_col": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "dthip_result_ngroups": (C.c_int64, [C.c_void_p]),
@@ -137,8 +138,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dthip_abi_version() != 3:
-        raise ImportError("libdthip.so ABI version %d != 3" % lib.dthip_abi_version())
+    if lib.dthip_abi_version() != 4:
+        raise ImportError("libdthip.so ABI version %d != 4" % lib.dthip_abi_version())
     _lib = lib
     return lib
 

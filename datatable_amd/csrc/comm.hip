@@ -36,6 +36,7 @@
 #include <dlfcn.h>
 #include <algorithm>
 #include <rccl/rccl.h>
+#include <chrono>
 #include "common.hpp"
 #include "split_plan.hpp"
 
@@ -50,6 +51,9 @@ struct dthip_comm {
   unsigned char* ag_send = nullptr;
   unsigned char* ag_recv = nullptr;
   size_t ag_cap = 0;                  // bytes per rank
+  // what the last sharded call moved (dthip_comm_last_stats): bytes / rows of the all-to-all-v that left this rank for
+  // OTHER ranks, that stayed on it, rows received, all-gather rounds
+  int64_t st_bytes_peer = 0, st_bytes_self = 0, st_rows_sent = 0, st_rows_recv = 0, st_allgathers = 0;
 };
 
 namespace dthip {
@@ -253,10 +257,29 @@ struct Job {
   uint32_t sig = 0;                    // signature of the query this rank was called with
 };
 
+// Wall-clock phases of a sharded call, recorded next to the per-kernel times when profiling is on (dthip_profile_enable):
+// "phase_local" (this rank's own work before the first exchange), "phase_allgather" (all small host-synchronous rounds),
+// "phase_plan" (splitters, cuts, receive buffers), "phase_alltoallv", "phase_merge".  A lap synchronises the streams, so
+// it is taken only while profiling -- the timed steps of bench.py run without it.
+struct PhaseClock {
+  std::vector<Job>* jobs; bool on; std::chrono::steady_clock::time_point t;
+  explicit PhaseClock(std::vector<Job>& j) : jobs(&j), on(j[0].ctx->prof), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* name) {
+    if (!on) return;
+    for (auto& j : *jobs) { (void)hipSetDevice(j.ctx->device); (void)hipStreamSynchronize(j.ctx->stream); }
+    const auto now = std::chrono::steady_clock::now();
+    ProfAcc& a = (*jobs)[0].ctx->acc[name];
+    a.ms += std::chrono::duration<double, std::milli>(now - t).count();
+    a.n++;
+    t = now;
+  }
+};
+
 // ---- exchange primitives -------------------------------------------------------------------------
 // every job's xin (same size on all ranks) -> every job's xout = concatenation over ranks
 static int exchange_allgather(dthip_comm* comm, std::vector<Job>& jobs) {
   const size_t bytes = jobs[0].xin.size();
+  comm->st_allgathers++;
   if (comm->kind == 1) {
     for (auto& j : jobs) {
       j.xout.resize(bytes * comm->world);
@@ -281,6 +304,16 @@ static int exchange_allgather(dthip_comm* comm, std::vector<Job>& jobs) {
 
 // all-to-all-v of every column of every job (send_off / send_cnt / recv_off / recv_cnt in rows)
 static int exchange_alltoallv(dthip_comm* comm, std::vector<Job>& jobs) {
+  {
+    const Job& j = jobs[0];
+    int64_t rowb = 0;
+    for (const auto& c : j.cols) rowb += c.elem;
+    for (int p = 0; p < comm->world; p++) {
+      if (p == j.rank) comm->st_bytes_self += j.send_cnt[p] * rowb; else comm->st_bytes_peer += j.send_cnt[p] * rowb;
+      comm->st_rows_sent += j.send_cnt[p];
+    }
+    comm->st_rows_recv += j.nrecv;
+  }
   if (comm->kind == 1) {
     for (auto& s : jobs) { DTHIP_CHECK_HIP(hipSetDevice(s.ctx->device)); DTHIP_CHECK_HIP(hipStreamSynchronize(s.ctx->stream)); }
     for (auto& d : jobs) {
@@ -476,6 +509,7 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
   const int np = (int)plan.partial.size();
   std::vector<std::vector<double*>> wsum(jobs.size());
   std::vector<std::vector<dthip_col>> kd(jobs.size()), vd(jobs.size());
+  PhaseClock clock(jobs);
   // ---- 1: local combiner + quantile samples of the partial groups' first key
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const AggArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
@@ -536,8 +570,10 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
     if (j.rc == DTHIP_OK) j.rc = local();
     blob_set(j, j.rc == DTHIP_OK ? j.nimg : 0, samples.data(), sizeof(u64) * SPLIT_SAMPLES);
   }
+  clock.lap("phase_local");
   DTHIP_TRY(exchange_allgather(comm, jobs));
   DTHIP_TRY(agree(comm, jobs, "the local aggregation"));
+  clock.lap("phase_allgather");
   // ---- 2: splitters -> contiguous slabs of the (ascending) partial groups
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const AggArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
@@ -565,8 +601,10 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
     j.nsend = j.nimg;
     counts_blob(j, world);
   }
+  clock.lap("phase_plan");
   DTHIP_TRY(exchange_allgather(comm, jobs));
   DTHIP_TRY(agree(comm, jobs, "the partition of the partial groups"));
+  clock.lap("phase_allgather");
   // ---- 3: receive buffers
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const AggArgs& a = args[q];
@@ -591,9 +629,12 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
     };
     j.rc = local();
   }
+  clock.lap("phase_plan");
   DTHIP_TRY(agree_round(comm, jobs, "the allocation of the receive buffers"));
+  clock.lap("phase_allgather");
   // ---- 4: all-to-all-v of keys + partial columns
   DTHIP_TRY(exchange_alltoallv(comm, jobs));
+  clock.lap("phase_alltoallv");
   // ---- merge on the owner
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const AggArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
@@ -641,6 +682,7 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
     }
     m->nrows = a.nrows;
   }
+  clock.lap("phase_merge");
   return DTHIP_OK;
 }
 
@@ -658,6 +700,7 @@ static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std:
   const int nkeys = args[0].nkeys, ncols = args[0].ncols;
   std::vector<std::vector<dthip_col>> kd(jobs.size()), cd(jobs.size());
   std::vector<long long*> rowid(jobs.size(), nullptr);
+  PhaseClock clock(jobs);
   // ---- 1
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const RowsArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
@@ -676,8 +719,10 @@ static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std:
     if (j.rc != DTHIP_OK) { j.range = RangeAcc{~0ULL, 0ULL, 0ULL}; j.nimg = 0; }
     blob_set(j, j.nimg, &j.range, sizeof(RangeAcc));
   }
+  clock.lap("phase_local");
   DTHIP_TRY(exchange_allgather(comm, jobs));
   DTHIP_TRY(agree(comm, jobs, "the key range scan"));
+  clock.lap("phase_allgather");
   // ---- 2
   const GlobalRange g = reduce_ranges(jobs[0], world);
   for (auto& j : jobs) {
@@ -687,8 +732,10 @@ static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std:
     hist.resize(SPLIT_BINS, 0);
     blob_set(j, j.nimg, hist.data(), sizeof(u64) * SPLIT_BINS);
   }
+  clock.lap("phase_local");
   DTHIP_TRY(exchange_allgather(comm, jobs));
   DTHIP_TRY(agree(comm, jobs, "the key histogram"));
+  clock.lap("phase_allgather");
   // ---- 3: destination of every row, slabs in sender row order
   const int npay = nkeys + ncols + 1;                 // keys, columns, global row id
   for (size_t q = 0; q < jobs.size(); q++) {
@@ -732,8 +779,10 @@ static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std:
     j.nsend = a.nrows;
     counts_blob(j, world);
   }
+  clock.lap("phase_local");
   DTHIP_TRY(exchange_allgather(comm, jobs));
   DTHIP_TRY(agree(comm, jobs, "the partition of the rows"));
+  clock.lap("phase_allgather");
   // ---- 4
   for (auto& j : jobs) {
     layout_from_counts(j, world);
@@ -744,9 +793,12 @@ static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std:
     };
     j.rc = local();
   }
+  clock.lap("phase_plan");
   DTHIP_TRY(agree_round(comm, jobs, "the allocation of the receive buffers"));
+  clock.lap("phase_allgather");
   // ---- 5
   DTHIP_TRY(exchange_alltoallv(comm, jobs));
+  clock.lap("phase_alltoallv");
   // one stable local grouping of what arrived (source-rank order = global row order)
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const RowsArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
@@ -756,6 +808,7 @@ static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std:
     for (int c = 0; c <= ncols; c++) mc[c] = dthip_col{j.cols[nkeys + c].recv, j.cols[nkeys + c].stype, 0};
     DTHIP_TRY(dthip_groupby_rows(ctx, mk.data(), nkeys, mc.data(), ncols + 1, j.nrecv, a.na_pos, DTHIP_DEVICE, 0, &j.out));
   }
+  clock.lap("phase_merge");
   return DTHIP_OK;
 }
 
@@ -838,6 +891,14 @@ int dthip_comm_destroy(dthip_ctx* ctx) {
   return DTHIP_OK;
 }
 
+int dthip_comm_last_stats(const dthip_ctx* ctx, int64_t* out, int n) {
+  if (!ctx || !ctx->comm || !out || n < 1) { set_error("dthip_comm_last_stats: no communicator / bad arguments"); return DTHIP_EINVAL; }
+  const dthip_comm* c = ctx->comm;
+  const int64_t v[5] = {c->st_bytes_peer, c->st_bytes_self, c->st_rows_sent, c->st_rows_recv, c->st_allgathers};
+  for (int i = 0; i < n; i++) out[i] = i < 5 ? v[i] : 0;
+  return DTHIP_OK;
+}
+
 int dthip_comm_rank(const dthip_ctx* ctx) { return (ctx && ctx->comm) ? ctx->comm_rank : -1; }
 int dthip_comm_world(const dthip_ctx* ctx) { return (ctx && ctx->comm) ? ctx->comm->world : 0; }
 
@@ -857,6 +918,7 @@ static int sharded_agg_impl(dthip_ctx* const* ctxs, int n, const std::vector<Agg
   if (!ctxs || !outs || n < 1) { set_error("null argument"); return DTHIP_EINVAL; }
   dthip_comm* comm = ctxs[0] ? ctxs[0]->comm : nullptr;
   DTHIP_TRY(check_jobs(comm, ctxs, n));
+  comm->st_bytes_peer = comm->st_bytes_self = comm->st_rows_sent = comm->st_rows_recv = comm->st_allgathers = 0;
   for (int i = 0; i < n; i++) outs[i] = nullptr;
   AggPlan plan;
   // argument errors of ONE rank of an RCCL communicator must not make it return alone (its peers would wait for it
@@ -919,6 +981,7 @@ static int sharded_rows_impl(dthip_ctx* const* ctxs, int n, const std::vector<Ro
   if (!ctxs || !outs || n < 1) { set_error("null argument"); return DTHIP_EINVAL; }
   dthip_comm* comm = ctxs[0] ? ctxs[0]->comm : nullptr;
   DTHIP_TRY(check_jobs(comm, ctxs, n));
+  comm->st_bytes_peer = comm->st_bytes_self = comm->st_rows_sent = comm->st_rows_recv = comm->st_allgathers = 0;
   for (int i = 0; i < n; i++) outs[i] = nullptr;
   auto validate = [&](const RowsArgs& a) -> int {
     if (!a.keys || a.nkeys < 1 || a.nkeys > MAX_KEYCOLS || a.ncols < 0 || (a.ncols > 0 && !a.cols) || a.nrows < 0 || a.nrows > (int64_t)INT32_MAX) {

@@ -245,6 +245,12 @@ class _ShardMixin:
     def comm_destroy(self):
         L.check(self._lib.dthip_comm_destroy(self._h))
 
+    def comm_last_stats(self):
+        """what the last sharded call moved: dict(bytes_to_peers, bytes_to_self, rows_sent, rows_received, allgathers)"""
+        out = (C.c_int64 * 5)()
+        L.check(self._lib.dthip_comm_last_stats(self._h, out, 5))
+        return dict(zip(("bytes_to_peers", "bytes_to_self", "rows_sent", "rows_received", "allgathers"), [int(x) for x in out]))
+
     @property
     def comm_rank(self):
         return self._lib.dthip_comm_rank(self._h)

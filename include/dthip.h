@@ -52,9 +52,10 @@
 extern "C" {
 #endif
 
-#define DTHIP_ABI_VERSION 3   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10
+#define DTHIP_ABI_VERSION 4   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10
                                  3: + dthip_comm_*, dthip_sharded_groupby_* (multi-GPU inside the library), DTHIP_FLAG_NONA,
-                                    dthip_host_register / dthip_host_unregister */
+                                    dthip_host_register / dthip_host_unregister
+                                 4: + dthip_comm_last_stats; options sort_path, msd_min_rows, msd_bucket_rows, filter_path */
 
 /* error codes */
 #define DTHIP_OK        0
@@ -160,6 +161,11 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    0: only when a count() aggregate asks for group sizes -- the reference's result
  *                    Frame of DT[:, sum(f.v), by(f.k)] holds keys and sums only, and not counting rows
  *                    lets the bucketed aggregation use twice as many table slots per bucket
+ *   "sort_path"      0 / 1 (default): the sort path orders rows with stable LSD radix passes; 2: MSD levels (two stable
+ *                    scatter levels + every final bucket ordered in LDS) whenever their preconditions hold (32-bit packed
+ *                    keys, rows >= "msd_min_rows", final buckets of about "msd_bucket_rows" rows); same results, bit for bit
+ *   "filter_path"    1 (default): row filters count, then write (two reads of the predicate column); 0: one pass whose tile
+ *                    offsets come from a decoupled look-back (measured slower on MI355X; kept for A/B runs)
  *   "f32_sum"        0 (default): sum(float32 column) accumulates in float64 and rounds once (the documented deviation at
  *                    DTHIP_SUM); 1: it accumulates in float32, the valid rows of a group added one by one in grouped row
  *                    order -- bit for bit the reference's SumProd_ColumnImpl<float> (column/sumprod.h:48-55); one thread
@@ -342,6 +348,11 @@ int  dthip_comm_init(dthip_ctx* ctx, int rank, int world, const void* id);
  * on one GPU and for tests; driven with the *_local entry points below (all ranks in one call). */
 int  dthip_comm_init_local(dthip_ctx* const* ctxs, int world);
 int  dthip_comm_destroy(dthip_ctx* ctx);
+/* what the LAST sharded call on this context's communicator moved: out[0] bytes of the all-to-all-v that left this rank
+   for other ranks (the xGMI traffic), out[1] bytes that stayed on it, out[2] rows sent, out[3] rows received,
+   out[4] all-gather rounds; n = number of values wanted (<= 5).  With dthip_profile_enable the per-kernel accounting also
+   carries the wall-clock phases "phase_local", "phase_allgather", "phase_plan", "phase_alltoallv", "phase_merge". */
+int  dthip_comm_last_stats(const dthip_ctx* ctx, int64_t* out, int n);
 int  dthip_comm_rank(const dthip_ctx* ctx);     /* -1 when ctx belongs to no communicator */
 int  dthip_comm_world(const dthip_ctx* ctx);    /* 0 when ctx belongs to no communicator */
 

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--configs", default="1,2,3,4,5")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--once", action="store_true", help="evaluate every query exactly once (rocprofv3 PMC passes: counters per query)")
     ap.add_argument("--agg-path", type=int, default=0)
     ap.add_argument("--bucket-variant", type=int, default=0)
     ap.add_argument("--c5-unfused", action="store_true", help="config 5 with filter_cmp + two gathers instead of filter_take")
@@ -31,6 +32,9 @@ def main():
     g = torch.Generator(device=dev)
 
     def timed(fn):
+        if args.once:
+            t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+            return time.perf_counter() - t0, r
         fn()                                   # warm-up (allocator, first-touch)
         torch.cuda.synchronize()
         best = 1e9

@@ -101,7 +101,7 @@ def test_bench_two_ranks_end_to_end(fake_rccl):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(DTHIP_RCCL_LIB=fake_rccl, DTHIP_BENCH_ONE_GPU="1", FAKE_RCCL_DIR=os.path.dirname(fake_rccl))
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rows", "20000000", "--groups", "200000", "--steps", "2",
-                          "--warmup", "1"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+                          "--warmup", "1", "--config-scale", "0.2"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
     assert out.returncode == 0, out.stderr.decode(errors="replace")[-3000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
@@ -111,3 +111,15 @@ def test_bench_two_ranks_end_to_end(fake_rccl):
     p = line["parity"]["properties"]
     assert p["groups"] == 200_000 and p["keys_strictly_ascending_within_and_across_ranks"] and p["sum_of_group_sums_equals_sum_of_values"]
     assert line["roofline"]["kernel"] and line["cpu_baseline"] is None
+    # round 4: the N > 1 line says what crossed the fabric and where the time went, for all three multi-GPU configs
+    ex = line["exchange"]
+    assert ex["bytes_to_peers_max"] > 0 and ex["allgathers"] >= 3 and 0 < ex["xgmi_frac_of_step"] < 1
+    assert set(ex["phases_ms_rank0"]) >= {"local", "allgather", "plan", "alltoallv", "merge"}
+    assert line["roofline"]["xgmi"]["xgmi_peak_GBs_per_gpu"] == 7 * 153.0
+    assert "error" not in line["configs"], line["configs"]
+    for c in ("C4", "C5"):
+        r = line["configs"][c]
+        assert r["ms"] > 0 and r["rows_per_s"] > 0 and r["bytes_to_peers_max"] > 0 and r["groups"] > 0, (c, r)
+        assert set(r["phases_ms_rank0"]) >= {"local", "allgather", "alltoallv", "merge"}, (c, r)
+        assert 0 < r["xgmi_frac_of_step"] < 1 and r["hbm_frac"] > 0
+    assert 3_000_000 < line["configs"]["C4"]["groups"] <= 3163 * 3163        # 4e6 rows over 1e7 possible (a, b) pairs
