@@ -574,9 +574,21 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
     DTHIP_TRY(sc.get<uint32_t>((size_t)nb1 * bins2 + 1, &fstart));
     DTHIP_TRY(launch_radix_tile_hist(ctx, kB, key64, (uint32_t)n, xa.pshift[p2], xa.pbits[p2], ntiles2, hg.tpg, G2, P, gtot2, d_tdesc, d_gdesc));
     DTHIP_TRY(launch_msd_scan(ctx, gtot2, d_gfirst, base + (size_t)p1 * HIST_STRIDE, msd.s2, nb1, (uint32_t)n, fstart, d_max));
+    // windows of the final level (whole buckets, together at most one tile of rows), planned on the device
+    const uint32_t nbk = nb1 * bins2;
+    const uint32_t nwmax = (uint32_t)(n / (tile / 2)) + 2;
+    uint32_t* wplan = nullptr;
+    DTHIP_TRY(sc.get<uint32_t>((size_t)2 * (nwmax + 2) + 4, &wplan));
+    uint32_t* wbounds = wplan; uint32_t* wfirst = wplan + nwmax + 2; uint32_t* winfo = wfirst + nwmax + 2;
+    DTHIP_CHECK_HIP(hipMemsetAsync(winfo, 0, 4 * sizeof(uint32_t), ctx->stream));
+    DTHIP_TRY(launch_msd_windows(ctx, fstart, nbk, (uint32_t)n, d_max, tile, nwmax, wbounds, wfirst, winfo));
+    uint32_t wi[4] = {0, 0, 0, 0};                     // {windows, rows per window step, most buckets in a window, -}
+    DTHIP_TRY(read_back(ctx, wi, winfo, sizeof(wi)));
     uint32_t maxsize = 0;
     DTHIP_TRY(read_back(ctx, &maxsize, d_max, sizeof(maxsize)));
-    if (maxsize <= tile) {
+    static const int win_env = getenv("DTHIP_MSD_WINDOWS") ? atoi(getenv("DTHIP_MSD_WINDOWS")) : 1;   // 0: one workgroup per bucket (A/B)
+    const bool windows = win_env != 0 && wi[0] > 0 && wi[2] >= 1 && wi[2] <= 512;
+    if (windows || maxsize <= tile) {
       rp.kin = kB; rp.kout = kA;
       rp.shift = xa.pshift[p2]; rp.bits = xa.pbits[p2];
       rp.P = P; rp.gpre = gtot2; rp.tpg = hg.tpg; rp.iota = 0;
@@ -591,8 +603,28 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
       rp.ntiles = nb1 * bins2; rp.tdesc = nullptr; rp.bounds = fstart;
       static const int fb_env = getenv("DTHIP_MSD_FINAL_BLOCK") ? atoi(getenv("DTHIP_MSD_FINAL_BLOCK")) : 0;
       rp.block = (fb_env != 512 && maxsize <= tile / 2) ? 256 : 0;      // DTHIP_MSD_FINAL_BLOCK=512: A/B against the big workgroup
+      if (windows) {
+        // a bucket of ~2000 rows per workgroup leaves a CU with too few rows in flight (5.9 ms for C5's 5e8 rows); windows
+        // of several whole buckets fill the tile (3.8 ms at ~6000 rows) at the price of a second ranking round in LDS
+        rp.ntiles = wi[0]; rp.bounds = wbounds; rp.wfirst = wfirst; rp.block = 0;
+        rp.bits2 = 1;
+        while ((1u << rp.bits2) < wi[2]) rp.bits2++;
+      }
       for (int c = 0; c < pay.n; c++) { rp.pay.in[c] = pbuf[1][c]; rp.pay.out[c] = pbuf[0][c]; }
       rp.label = "msd_final_kernel";
+#ifdef DTHIP_RP_EXPERIMENT
+      if (const char* fw = getenv("DTHIP_MSD_FAKE_WINDOW")) {
+        // TIMING EXPERIMENT ONLY (wrong results): the final level over fixed windows of W rows instead of buckets
+        const uint32_t W = (uint32_t)atoi(fw);
+        std::vector<uint32_t> wb;
+        for (uint64_t r = 0; r < (uint64_t)n; r += W) wb.push_back((uint32_t)r);
+        wb.push_back((uint32_t)n);
+        uint32_t* d_wb = nullptr;
+        DTHIP_TRY(sc.get<uint32_t>(wb.size(), &d_wb));
+        DTHIP_CHECK_HIP(hipMemcpyAsync(d_wb, wb.data(), wb.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        rp.bounds = d_wb; rp.ntiles = (uint32_t)wb.size() - 1; rp.block = 0;
+      }
+#endif
       DTHIP_TRY(launch_radix_pass(ctx, rp));
       out->keys = kB;
       for (int c = 0; c < pay.n; c++) out->pay[c] = pbuf[0][c];

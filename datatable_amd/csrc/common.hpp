@@ -245,11 +245,15 @@ struct RadixPass {
   const uint32_t* bounds;
   const char* label;             // nullable: name of this launch in the per-kernel accounting (dthip_profile_*)
   int block;                     // 0 / 256: workgroup size of the final MSD level (256: buckets of <= 4096 rows)
+  const uint32_t* wfirst;        // final MSD level over windows of whole buckets (two rounds in LDS): first bucket of every window
+  int bits2;                     //   and the bits of the bucket number inside a window
 };
 uint32_t radix_tile_items(int key64, int maxpaywidth);
 int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t n, int shift, int bits,
                            uint32_t ntiles, uint32_t tpg, uint32_t G, uint32_t* P, uint32_t* gtot,
                            const uint32_t* tdesc = nullptr, const uint32_t* gdesc = nullptr);
+int launch_msd_windows(dthip_ctx* ctx, const uint32_t* fstart, uint32_t nbk, uint32_t n, const uint32_t* maxsize, uint32_t tile,
+                       uint32_t nwmax, uint32_t* wbounds, uint32_t* wfirst, uint32_t* info);
 int launch_msd_scan(dthip_ctx* ctx, uint32_t* gtot, const uint32_t* gfirst, const uint32_t* pstart, int bits, uint32_t nb,
                     uint32_t n, uint32_t* fstart, uint32_t* maxsize);
 int launch_radix_pass(dthip_ctx* ctx, const RadixPass& p);

@@ -211,6 +211,8 @@ struct PassArgsT {
   const uint32_t* tdesc;
   const uint32_t* bounds;
   int seq;
+  const uint32_t* wfirst;   // R2: first bucket of every window
+  int bits2;                // R2: bits of the bucket number inside a window
   PayCols pay;
 };
 
@@ -289,6 +291,43 @@ __global__ void __launch_bounds__(HIST_STRIDE) msd_scan_kernel(uint32_t* __restr
   if (b + 1 == nb && d == 0) fstart[(size_t)nb * bins] = n;
 }
 
+// Windows of the final MSD level: window w = the buckets whose first row lies in [w * W, (w + 1) * W), W = tile - (largest
+// bucket), hence at most one tile of rows, whole buckets only, and no bucket in two windows.  wbounds[w] = first row,
+// wfirst[w] = first bucket; info = {number of windows, W, largest number of buckets in a window}.
+__global__ void __launch_bounds__(256) msd_window_kernel(const uint32_t* __restrict__ fstart, uint32_t nbk, uint32_t n, const uint32_t* __restrict__ maxsize,
+                                                         uint32_t tile, uint32_t nwmax, uint32_t* __restrict__ wbounds, uint32_t* __restrict__ wfirst,
+                                                         uint32_t* __restrict__ info) {
+  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t mx = *maxsize;
+  if (mx > tile / 2) { if (w == 0) { info[0] = 0; info[1] = 0; info[2] = 0; } return; }
+  const uint32_t W = tile - mx;
+  const uint32_t NW = (n + W - 1) / W;
+  if (w == 0) { info[0] = NW; info[1] = W; }
+  if (w > NW || w > nwmax) return;
+  auto first_bucket = [&](uint32_t ww) -> uint32_t {
+    const unsigned long long target = (unsigned long long)ww * W;
+    if (target >= n) return nbk;
+    uint32_t lo = 0, hi = nbk;                         // first b with fstart[b] >= target
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (fstart[mid] < target) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  const uint32_t b0 = first_bucket(w);
+  wfirst[w] = b0;
+  wbounds[w] = fstart[b0];
+  if (w < NW) {
+    // buckets that hold rows: from b0 to the last bucket starting before the next window (trailing EMPTY buckets, which
+    // share their start with the next window's first bucket, do not count)
+    const uint32_t b1 = first_bucket(w + 1);
+    if (b1 > b0) atomicMax(&info[2], b1 - b0);
+  }
+}
+
+int launch_msd_windows(dthip_ctx* ctx, const uint32_t* fstart, uint32_t nbk, uint32_t n, const uint32_t* maxsize, uint32_t tile,
+                       uint32_t nwmax, uint32_t* wbounds, uint32_t* wfirst, uint32_t* info) {
+  DTHIP_LAUNCH(ctx, "msd_window_kernel", msd_window_kernel, (nwmax + 1 + 255) / 256, 256, 0, fstart, nbk, n, maxsize, tile, nwmax, wbounds, wfirst, info);
+  return DTHIP_OK;
+}
+
 int launch_msd_scan(dthip_ctx* ctx, uint32_t* gtot, const uint32_t* gfirst, const uint32_t* pstart, int bits, uint32_t nb,
                     uint32_t n, uint32_t* fstart, uint32_t* maxsize) {
   DTHIP_LAUNCH(ctx, "msd_scan_kernel", msd_scan_kernel, nb, HIST_STRIDE, 0, gtot, gfirst, pstart, bits, nb, n, fstart, maxsize);
@@ -335,6 +374,90 @@ __device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t
   }
 }
 
+// One STABLE ranking round over the workgroup's rows (the lane-mask ranking of the pass kernel as a function): on entry
+// pos is don't-care, on exit pos[i] = number of rows of the tile that precede row i in the order (digit, current row
+// order).  wh / bin_excl / misc / exch as in the pass kernel; contains barriers, all threads must call.
+// nbal > 0: the lanes of an item that share a digit are found with nbal ballot rounds instead of the LDS lane masks --
+// for a digit of FEW values (the bucket number inside a window: ~3) dozens of lanes would pile their ds_or onto one
+// address and serialise (measured: the windowed final level 5.8 ms instead of 3.8).
+template <int BLOCK, int ITEMS, int RBMAX>
+__device__ __forceinline__ void rank_round(const uint32_t (&dig)[ITEMS], uint32_t vmask, int bins, uint16_t* wh, uint32_t* bin_excl,
+                                           uint32_t* misc, unsigned char* exch, uint32_t slice_bytes, uint32_t (&pos)[ITEMS], int nbal = 0) {
+  constexpr int WAVES = BLOCK / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < WAVES * bins / 2; i += BLOCK) reinterpret_cast<uint32_t*>(wh)[i] = 0;
+  unsigned long long* mk = reinterpret_cast<unsigned long long*>(exch + (size_t)wave * slice_bytes);
+  for (int b = lane; b < bins; b += 64) mk[b] = 0ULL;
+  __syncthreads();
+  uint16_t* mywh = wh + wave * bins;
+  const unsigned long long mybit = 1ULL << lane;
+  if (nbal > 0) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const bool valid = (vmask >> i) & 1u;
+      const uint32_t d = dig[i];
+      unsigned long long m = __ballot(valid);
+      for (int b = 0; b < nbal; b++) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+      }
+      const uint32_t below = mbcnt64(m);
+      uint32_t prev = 0;
+      __builtin_amdgcn_wave_barrier();
+      if (valid) prev = __hip_atomic_load(&mywh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      pos[i] = prev + below;
+      if (valid && below == 0) __hip_atomic_store(&mywh[d], (uint16_t)(prev + (uint32_t)__popcll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  } else
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    pos[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if ((vmask >> i) & 1u) {
+      const uint32_t d = dig[i];
+      __hip_atomic_fetch_or(&mk[d], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const unsigned long long m = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const uint32_t prev = __hip_atomic_load(&mywh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      const uint32_t below = mbcnt64(m);
+      pos[i] = prev + below;
+      if (below == 0) {
+        __hip_atomic_store(&mk[d], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_store(&mywh[d], (uint16_t)(prev + (uint32_t)__popcll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int KB = (1 << RBMAX) > BLOCK ? (1 << RBMAX) / BLOCK : 1;
+  uint32_t tc[KB], tsum = 0;
+#pragma unroll
+  for (int k = 0; k < KB; k++) {
+    const int b = tid * KB + k;
+    tc[k] = 0;
+    if (b < bins) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (int w = 0; w < WAVES; w++) {
+        const uint32_t c = wh[w * bins + b];
+        wh[w * bins + b] = (uint16_t)sum;
+        sum += c;
+      }
+      tc[k] = sum;
+    }
+    tsum += tc[k];
+  }
+  uint32_t excl = block_excl_scan_u32<BLOCK>(tsum, misc, nullptr);
+#pragma unroll
+  for (int k = 0; k < KB; k++) {
+    const int b = tid * KB + k;
+    if (b < bins) { bin_excl[b] = excl; excl += tc[k]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++)
+    if ((vmask >> i) & 1u) pos[i] += bin_excl[dig[i]] + wh[wave * bins + dig[i]];
+}
+
 // RB   = number of ballot rounds (>= bits of every pass run with this instance)
 // P0W  = byte width of payload column 0 when it is prefetched with the keys (0: none / iota)
 // P1W  = the same for payload column 1 (only with P0W == 8): both columns' loads are in flight before the ranking
@@ -348,7 +471,10 @@ __device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t
 // BLK  = threads per workgroup: RP_BLOCK, or 256 for the final MSD level over small buckets (a bucket of ~2000 rows gives
 //        a 512-thread workgroup four items per wave: too few bytes in flight per CU to cover the HBM latency of its
 //        load -> rank -> store chain; four 256-thread workgroups per CU hold twice as many)
-template <typename KeyT, int RB, int P0W, int P1W = 0, int RK = 0, int BLK = RP_BLOCK>
+// R2   = final MSD level over WINDOWS (whole consecutive buckets of the last scatter level, together at most one tile):
+//        two ranking rounds in LDS -- by the low a.bits bits, then by the bucket (key >> a.bits) - wfirst[tile], a.bits2 bits
+//        -- give every row its place in the window; rows, ordered, go back over the window's own row range
+template <typename KeyT, int RB, int P0W, int P1W = 0, int RK = 0, int BLK = RP_BLOCK, bool R2 = false>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) radix_pass_kernel(PassArgsT<KeyT> a) {
   constexpr int BLOCK = BLK, ITEMS = RP_ITEMS;
   constexpr int WAVES = BLOCK / 64, TILE = BLOCK * ITEMS;
@@ -356,12 +482,13 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bins = 1 << a.bits;
   const uint32_t dmask = (uint32_t)bins - 1u;
+  const int cbins = R2 ? (1 << (a.bits > a.bits2 ? a.bits : a.bits2)) : bins;      // the LDS arrays hold the wider of the two rounds
   // per-wave digit counts as 16-bit words (a wave holds 64 x ITEMS = 1024 keys, a tile 8192): at 512 bins the
   // 32-bit form took the LDS a second workgroup per CU needs, which is what made a 9-bit pass twice as slow
   uint16_t* wh = reinterpret_cast<uint16_t*>(smem);   // [WAVES][bins] per-wave digit counts
-  uint32_t* bin_excl = reinterpret_cast<uint32_t*>(wh + WAVES * bins);   // [bins] tile-local exclusive digit start
-  uint32_t* bin_delta = bin_excl + bins;               // [bins] global start - local start
-  uint32_t* misc = bin_delta + bins;                   // [16]
+  uint32_t* bin_excl = reinterpret_cast<uint32_t*>(wh + WAVES * cbins);   // [bins] tile-local exclusive digit start
+  uint32_t* bin_delta = bin_excl + cbins;              // [bins] global start - local start
+  uint32_t* misc = bin_delta + cbins;                  // [16]
   unsigned char* exch = reinterpret_cast<unsigned char*>(misc + 16);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -436,12 +563,50 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     }
   }
 
+  uint32_t pos[ITEMS];
+  if (R2) {
+    // ---- final MSD level over a window: two stable rounds, all in LDS ----------------------------------------------
+    constexpr uint32_t SLICE = 64u * ITEMS * (uint32_t)sizeof(KeyT);
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) vmask |= (RP_VALID(i) ? 1u : 0u) << i;
+    uint32_t dg[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) dg[i] = (uint32_t)key[i] & dmask;
+    __syncthreads();                                        // (full tiles: every wave has read its transposed keys)
+    rank_round<BLOCK, ITEMS, RB>(dg, vmask, bins, wh, bin_excl, misc, exch, SLICE, pos);
+    __syncthreads();
+    // rows into round-1 order: what round 2 needs of a row is its bucket number and where it came from
+    const uint32_t c0 = a.wfirst[tile];
+    uint32_t* e32 = reinterpret_cast<uint32_t*>(exch);
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++)
+      if ((vmask >> i) & 1u) e32[pos[i]] = ((((uint32_t)(key[i] >> a.bits)) - c0) << 13) | (wbase + 64u * i);
+    __syncthreads();
+    uint32_t org[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const uint32_t w = ((vmask >> i) & 1u) ? e32[wbase + 64u * i] : 0u;
+      dg[i] = w >> 13; org[i] = w & 8191u;
+    }
+    __syncthreads();
+    rank_round<BLOCK, ITEMS, RB>(dg, vmask, 1 << a.bits2, wh, bin_excl, misc, exch, SLICE, pos, a.bits2 <= 5 ? a.bits2 : 0);
+    __syncthreads();
+    uint16_t* fin = reinterpret_cast<uint16_t*>(exch);
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++)
+      if ((vmask >> i) & 1u) fin[org[i]] = (uint16_t)pos[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) pos[i] = ((vmask >> i) & 1u) ? fin[wbase + 64u * i] : 0u;
+    for (int b = tid; b < bins; b += BLOCK) bin_delta[b] = tile_base;
+    __syncthreads();
+  } else {
   // ---- stable rank of every key among equal digits of its wave --------------
   // (the cross-lane traffic below goes through wavefront-scope relaxed atomics, not `volatile`: volatile accesses lose
   // the LDS address space and become flat_load / flat_store ... sc0 sc1 with a full vmcnt(0) wait each -- rounds 1-3
   // paid that for the 16-bit counters, 32 flat accesses per lane and tile)
   uint16_t* mywh = wh + wave * bins;
-  uint32_t pos[ITEMS];
   if (RK == 1) {
     // the wave's own slice of `exch` (its transposed keys, all read by now: DS instructions of a wave run in order)
     // becomes its table of lane masks, one 64-bit word per digit
@@ -539,13 +704,17 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
   }
   __syncthreads();
 
+  }     // !R2
+
   // ---- keys: registers -> LDS in tile-sorted order -> global ---------------
   KeyT* ek = reinterpret_cast<KeyT*>(exch);
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
     if (RP_VALID(i)) {
-      const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
-      pos[i] += bin_excl[d] + wh[wave * bins + d];
+      if (!R2) {
+        const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
+        pos[i] += bin_excl[d] + wh[wave * bins + d];
+      }
       ek[pos[i]] = key[i];
     }
   }
@@ -644,21 +813,22 @@ int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t
   return DTHIP_OK;
 }
 
-template <typename KeyT, int RB, int P0W, int P1W, int RK, int BLK = RP_BLOCK>
+template <typename KeyT, int RB, int P0W, int P1W, int RK, int BLK = RP_BLOCK, bool R2 = false>
 static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
   PassArgsT<KeyT> a;
   a.kin = static_cast<const KeyT*>(p.kin); a.kout = static_cast<KeyT*>(p.kout);
   a.n = p.n; a.shift = p.shift; a.bits = p.bits; a.P = p.P; a.gpre = p.gpre; a.tpg = p.tpg;
   a.iota = p.iota; a.pay = p.pay;
   a.tdesc = p.tdesc; a.bounds = p.bounds; a.seq = p.bounds ? 1 : 0;
+  a.wfirst = p.wfirst; a.bits2 = p.bits2;
 #ifdef DTHIP_RP_EXPERIMENT
   if (getenv("DTHIP_RP_SEQ") && atoi(getenv("DTHIP_RP_SEQ"))) a.seq = 1;      // timing experiment: wrong results
 #endif
   int maxw = (int)sizeof(KeyT);
   for (int c = 0; c < p.pay.n; c++) maxw = p.pay.width[c] > maxw ? p.pay.width[c] : maxw;
-  const int bins = 1 << p.bits;
+  const int bins = 1 << (R2 && p.bits2 > p.bits ? p.bits2 : p.bits);
   const size_t lds = (size_t)(BLK / 64) * bins * 2 + (size_t)(2 * bins + 16) * 4 + (size_t)(BLK * RP_ITEMS) * maxw;
-  auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W, RK, BLK>;
+  auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W, RK, BLK, R2>;
   DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
   const uint32_t ntiles = p.ntiles ? p.ntiles : (p.n + RP_TILE - 1) / RP_TILE;
   DTHIP_LAUNCH(ctx, (p.label ? p.label : "radix_pass_kernel"), kfn, ntiles, BLK, lds, a);
@@ -669,6 +839,10 @@ static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
 template <typename KeyT, int RB, int P0W, int P1W = 0>
 static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
   static const int rank = getenv("DTHIP_RP_RANK") ? atoi(getenv("DTHIP_RP_RANK")) : 1;
+  if (p.wfirst) {        // final MSD level over windows: two rounds in LDS (4-byte keys, digits of <= 9 bits)
+    if (sizeof(KeyT) != 4 || RB != 9) { set_error("radix pass: the windowed final level takes 4-byte keys"); return DTHIP_EINVAL; }
+    return launch_pass_r<uint32_t, 9, P0W, P1W, 1, RP_BLOCK, true>(ctx, p);
+  }
   if (p.block == 256 && sizeof(KeyT) == 4) return launch_pass_r<uint32_t, RB, P0W, P1W, 1, 256>(ctx, p);   // final MSD level, small buckets
   if (rank == 0) return launch_pass_r<KeyT, RB, P0W, P1W, 0>(ctx, p);
 #ifdef DTHIP_RP_EXPERIMENT
@@ -693,7 +867,7 @@ static int launch_pass_k(dthip_ctx* ctx, const RadixPass& p) {
     if (p0w == 4) return launch_pass_r<uint32_t, 10, 4, 0, 0>(ctx, p);
     return launch_pass_r<uint32_t, 10, 0, 0, 0>(ctx, p);
   }
-  if (p.bits > 8) {
+  if (p.bits > 8 || p.wfirst) {
     if (p0w == 8 && p1w == 8) return launch_pass_t<KeyT, 9, 8, 8>(ctx, p);
     if (p0w == 8 && p1w == 4) return launch_pass_t<KeyT, 9, 8, 4>(ctx, p);
     if (p0w == 8) return launch_pass_t<KeyT, 9, 8>(ctx, p);
