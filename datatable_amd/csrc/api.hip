@@ -378,9 +378,12 @@ struct PaySpec {
   const void* in[MAX_PAYCOLS];
   int width[MAX_PAYCOLS];
   bool iota = false;            // column 0 is the row number
+  // single int32 / int64 key whose column is wanted in sorted order: the last pass writes its ORIGINAL values here
+  void* ukey_out = nullptr;
 };
 
 struct SortOut {
+  bool ukey_done = false;       // PaySpec::ukey_out was filled (then `keys` is NOT: the last pass wrote the original values instead)
   void* keys = nullptr;         // sorted packed keys (scratch-owned)
   int key64 = 0;
   void* pay[MAX_PAYCOLS];       // sorted payload columns (scratch-owned, or the input itself if nothing moved)
@@ -517,6 +520,7 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
       pbuf[1][c] = b1;
     }
   }
+  out->ukey_done = false;
   if (use_msd) {
     // ---- level 1: stable scatter by the top s1 bits (regular tiles) ------------------------------------------------
     const int p1 = 2, p2 = 1;
@@ -611,6 +615,12 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
         while ((1u << rp.bits2) < wi[2]) rp.bits2++;
       }
       for (int c = 0; c < pay.n; c++) { rp.pay.in[c] = pbuf[1][c]; rp.pay.out[c] = pbuf[0][c]; }
+      if (pay.ukey_out) {
+        const KeyColDev& kc = plan.col[plan.stage_first[stage]];
+        rp.ukout = pay.ukey_out; rp.uk_stype = kc.stype; rp.uk_desc = kc.desc; rp.uk_bits = bits;
+        rp.uk_edge = kc.edge; rp.uk_na_repl = kc.na_repl; rp.uk_inc = kc.inc;
+        out->ukey_done = true;
+      }
       rp.label = "msd_final_kernel";
 #ifdef DTHIP_RP_EXPERIMENT
       if (const char* fw = getenv("DTHIP_MSD_FAKE_WINDOW")) {
@@ -635,6 +645,7 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
     if (msd.rb > 9) { set_error("MSD levels with a 10-bit final digit (experiment) cannot fall back"); return DTHIP_ENOTIMPL; }
   }
   unsigned char* kin = kA; unsigned char* kout = kB;
+  out->ukey_done = false;
   for (int i = 0; i < nactive; i++) {
     const int p = active[i];
     hg.F = 1u << xa.pbits[p];
@@ -646,6 +657,16 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
     rp.shift = xa.pshift[p]; rp.bits = xa.pbits[p];
     rp.P = P; rp.gpre = gtot; rp.tpg = hg.tpg;
     rp.iota = (i == 0 && pay.iota) ? 1 : 0;
+    // (measured on C5: in an LSD pass the 8-byte key values are scattered runs like every other column -- the last pass
+    // got 1.05 ms slower and the group scan reads 8 instead of 4 bytes (+0.43), which eats the 1.52 ms of the untransform
+    // pass; the final MSD level writes in place and keeps 0.7 ms of it.  DTHIP_FUSE_UKEY=2 forces it here for A/B runs)
+    static const bool fuse_lsd = getenv("DTHIP_FUSE_UKEY") && atoi(getenv("DTHIP_FUSE_UKEY")) == 2;
+    if (i == nactive - 1 && pay.ukey_out && fuse_lsd) {
+      const KeyColDev& kc = plan.col[plan.stage_first[stage]];
+      rp.ukout = pay.ukey_out; rp.uk_stype = kc.stype; rp.uk_desc = kc.desc; rp.uk_bits = bits;
+      rp.uk_edge = kc.edge; rp.uk_na_repl = kc.na_repl; rp.uk_inc = kc.inc;
+      out->ukey_done = true;
+    }
     rp.pay.n = pay.n;
     for (int c = 0; c < pay.n; c++) {
       rp.pay.in[c] = (i == 0) ? pay.in[c] : pbuf[(i - 1) & 1][c];
@@ -1723,6 +1744,16 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
         slot[c] = ps.n;
         ps.in[ps.n] = cd[c].data; ps.width[ps.n] = stype_size(cd[c].stype); ps.n++;
       }
+      // one int32 / int64 key that is also a wanted column: the last pass writes its original values (no untransform pass)
+      static const bool fuse_ukey = !(getenv("DTHIP_FUSE_UKEY") && atoi(getenv("DTHIP_FUSE_UKEY")) == 0);
+      int ukc = -1;
+      if (fuse_ukey && nkeys == 1 && (kd[0].stype == DTHIP_INT64 || kd[0].stype == DTHIP_INT32))
+        for (int c = 0; c < ncols; c++) if (is_key[c] == 0) { ukc = c; break; }
+      if (ukc >= 0) {
+        void* q = nullptr;
+        if ((rc = result_alloc(ctx, res, (size_t)nrows * stype_size(kd[0].stype), &q)) != DTHIP_OK) break;
+        ps.ukey_out = q;
+      }
       rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so);
       if (rc == DTHIP_RETRY_EXACT) {
         // the sampled key range did not hold, so real keys lie OUTSIDE it: the exact range is usually WIDER, and with
@@ -1734,12 +1765,30 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
       if (rc != DTHIP_OK) break;
     }
     if (ride) {
+      if (so.ukey_done) {
+        // groups = runs of equal ORIGINAL key values (the transform is a bijection, NA <-> NA)
+        if ((rc = heads_to_offsets(ctx, sc, res, ps.ukey_out, kd[0].stype == DTHIP_INT64, nullptr, nrows, &g)) != DTHIP_OK) break;
+      } else
       if ((rc = heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, nrows, &g)) != DTHIP_OK) break;
       if (want_rowindex) { result_adopt(sc, res, so.pay[0]); res->rowindex = static_cast<int32_t*>(so.pay[0]); }
+      bool ukey_used = false;
       for (int c = 0; c < ncols && rc == DTHIP_OK; c++) {
         if (is_key[c] >= 0) {
           void* q = nullptr;
-          if ((rc = result_alloc(ctx, res, (size_t)nrows * stype_size(cd[c].stype), &q)) != DTHIP_OK) break;
+          if (so.ukey_done && ps.ukey_out && res->col[c] == nullptr && is_key[c] == 0) {
+            // the first copy of the key column is the buffer the last pass filled; further copies are duplicated from it
+            bool first = true;
+            for (int c2 = 0; c2 < c; c2++) if (is_key[c2] == 0) first = false;
+            if (first) { res->col[c] = ps.ukey_out; continue; }
+            const size_t bytes = (size_t)nrows * stype_size(cd[c].stype);
+            if ((rc = result_alloc(ctx, res, bytes, &q)) != DTHIP_OK) break;
+            if (hipMemcpyAsync(q, ps.ukey_out, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { set_error("D2D copy failed"); rc = DTHIP_EDEVICE; break; }
+            res->col[c] = q;
+            continue;
+          }
+          if (so.ukey_done) { set_error("groupby_rows: internal: packed keys missing"); rc = DTHIP_EDEVICE; break; }
+          if (ps.ukey_out && is_key[c] == 0 && !ukey_used) { q = ps.ukey_out; ukey_used = true; }      // the buffer set aside for the last pass
+          else if ((rc = result_alloc(ctx, res, (size_t)nrows * stype_size(cd[c].stype), &q)) != DTHIP_OK) break;
           rc = launch_untransform_keys(ctx, so.keys, so.key64, nullptr, nrows, plan.col[is_key[c]], plan.nsig[is_key[c]], q);
           res->col[c] = q;
           continue;

@@ -247,6 +247,9 @@ struct RadixPass {
   int block;                     // 0 / 256: workgroup size of the final MSD level (256: buckets of <= 4096 rows)
   const uint32_t* wfirst;        // final MSD level over windows of whole buckets (two rounds in LDS): first bucket of every window
   int bits2;                     //   and the bits of the bucket number inside a window
+  // last pass only: write the original values of ONE int32 / int64 key column here instead of the packed keys
+  void* ukout; int uk_stype; int uk_desc; int uk_bits;
+  unsigned long long uk_edge, uk_na_repl, uk_inc;
 };
 uint32_t radix_tile_items(int key64, int maxpaywidth);
 int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t n, int shift, int bits,

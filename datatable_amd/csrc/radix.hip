@@ -213,6 +213,10 @@ struct PassArgsT {
   int seq;
   const uint32_t* wfirst;   // R2: first bucket of every window
   int bits2;                // R2: bits of the bucket number inside a window
+  // last pass of a single-key sort whose key column is wanted in sorted order: the ORIGINAL key values (int32 / int64)
+  // are written instead of the packed transformed keys (saves the untransform pass: 4 B read + 8 B written per row)
+  void* ukout; int uk_stype; int uk_desc; int uk_bits;
+  unsigned long long uk_edge, uk_na_repl, uk_inc;
   PayCols pay;
 };
 
@@ -734,7 +738,26 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
       gp[j] = bin_delta[d] + s0 + j;
       gpos[g * 4 + j] = gp[j];
     }
-    if (nv) store_group4<KeyT>(a.kout, gp, kk, nv);
+    if (a.ukout) {
+      // inverse of the integer key transform (sort.cc:728-776), as in group.hip's untransform_kernel
+      long long uv[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        unsigned long long k = (unsigned long long)kk[j];
+        if (a.uk_bits < 64) k &= (1ULL << a.uk_bits) - 1ULL;
+        const unsigned long long u = a.uk_desc ? a.uk_edge - (k - a.uk_inc) : (k - a.uk_inc) + a.uk_edge;
+        uv[j] = (k == a.uk_na_repl) ? (a.uk_stype == DTHIP_INT64 ? (long long)INT64_MIN : (long long)INT32_MIN) : (long long)u;
+      }
+      if (nv) {
+        if (a.uk_stype == DTHIP_INT64) store_group4<long long>(static_cast<long long*>(a.ukout), gp, uv, nv);
+        else {
+          uint32_t u4[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) u4[j] = (uint32_t)(int32_t)uv[j];
+          store_group4<uint32_t>(static_cast<uint32_t*>(a.ukout), gp, u4, nv);
+        }
+      }
+    } else if (nv) store_group4<KeyT>(a.kout, gp, kk, nv);
   }
 
   // ---- payload columns follow the same permutation --------------------------
@@ -821,6 +844,8 @@ static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
   a.iota = p.iota; a.pay = p.pay;
   a.tdesc = p.tdesc; a.bounds = p.bounds; a.seq = p.bounds ? 1 : 0;
   a.wfirst = p.wfirst; a.bits2 = p.bits2;
+  a.ukout = p.ukout; a.uk_stype = p.uk_stype; a.uk_desc = p.uk_desc; a.uk_bits = p.uk_bits;
+  a.uk_edge = p.uk_edge; a.uk_na_repl = p.uk_na_repl; a.uk_inc = p.uk_inc;
 #ifdef DTHIP_RP_EXPERIMENT
   if (getenv("DTHIP_RP_SEQ") && atoi(getenv("DTHIP_RP_SEQ"))) a.seq = 1;      // timing experiment: wrong results
 #endif

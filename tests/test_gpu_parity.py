@@ -519,6 +519,38 @@ def test_speculative_key_range_on_the_sort_path(ctx):
         ctx.set_option("spec_min_rows", 1 << 23)
 
 
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+def test_rows_key_column_written_by_the_last_pass(ctx, dtype):
+    """dthip_groupby_rows with ONE int32 / int64 key that is also a wanted column: the last radix pass writes the original key
+    values itself (round 4; no untransform pass, groups found on that column) -- ascending / descending, NA first / last,
+    the key wanted twice, a constant key (no pass runs: the untransform path), on both sort paths"""
+    rng = np.random.default_rng(92)
+    n = 400_000
+    lim = 2**40 if dtype == np.int64 else 2**20
+    k = rng.integers(-lim // 3, lim, n).astype(dtype)
+    k[rng.random(n) < 0.02] = np.iinfo(dtype).min
+    x = rng.standard_normal(n)
+    w = rng.integers(-5, 5, n).astype(np.int32)
+    for sp in (1, 2):
+        ctx.set_option("sort_path", sp); ctx.set_option("msd_min_rows", 1)
+        try:
+            for desc in (False, True):
+                for na_last in (False, True):
+                    ri, off = o.group([k], desc=[desc], na_last=na_last)
+                    for cols in ([k, x], [x, k, w, k], [k]):
+                        r = ctx.groupby_rows([k], cols, desc=[desc], na_last=na_last, want_rowindex=True)
+                        assert_same(r.offsets(), off, "offsets"); assert_same(r.rowindex(), ri, "rowindex")
+                        for c, col in enumerate(cols):
+                            assert_same(r.col(c), col[ri], "column %d (sort_path %d, desc %s, na_last %s)" % (c, sp, desc, na_last))
+                        r.free()
+            kc = np.full(1000, 7, dtype)
+            r = ctx.groupby_rows([kc], [kc, x[:1000]], want_rowindex=False)
+            assert r.ngroups == 1 and np.array_equal(r.col(0), kc) and np.array_equal(r.col(1), x[:1000])
+            r.free()
+        finally:
+            ctx.set_option("sort_path", 0); ctx.set_option("msd_min_rows", 1 << 26)
+
+
 def _unsampled_rows(n, elem_bytes, want, nsamp=1 << 17):
     """rows that stats.hip::minmax_sample_kernel does NOT read (nsamp evenly spaced 16-byte pieces + the last piece)"""
     e = 16 // elem_bytes
