@@ -230,8 +230,10 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_tile_hist_kernel(const KeyT* _
   __shared__ uint32_t cnt[HIST_STRIDE];
   const int tid = threadIdx.x;
   const uint32_t bins = 1u << bits, dmask = bins - 1u;
-  uint32_t run = 0;
-  if (tid < HIST_STRIDE) cnt[tid] = 0;
+  constexpr int HK = (HIST_STRIDE + RP_BLOCK - 1) / RP_BLOCK;      // bins per thread (1 unless the tile has fewer threads than bins)
+  uint32_t run[HK];
+#pragma unroll
+  for (int k = 0; k < HK; k++) { run[k] = 0; if (tid + k * RP_BLOCK < HIST_STRIDE) cnt[tid + k * RP_BLOCK] = 0; }
   __syncthreads();
   uint32_t t0 = blockIdx.x * tpg, t1 = (t0 + tpg < ntiles) ? t0 + tpg : ntiles;
   if (gdesc) { t0 = gdesc[2 * blockIdx.x]; t1 = t0 + gdesc[2 * blockIdx.x + 1]; }
@@ -254,15 +256,23 @@ __global__ void __launch_bounds__(RP_BLOCK) radix_tile_hist_kernel(const KeyT* _
       for (uint32_t i = tid; i < nvalid; i += RP_BLOCK) (void)lds_count_rank(cnt, (uint32_t)(keys[tile_base + i] >> shift) & dmask);
     }
     __syncthreads();
-    if ((uint32_t)tid < bins) {
-      const uint32_t c = cnt[tid];
-      cnt[tid] = 0;
-      P[(size_t)t * bins + tid] = run;
-      run += c;
+#pragma unroll
+    for (int k = 0; k < HK; k++) {
+      const uint32_t b = (uint32_t)tid + (uint32_t)k * RP_BLOCK;
+      if (b < bins) {
+        const uint32_t c = cnt[b];
+        cnt[b] = 0;
+        P[(size_t)t * bins + b] = run[k];
+        run[k] += c;
+      }
     }
     __syncthreads();
   }
-  if ((uint32_t)tid < bins) gtot[(size_t)blockIdx.x * bins + tid] = run;
+#pragma unroll
+  for (int k = 0; k < HK; k++) {
+    const uint32_t b = (uint32_t)tid + (uint32_t)k * RP_BLOCK;
+    if (b < bins) gtot[(size_t)blockIdx.x * bins + b] = run[k];
+  }
 }
 
 // MSD level below the first: the groups of parent bucket b are [gfirst[b], gfirst[b+1]).  One workgroup per parent
@@ -432,7 +442,7 @@ __device__ __forceinline__ void rank_round(const uint32_t (&dig)[ITEMS], uint32_
     }
   }
   __syncthreads();
-  constexpr int KB = (1 << RBMAX) > BLOCK ? (1 << RBMAX) / BLOCK : 1;
+  constexpr int KB = ((1 << RBMAX) + BLOCK - 1) / BLOCK;
   uint32_t tc[KB], tsum = 0;
 #pragma unroll
   for (int k = 0; k < KB; k++) {
@@ -678,7 +688,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
 
   // ---- per-digit: wave offsets, tile count, global position of the run ----------
   // (KB consecutive digits per thread: 1 unless the workgroup has fewer threads than bins)
-  constexpr int KB = (1 << RB) > BLOCK ? (1 << RB) / BLOCK : 1;
+  constexpr int KB = ((1 << RB) + BLOCK - 1) / BLOCK;
   uint32_t tc[KB], tsum = 0;
 #pragma unroll
   for (int k = 0; k < KB; k++) {

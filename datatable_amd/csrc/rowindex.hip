@@ -169,13 +169,35 @@ int launch_compact(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* out, i
 // DT[f.x > 0, cols] materialised (init_from_boolean_column + _materialize_fw of every column through
 // the new RowIndex, rowindex_array.cc:130-170, column_impl.cc:78-101).  The columns are read
 // sequentially next to the predicate column instead of being gathered through the finished RowIndex.
+// PV8: the predicate column is an 8-byte column (float64 / int64, not a mask): its values stay in registers after the
+// predicate is evaluated, and a taken column that IS the predicate column (DT[f.x > 0, :] takes x) is written from them --
+// round 3 loaded it a second time, and the PMC passes showed those 8 GB per 1e9 rows coming from HBM again, not from L2
+// (compact_take_kernel: 24 GB fetched for 16 GB of input, profiles/r04_c5_pmc.txt)
+template <bool PV8>
 __global__ void __launch_bounds__(CP_BLOCK) compact_take_kernel(PredArgs p, uint32_t n, const uint32_t* tile_base,
                                                                 int32_t* out_ri, TakeCols tc) {
   __shared__ uint32_t wc[CP_BLOCK / 64];
   const int lane = lane_id(), wave = wave_id();
   const uint32_t wave_base = blockIdx.x * CP_TILE + wave * (64 * CP_ITEMS);
-  uint32_t cnt;
-  const uint32_t bits = sweep_pred(p, n, wave_base, &cnt);
+  uint32_t cnt = 0, bits = 0;
+  unsigned long long pv[PV8 ? CP_ITEMS : 1];
+  if (PV8) {
+    const unsigned long long* px = static_cast<const unsigned long long*>(p.data);
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; k++) {
+      const uint32_t idx = wave_base + 64u * k + lane;
+      pv[k] = idx < n ? px[idx] : 0ULL;
+    }
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; k++) {
+      const uint32_t idx = wave_base + 64u * k + lane;
+      const bool f = idx < n && pred_val8(p, pv[k]);
+      bits |= (uint32_t)f << k;
+      cnt += (uint32_t)__popcll(__ballot(f));
+    }
+  } else {
+    bits = sweep_pred(p, n, wave_base, &cnt);
+  }
   if (lane == 0) wc[wave] = cnt;
   __syncthreads();
   uint32_t running = tile_base[blockIdx.x];
@@ -188,6 +210,7 @@ __global__ void __launch_bounds__(CP_BLOCK) compact_take_kernel(PredArgs p, uint
       const uint32_t src = wave_base + 64u * k + lane, dst = running + mbcnt64(bal);
       if (out_ri) out_ri[dst] = (int32_t)src;
       for (int c = 0; c < tc.n; c++) {
+        if (PV8 && tc.in[c] == p.data) { static_cast<unsigned long long*>(tc.out[c])[dst] = pv[k]; continue; }
         switch (tc.width[c]) {
           case 8: static_cast<unsigned long long*>(tc.out[c])[dst] = static_cast<const unsigned long long*>(tc.in[c])[src]; break;
           case 4: static_cast<uint32_t*>(tc.out[c])[dst] = static_cast<const uint32_t*>(tc.in[c])[src]; break;
@@ -210,7 +233,9 @@ int launch_compact_take(dthip_ctx* ctx, const PredArgs& p, int64_t n, int32_t* o
   DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, &tile_counts));
   DTHIP_LAUNCH(ctx, "compact_count_kernel", compact_count_kernel, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts);
   DTHIP_TRY(launch_scan_tiles(ctx, tile_counts, nt, tile_counts + nt));
-  DTHIP_LAUNCH(ctx, "compact_take_kernel", compact_take_kernel, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts, out_ri, tc);
+  const bool pv8 = !p.is_mask && (p.stype == DTHIP_FLOAT64 || p.stype == DTHIP_INT64);
+  if (pv8) { DTHIP_LAUNCH(ctx, "compact_take_kernel", compact_take_kernel<true>, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts, out_ri, tc); }
+  else { DTHIP_LAUNCH(ctx, "compact_take_kernel", compact_take_kernel<false>, nt, CP_BLOCK, 0, p, (uint32_t)n, tile_counts, out_ri, tc); }
   uint32_t total = 0;
   DTHIP_TRY(read_back(ctx, &total, tile_counts + nt, sizeof(total)));
   *nout_host = total;

@@ -646,6 +646,9 @@ def _threshold(frame, expr, ci, op, text):
     return ("ge" if up else "le", t.item())
 
 
+_TH_CACHE = {}
+
+
 def match_filter(frame, item):
     """DT[f.col <cmp> scalar, cols] -> (predicate column, ("ge"|"le"|"eq"|..., value), selected columns) or None"""
     if not (isinstance(item, tuple) and len(item) == 2):
@@ -660,10 +663,20 @@ def match_filter(frame, item):
     cols = _jcols(frame, j)
     if ci is None or cols is None or not cols or not _accel(frame, cols + [ci]) or frame.nrows == 0:
         return None
-    try:
-        th = _threshold(frame, i, ci, m.group(2), m.group(3))
-    except Exception:
-        return None
+    # the probing costs ~3 ms of reference evaluations: remembered per predicate OBJECT (the repr cannot be the key -- it
+    # prints six decimals, two different scalars may print alike) and per stype of the column it was probed on
+    ck = (id(i), frame.stypes[ci].value, m.group(2), m.group(3))
+    hit = _TH_CACHE.get(ck)
+    if hit is not None and hit[0] is i:
+        th = hit[1]
+    else:
+        try:
+            th = _threshold(frame, i, ci, m.group(2), m.group(3))
+        except Exception:
+            return None
+        if len(_TH_CACHE) >= 64:
+            _TH_CACHE.pop(next(iter(_TH_CACHE)))
+        _TH_CACHE[ck] = (i, th)              # holding the object keeps its id() from being reused
     return None if th is None else (ci, th, cols)
 
 
