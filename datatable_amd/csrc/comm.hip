@@ -500,8 +500,9 @@ struct AggArgs {
 //      that partial sums cross the fabric unrounded (the single-GPU path accumulates float32 sums in float64 and
 //      rounds once; rounding every partial to float32 first would differ by more than a re-association);
 //      1024 local quantiles of the first key's image                          -> all-gather A
-//   2  splitters (same on every rank), cuts of the ascending partials          -> all-gather B (send counts)
-//   3  receive buffers                                                         -> all-gather C (status only)
+//   2  splitters (same on every rank), cuts of the ascending partials, receive buffers of the splitters' guaranteed
+//      bound                                                                   -> all-gather B (send counts + status)
+//   3  exact layout; only if a share exceeds the bound (every rank sees that): exact buffers -> all-gather C (status)
 //   4  all-to-all-v of keys + partial columns, merge on the owner
 static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::vector<AggArgs>& args, const AggPlan& plan) {
   const int world = comm->world;
@@ -575,6 +576,30 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
   DTHIP_TRY(agree(comm, jobs, "the local aggregation"));
   clock.lap("phase_allgather");
   // ---- 2: splitters -> contiguous slabs of the (ascending) partial groups
+  int64_t recv_bound = 0;
+  {
+    long long total = 0;
+    for (int r = 0; r < world; r++) total += hdr_of(jobs[0], r).n;
+    recv_bound = total / world + total / SPLIT_SAMPLES + 2 * (int64_t)world + 16;
+  }
+  auto alloc_recv = [&](size_t q, int64_t rows) -> int {
+    Job& j = jobs[q]; const AggArgs& a = args[q];
+    j.cols.clear();
+    for (int k = 0; k < nkeys; k++) {
+      XCol c; c.stype = a.keys[k].stype; c.elem = stype_size(c.stype); c.send = j.local->key[k];
+      unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)rows * c.elem + 16, &r)); c.recv = r;
+      j.cols.push_back(c);
+    }
+    for (int i = 0; i < np; i++) {
+      XCol c;
+      if (plan.partial[i].op == DTHIP_MEAN) { c.stype = DTHIP_FLOAT64; c.send = wsum[q][i]; }
+      else { c.stype = j.local->agg_stype[i]; c.send = j.local->agg[i]; }
+      c.elem = stype_size(c.stype);
+      unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)rows * c.elem + 16, &r)); c.recv = r;
+      j.cols.push_back(c);
+    }
+    return DTHIP_OK;
+  };
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const AggArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
     std::vector<u64> smp((size_t)world * SPLIT_SAMPLES);
@@ -595,7 +620,11 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
         DTHIP_TRY(read_back(ctx, cuts.data() + 1, d_c, sizeof(uint32_t) * (world - 1)));
       }
       for (int k = 0; k < world; k++) { j.send_off[k] = cuts[k]; j.send_cnt[k] = (int64_t)cuts[k + 1] - (int64_t)cuts[k]; }
-      return DTHIP_OK;
+      // receive buffers BEFORE the send counts are known (round 4: saves the status-only all-gather that used to follow
+      // their allocation): quantile splitters give a rank at most its fair share + total / SPLIT_SAMPLES partial groups
+      // + the <= world partials that share a boundary key (split_plan.hpp::sample_bounds) -- the same number on every
+      // rank, checked against the exact counts after the next all-gather
+      return alloc_recv(q, recv_bound);
     };
     j.rc = local();
     j.nsend = j.nimg;
@@ -603,35 +632,27 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
   }
   clock.lap("phase_plan");
   DTHIP_TRY(exchange_allgather(comm, jobs));
-  DTHIP_TRY(agree(comm, jobs, "the partition of the partial groups"));
+  DTHIP_TRY(agree(comm, jobs, "the partition of the partial groups / the allocation of the receive buffers"));
   clock.lap("phase_allgather");
-  // ---- 3: receive buffers
-  for (size_t q = 0; q < jobs.size(); q++) {
-    Job& j = jobs[q]; const AggArgs& a = args[q];
-    layout_from_counts(j, world);
-    auto local = [&]() -> int {
-      DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device));
-      j.cols.clear();
-      for (int k = 0; k < nkeys; k++) {
-        XCol c; c.stype = a.keys[k].stype; c.elem = stype_size(c.stype); c.send = j.local->key[k];
-        unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r;
-        j.cols.push_back(c);
-      }
-      for (int i = 0; i < np; i++) {
-        XCol c;
-        if (plan.partial[i].op == DTHIP_MEAN) { c.stype = DTHIP_FLOAT64; c.send = wsum[q][i]; }
-        else { c.stype = j.local->agg_stype[i]; c.send = j.local->agg[i]; }
-        c.elem = stype_size(c.stype);
-        unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r;
-        j.cols.push_back(c);
-      }
-      return DTHIP_OK;
-    };
-    j.rc = local();
+  // ---- 3: exact receive layout; every rank sees the whole count matrix, so all ranks agree WITHOUT another round on
+  // whether somebody's share exceeds the bound (then: exact buffers and the status round of rounds 2-3)
+  bool exceeded = false;
+  for (auto& j : jobs) layout_from_counts(j, world);
+  for (int r = 0; r < world; r++) {
+    int64_t recv_r = 0;
+    for (int s_ = 0; s_ < world; s_++) { int64_t c = 0; memcpy(&c, blob_of(jobs[0], s_) + sizeof(int64_t) * (size_t)r, sizeof(c)); recv_r += c; }
+    if (recv_r > recv_bound) exceeded = true;
   }
-  clock.lap("phase_plan");
-  DTHIP_TRY(agree_round(comm, jobs, "the allocation of the receive buffers"));
-  clock.lap("phase_allgather");
+  if (exceeded) {
+    for (size_t q = 0; q < jobs.size(); q++) {
+      Job& j = jobs[q];
+      auto local = [&]() -> int { DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device)); return alloc_recv(q, j.nrecv); };
+      j.rc = local();
+    }
+    clock.lap("phase_plan");
+    DTHIP_TRY(agree_round(comm, jobs, "the allocation of the receive buffers"));
+    clock.lap("phase_allgather");
+  }
   // ---- 4: all-to-all-v of keys + partial columns
   DTHIP_TRY(exchange_alltoallv(comm, jobs));
   clock.lap("phase_alltoallv");

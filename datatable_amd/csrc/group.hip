@@ -393,9 +393,51 @@ __global__ void __launch_bounds__(256) untransform_kernel(UntransformArgs a) {
   }
 }
 
+// The streaming case of the above (every row, no offsets): 32-bit packed keys -> an int64 column, FOUR consecutive rows per
+// thread: one 16-byte load, two 16-byte stores (the one-row-per-thread form moved 6 GB per 5e8 rows at 4.0 TB/s)
+typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) untransform_u32_i64_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, int bits, int desc,
+                                                                  unsigned long long edge, unsigned long long na_repl, unsigned long long inc,
+                                                                  long long* __restrict__ out) {
+  typedef unsigned long long u64;
+  const uint32_t g4 = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t r0 = g4 * 4u;
+  if (r0 >= n) return;
+  const u64 mask = bits < 64 ? (1ULL << bits) - 1ULL : ~0ULL;
+  if (r0 + 4u <= n) {
+    const gu32x4 w = *reinterpret_cast<const gu32x4*>(keys + r0);
+    const uint32_t kk[4] = {w.x, w.y, w.z, w.w};
+    long long v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const u64 k = ((u64)kk[j] >> shift) & mask;
+      const u64 u = desc ? edge - (k - inc) : (k - inc) + edge;
+      v[j] = (k == na_repl) ? (long long)INT64_MIN : (long long)u;
+    }
+    gu32x4 o0, o1;
+    o0.x = (uint32_t)v[0]; o0.y = (uint32_t)((u64)v[0] >> 32); o0.z = (uint32_t)v[1]; o0.w = (uint32_t)((u64)v[1] >> 32);
+    o1.x = (uint32_t)v[2]; o1.y = (uint32_t)((u64)v[2] >> 32); o1.z = (uint32_t)v[3]; o1.w = (uint32_t)((u64)v[3] >> 32);
+    gu32x4* op = reinterpret_cast<gu32x4*>(out + r0);
+    op[0] = o0; op[1] = o1;
+  } else {
+    for (uint32_t r = r0; r < n; r++) {
+      const u64 k = ((u64)keys[r] >> shift) & mask;
+      const u64 u = desc ? edge - (k - inc) : (k - inc) + edge;
+      out[r] = (k == na_repl) ? (long long)INT64_MIN : (long long)u;
+    }
+  }
+}
+
 int launch_untransform_keys(dthip_ctx* ctx, const void* sorted_keys, int key64, const int32_t* offsets,
                             int64_t ngroups, const KeyColDev& col, int bits, void* out) {
   if (ngroups == 0) return DTHIP_OK;
+  if (!offsets && !key64 && col.stype == DTHIP_INT64 && ngroups >= 4096 &&
+      ((reinterpret_cast<uintptr_t>(sorted_keys) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const unsigned grid = (unsigned)((ngroups + 1023) / 1024);
+    DTHIP_LAUNCH(ctx, "untransform_kernel", untransform_u32_i64_kernel, grid, 256, 0, static_cast<const uint32_t*>(sorted_keys), (uint32_t)ngroups,
+                 col.shift, bits, col.desc, col.edge, col.na_repl, col.inc, static_cast<long long*>(out));
+    return DTHIP_OK;
+  }
   UntransformArgs a;
   a.keys = sorted_keys; a.key64 = key64; a.offsets = offsets; a.ngroups = (uint32_t)ngroups;
   a.stype = col.stype; a.desc = col.desc; a.edge = col.edge; a.na_repl = col.na_repl; a.inc = col.inc;

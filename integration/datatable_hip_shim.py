@@ -284,11 +284,21 @@ def _colspec(frame, text):
     return _colindex(frame, m.group(1) or m.group(2))
 
 
+_MANGLED = {}
+
+
 def _mangled(names):
-    """result names as the reference would make them: duplicates mangled (names.cc:232-266), "" auto-named"""
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore", dt.exceptions.DatatableWarning)
-        return list(dt.Frame([[]] * len(names), names=list(names)).names) if names else []
+    """result names as the reference would make them: duplicates mangled (names.cc:232-266), "" auto-named
+    (asked of the reference itself on a zero-row Frame; remembered per tuple of names)"""
+    key = tuple(names)
+    hit = _MANGLED.get(key)
+    if hit is None:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", dt.exceptions.DatatableWarning)
+            hit = list(dt.Frame([[]] * len(names), names=list(names)).names) if names else []
+        if len(_MANGLED) < 4096:
+            _MANGLED[key] = hit
+    return list(hit)
 
 
 class _Out:

@@ -130,8 +130,13 @@ def sharded_groupby_agg(local_agg, keys, values, aggs, sig=1, fail=False, na_las
                                      bounds.ctypes.data_as(C.c_void_p))
     cuts = [0] + [int(np.searchsorted(img, b, side="left")) for b in bounds[:world - 1]] + [ng]    # lower_bound_kernel
     send_cnt = np.diff(cuts)
-    recv_cnt = _exchange_counts(send_cnt, sig)                                          # all-gather B
-    _check(allgather_blob(0, sig, 0, b""))                                              # all-gather C (status)
+    # round 4: the receive buffers are sized BEFORE the counts are known -- the splitters' guaranteed bound, the same number
+    # on every rank -- so their allocation status travels with the counts and the status-only all-gather C is gone;
+    # only a share above the bound (every rank sees the whole count matrix) brings it back
+    total = int(counts.sum())
+    recv_bound = total // world + total // Q + 2 * world + 16
+    recv_cnt = _exchange_counts(send_cnt, sig)                                          # all-gather B (counts + status)
+    assert int(sum(recv_cnt)) <= recv_bound, "a rank share exceeds the bound of the splitters"
     rk = [_a2av(torch.from_numpy(np.ascontiguousarray(k)), send_cnt, recv_cnt).numpy() for k in gk]
     rp = [_a2av(torch.from_numpy(np.ascontiguousarray(c)), send_cnt, recv_cnt).numpy() for c in cols]
     # merge on the owner: sums of sums / counts, min of mins, max of maxs
