@@ -113,7 +113,7 @@ def test_bench_two_ranks_end_to_end(fake_rccl):
     assert line["roofline"]["kernel"] and line["cpu_baseline"] is None
     # round 4: the N > 1 line says what crossed the fabric and where the time went, for all three multi-GPU configs
     ex = line["exchange"]
-    assert ex["bytes_to_peers_max"] > 0 and ex["allgathers"] >= 3 and 0 < ex["xgmi_frac_of_step"] < 1
+    assert ex["bytes_to_peers_max"] > 0 and ex["allgathers"] == 2 and 0 < ex["xgmi_frac_of_step"] < 1      # samples, counts + status
     assert set(ex["phases_ms_rank0"]) >= {"local", "allgather", "plan", "alltoallv", "merge"}
     assert line["roofline"]["xgmi"]["xgmi_peak_GBs_per_gpu"] == 7 * 153.0
     assert "error" not in line["configs"], line["configs"]
