@@ -404,9 +404,10 @@ struct MsdPlan { bool ok = false; int s1 = 0, s2 = 0, rb = 0; };
 
 static MsdPlan msd_plan(const dthip_ctx* ctx, int64_t n, int bits, int key64, uint32_t tile) {
   MsdPlan m;
-  // measured (C5, 5e8 rows, 27 bits, MI355X): levels 4.8 + 5.0 + final 5.9 ms against 3 x 5.1 ms of LSD passes -- the final level's
-  // buckets of ~1900 rows leave a CU with too few rows in flight, so the levels run on request only
-  if (ctx->sort_path != 2 || key64 || n < ctx->msd_min_rows || n < 2) return m;
+  // measured (C5, 5e8 rows, 27 bits, MI355X, one box): levels 4.3 + 4.5 + final 4.4 ms (windows of whole buckets) and two
+  // histogram passes against 3 x 4.7 ms of LSD passes and three: ~1 ms per call, more when the final level also writes the
+  // original key column.  Below msd_min_rows the LSD passes are quick and the final buckets would be tiny.
+  if (ctx->sort_path == 1 || key64 || n < ctx->msd_min_rows || n < 2) return m;
   int S = 2;
   while (S < 18 && (n >> S) > (int64_t)ctx->msd_bucket_rows) S++;
   if ((n >> S) > (int64_t)(tile * 9 / 16)) return m;      // average final bucket beyond 56 % of a tile: skew would overflow it
@@ -591,7 +592,16 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
     uint32_t maxsize = 0;
     DTHIP_TRY(read_back(ctx, &maxsize, d_max, sizeof(maxsize)));
     static const int win_env = getenv("DTHIP_MSD_WINDOWS") ? atoi(getenv("DTHIP_MSD_WINDOWS")) : 1;   // 0: one workgroup per bucket (A/B)
-    const bool windows = win_env != 0 && wi[0] > 0 && wi[2] >= 1 && wi[2] <= 512;
+    // the (bucket, digit) counts of a window and their prefix live in the tile's exchange buffer: 2 x buckets x bins words
+    int wbits2 = 1;
+    while ((1u << wbits2) < wi[2]) wbits2++;
+    int maxw_w = 4;
+    for (int c = 0; c < pay.n; c++) maxw_w = std::max(maxw_w, pay.width[c]);
+    const bool windows = win_env != 0 && wi[0] > 0 && wi[2] >= 1 && wi[2] <= 16 &&
+                         (size_t)2 * ((size_t)1 << wbits2) * ((size_t)1 << msd.rb) * 4 <= (size_t)tile * maxw_w;
+    if (getenv("DTHIP_MSD_DEBUG"))
+      fprintf(stderr, "[dthip msd] n=%lld s1=%d s2=%d rb=%d tiles2=%u groups2=%u largest bucket=%u windows=%u step=%u max buckets/window=%u -> %s\n",
+              (long long)n, msd.s1, msd.s2, msd.rb, ntiles2, G2, maxsize, wi[0], wi[1], wi[2], windows ? "windows" : (maxsize <= tile ? "per bucket" : "LSD"));
     if (windows || maxsize <= tile) {
       rp.kin = kB; rp.kout = kA;
       rp.shift = xa.pshift[p2]; rp.bits = xa.pbits[p2];
@@ -613,6 +623,10 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
         rp.ntiles = wi[0]; rp.bounds = wbounds; rp.wfirst = wfirst; rp.block = 0;
         rp.bits2 = 1;
         while ((1u << rp.bits2) < wi[2]) rp.bits2++;
+#ifdef DTHIP_RP_EXPERIMENT
+        if (getenv("DTHIP_MSD_R1ONLY")) rp.bits2 = 99;        // timing experiment: wrong results
+        if (getenv("DTHIP_MSD_WIN_NOR2")) rp.wfirst = nullptr; // timing experiment: the one-round kernel over the real windows
+#endif
       }
       for (int c = 0; c < pay.n; c++) { rp.pay.in[c] = pbuf[1][c]; rp.pay.out[c] = pbuf[0][c]; }
       if (pay.ukey_out) {

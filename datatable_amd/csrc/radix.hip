@@ -326,14 +326,33 @@ __global__ void __launch_bounds__(256) msd_window_kernel(const uint32_t* __restr
     return lo;
   };
   const uint32_t b0 = first_bucket(w);
-  wfirst[w] = b0;
-  wbounds[w] = fstart[b0];
+  const uint32_t row0 = fstart[b0];
+  wbounds[w] = row0;
+  // EMPTY buckets share their first row with the next bucket that holds rows: the window's bucket numbers run from the
+  // LAST bucket starting at row0 (the one that holds its first row) to the last bucket starting before the window's end --
+  // empty buckets in front of and behind the window's rows (the unused top of the key range: 63780 of them behind C5's
+  // last row) must not count
+  auto last_at = [&](uint32_t row) -> uint32_t {       // last b <= nbk with fstart[b] <= row
+    uint32_t lo = 0, hi = nbk + 1;
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (fstart[mid] <= row) lo = mid + 1; else hi = mid; }
+    return lo - 1;
+  };
+  auto first_at = [&](uint32_t row) -> uint32_t {      // first b <= nbk with fstart[b] >= row
+    uint32_t lo = 0, hi = nbk;
+    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (fstart[mid] < row) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  uint32_t c0 = b0;
   if (w < NW) {
-    // buckets that hold rows: from b0 to the last bucket starting before the next window (trailing EMPTY buckets, which
-    // share their start with the next window's first bucket, do not count)
     const uint32_t b1 = first_bucket(w + 1);
-    if (b1 > b0) atomicMax(&info[2], b1 - b0);
+    const uint32_t row1 = fstart[b1];
+    if (row1 > row0) {
+      c0 = last_at(row0);                               // holds the window's first row
+      const uint32_t cend = first_at(row1);             // first bucket starting at the window's end: cend - 1 holds its last row
+      atomicMax(&info[2], cend - c0);
+    }
   }
+  wfirst[w] = c0;
 }
 
 int launch_msd_windows(dthip_ctx* ctx, const uint32_t* fstart, uint32_t nbk, uint32_t n, const uint32_t* maxsize, uint32_t tile,
@@ -394,8 +413,10 @@ __device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t
 // nbal > 0: the lanes of an item that share a digit are found with nbal ballot rounds instead of the LDS lane masks --
 // for a digit of FEW values (the bucket number inside a window: ~3) dozens of lanes would pile their ds_or onto one
 // address and serialise (measured: the windowed final level 5.8 ms instead of 3.8).
-template <int BLOCK, int ITEMS, int RBMAX>
-__device__ __forceinline__ void rank_round(const uint32_t (&dig)[ITEMS], uint32_t vmask, int bins, uint16_t* wh, uint32_t* bin_excl,
+// (the digit of item i is dig(i): recomputed where it is needed instead of held in ITEMS more registers -- the two-round
+// final level was register-starved: 6.4 ms for its first round alone against 3.85 for the one-round kernel)
+template <int BLOCK, int ITEMS, int RBMAX, typename DigF>
+__device__ __forceinline__ void rank_round(DigF dig, uint32_t vmask, int bins, uint16_t* wh, uint32_t* bin_excl,
                                            uint32_t* misc, unsigned char* exch, uint32_t slice_bytes, uint32_t (&pos)[ITEMS], int nbal = 0) {
   constexpr int WAVES = BLOCK / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -409,7 +430,7 @@ __device__ __forceinline__ void rank_round(const uint32_t (&dig)[ITEMS], uint32_
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
       const bool valid = (vmask >> i) & 1u;
-      const uint32_t d = dig[i];
+      const uint32_t d = dig(i);
       unsigned long long m = __ballot(valid);
       for (int b = 0; b < nbal; b++) {
         const bool bit = (d >> b) & 1u;
@@ -429,7 +450,7 @@ __device__ __forceinline__ void rank_round(const uint32_t (&dig)[ITEMS], uint32_
     pos[i] = 0;
     __builtin_amdgcn_wave_barrier();
     if ((vmask >> i) & 1u) {
-      const uint32_t d = dig[i];
+      const uint32_t d = dig(i);
       __hip_atomic_fetch_or(&mk[d], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       const unsigned long long m = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       const uint32_t prev = __hip_atomic_load(&mywh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -469,7 +490,7 @@ __device__ __forceinline__ void rank_round(const uint32_t (&dig)[ITEMS], uint32_
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < ITEMS; i++)
-    if ((vmask >> i) & 1u) pos[i] += bin_excl[dig[i]] + wh[wave * bins + dig[i]];
+    if ((vmask >> i) & 1u) { const uint32_t d = dig(i); pos[i] += bin_excl[d] + wh[wave * bins + d]; }
 }
 
 // RB   = number of ballot rounds (>= bits of every pass run with this instance)
@@ -496,7 +517,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bins = 1 << a.bits;
   const uint32_t dmask = (uint32_t)bins - 1u;
-  const int cbins = R2 ? (1 << (a.bits > a.bits2 ? a.bits : a.bits2)) : bins;      // the LDS arrays hold the wider of the two rounds
+  const int cbins = R2 ? (1 << ((a.bits > a.bits2 || a.bits2 > 31) ? a.bits : a.bits2)) : bins;      // the LDS arrays hold the wider of the two rounds
   // per-wave digit counts as 16-bit words (a wave holds 64 x ITEMS = 1024 keys, a tile 8192): at 512 bins the
   // 32-bit form took the LDS a second workgroup per CU needs, which is what made a 9-bit pass twice as slow
   uint16_t* wh = reinterpret_cast<uint16_t*>(smem);   // [WAVES][bins] per-wave digit counts
@@ -584,37 +605,60 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     uint32_t vmask = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) vmask |= (RP_VALID(i) ? 1u : 0u) << i;
-    uint32_t dg[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) dg[i] = (uint32_t)key[i] & dmask;
     __syncthreads();                                        // (full tiles: every wave has read its transposed keys)
-    rank_round<BLOCK, ITEMS, RB>(dg, vmask, bins, wh, bin_excl, misc, exch, SLICE, pos);
+    rank_round<BLOCK, ITEMS, RB>([&](int i) { return (uint32_t)key[i] & dmask; }, vmask, bins, wh, bin_excl, misc, exch, SLICE, pos);
     __syncthreads();
-    // rows into round-1 order: what round 2 needs of a row is its bucket number and where it came from
+#ifdef DTHIP_RP_EXPERIMENT
+    if (a.bits2 == 99) {       // TIMING EXPERIMENT (wrong results): round 1 only
+      for (int b = tid; b < bins; b += BLOCK) bin_delta[b] = tile_base;
+      __syncthreads();
+    } else {
+#endif
+    // The window's rows arrive ordered by bucket (the scatter levels put them there), so the round above -- stable by
+    // the low digit d -- leaves every d-group ordered by bucket.  The wanted order is (bucket, d): a row's place is
+    //   first row of its (bucket, d) group  +  its rank inside the group
+    //   = exclusive prefix of the counts cnt[bucket][d] in (bucket, d) order
+    //   + (rank among all rows with digit d) - (rows with digit d in EARLIER buckets of the window)
+    // One DS atomic per row for the counts and one scan over buckets x bins words: no second ranking round, no exchange
+    // of rows (the first version of this level did both: 1.15 ms of its 5.5).
     const uint32_t c0 = a.wfirst[tile];
-    uint32_t* e32 = reinterpret_cast<uint32_t*>(exch);
+    const uint32_t nseg = 1u << a.bits2;
+    const uint32_t total2 = nseg * (uint32_t)bins;
+    uint32_t* cnt2 = reinterpret_cast<uint32_t*>(exch);              // [nseg][bins] rows of (bucket, digit); then: in earlier buckets
+    uint32_t* base2 = cnt2 + total2;                                 // [nseg][bins] first place of the (bucket, digit) group
+    for (uint32_t f = tid; f < total2; f += BLOCK) cnt2[f] = 0;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; i++)
-      if ((vmask >> i) & 1u) e32[pos[i]] = ((((uint32_t)(key[i] >> a.bits)) - c0) << 13) | (wbase + 64u * i);
+      if ((vmask >> i) & 1u) atomicAdd(&cnt2[(((uint32_t)(key[i] >> a.bits)) - c0) * (uint32_t)bins + ((uint32_t)key[i] & dmask)], 1u);
     __syncthreads();
-    uint32_t org[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-      const uint32_t w = ((vmask >> i) & 1u) ? e32[wbase + 64u * i] : 0u;
-      dg[i] = w >> 13; org[i] = w & 8191u;
+    {
+      const uint32_t per = (total2 + BLOCK - 1) / BLOCK, f0 = (uint32_t)tid * per;
+      uint32_t sum = 0;
+      for (uint32_t j = 0; j < per; j++) if (f0 + j < total2) sum += cnt2[f0 + j];
+      uint32_t e = block_excl_scan_u32<BLOCK>(sum, misc, nullptr);
+      for (uint32_t j = 0; j < per; j++) if (f0 + j < total2) { base2[f0 + j] = e; e += cnt2[f0 + j]; }
     }
     __syncthreads();
-    rank_round<BLOCK, ITEMS, RB>(dg, vmask, 1 << a.bits2, wh, bin_excl, misc, exch, SLICE, pos, a.bits2 <= 5 ? a.bits2 : 0);
-    __syncthreads();
-    uint16_t* fin = reinterpret_cast<uint16_t*>(exch);
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++)
-      if ((vmask >> i) & 1u) fin[org[i]] = (uint16_t)pos[i];
+    for (int b = tid; b < bins; b += BLOCK) {
+      uint32_t run = 0;
+      for (uint32_t sg = 0; sg < nseg; sg++) { const uint32_t c = cnt2[sg * bins + b]; cnt2[sg * bins + b] = run; run += c; }
+    }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) pos[i] = ((vmask >> i) & 1u) ? fin[wbase + 64u * i] : 0u;
+    for (int i = 0; i < ITEMS; i++) {
+      if ((vmask >> i) & 1u) {
+        const uint32_t d = (uint32_t)key[i] & dmask;
+        const uint32_t f = (((uint32_t)(key[i] >> a.bits)) - c0) * (uint32_t)bins + d;
+        pos[i] = base2[f] + (pos[i] - bin_excl[d] - cnt2[f]);
+      }
+    }
+    __syncthreads();
     for (int b = tid; b < bins; b += BLOCK) bin_delta[b] = tile_base;
     __syncthreads();
+#ifdef DTHIP_RP_EXPERIMENT
+    }
+#endif
   } else {
   // ---- stable rank of every key among equal digits of its wave --------------
   // (the cross-lane traffic below goes through wavefront-scope relaxed atomics, not `volatile`: volatile accesses lose
@@ -861,7 +905,7 @@ static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
 #endif
   int maxw = (int)sizeof(KeyT);
   for (int c = 0; c < p.pay.n; c++) maxw = p.pay.width[c] > maxw ? p.pay.width[c] : maxw;
-  const int bins = 1 << (R2 && p.bits2 > p.bits ? p.bits2 : p.bits);
+  const int bins = 1 << (R2 && p.bits2 > p.bits && p.bits2 < 32 ? p.bits2 : p.bits);
   const size_t lds = (size_t)(BLK / 64) * bins * 2 + (size_t)(2 * bins + 16) * 4 + (size_t)(BLK * RP_ITEMS) * maxw;
   auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W, RK, BLK, R2>;
   DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));

@@ -161,9 +161,11 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    0: only when a count() aggregate asks for group sizes -- the reference's result
  *                    Frame of DT[:, sum(f.v), by(f.k)] holds keys and sums only, and not counting rows
  *                    lets the bucketed aggregation use twice as many table slots per bucket
- *   "sort_path"      0 / 1 (default): the sort path orders rows with stable LSD radix passes; 2: MSD levels (two stable
- *                    scatter levels + every final bucket ordered in LDS) whenever their preconditions hold (32-bit packed
- *                    keys, rows >= "msd_min_rows", final buckets of about "msd_bucket_rows" rows); same results, bit for bit
+ *   "sort_path"      0 (default): inputs of at least "msd_min_rows" (2^26) rows whose packed key has <= 32 bits are ordered by
+ *                    MSD levels -- two stable scatter levels, then every final bucket (about "msd_bucket_rows" rows; windows of
+ *                    whole buckets fill a tile) ordered in LDS and written in place -- and fall back to the LSD passes when
+ *                    a final bucket would not fit a tile (heavy duplicates over a wide range); everything else takes stable
+ *                    LSD radix passes; 1: LSD passes only.  Same results, bit for bit
  *   "filter_path"    1 (default): row filters count, then write (two reads of the predicate column); 0: one pass whose tile
  *                    offsets come from a decoupled look-back (measured slower on MI355X; kept for A/B runs)
  *   "f32_sum"        0 (default): sum(float32 column) accumulates in float64 and rounds once (the documented deviation at
