@@ -380,9 +380,12 @@ struct PaySpec {
   bool iota = false;            // column 0 is the row number
   // single int32 / int64 key whose column is wanted in sorted order: the last pass writes its ORIGINAL values here
   void* ukey_out = nullptr;
+  // zeroed bitmap of n bits: the final MSD level marks the first row of every run of equal keys (SortOut::heads_done)
+  unsigned long long* head_bitmap = nullptr;
 };
 
 struct SortOut {
+  bool heads_done = false;      // PaySpec::head_bitmap was filled
   bool ukey_done = false;       // PaySpec::ukey_out was filled (then `keys` is NOT: the last pass wrote the original values instead)
   void* keys = nullptr;         // sorted packed keys (scratch-owned)
   int key64 = 0;
@@ -521,7 +524,7 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
       pbuf[1][c] = b1;
     }
   }
-  out->ukey_done = false;
+  out->ukey_done = false; out->heads_done = false;
   if (use_msd) {
     // ---- level 1: stable scatter by the top s1 bits (regular tiles) ------------------------------------------------
     const int p1 = 2, p2 = 1;
@@ -635,6 +638,11 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
         rp.uk_edge = kc.edge; rp.uk_na_repl = kc.na_repl; rp.uk_inc = kc.inc;
         out->ukey_done = true;
       }
+      // the final level can also mark the group heads (its keys sit in LDS in sorted order): built, bit-exact on the forced
+      // suites, and measured a LOSS -- the level 4.75 -> 6.04 ms for a count_heads pass of 0.73 ms saved -- so it stays off
+      // (DTHIP_FUSE_HEADS=1 switches it on for A/B runs)
+      static const bool fuse_heads = getenv("DTHIP_FUSE_HEADS") && atoi(getenv("DTHIP_FUSE_HEADS")) == 1;
+      if (pay.head_bitmap && fuse_heads) { rp.headbits = reinterpret_cast<uint32_t*>(pay.head_bitmap); out->heads_done = true; }
       rp.label = "msd_final_kernel";
 #ifdef DTHIP_RP_EXPERIMENT
       if (const char* fw = getenv("DTHIP_MSD_FAKE_WINDOW")) {
@@ -730,14 +738,24 @@ struct Grouping {
   void* pay[MAX_PAYCOLS];
 };
 
+static int alloc_head_bitmap(dthip_ctx* ctx, Scratch& sc, int64_t n, unsigned long long** bitmap) {
+  const size_t words = (size_t)((n + 63) / 64) + 1;
+  DTHIP_TRY(sc.get<unsigned long long>(words, bitmap));
+  DTHIP_CHECK_HIP(hipMemsetAsync(*bitmap, 0, words * 8, ctx->stream));
+  return DTHIP_OK;
+}
+
+// ready: a head bitmap the sort itself filled (final MSD level) -- no pass over the keys
 static int heads_to_offsets(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const void* keys, int key64,
-                            const uint8_t* heads, int64_t n, Grouping* g) {
+                            const uint8_t* heads, int64_t n, Grouping* g, unsigned long long* ready = nullptr) {
   const uint32_t nt = (uint32_t)((n + SEG_TILE - 1) / SEG_TILE);
   uint32_t* tile_counts = nullptr;
   DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, &tile_counts));
-  unsigned long long* bitmap = nullptr;
-  DTHIP_TRY(sc.get<unsigned long long>((size_t)((n + 63) / 64) + 1, &bitmap));
+  unsigned long long* bitmap = ready;
+  if (!bitmap) DTHIP_TRY(sc.get<unsigned long long>((size_t)((n + 63) / 64) + 1, &bitmap));
   int64_t ng = 0;
+  if (ready) DTHIP_TRY(launch_heads_from_bitmap(ctx, bitmap, n, tile_counts, tile_counts + nt, &ng));
+  else
   DTHIP_TRY(launch_count_heads(ctx, keys, key64, heads, n, tile_counts, bitmap, tile_counts + nt, &ng));
   void* off = nullptr;
   DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * (size_t)(ng + 1), &off));
@@ -754,6 +772,7 @@ static int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthi
   // int64 column); the key-transform pass of every stage verifies the guess, a wrong one costs one more round
   const int32_t* order = nullptr;
   SortOut so;
+  unsigned long long* gc_bitmap = nullptr;
   for (int attempt = 0; attempt < 2; attempt++) {
     DTHIP_TRY(plan_keys(ctx, sc, keys_dev, nkeys, n, na_pos, plan, attempt == 0, true));
     order = nullptr;
@@ -762,6 +781,10 @@ static int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthi
       PaySpec ps;
       ps.n = 1; ps.width[0] = 4;
       if (order) { ps.in[0] = order; ps.iota = false; } else { ps.in[0] = nullptr; ps.iota = true; }
+      if (plan->nstages == 1) {
+        if (!gc_bitmap) DTHIP_TRY(alloc_head_bitmap(ctx, sc, n, &gc_bitmap));
+        ps.head_bitmap = gc_bitmap;
+      }
       rc = sort_stage(ctx, sc, *plan, s, n, order, ps, &so);
       if (rc != DTHIP_OK) break;
       order = static_cast<const int32_t*>(so.pay[0]);
@@ -774,7 +797,7 @@ static int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthi
   g->rowindex = const_cast<int32_t*>(order);
   g->sorted_keys = so.keys; g->key64 = so.key64;
   if (plan->nstages == 1) {
-    DTHIP_TRY(heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, n, g));
+    DTHIP_TRY(heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, n, g, so.heads_done ? gc_bitmap : nullptr));
   } else {
     uint8_t* heads = nullptr;
     DTHIP_TRY(sc.get<uint8_t>((size_t)n, &heads));
@@ -1768,6 +1791,7 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
         if ((rc = result_alloc(ctx, res, (size_t)nrows * stype_size(kd[0].stype), &q)) != DTHIP_OK) break;
         ps.ukey_out = q;
       }
+      if ((rc = alloc_head_bitmap(ctx, sc, nrows, &ps.head_bitmap)) != DTHIP_OK) break;
       rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so);
       if (rc == DTHIP_RETRY_EXACT) {
         // the sampled key range did not hold, so real keys lie OUTSIDE it: the exact range is usually WIDER, and with
@@ -1779,7 +1803,9 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
       if (rc != DTHIP_OK) break;
     }
     if (ride) {
-      if (so.ukey_done) {
+      if (so.heads_done) {
+        if ((rc = heads_to_offsets(ctx, sc, res, nullptr, 0, nullptr, nrows, &g, ps.head_bitmap)) != DTHIP_OK) break;
+      } else if (so.ukey_done) {
         // groups = runs of equal ORIGINAL key values (the transform is a bijection, NA <-> NA)
         if ((rc = heads_to_offsets(ctx, sc, res, ps.ukey_out, kd[0].stype == DTHIP_INT64, nullptr, nrows, &g)) != DTHIP_OK) break;
       } else

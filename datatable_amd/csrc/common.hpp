@@ -250,6 +250,7 @@ struct RadixPass {
   // last pass only: write the original values of ONE int32 / int64 key column here instead of the packed keys
   void* ukout; int uk_stype; int uk_desc; int uk_bits;
   unsigned long long uk_edge, uk_na_repl, uk_inc;
+  uint32_t* headbits;            // final MSD level only: 1 bit per row, set where a run of equal keys starts (zeroed by the caller)
 };
 uint32_t radix_tile_items(int key64, int maxpaywidth);
 int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t n, int shift, int bits,
@@ -270,6 +271,8 @@ int launch_scan_tiles(dthip_ctx* ctx, uint32_t* counts, uint32_t m, uint32_t* to
 int launch_count_heads(dthip_ctx* ctx, const void* keys, int key64, const uint8_t* heads, int64_t n,
                        uint32_t* tile_counts, unsigned long long* bitmap, uint32_t* d_total,
                        int64_t* ngroups_host);
+int launch_heads_from_bitmap(dthip_ctx* ctx, const unsigned long long* bitmap, int64_t n, uint32_t* tile_counts, uint32_t* d_total,
+                             int64_t* ngroups_host);
 int launch_write_offsets(dthip_ctx* ctx, const unsigned long long* bitmap, int64_t n,
                          const uint32_t* tile_base, int64_t ngroups, int32_t* offsets);
 int launch_mark_heads(dthip_ctx* ctx, const void* keys, int key64, int64_t n, uint8_t* heads);

@@ -217,6 +217,8 @@ struct PassArgsT {
   // are written instead of the packed transformed keys (saves the untransform pass: 4 B read + 8 B written per row)
   void* ukout; int uk_stype; int uk_desc; int uk_bits;
   unsigned long long uk_edge, uk_na_repl, uk_inc;
+  uint32_t* headbits;       // final MSD level: head bitmap of the sorted order (the tile's keys sit in LDS in sorted order anyway)
+  uint32_t hw_off;          // byte offset of the head-bitmap words inside the workgroup's LDS
   PayCols pay;
 };
 
@@ -777,6 +779,43 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     }
   }
   __syncthreads();
+  if (a.headbits) {
+    // group heads of the final order: the tile (a bucket, or a window of whole buckets) starts a new key prefix, inside it
+    // a row is a head when its key differs from its predecessor's.  Lane = slot (conflict-free LDS reads), one ballot per
+    // 64 slots, the tile's piece of the bitmap is assembled in LDS (bit = row - first row of the tile's first WORD) and
+    // written out as words: the first and the last may be shared with the neighbouring tiles (atomic OR into the zeroed
+    // bitmap), the others are the tile's own.  (A first version looped over bitmap bytes per thread -- eight strided
+    // LDS reads each, 8-way bank conflicts: +1.2 ms on the level; this one costs ~0.1.)
+    // [TILE / 32 + 2] words: in the per-wave digit counters (dead by now) when they are big enough -- one more KB of LDS
+    // would cost the second workgroup per CU (measured: the level 5.0 -> 6.3 ms) --, else behind the exchange buffer
+    uint32_t* hw = reinterpret_cast<uint32_t*>(smem + a.hw_off);
+    const uint32_t r = tile_base & 31u, nwords = (r + nvalid + 31u) >> 5;
+    for (uint32_t w = tid; w < nwords; w += BLOCK) hw[w] = 0u;
+    __syncthreads();
+    for (uint32_t s0 = (uint32_t)wave * 64u; s0 < nvalid; s0 += BLOCK) {
+      const uint32_t sl = s0 + (uint32_t)lane;
+      const bool h = sl < nvalid && (sl == 0u || ek[sl] != ek[sl - 1u]);
+      const unsigned long long bal = __ballot(h);
+      if (lane < 3) {
+        // the wave's 64 bits start at bit (r + s0) of the tile's piece: they fall into three consecutive words at most
+        const uint32_t bit0 = r + s0, w0 = bit0 >> 5, sh = bit0 & 31u;
+        const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
+        uint32_t v;
+        if (lane == 0) v = lo << sh;
+        else if (lane == 1) v = (sh ? (lo >> (32u - sh)) : 0u) | (hi << sh);
+        else v = sh ? (hi >> (32u - sh)) : 0u;
+        if (v) atomicOr(&hw[w0 + (uint32_t)lane], v);
+      }
+    }
+    __syncthreads();
+    uint32_t* gw = a.headbits + (tile_base >> 5);
+    for (uint32_t w = tid; w < nwords; w += BLOCK) {
+      const uint32_t v = hw[w];
+      if (w == 0 || w + 1 == nwords) { if (v) atomicOr(&gw[w], v); }
+      else gw[w] = v;
+    }
+    __syncthreads();
+  }
   // thread owns slots (g*BLOCK + tid)*4 .. +3 for g in [0, GROUPS)
   uint32_t gpos[ITEMS];
 #pragma unroll
@@ -900,13 +939,19 @@ static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
   a.wfirst = p.wfirst; a.bits2 = p.bits2;
   a.ukout = p.ukout; a.uk_stype = p.uk_stype; a.uk_desc = p.uk_desc; a.uk_bits = p.uk_bits;
   a.uk_edge = p.uk_edge; a.uk_na_repl = p.uk_na_repl; a.uk_inc = p.uk_inc;
+  a.headbits = p.bounds ? p.headbits : nullptr;
 #ifdef DTHIP_RP_EXPERIMENT
   if (getenv("DTHIP_RP_SEQ") && atoi(getenv("DTHIP_RP_SEQ"))) a.seq = 1;      // timing experiment: wrong results
 #endif
   int maxw = (int)sizeof(KeyT);
   for (int c = 0; c < p.pay.n; c++) maxw = p.pay.width[c] > maxw ? p.pay.width[c] : maxw;
   const int bins = 1 << (R2 && p.bits2 > p.bits && p.bits2 < 32 ? p.bits2 : p.bits);
-  const size_t lds = (size_t)(BLK / 64) * bins * 2 + (size_t)(2 * bins + 16) * 4 + (size_t)(BLK * RP_ITEMS) * maxw;
+  size_t lds = (size_t)(BLK / 64) * bins * 2 + (size_t)(2 * bins + 16) * 4 + (size_t)(BLK * RP_ITEMS) * maxw;
+  a.hw_off = 0;
+  if (a.headbits) {
+    const size_t need = (size_t)((BLK * RP_ITEMS) / 32 + 4) * 4;
+    if ((size_t)(BLK / 64) * bins * 2 < need) { a.hw_off = (uint32_t)lds; lds += need; }
+  }
   auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W, RK, BLK, R2>;
   DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
   const uint32_t ntiles = p.ntiles ? p.ntiles : (p.n + RP_TILE - 1) / RP_TILE;
