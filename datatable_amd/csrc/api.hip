@@ -505,7 +505,24 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
     hg.tpg = (ntiles + gmax - 1) / gmax; if (hg.tpg == 0) hg.tpg = 1;
     hg.G = (ntiles + hg.tpg - 1) / hg.tpg;
   }
-  const bool use_msd = msd.ok && nactive == 3;
+  bool use_msd = msd.ok && nactive == 3;
+  if (use_msd) {
+    // The levels give up when a final bucket outgrows a tile, AFTER level 1 and two histogram passes.  The digit histograms
+    // already on the host say when that is certain or likely, for nothing: rows can only land in (level-1 digit, level-2
+    // digit) cells whose two marginal bins are non-empty, so fewer such cells than n / tile means an overflow for sure
+    // (few distinct keys over a wide range); and if the two digits were independent the fullest cell would hold
+    // max1 * max2 / n rows (a hot key, clustered keys).  Either way the LSD passes run at once.
+    uint64_t nz1 = 0, nz2 = 0, mx1 = 0, mx2 = 0;
+    for (int d = 0; d < (1 << xa.pbits[2]); d++) { const uint32_t c = hh[(size_t)2 * HIST_STRIDE + d]; nz1 += c != 0; mx1 = std::max<uint64_t>(mx1, c); }
+    for (int d = 0; d < (1 << xa.pbits[1]); d++) { const uint32_t c = hh[(size_t)1 * HIST_STRIDE + d]; nz2 += c != 0; mx2 = std::max<uint64_t>(mx2, c); }
+    if ((double)n / (double)(nz1 * nz2) > (double)tile || (double)mx1 * (double)mx2 / (double)n > (double)tile) use_msd = false;
+    if (getenv("DTHIP_MSD_DEBUG"))
+      fprintf(stderr, "[dthip msd] n=%lld bits=%d digits %d+%d+%d: non-empty bins %llu x %llu, fullest %llu / %llu -> %s\n", (long long)n, bits,
+              msd.s1, msd.s2, msd.rb, (unsigned long long)nz1, (unsigned long long)nz2, (unsigned long long)mx1, (unsigned long long)mx2,
+              use_msd ? "levels" : "LSD passes (overflow certain or likely)");
+  } else if (getenv("DTHIP_MSD_DEBUG")) {
+    fprintf(stderr, "[dthip msd] n=%lld bits=%d key64=%d: plan %s, active digits %d\n", (long long)n, bits, key64, msd.ok ? "ok" : "not applicable", nactive);
+  }
   uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
   DTHIP_TRY(sc.get<uint32_t>((size_t)(ntiles + (use_msd ? (2u << msd.s1) : 0u)) << maxbits, &P));
   DTHIP_TRY(sc.get<uint32_t>((size_t)hg.G << maxbits, &gtot));

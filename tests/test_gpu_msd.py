@@ -97,10 +97,18 @@ def test_msd_falls_back_when_a_final_bucket_overflows(msd):
     rng = np.random.default_rng(7)
     n = 1_500_000
     msd.set_option("msd_bucket_rows", 512)
-    vals = rng.integers(0, 2**20, 37).astype(np.int64)
-    k = vals[rng.integers(0, len(vals), n)]
     x = rng.standard_normal(n)
-    _check(msd, [k], [x], expect_msd=True)      # the histogram kernels ran; the result is the LSD path's
+    # the two scatter digits CORRELATED (level-1 digit == level-2 digit): both marginal histograms are flat, so the cheap
+    # predictor lets the levels start, and the level-2 histogram then finds 64 cells of n / 64 rows: the real fallback
+    d = rng.integers(0, 63, n).astype(np.int64)
+    k = (d << 15) | (d << 9) | rng.integers(0, 512, n).astype(np.int64)
+    k[0], k[1] = 0, 2**21 - 2                      # pins the key range: 21 bits = 6 + 6 + 9
+    _check(msd, [k], [x], expect_msd=True)         # the histogram kernels ran; the result is the LSD path's
+    # few distinct keys over a wide range: 37 of them may still hide behind 27 x 29 non-empty marginal bins (the levels
+    # start and give up after the level-2 histogram); 5 of them cannot (<= 25 cells for 1.5e6 rows: LSD at once)
+    vals = rng.integers(0, 2**20, 37).astype(np.int64)
+    _check(msd, [vals[rng.integers(0, len(vals), n)]], [x], expect_msd=None)
+    _check(msd, [vals[rng.integers(0, 5, n)]], [x], expect_msd=False)
     # clustered: sorted keys with long runs
     k2 = np.sort(rng.integers(0, 2**20, n).astype(np.int64))
     _check(msd, [k2], [x], expect_msd=None)
