@@ -11,6 +11,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include "common.hpp"
+#include "msd_plan.hpp"
 
 namespace dthip {
 
@@ -403,22 +404,13 @@ struct SortOut {
 // level is a stable partition), so no row id has to travel.  Against three LSD passes: the last pass loses its write
 // amplification (a (tile, digit) run of 16 rows shares its first and last 64-byte sector with the neighbouring tiles'
 // runs: 1.74x the algorithmic bytes reach HBM, 4.55 ms per pass of C5; written in place: 3.1 ms) and one histogram pass.
-struct MsdPlan { bool ok = false; int s1 = 0, s2 = 0, rb = 0; };
-
 static MsdPlan msd_plan(const dthip_ctx* ctx, int64_t n, int bits, int key64, uint32_t tile) {
-  MsdPlan m;
   // measured (C5, 5e8 rows, 27 bits, MI355X, one box): levels 4.3 + 4.5 + final 4.4 ms (windows of whole buckets) and two
   // histogram passes against 3 x 4.7 ms of LSD passes and three: ~1 ms per call, more when the final level also writes the
   // original key column.  Below msd_min_rows the LSD passes are quick and the final buckets would be tiny.
-  if (ctx->sort_path == 1 || key64 || n < ctx->msd_min_rows || n < 2) return m;
-  int S = 2;
-  while (S < 18 && (n >> S) > (int64_t)ctx->msd_bucket_rows) S++;
-  if ((n >> S) > (int64_t)(tile * 9 / 16)) return m;      // average final bucket beyond 56 % of a tile: skew would overflow it
+  if (ctx->sort_path == 1 || key64 || n < ctx->msd_min_rows) return MsdPlan();
   static const int rbmax = getenv("DTHIP_MSD_RBMAX") ? atoi(getenv("DTHIP_MSD_RBMAX")) : 9;
-  if (bits - S > rbmax || bits - S < 1) return m;         // the final level orders <= 9 (10) bits in one LDS pass; rb = 0: nothing left to order
-  m.s1 = (S + 1) / 2; m.s2 = S - m.s1; m.rb = bits - S;
-  m.ok = m.s2 >= 1;
-  return m;
+  return msd_split(n, bits, tile, ctx->msd_bucket_rows, rbmax);       // (host logic: csrc/msd_plan.hpp, tests/test_msd_plan.py)
 }
 
 // Stable sort of rows by one stage of packed keys, moving the payload columns along.
@@ -512,13 +504,9 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
     // digit) cells whose two marginal bins are non-empty, so fewer such cells than n / tile means an overflow for sure
     // (few distinct keys over a wide range); and if the two digits were independent the fullest cell would hold
     // max1 * max2 / n rows (a hot key, clustered keys).  Either way the LSD passes run at once.
-    uint64_t nz1 = 0, nz2 = 0, mx1 = 0, mx2 = 0;
-    for (int d = 0; d < (1 << xa.pbits[2]); d++) { const uint32_t c = hh[(size_t)2 * HIST_STRIDE + d]; nz1 += c != 0; mx1 = std::max<uint64_t>(mx1, c); }
-    for (int d = 0; d < (1 << xa.pbits[1]); d++) { const uint32_t c = hh[(size_t)1 * HIST_STRIDE + d]; nz2 += c != 0; mx2 = std::max<uint64_t>(mx2, c); }
-    if ((double)n / (double)(nz1 * nz2) > (double)tile || (double)mx1 * (double)mx2 / (double)n > (double)tile) use_msd = false;
+    if (msd_overflow_expected(&hh[(size_t)2 * HIST_STRIDE], 1 << xa.pbits[2], &hh[(size_t)1 * HIST_STRIDE], 1 << xa.pbits[1], n, tile)) use_msd = false;
     if (getenv("DTHIP_MSD_DEBUG"))
-      fprintf(stderr, "[dthip msd] n=%lld bits=%d digits %d+%d+%d: non-empty bins %llu x %llu, fullest %llu / %llu -> %s\n", (long long)n, bits,
-              msd.s1, msd.s2, msd.rb, (unsigned long long)nz1, (unsigned long long)nz2, (unsigned long long)mx1, (unsigned long long)mx2,
+      fprintf(stderr, "[dthip msd] n=%lld bits=%d digits %d+%d+%d -> %s\n", (long long)n, bits, msd.s1, msd.s2, msd.rb,
               use_msd ? "levels" : "LSD passes (overflow certain or likely)");
   } else if (getenv("DTHIP_MSD_DEBUG")) {
     fprintf(stderr, "[dthip msd] n=%lld bits=%d key64=%d: plan %s, active digits %d\n", (long long)n, bits, key64, msd.ok ? "ok" : "not applicable", nactive);
@@ -560,31 +548,8 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
     rp.label = "msd_level1_kernel";
     DTHIP_TRY(launch_radix_pass(ctx, rp));
     // ---- level 2: the same inside every level-1 bucket: ragged tiles, planned on the host from the level-1 histogram
-    std::vector<uint32_t> tdesc, gdesc, gfirst(nb1 + 1, 0);
-    tdesc.reserve(((size_t)ntiles + 2 * nb1) * 4);
-    {
-      uint32_t row = 0;
-      for (uint32_t b = 0; b < nb1; b++) {
-        const uint32_t sz = hh[(size_t)p1 * HIST_STRIDE + b];
-        gfirst[b] = (uint32_t)(gdesc.size() / 2);
-        // the first tile of a bucket is cut short by (first row mod 4) rows, so that every other tile of the bucket starts
-        // on a 16-byte boundary of a 4-byte key array and takes the vector-load path
-        uint32_t off = 0, t = 0;
-        while (off < sz) {
-          uint32_t len = (t == 0) ? tile - (row & 3u) : tile;
-          if (len > sz - off) len = sz - off;
-          if (t % hg.tpg == 0) { gdesc.push_back((uint32_t)(tdesc.size() / 4)); gdesc.push_back(0); }
-          gdesc[gdesc.size() - 1]++;
-          tdesc.push_back(row + off);
-          tdesc.push_back(len);
-          tdesc.push_back((uint32_t)(gdesc.size() / 2 - 1));
-          tdesc.push_back(b);
-          off += len; t++;
-        }
-        row += sz;
-      }
-      gfirst[nb1] = (uint32_t)(gdesc.size() / 2);
-    }
+    std::vector<uint32_t> tdesc, gdesc, gfirst;
+    msd_level2_tiles(&hh[(size_t)p1 * HIST_STRIDE], nb1, tile, hg.tpg, &tdesc, &gdesc, &gfirst);
     const uint32_t ntiles2 = (uint32_t)(tdesc.size() / 4), G2 = (uint32_t)(gdesc.size() / 2);
     uint32_t* d_plan = nullptr;
     DTHIP_TRY(sc.get<uint32_t>(tdesc.size() + gdesc.size() + gfirst.size() + 4, &d_plan));
