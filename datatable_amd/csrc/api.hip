@@ -620,11 +620,7 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
         rp.uk_edge = kc.edge; rp.uk_na_repl = kc.na_repl; rp.uk_inc = kc.inc;
         out->ukey_done = true;
       }
-      // the final level can also mark the group heads (its keys sit in LDS in sorted order): built, bit-exact on the forced
-      // suites, and measured a LOSS -- the level 4.75 -> 6.04 ms for a count_heads pass of 0.73 ms saved -- so it stays off
-      // (DTHIP_FUSE_HEADS=1 switches it on for A/B runs)
-      static const bool fuse_heads = getenv("DTHIP_FUSE_HEADS") && atoi(getenv("DTHIP_FUSE_HEADS")) == 1;
-      if (pay.head_bitmap && fuse_heads) { rp.headbits = reinterpret_cast<uint32_t*>(pay.head_bitmap); out->heads_done = true; }
+      if (pay.head_bitmap) { rp.headbits = reinterpret_cast<uint32_t*>(pay.head_bitmap); out->heads_done = true; }
       rp.label = "msd_final_kernel";
 #ifdef DTHIP_RP_EXPERIMENT
       if (const char* fw = getenv("DTHIP_MSD_FAKE_WINDOW")) {
@@ -720,7 +716,17 @@ struct Grouping {
   void* pay[MAX_PAYCOLS];
 };
 
+// the final MSD level can mark the group heads (its keys sit in LDS in sorted order): built, bit-exact on the forced
+// suites, and measured a LOSS -- the level 4.75 -> 6.04 ms for a count_heads pass of 0.73 ms saved -- so it stays off
+// (DTHIP_FUSE_HEADS=1 switches it on for A/B runs)
+static bool fuse_heads_enabled() {
+  static const bool on = getenv("DTHIP_FUSE_HEADS") && atoi(getenv("DTHIP_FUSE_HEADS")) == 1;
+  return on;
+}
+
 static int alloc_head_bitmap(dthip_ctx* ctx, Scratch& sc, int64_t n, unsigned long long** bitmap) {
+  *bitmap = nullptr;
+  if (!fuse_heads_enabled()) return DTHIP_OK;
   const size_t words = (size_t)((n + 63) / 64) + 1;
   DTHIP_TRY(sc.get<unsigned long long>(words, bitmap));
   DTHIP_CHECK_HIP(hipMemsetAsync(*bitmap, 0, words * 8, ctx->stream));
@@ -764,7 +770,7 @@ static int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthi
       ps.n = 1; ps.width[0] = 4;
       if (order) { ps.in[0] = order; ps.iota = false; } else { ps.in[0] = nullptr; ps.iota = true; }
       if (plan->nstages == 1) {
-        if (!gc_bitmap) DTHIP_TRY(alloc_head_bitmap(ctx, sc, n, &gc_bitmap));
+        if (!gc_bitmap) DTHIP_TRY(alloc_head_bitmap(ctx, sc, n, &gc_bitmap));      // (null unless DTHIP_FUSE_HEADS=1)
         ps.head_bitmap = gc_bitmap;
       }
       rc = sort_stage(ctx, sc, *plan, s, n, order, ps, &so);
