@@ -857,7 +857,11 @@ static int reduce_outs_for(int op, void* dst, ReduceOuts* o) {
 
 // ---- bucketed aggregation (bucket.hip): DT[:, aggs, by(keys)] without a sort -------------
 // Accumulators each value column needs for the requested reducers.
-static int acc_flags_for(const dthip_agg* aggs, int naggs, int col, int vstype, int colflags = 0) {
+constexpr int DTHIP_RETRY_NA = 3;                 // internal: a value column guessed NA-free holds an NA, aggregate again with valid counts
+
+// guess_nona: the column is believed to hold no NA (sampled): its valid count IS the group size, so the per-column
+// counter (one DS atomic per row) is dropped and the kernels verify the belief on every row instead (ACC_CHKNA)
+static int acc_flags_for(const dthip_agg* aggs, int naggs, int col, int vstype, int colflags = 0, bool guess_nona = false) {
   int f = (colflags & DTHIP_FLAG_NONA) ? ACC_NONA : 0;
   const bool isf = stype_is_float(vstype);
   for (int a = 0; a < naggs; a++) {
@@ -871,6 +875,7 @@ static int acc_flags_for(const dthip_agg* aggs, int naggs, int col, int vstype, 
       default: break;
     }
   }
+  if (guess_nona && (f & ACC_VCNT) && !(f & ACC_NONA)) f = (f & ~ACC_VCNT) | ACC_CHKNA;
   return f;
 }
 
@@ -888,19 +893,19 @@ static bool bucket_need_counts(const dthip_ctx* ctx, const dthip_agg* aggs, int 
 
 // Decides whether the bucket path applies; fills the slot-bit count r.
 static bool bucket_eligible(const dthip_ctx* ctx, const KeyPlan& plan, const std::vector<dthip_col>& vd,
-                            const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int* r_out) {
+                            const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int* r_out, bool guess_nona = false) {
   if (ctx->agg_path == 1) return false;
   if (plan.nstages != 1) return false;
   const int B = plan.stage_bits[0];
   if (B > 32 || B < 1) return false;
-  const int first_flag = bucket_need_counts(ctx, aggs, naggs) ? ACC_CNT : ACC_PRES;
+  const int first_flag = (bucket_need_counts(ctx, aggs, naggs) || guess_nona) ? ACC_CNT : ACC_PRES;
   int r = BUCKET_MAX_R;
   bool first = true;
   auto fit = [&](int f) { int rc = BUCKET_MAX_R; while (rc > 0 && table_agg_lds_bytes(f, 1u << rc) > BUCKET_LDS_TABLE) rc--; return rc; };
   for (int c : used) {
     const int sz = stype_size(vd[c].stype);
     if (sz != 4 && sz != 8) return false;
-    const int f = acc_flags_for(aggs, naggs, c, vd[c].stype) | (first ? first_flag : 0);
+    const int f = acc_flags_for(aggs, naggs, c, vd[c].stype, vd[c].flags, guess_nona) | (first ? first_flag : 0);
     first = false;
     r = std::min(r, fit(f));
   }
@@ -916,7 +921,7 @@ static bool bucket_eligible(const dthip_ctx* ctx, const KeyPlan& plan, const std
 
 static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const KeyPlan& plan,
                               const std::vector<dthip_col>& kd, const std::vector<dthip_col>& vd,
-                              const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int r) {
+                              const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int r, bool guess_nona = false) {
   const int nkeys = plan.nkeys;
   const int B = plan.stage_bits[0];
   KeyXform kx;
@@ -940,7 +945,10 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   bucket_geometry(ctx, n, B, r, km, &g);
   const size_t nslots = (size_t)g.F * g.S;
 
-  const bool need_cnt = bucket_need_counts(ctx, aggs, naggs);
+  // want_offsets: group sizes are part of the result; need_cnt: rows per slot are COUNTED -- also when value columns are
+  // guessed NA-free, whose valid counts the row counts then stand for
+  const bool want_offsets = bucket_need_counts(ctx, aggs, naggs);
+  const bool need_cnt = want_offsets || guess_nona;
   const int first_flag = need_cnt ? ACC_CNT : ACC_PRES;
   // --- partition (skipped when one table holds the whole key range) ---
   uint16_t* kpart = nullptr;
@@ -1040,7 +1048,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   bool first = true;
   for (int c : used) {
     AggTable& t = tabs[c];
-    int f = acc_flags_for(aggs, naggs, c, vd[c].stype, vd[c].flags);
+    int f = acc_flags_for(aggs, naggs, c, vd[c].stype, vd[c].flags, guess_nona);
     if (first) { f |= first_flag; if (need_cnt) t.cnt = d_cnt; else t.pres = d_cnt; }
     tflags[c] = f;
     if (f & ACC_SUM) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.sum)); DTHIP_CHECK_HIP(hipMemsetAsync(t.sum, 0, nslots * 8, ctx->stream)); }
@@ -1052,7 +1060,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
       TableAggSegArgs sa;
       memset(&sa, 0, sizeof(sa));
       sa.items = items; sa.nitems = nitems; sa.max_items = max_items; sa.kpart = kpart; sa.val = vsrc[c]; sa.vstype = vd[c].stype;
-      sa.dirT = dirT; sa.dstride = dstride; sa.tile_rows = g.tile; sa.S = g.S; sa.flags = f; sa.tab = t;
+      sa.dirT = dirT; sa.dstride = dstride; sa.tile_rows = g.tile; sa.S = g.S; sa.flags = f; sa.tab = t; sa.bad = d_bad;
       DTHIP_TRY(launch_table_agg_seg(ctx, sa));
       first = false;
       continue;
@@ -1089,13 +1097,14 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   pa.data = d_cnt; pa.stype = DTHIP_INT32; pa.cmp = DTHIP_GT; pa.ci = 0; pa.is_mask = need_cnt ? 0 : 2;
   int64_t ng = 0;
   DTHIP_TRY(launch_compact(ctx, pa, (int64_t)nslots, idx, &ng));
-  if (plan.speculative) {
+  if (plan.speculative || guess_nona) {
     uint32_t bad = 0;
     DTHIP_TRY(read_back(ctx, &bad, d_bad, sizeof(bad)));
-    if (bad) return DTHIP_RETRY_EXACT;
+    if (plan.speculative && (bad & 1u)) return DTHIP_RETRY_EXACT;
+    if (bad & 2u) return DTHIP_RETRY_NA;
   }
   res->nrows = n; res->ngroups = ng;
-  if (need_cnt) {
+  if (want_offsets) {
     // offsets = exclusive scan of the group sizes (Groupby offsets, groupby.h:54-91)
     void* off = nullptr;
     DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * ((size_t)ng + 2 + (size_t)ng / 8192 + 1), &off));
@@ -1119,6 +1128,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     TableFinArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.idx = idx; fa.ng = (uint32_t)ng; fa.tab = tabs[c]; fa.vstype = vd[c].stype;
+    if (tflags[c] & ACC_CHKNA) fa.tab.vcnt = d_cnt;        // verified NA-free: the valid count of a group is its size
     std::vector<std::pair<int, int>> dups;
     int first_of_op[6] = {-1, -1, -1, -1, -1, -1};
     for (int a = 0; a < naggs; a++) {
@@ -1486,6 +1496,7 @@ int dthip_init(int device, void* stream, dthip_ctx** out) {
   if (const char* e = getenv("DTHIP_SORT_PATH")) ctx->sort_path = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;
   if (const char* e = getenv("DTHIP_MSD_MIN_ROWS")) ctx->msd_min_rows = atoll(e);
   if (const char* e = getenv("DTHIP_FILTER_PATH")) ctx->filter_path = atoi(e) == 0 ? 0 : 1;
+  if (const char* e = getenv("DTHIP_NONA_GUESS")) ctx->nona_guess = atoi(e) == 0 ? 0 : 1;
   if (const char* e = getenv("DTHIP_MSD_BUCKET_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= 4096) ctx->msd_bucket_rows = v; }
   if (const char* e = getenv("DTHIP_GUARD")) { const int g = atoi(e); ctx->guard = (g >= 1 && g <= 3) ? g : 0; if (ctx->guard) guard_install_handler(); }
   (void)hipEventCreate(&ctx->t0);
@@ -1561,6 +1572,11 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "filter_path")) {
     if (value < 0 || value > 1) { set_error("filter_path must be 0 (one pass) or 1 (count pass + write pass)"); return DTHIP_EINVAL; }
     ctx->filter_path = (int)value;
+    return DTHIP_OK;
+  }
+  if (!strcmp(name, "nona_guess")) {
+    if (value < 0 || value > 1) { set_error("nona_guess must be 0 or 1"); return DTHIP_EINVAL; }
+    ctx->nona_guess = (int)value;
     return DTHIP_OK;
   }
   if (!strcmp(name, "msd_bucket_rows")) {
@@ -1894,6 +1910,25 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
       // path does not apply, or the guess was wrong, plan again with the exact ranges
       int slot_bits = 0;
       bool done = false, hash_tried = false;
+      // value columns whose reducers need a valid count: guess from a sample that they hold no NA; the bucketed path then
+      // drops their per-row counter and verifies the guess on every row (DTHIP_RETRY_NA: aggregate again, counting)
+      bool guess_nona = false;
+      if (ctx->nona_guess && nrows >= ((int64_t)1 << 20)) {
+        uint32_t* d_na = nullptr;
+        std::vector<int> cand;
+        for (int c : used)
+          if (!(vd[c].flags & DTHIP_FLAG_NONA) && (acc_flags_for(aggs, naggs, c, vd[c].stype) & ACC_VCNT)) cand.push_back(c);
+        if (!cand.empty()) {
+          if ((rc = sc.get<uint32_t>(1, &d_na)) != DTHIP_OK) break;
+          if (hipMemsetAsync(d_na, 0, sizeof(uint32_t), ctx->stream) != hipSuccess) { set_error("memset failed"); rc = DTHIP_EDEVICE; break; }
+          for (int c : cand)
+            if ((rc = launch_value_na_sample(ctx, vd[c].data, vd[c].stype, nrows, d_na)) != DTHIP_OK) break;
+          if (rc != DTHIP_OK) break;
+          uint32_t seen = 0;
+          if ((rc = read_back(ctx, &seen, d_na, sizeof(seen))) != DTHIP_OK) break;
+          guess_nona = seen == 0;
+        }
+      }
       for (int attempt = (ctx->agg_path == 1 ? 1 : 0); attempt < 2 && !done; attempt++) {
         if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan, attempt == 0)) != DTHIP_OK) break;
         if (attempt == 0 && !plan.speculative) attempt = 1;      // nothing was guessed: this IS the exact plan
@@ -1916,8 +1951,11 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
           drop_partial_result(ctx, res);
           continue;
         }
-        if (bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &slot_bits)) {
-          rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits);
+        if (bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &slot_bits, guess_nona)) {
+          rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits, guess_nona);
+          if (rc == DTHIP_RETRY_NA) {                    // same plan once more, with valid counts
+            guess_nona = false; rc = DTHIP_OK; drop_partial_result(ctx, res); attempt--; continue;
+          }
           if (rc == DTHIP_RETRY_EXACT && attempt == 0) { rc = DTHIP_OK; continue; }
           if (rc == DTHIP_RETRY_EXACT) { set_error("bucketed aggregation: exact key range violated"); rc = DTHIP_EDEVICE; }
           done = true;

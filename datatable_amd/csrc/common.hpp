@@ -82,6 +82,8 @@ struct dthip_ctx {
   int cluster_mode = 0;      // clustered-key kernel variants: 0 decide from a sample, 1 never, 2 always
   int agg_offsets = 1;       // dthip_groupby_agg results carry group offsets (= sizes) even when no count() asks for them
   int f32_sum_ref = 0;       // 1: sum(float32) accumulates in float32, row by row, like the reference (slow path)
+  int nona_guess = 1;        // bucketed aggregation: value columns whose sample shows no NA are aggregated without a valid counter
+                             // (one DS atomic per row and column less), every row verified; a wrong guess aggregates again
   int filter_path = 1;       // row filters: 1 count pass + write pass (default: 1.3 + 5.8 ms per 1e9 float64 rows with two 8-byte columns
                              // taken); 0 ONE pass, tile offsets by decoupled look-back (measured 8.6-9.2 ms: the look-back chain costs
                              // more than the second read of the predicate column; kept selectable)
@@ -299,7 +301,8 @@ struct BucketGeom {
 };
 struct WorkItem { uint32_t bucket, begin, end, single; };
 enum { ACC_CNT = 1, ACC_SUM = 2, ACC_MIN = 4, ACC_MAX = 8, ACC_VCNT = 16, ACC_FSUM = 32, ACC_PRES = 64,
-       ACC_NONA = 128 /* DTHIP_FLAG_NONA: every bit pattern of the value column is a value */ };
+       ACC_NONA = 128 /* DTHIP_FLAG_NONA: every bit pattern of the value column is a value */,
+       ACC_CHKNA = 256 /* the column was GUESSED to hold no NA (no valid count kept): an NA row sets bit 1 of *bad */ };
 // dense accumulator arrays of F*S slots (slot index == transformed key)
 struct AggTable {
   uint32_t* cnt = nullptr;              // rows per slot
@@ -333,8 +336,10 @@ struct TableAggSegArgs {
   const uint16_t* kpart; const void* val; int vstype;
   const uint16_t* dirT; uint32_t dstride; uint32_t tile_rows;
   uint32_t S; int flags; AggTable tab;
+  uint32_t* bad;
 };
 int launch_table_agg_seg(dthip_ctx* ctx, const TableAggSegArgs& a);
+int launch_value_na_sample(dthip_ctx* ctx, const void* data, int stype, int64_t n, uint32_t* flag);
 struct TableAggArgs {
   const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
   int src;                    // 0: kpart + val of the partitioned rows, 1: raw rows (kx + val)

@@ -166,6 +166,9 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    whole buckets fill a tile) ordered in LDS and written in place -- and fall back to the LSD passes when
  *                    a final bucket would not fit a tile (heavy duplicates over a wide range); everything else takes stable
  *                    LSD radix passes; 1: LSD passes only.  Same results, bit for bit
+ *   "nona_guess"     1 (default): groupby_agg samples the value columns; a column whose sample holds no NA is aggregated
+ *                    without its valid counter (the group size stands for it) while every row is checked -- an NA found
+ *                    anyway makes the call aggregate once more, counting.  0: always count.  Results are identical.
  *   "filter_path"    1 (default): row filters count, then write (two reads of the predicate column); 0: one pass whose tile
  *                    offsets come from a decoupled look-back (measured slower on MI355X; kept for A/B runs)
  *   "f32_sum"        0 (default): sum(float32 column) accumulates in float64 and rounds once (the documented deviation at

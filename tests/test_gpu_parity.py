@@ -851,3 +851,77 @@ def test_float32_sum_reference_order_switch(ctx):
     got = r.agg(0); r.free()
     scale = np.add.reduceat(np.abs(np.nan_to_num(v[ri].astype(np.float64))), off[:-1])
     assert np.all(np.abs(got.astype(np.float64) - exp.astype(np.float64)) <= 1e-4 * np.abs(exp) + 4e-7 * scale + 1e-30)
+
+
+def _value_sample_free_rows(n, want, nsamp=1 << 16):
+    """rows that bucket.hip::value_na_sample_kernel does NOT read (row gid * n / nsamp for gid < nsamp)"""
+    seen = np.zeros(n, dtype=bool)
+    seen[((np.arange(nsamp, dtype=np.uint64) * np.uint64(n)) // np.uint64(nsamp)).astype(np.int64)] = True
+    free = np.flatnonzero(~seen)
+    return free[np.linspace(0, len(free) - 1, want).astype(np.int64)]
+
+
+def _agg_launches(ctx):
+    return ctx.profile_get("table_agg_kernel")[1] + ctx.profile_get("table_agg_seg_kernel")[1]
+
+
+@pytest.mark.parametrize("layout", ["tile_local", "exact", "one_table", "sorted"])
+def test_value_column_guessed_na_free(ctx, layout):
+    """round 4: value columns whose sample shows no NA are aggregated WITHOUT a valid counter, every row checked
+    (ACC_CHKNA).  (1) really NA-free: same results, one aggregation per column; (2) a single NA at a row the sample skips:
+    the call must notice, aggregate once more with counters, and return exactly what nona_guess=0 returns"""
+    rng = np.random.default_rng(90)
+    n = 5_000_000 if layout == "tile_local" else 1_500_000
+    kmax = {"tile_local": 2_000_000, "exact": 300_000, "one_table": 900, "sorted": 40_000}[layout]
+    k = rng.integers(0, kmax, n).astype(np.int32)
+    if layout == "sorted":
+        k.sort()
+    vals = [rng.standard_normal(n), rng.integers(-1000, 1000, n).astype(np.int32),
+            rng.integers(-10**12, 10**12, n).astype(np.int64), rng.standard_normal(n).astype(np.float32)]
+    NA = [np.nan, -2**31, -2**63, np.nan]
+    rows = _value_sample_free_rows(n, 4)
+    ops = ("sum", "mean", "min", "max", "count")
+    alist = [(opn, vi) for vi in range(len(vals)) for opn in ops]
+    if layout == "exact":
+        ctx.set_option("bucket_variant", 2)
+    ctx.profile(True)
+    try:
+        ri, off = o.group([k])
+        for with_na in (False, True):
+            vv = [v.copy() for v in vals]
+            if with_na:
+                vv[0][rows[0]] = NA[0]; vv[2][rows[2]] = NA[2]          # two of the four columns: one retry serves both
+            launches = {}
+            res = {}
+            for guess in (1, 0):
+                ctx.set_option("nona_guess", guess)
+                ctx.profile_reset()
+                r = ctx.groupby_agg([k], vv, alist)
+                launches[guess] = (_agg_launches(ctx), ctx.profile_get("value_na_sample_kernel")[1])
+                assert_same(r.offsets(), off, "offsets (guess %d, na %s)" % (guess, with_na))
+                res[guess] = [r.agg(a) for a in range(len(alist))]
+                for a, (opn, vi) in enumerate(alist):
+                    check_agg(res[guess][a], o.reduce(opn, vv[vi], ri, off), opn, vv[vi], ri, off,
+                              "%s(v%d) guess %d na %s %s" % (opn, vi, guess, with_na, layout))
+                r.free()
+            for a in range(len(alist)):
+                if alist[a][0] in ("min", "max", "count"):
+                    assert_same(res[1][a], res[0][a], "%s(v%d): guessed == counted" % alist[a])
+            assert launches[0][1] == 0 and launches[1][1] == len(vals), launches
+            assert launches[0][0] > 0
+            # NA-free: the guess holds, one aggregation per column; one unsampled NA: everything aggregated twice
+            assert launches[1][0] == (2 if with_na else 1) * launches[0][0], (layout, with_na, launches)
+        # an NA the sample SEES: nothing is guessed for any column of the call
+        vv = [v.copy() for v in vals]
+        vv[1][0] = NA[1]
+        ctx.set_option("nona_guess", 1)
+        ctx.profile_reset()
+        r = ctx.groupby_agg([k], vv, alist)
+        assert _agg_launches(ctx) == launches[0][0]
+        for a, (opn, vi) in enumerate(alist):
+            check_agg(r.agg(a), o.reduce(opn, vv[vi], ri, off), opn, vv[vi], ri, off, "%s(v%d) sampled NA" % (opn, vi))
+        r.free()
+    finally:
+        ctx.profile(False)
+        ctx.set_option("nona_guess", 1)
+        ctx.set_option("bucket_variant", 0)
