@@ -191,7 +191,8 @@ int dev_trim(dthip_ctx* ctx) {
 
 int read_back(dthip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
   if (bytes > ctx->pinned_bytes) {
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->host_words) (void)hipHostFree(ctx->host_words);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     ctx->pinned = nullptr;
     size_t nb = std::max<size_t>(bytes, 1 << 16);
     DTHIP_CHECK_HIP(hipHostMalloc(&ctx->pinned, nb, hipHostMallocDefault));
@@ -201,6 +202,17 @@ int read_back(dthip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes)
   DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   memcpy(host_dst, ctx->pinned, bytes);
   return DTHIP_OK;
+}
+
+// 16 words of pinned host memory mapped into the device's address space (lazily; null when the runtime refuses)
+static bool host_words(dthip_ctx* ctx) {
+  if (ctx->host_words) return true;
+  void* h = nullptr; void* d = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return false; }
+  ctx->host_words = static_cast<uint32_t*>(h);
+  ctx->host_words_dev = static_cast<uint32_t*>(d);
+  return true;
 }
 
 hipEvent_t prof_event(dthip_ctx* ctx) {
@@ -959,7 +971,22 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   nitems = bbase + g.F + 1;
   uint32_t* d_bad = bbase + g.F + 2;
   uint32_t* d_clustered = bbase + g.F + 3;        // [2]
-  DTHIP_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
+  // SMALL path (one table of <= SMALL_SLOTS slots: BASELINE C1, 1e6 rows / 100 groups, is bound by its ~17 launches, not by
+  // bytes): the plan kernel also initialises every table, and one single-workgroup kernel turns the slot counts into the
+  // group list, the offsets and the group count
+  const bool small = ctx->small_path != 0 && g.d == 0 && nslots <= SMALL_SLOTS;
+  FillList fills;
+  fills.n = 0;
+  auto fill = [&](void* p, size_t bytes, int byte) -> int {
+    if (small && fills.n < 12 && (bytes & 3) == 0) {
+      fills.p[fills.n] = static_cast<uint32_t*>(p); fills.words[fills.n] = (uint32_t)(bytes / 4); fills.val[fills.n] = byte ? 0xFFFFFFFFu : 0u;
+      fills.n++;
+      return DTHIP_OK;
+    }
+    DTHIP_CHECK_HIP(hipMemsetAsync(p, byte, bytes, ctx->stream));
+    return DTHIP_OK;
+  };
+  DTHIP_TRY(fill(d_bad, sizeof(uint32_t), 0));
   uint32_t M;
   {
     // with fewer buckets than CUs (BASELINE C2: 32) the aggregation is bound by its DS atomics, one 1024-thread workgroup
@@ -1034,7 +1061,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     }
     src = 0;
     DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, P, gtot, kpart, pc, clustered));
-  } else {
+  } else if (!small) {
     DTHIP_TRY(launch_bucket_plan(ctx, nullptr, 1, (uint32_t)n, M, bbase, items, nitems));
   }
 
@@ -1042,20 +1069,27 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   uint32_t* d_cnt = nullptr;      // rows per slot, or (no counts wanted) one presence bit per slot
   const size_t cnt_words = need_cnt ? nslots : (nslots + 31) / 32;
   DTHIP_TRY(sc.get<uint32_t>(cnt_words, &d_cnt));
-  DTHIP_CHECK_HIP(hipMemsetAsync(d_cnt, 0, cnt_words * 4, ctx->stream));
+  DTHIP_TRY(fill(d_cnt, cnt_words * 4, 0));
   std::vector<AggTable> tabs(vd.size());
   std::vector<int> tflags(vd.size(), 0);
   bool first = true;
-  for (int c : used) {
+  for (int c : used) {              // tables first (all of them: the small path initialises them in ONE kernel) ...
     AggTable& t = tabs[c];
     int f = acc_flags_for(aggs, naggs, c, vd[c].stype, vd[c].flags, guess_nona);
     if (first) { f |= first_flag; if (need_cnt) t.cnt = d_cnt; else t.pres = d_cnt; }
+    first = false;
     tflags[c] = f;
-    if (f & ACC_SUM) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.sum)); DTHIP_CHECK_HIP(hipMemsetAsync(t.sum, 0, nslots * 8, ctx->stream)); }
-    if (f & ACC_MIN) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.mn)); DTHIP_CHECK_HIP(hipMemsetAsync(t.mn, 0xFF, nslots * 8, ctx->stream)); }
-    if (f & ACC_MAX) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.mx)); DTHIP_CHECK_HIP(hipMemsetAsync(t.mx, 0, nslots * 8, ctx->stream)); }
-    if (f & ACC_FSUM) { DTHIP_TRY(sc.get<double>(nslots, &t.fsum)); DTHIP_CHECK_HIP(hipMemsetAsync(t.fsum, 0, nslots * 8, ctx->stream)); }
-    if (f & ACC_VCNT) { DTHIP_TRY(sc.get<uint32_t>(nslots, &t.vcnt)); DTHIP_CHECK_HIP(hipMemsetAsync(t.vcnt, 0, nslots * 4, ctx->stream)); }
+    if (f & ACC_SUM) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.sum)); DTHIP_TRY(fill(t.sum, nslots * 8, 0)); }
+    if (f & ACC_MIN) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.mn)); DTHIP_TRY(fill(t.mn, nslots * 8, 0xFF)); }
+    if (f & ACC_MAX) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.mx)); DTHIP_TRY(fill(t.mx, nslots * 8, 0)); }
+    if (f & ACC_FSUM) { DTHIP_TRY(sc.get<double>(nslots, &t.fsum)); DTHIP_TRY(fill(t.fsum, nslots * 8, 0)); }
+    if (f & ACC_VCNT) { DTHIP_TRY(sc.get<uint32_t>(nslots, &t.vcnt)); DTHIP_TRY(fill(t.vcnt, nslots * 4, 0)); }
+  }
+  if (small) DTHIP_TRY(launch_bucket_plan(ctx, nullptr, 1, (uint32_t)n, M, bbase, items, nitems, &fills));
+  first = true;
+  for (int c : used) {              // ... then one aggregation launch per value column
+    const AggTable& t = tabs[c];
+    const int f = tflags[c];
     if (src == 2) {
       TableAggSegArgs sa;
       memset(&sa, 0, sizeof(sa));
@@ -1096,15 +1130,40 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   memset(&pa, 0, sizeof(pa));
   pa.data = d_cnt; pa.stype = DTHIP_INT32; pa.cmp = DTHIP_GT; pa.ci = 0; pa.is_mask = need_cnt ? 0 : 2;
   int64_t ng = 0;
-  DTHIP_TRY(launch_compact(ctx, pa, (int64_t)nslots, idx, &ng));
-  if (plan.speculative || guess_nona) {
-    uint32_t bad = 0;
-    DTHIP_TRY(read_back(ctx, &bad, d_bad, sizeof(bad)));
-    if (plan.speculative && (bad & 1u)) return DTHIP_RETRY_EXACT;
-    if (bad & 2u) return DTHIP_RETRY_NA;
+  if (small) {
+    void* off = nullptr;
+    if (want_offsets) DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * (nslots + 2), &off));
+    SmallGroupsArgs ga;
+    ga.cnt = d_cnt; ga.bits = need_cnt ? 0 : 1; ga.nslots = (uint32_t)nslots; ga.idx = idx;
+    ga.off = static_cast<uint32_t*>(off); ga.bad = d_bad;
+    uint32_t w[2] = {0, 0};
+    if (ctx->small_path == 2 && host_words(ctx)) {
+      // the kernel writes its two words straight into mapped host memory: no copy command, one stream wait
+      ga.out = ctx->host_words_dev;
+      DTHIP_TRY(launch_small_groups(ctx, ga));
+      DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      w[0] = reinterpret_cast<volatile uint32_t*>(ctx->host_words)[0];
+      w[1] = reinterpret_cast<volatile uint32_t*>(ctx->host_words)[1];
+    } else {
+      ga.out = d_clustered;                        // its two words were read before the partition and are free now
+      DTHIP_TRY(launch_small_groups(ctx, ga));
+      DTHIP_TRY(read_back(ctx, w, d_clustered, sizeof(w)));
+    }
+    if (plan.speculative && (w[1] & 1u)) return DTHIP_RETRY_EXACT;
+    if (w[1] & 2u) return DTHIP_RETRY_NA;
+    ng = w[0];
+    res->offsets = static_cast<int32_t*>(off);
+  } else {
+    DTHIP_TRY(launch_compact(ctx, pa, (int64_t)nslots, idx, &ng));
+    if (plan.speculative || guess_nona) {
+      uint32_t bad = 0;
+      DTHIP_TRY(read_back(ctx, &bad, d_bad, sizeof(bad)));
+      if (plan.speculative && (bad & 1u)) return DTHIP_RETRY_EXACT;
+      if (bad & 2u) return DTHIP_RETRY_NA;
+    }
   }
   res->nrows = n; res->ngroups = ng;
-  if (want_offsets) {
+  if (want_offsets && !small) {
     // offsets = exclusive scan of the group sizes (Groupby offsets, groupby.h:54-91)
     void* off = nullptr;
     DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * ((size_t)ng + 2 + (size_t)ng / 8192 + 1), &off));
@@ -1496,6 +1555,7 @@ int dthip_init(int device, void* stream, dthip_ctx** out) {
   if (const char* e = getenv("DTHIP_SORT_PATH")) ctx->sort_path = atoi(e) >= 0 && atoi(e) <= 2 ? atoi(e) : 0;
   if (const char* e = getenv("DTHIP_MSD_MIN_ROWS")) ctx->msd_min_rows = atoll(e);
   if (const char* e = getenv("DTHIP_FILTER_PATH")) ctx->filter_path = atoi(e) == 0 ? 0 : 1;
+  if (const char* e = getenv("DTHIP_SMALL_PATH")) ctx->small_path = std::min(2, std::max(0, atoi(e)));
   if (const char* e = getenv("DTHIP_NONA_GUESS")) ctx->nona_guess = atoi(e) == 0 ? 0 : 1;
   if (const char* e = getenv("DTHIP_MSD_BUCKET_ROWS")) { const int v = atoi(e); if (v >= 1 && v <= 4096) ctx->msd_bucket_rows = v; }
   if (const char* e = getenv("DTHIP_GUARD")) { const int g = atoi(e); ctx->guard = (g >= 1 && g <= 3) ? g : 0; if (ctx->guard) guard_install_handler(); }
@@ -1572,6 +1632,11 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "filter_path")) {
     if (value < 0 || value > 1) { set_error("filter_path must be 0 (one pass) or 1 (count pass + write pass)"); return DTHIP_EINVAL; }
     ctx->filter_path = (int)value;
+    return DTHIP_OK;
+  }
+  if (!strcmp(name, "small_path")) {
+    if (value < 0 || value > 2) { set_error("small_path must be 0, 1 or 2"); return DTHIP_EINVAL; }
+    ctx->small_path = (int)value;
     return DTHIP_OK;
   }
   if (!strcmp(name, "nona_guess")) {

@@ -369,9 +369,11 @@ __global__ void __launch_bounds__(1024) bucket_gscan_kernel(uint32_t* gtot, uint
 
 // bucket sizes -> bucket starts + the aggregation work list (parts of <= M rows)
 __global__ void __launch_bounds__(1024) bucket_plan_kernel(const uint32_t* tot, uint32_t F, uint32_t n_raw, uint32_t M,
-                                                           uint32_t* bbase, WorkItem* items, uint32_t* nitems) {
+                                                           uint32_t* bbase, WorkItem* items, uint32_t* nitems, FillList fl) {
   __shared__ uint32_t scratch[16];
   const int tid = threadIdx.x;
+  for (int i = 0; i < fl.n; i++)
+    for (uint32_t w = tid; w < fl.words[i]; w += 1024) fl.p[i][w] = fl.val[i];
   uint32_t sz[2], np[2], s = 0, ps = 0;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
@@ -628,9 +630,45 @@ int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uin
 }
 
 int launch_bucket_plan(dthip_ctx* ctx, const uint32_t* tot, uint32_t F, uint32_t n_raw, uint32_t M,
-                       uint32_t* bbase, WorkItem* items, uint32_t* nitems) {
+                       uint32_t* bbase, WorkItem* items, uint32_t* nitems, const FillList* fills) {
   if (F > 2048) { set_error("bucket plan: F=%u > 2048", F); return DTHIP_EINVAL; }
-  DTHIP_LAUNCH(ctx, "bucket_plan_kernel", bucket_plan_kernel, 1, 1024, 0, tot, F, n_raw, M, bbase, items, nitems);
+  FillList fl;
+  if (fills) fl = *fills; else fl.n = 0;
+  DTHIP_LAUNCH(ctx, "bucket_plan_kernel", bucket_plan_kernel, 1, 1024, 0, tot, F, n_raw, M, bbase, items, nitems, fl);
+  return DTHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// small slot tables: the group list in one launch.  Chunks of 1024 slots, two block scans per chunk (non-empty slots,
+// rows); slot order == key order, so idx is ascending and off the Groupby offsets (groupby.h:54-91) of the result.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) small_groups_kernel(SmallGroupsArgs a) {
+  __shared__ uint32_t scratch[16];
+  const uint32_t tid = threadIdx.x;
+  uint32_t g0 = 0, r0 = 0;
+  for (uint32_t base = 0; base < a.nslots; base += 1024) {
+    const uint32_t s = base + tid;
+    uint32_t c = 0;
+    if (s < a.nslots) c = a.bits ? (a.cnt[s >> 5] >> (s & 31)) & 1u : a.cnt[s];
+    const uint32_t f = c ? 1u : 0u;
+    uint32_t gt = 0, rt = 0, re = 0;
+    const uint32_t ge = block_excl_scan_u32<1024>(f, scratch, &gt);
+    if (a.off) re = block_excl_scan_u32<1024>(c, scratch, &rt);
+    if (f) {
+      a.idx[g0 + ge] = (int32_t)s;
+      if (a.off) a.off[g0 + ge] = r0 + re;
+    }
+    g0 += gt; r0 += rt;
+  }
+  if (tid == 0) {
+    if (a.off) a.off[g0] = r0;
+    a.out[0] = g0;
+    a.out[1] = a.bad ? *a.bad : 0u;
+  }
+}
+
+int launch_small_groups(dthip_ctx* ctx, const SmallGroupsArgs& a) {
+  DTHIP_LAUNCH(ctx, "small_groups_kernel", small_groups_kernel, 1, 1024, 0, a);
   return DTHIP_OK;
 }
 

@@ -166,6 +166,10 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    whole buckets fill a tile) ordered in LDS and written in place -- and fall back to the LSD passes when
  *                    a final bucket would not fit a tile (heavy duplicates over a wide range); everything else takes stable
  *                    LSD radix passes; 1: LSD passes only.  Same results, bit for bit
+ *   "small_path"     2 (default): a groupby_agg whose keys fit ONE table of <= 8192 slots runs a launch-lean sequence (tables
+ *                    initialised by the plan kernel; group list + offsets + count from one single-workgroup kernel, which
+ *                    writes its counts into mapped host memory -- no copy command); 1: the counts are copied back instead;
+ *                    0: the general sequence.  1e6 rows / 100 groups: 0.116 ms (0), 0.087 (1), 0.085 (2).  Same results
  *   "nona_guess"     1 (default): groupby_agg samples the value columns; a column whose sample holds no NA is aggregated
  *                    without its valid counter (the group size stands for it) while every row is checked -- an NA found
  *                    anyway makes the call aggregate once more, counting.  0: always count.  Results are identical.

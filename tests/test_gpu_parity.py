@@ -925,3 +925,53 @@ def test_value_column_guessed_na_free(ctx, layout):
         ctx.profile(False)
         ctx.set_option("nona_guess", 1)
         ctx.set_option("bucket_variant", 0)
+
+
+@pytest.mark.parametrize("small_path", [0, 1, 2])
+def test_small_table_sequence(ctx, small_path):
+    """round 4: key ranges that fit ONE table of <= 8192 slots take a launch-lean sequence (option small_path; BASELINE C1
+    is bound by launches): tables initialised by the plan kernel, group list + offsets + group count from one
+    single-workgroup kernel (2: counts written to mapped host memory).  Same results as the general sequence (0), also
+    when a guessed key range or a guessed NA-free column turns out wrong."""
+    rng = np.random.default_rng(91 + small_path)
+    ctx.set_option("small_path", small_path)
+    ctx.profile(True)
+    try:
+        for n, kmax in ((1, 1), (5, 3), (1000, 7), (70_000, 100), (300_000, 8000), (300_000, 8192), (300_000, 8300), (40_000, 5000)):
+            k = rng.integers(0, kmax, n).astype(np.int64) - kmax // 2
+            if n > 100:
+                k[rng.random(n) < 0.01] = -2**63
+            v = rng.standard_normal(n); v[rng.random(n) < 0.05] = np.nan
+            w = rng.integers(-99, 99, n).astype(np.int32)
+            ctx.profile_reset()
+            _vs_oracle(ctx, [k], [v, w], check_ri=False)
+            used = ctx.profile_get("small_groups_kernel")[1]
+            if small_path == 0 or kmax >= 8192:      # (in between, the LDS table of the widest column decides: one table or buckets)
+                assert used == 0, (n, kmax, used)
+            elif kmax <= 100:
+                assert used > 0, (n, kmax, used)
+        # two keys, presence bits only (agg_offsets=0 inside _vs_oracle), all rows one group, sorted keys
+        a = rng.integers(0, 40, 200_000).astype(np.int32); b = rng.integers(-3, 60, 200_000).astype(np.int32)
+        _vs_oracle(ctx, [a, b], [rng.standard_normal(200_000)], check_ri=False)
+        _vs_oracle(ctx, [np.zeros(100_000, np.int32)], [np.ones(100_000)], check_ri=False)
+        _vs_oracle(ctx, [np.sort(rng.integers(0, 3000, 500_000)).astype(np.int32)], [rng.standard_normal(500_000)], check_ri=False)
+        # a guessed key range broken by one unsampled row (retry with the exact range), then a guessed NA-free column with
+        # one unsampled NA (retry with counters): both verdicts travel in the small kernel's second word
+        n = 3_000_000
+        k = rng.integers(100, 900, n).astype(np.int64); k[0], k[-1] = 100, 899
+        v = rng.standard_normal(n)
+        k2 = k.copy(); k2[_unsampled_rows(n, 8, 1)[0]] = 5000
+        v2 = v.copy(); v2[_value_sample_free_rows(n, 3)[1]] = np.nan
+        ctx.set_option("spec_min_rows", 1)
+        for kk, vv in ((k, v), (k2, v), (k, v2), (k2, v2)):
+            ri, off = o.group([kk])
+            r = ctx.groupby_agg([kk], [vv], [("sum", 0), ("mean", 0), ("min", 0), ("count", 0), ("count0", None)])
+            assert_same(r.offsets(), off, "offsets"); assert_same(r.key(0), kk[ri[off[:-1]]], "keys")
+            for a_, opn in enumerate(("sum", "mean", "min", "count")):
+                check_agg(r.agg(a_), o.reduce(opn, vv, ri, off), opn, vv, ri, off, "%s small_path=%d" % (opn, small_path))
+            assert_same(r.agg(4), np.diff(off).astype(np.int64), "count()")
+            r.free()
+    finally:
+        ctx.profile(False)
+        ctx.set_option("small_path", 2)
+        ctx.set_option("spec_min_rows", 1 << 23)
