@@ -374,6 +374,18 @@ __global__ void __launch_bounds__(1024) bucket_plan_kernel(const uint32_t* tot, 
   const int tid = threadIdx.x;
   for (int i = 0; i < fl.n; i++)
     for (uint32_t w = tid; w < fl.words[i]; w += 1024) fl.p[i][w] = fl.val[i];
+  if (!tot && F == 1) {
+    // ONE table for all rows (no partition): its parts are written by all threads -- one thread writing 245 items in a
+    // row made this kernel the second longest (14 us) of a 1e6-row call (BASELINE C1)
+    const uint32_t np1 = (n_raw + M - 1) / M;
+    for (uint32_t i = tid; i < np1; i += 1024) {
+      WorkItem it;
+      it.bucket = 0; it.begin = i * M; it.end = (i + 1 == np1) ? n_raw : (i + 1) * M; it.single = np1 == 1 ? 1u : 0u;
+      items[i] = it;
+    }
+    if (tid == 0) { bbase[0] = 0; bbase[1] = n_raw; *nitems = np1; }
+    return;
+  }
   uint32_t sz[2], np[2], s = 0, ps = 0;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
