@@ -730,10 +730,16 @@ struct Grouping {
 
 // the final MSD level can mark the group heads (its keys sit in LDS in sorted order): built, bit-exact on the forced
 // suites, and measured a LOSS -- the level 4.75 -> 6.04 ms for a count_heads pass of 0.73 ms saved -- so it stays off
-// (DTHIP_FUSE_HEADS=1 switches it on for A/B runs)
+// AND out of the product build: with the head phase compiled in, the ordinary scatter variant of radix_pass_kernel spilled
+// 60 instead of 24 VGPRs and C5's two scatter levels went from 4.3 + 4.9 to 5.7 + 6.0 ms although the phase never ran.
+// `make -C datatable_amd/csrc heads` builds the flavour (-DDTHIP_RP_HEADS); there DTHIP_FUSE_HEADS=1 switches it on.
 static bool fuse_heads_enabled() {
+#ifdef DTHIP_RP_HEADS
   static const bool on = getenv("DTHIP_FUSE_HEADS") && atoi(getenv("DTHIP_FUSE_HEADS")) == 1;
   return on;
+#else
+  return false;
+#endif
 }
 
 static int alloc_head_bitmap(dthip_ctx* ctx, Scratch& sc, int64_t n, unsigned long long** bitmap) {
@@ -2021,7 +2027,7 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
           if (rc == DTHIP_RETRY_NA) {                    // same plan once more, with valid counts
             guess_nona = false; rc = DTHIP_OK; drop_partial_result(ctx, res); attempt--; continue;
           }
-          if (rc == DTHIP_RETRY_EXACT && attempt == 0) { rc = DTHIP_OK; continue; }
+          if (rc == DTHIP_RETRY_EXACT && attempt == 0) { rc = DTHIP_OK; drop_partial_result(ctx, res); continue; }
           if (rc == DTHIP_RETRY_EXACT) { set_error("bucketed aggregation: exact key range violated"); rc = DTHIP_EDEVICE; }
           done = true;
         }

@@ -767,6 +767,9 @@ struct LdsTab {
   uint32_t* naflag;      // ACC_CHKNA: set when a value turned out to be NA (the column was GUESSED to hold none)
 };
 
+// accumulators (or checks) that look at the VALUE of a row; without any of them the value column is not even read
+constexpr int ACC_VALUE_MASK = ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM | ACC_CHKNA;
+
 __device__ __forceinline__ LdsTab carve_tab(unsigned char* smem, uint32_t S, int flags) {
   LdsTab t;
   unsigned char* p = smem;
@@ -810,7 +813,7 @@ __device__ __forceinline__ void acc_wave_uniform(const LdsTab& t, int flags, uin
   const bool lead = (threadIdx.x & 63) == 0;
   if (lead && (flags & ACC_CNT)) atomicAdd(&t.cnt[slot], 64u);
   if (lead && (flags & ACC_PRES)) atomicOr(&t.pres[slot >> 5], 1u << (slot & 31));
-  if (!(flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM))) return;
+  if (!(flags & (ACC_VALUE_MASK))) return;
   const bool ok = (flags & ACC_NONA) || !ValTraits<VT>::isna(v);
   const uint32_t nok = (uint32_t)__popcll(__ballot(ok));
   if ((flags & ACC_CHKNA) && nok != 64u && lead) *t.naflag = 1u;
@@ -838,7 +841,7 @@ __device__ __forceinline__ void acc_row(const LdsTab& t, int flags, uint32_t slo
   }
   if (flags & ACC_CNT) atomicAdd(&t.cnt[slot], 1u);
   if (flags & ACC_PRES) atomicOr(&t.pres[slot >> 5], 1u << (slot & 31));
-  if (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) {
+  if (flags & (ACC_VALUE_MASK)) {
     if ((flags & ACC_NONA) || !ValTraits<VT>::isna(v)) {
       if (flags & ACC_VCNT) atomicAdd(&t.vcnt[slot], 1u);
       if (ValTraits<VT>::is_float) {
@@ -936,7 +939,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
   init_table(t, S, flags, tid);
   __syncthreads();
   const VT* __restrict__ val = static_cast<const VT*>(a.val);
-  const bool hasval = (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) != 0;
+  const bool hasval = (flags & (ACC_VALUE_MASK)) != 0;
   if (RAW) {
     bool bad = false;
     for (uint32_t row = it.begin + tid; row < it.end; row += TA_BLOCK) {
@@ -1057,7 +1060,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_seg_kernel(TableAggSegDev 
   __syncthreads();
   const VT* __restrict__ val = static_cast<const VT*>(a.val);
   const uint16_t* __restrict__ kp = a.kpart;
-  const bool hasval = (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) != 0;
+  const bool hasval = (flags & (ACC_VALUE_MASK)) != 0;
   const uint16_t* __restrict__ ds = a.dirT + (size_t)it.bucket * a.dstride;
   const uint16_t* __restrict__ de = ds + a.dstride;
   const uint32_t t0 = it.begin, t1 = it.end;

@@ -779,6 +779,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     }
   }
   __syncthreads();
+#ifdef DTHIP_RP_HEADS          // a build flavour only (`make heads`): compiled in, the phase costs every variant registers
   if (a.headbits) {
     // group heads of the final order: the tile (a bucket, or a window of whole buckets) starts a new key prefix, inside it
     // a row is a head when its key differs from its predecessor's.  Lane = slot (conflict-free LDS reads), one ballot per
@@ -816,6 +817,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     }
     __syncthreads();
   }
+#endif
   // thread owns slots (g*BLOCK + tid)*4 .. +3 for g in [0, GROUPS)
   uint32_t gpos[ITEMS];
 #pragma unroll
@@ -940,6 +942,9 @@ static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
   a.ukout = p.ukout; a.uk_stype = p.uk_stype; a.uk_desc = p.uk_desc; a.uk_bits = p.uk_bits;
   a.uk_edge = p.uk_edge; a.uk_na_repl = p.uk_na_repl; a.uk_inc = p.uk_inc;
   a.headbits = p.bounds ? p.headbits : nullptr;
+#ifndef DTHIP_RP_HEADS
+  if (a.headbits) { set_error("radix pass: head marking is a build flavour (make heads), not part of this library"); return DTHIP_ENOTIMPL; }
+#endif
 #ifdef DTHIP_RP_EXPERIMENT
   if (getenv("DTHIP_RP_SEQ") && atoi(getenv("DTHIP_RP_SEQ"))) a.seq = 1;      // timing experiment: wrong results
 #endif

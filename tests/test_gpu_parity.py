@@ -877,20 +877,24 @@ def test_value_column_guessed_na_free(ctx, layout):
     if layout == "sorted":
         k.sort()
     vals = [rng.standard_normal(n), rng.integers(-1000, 1000, n).astype(np.int32),
-            rng.integers(-10**12, 10**12, n).astype(np.int64), rng.standard_normal(n).astype(np.float32)]
-    NA = [np.nan, -2**31, -2**63, np.nan]
-    rows = _value_sample_free_rows(n, 4)
+            rng.integers(-10**12, 10**12, n).astype(np.int64), rng.standard_normal(n).astype(np.float32),
+            rng.standard_normal(n)]
+    NA = [np.nan, -2**31, -2**63, np.nan, np.nan]
+    rows = _value_sample_free_rows(n, 5)
     ops = ("sum", "mean", "min", "max", "count")
-    alist = [(opn, vi) for vi in range(len(vals)) for opn in ops]
+    # the last column is only COUNTED: guessed NA-free it has no accumulator at all, and must still be read and verified
+    alist = [(opn, vi) for vi in range(len(vals) - 1) for opn in ops] + [("count", len(vals) - 1)]
     if layout == "exact":
         ctx.set_option("bucket_variant", 2)
     ctx.profile(True)
     try:
         ri, off = o.group([k])
-        for with_na in (False, True):
+        for with_na in (False, True, "counted column only"):
             vv = [v.copy() for v in vals]
-            if with_na:
-                vv[0][rows[0]] = NA[0]; vv[2][rows[2]] = NA[2]          # two of the four columns: one retry serves both
+            if with_na == "counted column only":
+                vv[4][rows[4]] = NA[4]
+            elif with_na:
+                vv[0][rows[0]] = NA[0]; vv[2][rows[2]] = NA[2]          # two of the columns: one retry serves both
             launches = {}
             res = {}
             for guess in (1, 0):
