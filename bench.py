@@ -418,7 +418,7 @@ def dist_one_rank_leg(ctx, keys, vals, steps, local_ms):
         torch.cuda.synchronize(); ctx.profile(False)
         prof = {nm: ctx.profile_get(nm) for nm in ctx.profile_names()}
         return {"ms_per_step": ms, "local_ms_per_step": local_ms, "overhead_ms": ms - local_ms, "rows": n,
-                "what": "dthip_sharded_groupby_agg on a 1-rank RCCL communicator: 3 all-gathers (samples, send counts, status), "
+                "what": "dthip_sharded_groupby_agg on a 1-rank RCCL communicator: 2 all-gathers (samples; send counts + status), "
                         "all-to-all-v to self, merge of the partial groups",
                 "kernel_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},
                 "kernel_launches": int(sum(v[1] for v in prof.values()))}
