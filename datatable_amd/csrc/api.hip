@@ -208,7 +208,7 @@ int read_back(dthip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes)
 static bool host_words(dthip_ctx* ctx) {
   if (ctx->host_words) return true;
   void* h = nullptr; void* d = nullptr;
-  if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return false; }
   if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return false; }
   ctx->host_words = static_cast<uint32_t*>(h);
   ctx->host_words_dev = static_cast<uint32_t*>(d);
