@@ -987,6 +987,11 @@ static int launch_pass_k(dthip_ctx* ctx, const RadixPass& p) {
   int p1w = (p0w == 8 && p.pay.n > 1) ? p.pay.width[1] : 0;
   if (prefetch < 2) p1w = 0;
   if (prefetch < 1) p0w = 0;
+  // TWO 8-byte columns prefetched next to the keys cost the kernel 96 spilled VGPRs (scripts/kernel_resources.sh) and lose
+  // to loading the second one after the ranking: 5e8 rows, int64 key + two float64 columns riding, MSD levels 8.7 + 8.7 + 9.1
+  // -> 6.0 + 6.3 + 5.4 ms (29.9 -> 21.1 ms; scripts/sort88_bench.py).  8 + 4 bytes (config 5: value + RowIndex) stay
+  // prefetched: there the spills (24) are cheaper than the exposed load (profiles/r04_rank_ab.txt).  3: the old dispatch
+  if (p1w == 8 && prefetch != 3) p1w = 0;
   if (p.bits > 9) {
     // final MSD level over 10 bits: 1024 bins rule the per-wave mask tables out (8 KB each), the ballot ranking needs none
     if (sizeof(KeyT) != 4 || !p.bounds) { set_error("radix pass: a 10-bit digit is for the final MSD level only"); return DTHIP_EINVAL; }
