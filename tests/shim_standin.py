@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE -- a NumPy / oracle stand-in for the few libdthip entry points the reference-side binding
-(integration/datatable_hip_shim.py) calls on its fused-aggregate, row-filter, rows-in-grouped-order and sort routes, so
+(integration/datatable_hip_shim.py) calls on its fused-aggregate, S-red (other reducers, cumulative operators), row-filter, rows-in-grouped-order and sort routes, so
 that the binding's HOST logic (query matching, pointer and stype plumbing, residency cache, lazy DeviceFrame results,
 result assembly, names) runs end to end against the real reference on a machine without a GPU.
 
@@ -150,6 +150,79 @@ class StandinLib:
         if _addr(out_ri):
             _store(out_ri, np.flatnonzero(m).astype(np.int32))
         k._obj.value = int(m.sum())
+        return 0
+
+    # ---- S-red: dthip_groupby once, then one call per j item ---------------------------------------------------------
+    def dthip_groupby(self, h, karr, nkeys, n, na_pos, mem, want_ri, out):
+        self.calls.append(("groupby", mem))
+        keys, ri, off = self._group(karr, nkeys, n, L.NA_FIRST if na_pos == L.NA_REMOVE else na_pos)
+        r = _Res()
+        if na_pos == L.NA_REMOVE:
+            # include/dthip.h: ordered NA first, then as many rows as the LAST key column has NAs are cut off the front
+            last = keys[-1]
+            cut = int((np.isnan(last) if last.dtype.kind == "f" else last == np.iinfo(last.dtype).min).sum())
+            ri = ri[cut:]
+            off = np.unique(np.clip(off.astype(np.int64) - cut, 0, None)).astype(np.int32)
+        r.nrows, r.ngroups = len(ri), len(off) - 1
+        r.rowindex, r.offsets = np.ascontiguousarray(ri, np.int32), np.ascontiguousarray(off, np.int32)
+        return self._new(r, out)
+
+    def dthip_gather(self, h, col, ri, nout, mem, dst):
+        c = col._obj
+        idx = _view(ri, nout, L.INT32)
+        n = int(idx.max()) + 1 if nout else 0
+        _store(dst, _view(c.data, n, c.stype)[idx])
+        return 0
+
+    def dthip_result_group_keys(self, ctx, h, col, mem, dst):
+        r, c = self._r(h), col._obj
+        first = r.rowindex[r.offsets[:-1]]
+        n = int(first.max()) + 1 if len(first) else 0
+        _store(dst, _view(c.data, n, c.stype)[first])
+        return 0
+
+    # the stype rules are host code of the REAL library (no GPU needed to ask it)
+    def dthip_reduce_out_stype(self, op, st): return L.load().dthip_reduce_out_stype(op, st)
+    def dthip_reduce2_out_stype(self, a, b): return L.load().dthip_reduce2_out_stype(a, b)
+    def dthip_cumulate_out_stype(self, op, st): return L.load().dthip_cumulate_out_stype(op, st)
+
+    def dthip_reduce(self, h, op, col, ri, off, ng, n, mem, dst):
+        self.calls.append(("reduce", mem))
+        offs = _view(off, ng + 1, L.INT32)
+        if op == L.COUNT0:
+            _store(dst, np.diff(offs).astype(np.int64)); return 0
+        c = col._obj
+        idx = _view(ri, n, L.INT32)
+        v = _view(c.data, (int(idx.max()) + 1) if n else 0, c.stype)
+        if op in (L.FIRST, L.LAST):
+            res = v[idx[offs[:-1]]] if op == L.FIRST else v[idx[offs[1:] - 1]]
+        elif op in OPNAME:
+            res = o.reduce(OPNAME[op], v, idx, offs, stype=c.stype)
+        else:
+            res = o.reducex({L.SD: "sd", L.MEDIAN: "median", L.NUNIQUE: "nunique"}[op], v, idx, offs, stype=c.stype)
+        _store(dst, res)
+        return 0
+
+    def dthip_reduce2(self, h, op, ca, cb, ri, off, ng, n, mem, dst):
+        self.calls.append(("reduce2", mem))
+        offs, idx = _view(off, ng + 1, L.INT32), _view(ri, n, L.INT32)
+        a, b = ca._obj, cb._obj
+        m = (int(idx.max()) + 1) if n else 0
+        _store(dst, o.reduce2({L.COV: "cov", L.CORR: "corr"}[op], _view(a.data, m, a.stype), _view(b.data, m, b.stype), idx, offs,
+                              stypes=(a.stype, b.stype)))
+        return 0
+
+    def dthip_cumulate(self, h, op, col, ri, off, ng, n, reverse, mem, dst):
+        self.calls.append(("cumulate", mem))
+        offs = _view(off, ng + 1, L.INT32)
+        name = {L.CUMSUM: "cumsum", L.CUMPROD: "cumprod", L.CUMMIN: "cummin", L.CUMMAX: "cummax", L.CUMCOUNT: "cumcount",
+                L.NGROUP: "ngroup"}[op]
+        if col is None:
+            _store(dst, o.cumulate(name, None, None, offs, reverse=bool(reverse))); return 0
+        c = col._obj
+        idx = _view(ri, n, L.INT32)
+        v = _view(c.data, (int(idx.max()) + 1) if n else 0, c.stype)
+        _store(dst, o.cumulate(name, v, idx, offs, reverse=bool(reverse), stype=c.stype))
         return 0
 
     # ---- results ----------------------------------------------------------------------------------------------------

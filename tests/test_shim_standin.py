@@ -125,3 +125,40 @@ def test_unrouted_statements_reach_the_reference(env):
     with pytest.raises(NotImplementedError):                   # the reference's own refusal of i + by comes through
         DT[f.v > 1, :, shim.by(f.k)]
     assert not ctx._lib.calls
+
+
+@pytest.mark.parametrize("mode", ["off", "auto", "lazy"])
+def test_sred_routes(env, mode):
+    """the other reducers and the cumulative operators: dthip_groupby once, then one call per j item"""
+    shim, ctx = env
+    shim.options.residency = mode
+    import datatable
+    from datatable import f
+    for n in (1, 29, 3000):
+        DT = make_frame(shim, n, seed=100 + n)
+        j = [datatable.sd(f.f8), datatable.sd(f.i4), datatable.median(f.f8), datatable.median(f.i2), datatable.nunique(f.i1),
+             datatable.nunique(f.f4), datatable.first(f.f8), datatable.last(f.i8), datatable.first(f.b), datatable.last(f.b),
+             datatable.cov(f.f8, f.i4), datatable.corr(f.f4, f.f8), datatable.count()]
+        got = _as_frame(shim, DT[:, j, shim.by(f.k)])
+        assert_frames_equal(dt, got, dt.Frame.__getitem__(DT, (slice(None), j, dt.by(f.k))))
+        DT[:, "f8"] = DT[:, dt.ifelse(dt.math.isinf(f.f8), 1.0, f.f8)]
+        for reverse in (False, True):
+            j = [datatable.cumsum(f.f8, reverse=reverse), datatable.cumsum(f.i4, reverse=reverse),
+                 datatable.cummin(f.f4, reverse=reverse), datatable.cummax(f.i8, reverse=reverse),
+                 datatable.cummax(f.b, reverse=reverse), datatable.cumprod(f.i1, reverse=reverse),
+                 datatable.cumcount(reverse=reverse), datatable.ngroup(reverse=reverse)]
+            got = _as_frame(shim, DT[:, j, shim.by(f.k, f.k2)])
+            assert_frames_equal(dt, got, dt.Frame.__getitem__(DT, (slice(None), j, dt.by(f.k, f.k2))))
+    kinds = {c[0] for c in ctx._lib.calls}
+    assert {"groupby", "reduce", "reduce2", "cumulate"} <= kinds
+
+
+def test_sort_with_na_removed(env):
+    shim, ctx = env
+    from datatable import f
+    DF = make_frame(shim, 3000, seed=501, key="float64")
+    for c in (dict(cols=[f.i1], na_position="remove"), dict(cols=[f.k2, f.i2], na_position="remove"),
+              dict(cols=[f.k], reverse=True, na_position="remove")):
+        cols = c.pop("cols")
+        got = DF[:, :, shim.sort(*cols, **c)]
+        assert_rows_equal(dt, _as_frame(shim, got), dt.Frame.__getitem__(DF, (slice(None), slice(None), dt.sort(*cols, **c))))
