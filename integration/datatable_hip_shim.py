@@ -822,16 +822,48 @@ def run_sort(frame, keys, desc, na_pos, cols, ctx=None):
     return _rows_call(frame, keys, desc, cols, na_pos, ctx).finish(frame, wrap=True)
 
 
+def _dict_j(item):
+    """DT[i, {"name": expr, ...}, ...] -> (the same statement with j as a list, [names]): the reference evaluates the
+    values like a list and names the j columns after the keys (by-columns first; duplicates mangled, names.cc:232-266)"""
+    if isinstance(item, tuple) and len(item) >= 2 and isinstance(item[1], dict) and item[1] and \
+            all(isinstance(k, str) for k in item[1]):
+        return (item[0], list(item[1].values())) + tuple(item[2:]), list(item[1])
+    return item, None
+
+
+def _renamed(res, names, nhead):
+    """the j columns of an accelerated result take the names of a dict-form j; None when the shape is not by-columns + j"""
+    nc = res.ncols
+    if nc != nhead + len(names):
+        return None
+    new = _mangled(list(res.names[:nhead]) + list(names))
+    if isinstance(res, DeviceFrame):
+        res._names = tuple(new)
+        if res._frame is not None:
+            res._frame.names = new
+    else:
+        res.names = new
+    return res
+
+
 def _route(frame, item):
     """the accelerated evaluation of frame[item], or NotImplemented"""
+    item, names = _dict_j(item)
+    res = NotImplemented
     plan = match(frame, item)
     if plan is not None:
-        return run(frame, *plan)
-    for matcher, runner in ((match_filter, run_filter), (match_rows, run_rows), (match_sort, run_sort)):
-        plan = matcher(frame, item)
-        if plan is not None:
-            return runner(frame, *plan)
-    return NotImplemented
+        res = run(frame, *plan)
+    else:
+        for matcher, runner in ((match_filter, run_filter), (match_rows, run_rows), (match_sort, run_sort)):
+            plan = matcher(frame, item)
+            if plan is not None:
+                res = runner(frame, *plan)
+                break
+    if res is NotImplemented or names is None:
+        return res
+    nhead = len(item[2].cols) if len(item) == 3 and isinstance(item[2], by) else 0
+    res = _renamed(res, names, nhead)
+    return NotImplemented if res is None else res
 
 
 def _native(item):

@@ -404,3 +404,19 @@ def test_f32_sum_switch_gives_the_reference_bits(env):
         assert np.allclose(got[:, 1].to_numpy(), exp[:, 1].to_numpy(), rtol=1e-4, atol=0.5)
     finally:
         shim.options.f32_sum = old
+
+
+def test_dict_form_of_j(env):
+    """`DT[:, {"name": expr, ...}, by()]`: evaluated like the list form on the GPU, j columns named after the keys
+    (tests/test_shim_standin.py runs the full matrix of routes and residency modes on the CPU stand-in)"""
+    dt, shim = env
+    from datatable import f, sum, mean, count
+    DT = make_frame(shim, 20_000, seed=77)
+    j = {"total": sum(f.f8), "k": mean(f.i4), "n": count()}
+    got = DT[:, j, shim.by(f.k)]
+    exp = dt.Frame.__getitem__(DT, (slice(None), j, dt.by(f.k)))
+    assert got.names == exp.names == ("k", "total", "k.0", "n")
+    assert_frames_equal(dt, got, exp)
+    j = {"a": f.f8, "b": f.i4}
+    assert_rows_equal(dt, DT[:, j, shim.by(f.k2)], dt.Frame.__getitem__(DT, (slice(None), j, dt.by(f.k2))))
+    assert_rows_equal(dt, DT[f.f8 > 0, j], dt.Frame.__getitem__(DT, (f.f8 > 0, j)))

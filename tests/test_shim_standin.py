@@ -162,3 +162,32 @@ def test_sort_with_na_removed(env):
         cols = c.pop("cols")
         got = DF[:, :, shim.sort(*cols, **c)]
         assert_rows_equal(dt, _as_frame(shim, got), dt.Frame.__getitem__(DF, (slice(None), slice(None), dt.sort(*cols, **c))))
+
+
+@pytest.mark.parametrize("mode", ["off", "auto", "lazy"])
+def test_dict_form_of_j_names_the_result(env, mode):
+    """DT[:, {"total": sum(f.x), ...}, by(...)] and the dict form on the row-returning routes: evaluated like a list, the j
+    columns named after the keys, duplicates mangled the reference's way"""
+    shim, ctx = env
+    shim.options.residency = mode
+    import datatable
+    from datatable import f, sum, mean, count
+    DT = make_frame(shim, 2000, seed=9)
+    for j in ({"total": sum(f.f8), "n": count()}, {"k": sum(f.f8)}, {"total": sum(f.f8), "f8": mean(f.f8), "total2": sum(f.i4)},
+              {"s": datatable.sd(f.f8), "m": datatable.median(f.i2)}, {"c": datatable.cumsum(f.i4), "r": datatable.cumcount()}):
+        got = DT[:, j, shim.by(f.k)]
+        exp = dt.Frame.__getitem__(DT, (slice(None), j, dt.by(f.k)))
+        assert (type(got) is shim.DeviceFrame) == (mode == "lazy") and tuple(got.names) == exp.names
+        assert_frames_equal(dt, _as_frame(shim, got), exp)
+    for j in ({"a": f.f8}, {"a": f.f8, "kk": f.k}, {"f8": f.i4, "i4": f.f8}):
+        for extra, ref_extra in (((shim.by(f.k),), (dt.by(f.k),)), ((shim.sort(f.k2, f.i8),), (dt.sort(f.k2, f.i8),))):
+            got = DT[(slice(None), j) + extra]
+            exp = dt.Frame.__getitem__(DT, (slice(None), j) + ref_extra)
+            assert tuple(got.names) == exp.names
+            assert_rows_equal(dt, _as_frame(shim, got), exp)
+        got = DT[f.f8 > 0, j]
+        assert_rows_equal(dt, _as_frame(shim, got), dt.Frame.__getitem__(DT, (f.f8 > 0, j)))
+    assert ctx._lib.calls
+    n0 = len(ctx._lib.calls)
+    R = DT[:, {"z": f.f8 + 1}, shim.by(f.k)]                   # a computed column: the reference's, with its names
+    assert type(R) is dt.Frame and R.names == ("k", "z") and len(ctx._lib.calls) == n0
