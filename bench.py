@@ -170,9 +170,10 @@ def _cmp_exact(got, exp):
     return bool(got.dtype == exp.dtype and got.shape == exp.shape and np.array_equal(got, exp, equal_nan=(exp.dtype.kind == "f")))
 
 
-def verify_agg(ctx, name, keys_t, vals_t, aggs, threads):
+def verify_agg(ctx, name, keys_t, vals_t, aggs, threads, keep=None):
     """GPU result of DT[:, aggs, by(keys)] on ALL rows of the config vs the OpenMP oracle (oracle/dt_oracle.c): group
-    keys, counts, min / max bit-exact, float64 sums / means within RTOL (+ATOL); raises on mismatch"""
+    keys, counts, min / max bit-exact, float64 sums / means within RTOL (+ATOL); raises on mismatch.
+    keep (dict): receives the single-GPU result arrays ("keys", "aggs") for the sharded-vs-single-GPU comparison"""
     import numpy as np
     from oracle import oracle as o
     from datatable_amd.torch_bridge import devcol
@@ -181,6 +182,8 @@ def verify_agg(ctx, name, keys_t, vals_t, aggs, threads):
     gk = [r.key(i) for i in range(len(keys_t))]
     ga = [r.agg(a) for a in range(len(aggs))]
     r.free()
+    if keep is not None:
+        keep["keys"], keep["aggs"] = gk, ga
     hk = [to_host(k) for k in keys_t]
     hv = [to_host(v) for v in vals_t]
     o.lib(); o.set_threads(threads)
@@ -209,9 +212,10 @@ def verify_agg(ctx, name, keys_t, vals_t, aggs, threads):
     return out, (hk, hv)
 
 
-def verify_c5(ctx, k_t, x_t, threads):
+def verify_c5(ctx, k_t, x_t, threads, keep=None):
     """config 5 on ALL rows: the filter's RowIndex, the rows in grouped order (key, x, the composed RowIndex riding
-    through the sort) and the offsets, all bit-exact against the oracle's filter -> gather -> group"""
+    through the sort) and the offsets, all bit-exact against the oracle's filter -> gather -> group.
+    keep (dict): receives the single-GPU result arrays (offsets, key / x / composed-RowIndex columns)"""
     import numpy as np
     import torch
     from oracle import oracle as o
@@ -227,6 +231,8 @@ def verify_c5(ctx, k_t, x_t, threads):
     g_off = r.offsets()
     g_k, g_x, g_ri = r.col(0), r.col(1), r.col(2)
     r.free()
+    if keep is not None:
+        keep.update(offsets=g_off, k=g_k, x=g_x, ri=g_ri)
     g_filter = to_host(ri_t[:npass])
     del ri_t, kb, xb
     torch.cuda.empty_cache()
@@ -537,7 +543,248 @@ def shim_resident_leg(steps, rows_c3, groups_c3, rows_c5, raw_c3_ms, raw_c5_ms):
     return out
 
 
-def sharded_config_legs(ctx, dev, rank, world, n_total, steps, dist):
+# ---- --gpus N: the sharded results are CHECKED, not only timed ---------------------------------------------------------
+# Every rank draws its row block [r n / W, (r + 1) n / W) from its own seed; rank 0 can therefore rebuild the WHOLE frame
+# on its GPU (16 GB at 1e9 rows), run the single-GPU path on it -- itself compared with the OpenMP oracle on all rows,
+# exactly as the N = 1 line does -- and compare what the ranks returned (gathered over gloo, outside every timed region)
+# with that: keys, counts, offsets and the RowIndex bit for bit, float64 sums within RTOL.  A mismatch aborts all ranks.
+def shard_bounds(r, world, n_total):
+    return r * n_total // world, (r + 1) * n_total // world
+
+
+def gen_c3(dev, r, world, n_total, groups):
+    import torch
+    lo, hi = shard_bounds(r, world, n_total)
+    g = torch.Generator(device=dev); g.manual_seed(1234 + 3 + 1000 * r)
+    keys = torch.randint(0, groups, (hi - lo,), dtype=torch.int64, device=dev, generator=g)
+    vals = torch.randn(hi - lo, dtype=torch.float64, device=dev, generator=g)
+    return [keys], [vals]
+
+
+def gen_c4(dev, r, world, n_total):
+    import torch
+    lo, hi = shard_bounds(r, world, n_total)
+    g = torch.Generator(device=dev); g.manual_seed(1238 + 1000 * r)
+    a = torch.randint(0, 3163, (hi - lo,), dtype=torch.int32, device=dev, generator=g)
+    b = torch.randint(0, 3163, (hi - lo,), dtype=torch.int32, device=dev, generator=g)
+    v = torch.randn(hi - lo, dtype=torch.float64, device=dev, generator=g)
+    return [a, b], [v]
+
+
+def gen_c5(dev, r, world, n_total):
+    import torch
+    lo, hi = shard_bounds(r, world, n_total)
+    g = torch.Generator(device=dev); g.manual_seed(1239 + 1000 * r)
+    k = torch.randint(0, 100_000_000, (hi - lo,), dtype=torch.int64, device=dev, generator=g)
+    x = torch.randn(hi - lo, dtype=torch.float64, device=dev, generator=g)
+    return [k], [x]
+
+
+def tensor_checksum(ts):
+    """order-dependent 64-bit checksums of device tensors (wrapping int64 arithmetic on the bit patterns): enough to tell
+    that a shard rebuilt on rank 0 from the rank's seed IS the shard that rank computed on"""
+    import torch
+    out = []
+    for t in ts:
+        b = t.view(torch.int64) if t.element_size() == 8 else t.to(torch.int64)
+        w = torch.arange(1, b.numel() + 1, dtype=torch.int64, device=t.device)
+        out.append(int(((b * 0x9E3779B1 + 12345) * (w | 1)).sum().item()))
+        del w, b
+    return out
+
+
+def gather_to_rank0(dist, rank, world, t, chunk=1 << 25):
+    """every rank's 1-D device tensor -> ONE numpy array on rank 0, slabs in rank order (gloo point-to-point through a
+    pinned bounce buffer; control plane only, never inside a timed region).  Returns (array or None, slab lengths)."""
+    import numpy as np
+    import torch
+    t = t.contiguous().view(-1)
+    mine = torch.tensor([t.numel()], dtype=torch.int64)
+    ns = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(ns, mine)
+    ns = [int(x.item()) for x in ns]
+    pin = torch.empty(max(1, min(chunk, max(ns))), dtype=t.dtype).pin_memory()
+    if rank == 0:
+        out = torch.empty(sum(ns), dtype=t.dtype)
+        for s in range(0, ns[0], chunk):
+            e = min(s + chunk, ns[0])
+            pin[:e - s].copy_(t[s:e]); torch.cuda.synchronize()
+            out[s:e].copy_(pin[:e - s])
+        pos = ns[0]
+        for r in range(1, world):
+            for s in range(0, ns[r], chunk):
+                e = min(s + chunk, ns[r])
+                dist.recv(out[pos + s:pos + e], src=r)
+            pos += ns[r]
+        return out.numpy(), ns
+    for s in range(0, ns[rank], chunk):
+        e = min(s + chunk, ns[rank])
+        pin[:e - s].copy_(t[s:e]); torch.cuda.synchronize()
+        dist.send(pin[:e - s], dst=0)
+    return None, ns
+
+
+def agree(dist, rank, verdict):
+    """rank 0's verdict reaches every rank; a failed check takes ALL ranks down (nobody waits for a peer that left)"""
+    box = [verdict if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    v = box[0]
+    assert v is None or v.get("ok") or v.get("skipped"), v
+    return v
+
+
+def rebuild_frame(gen, dev, rank, world, own, sums_by_rank):
+    """rank 0: the whole frame on ITS GPU = the ranks' shards in rank order, every shard drawn again from its seed and
+    checked against the checksum the owning rank took of the tensors it really used"""
+    import torch
+    parts_k, parts_v, same = None, None, True
+    for r in range(world):
+        kk, vv = own if r == rank else gen(r)
+        if r != rank:
+            same = same and tensor_checksum(kk + vv) == sums_by_rank[r]
+        parts_k = [[x] for x in kk] if parts_k is None else [p + [x] for p, x in zip(parts_k, kk)]
+        parts_v = [[x] for x in vv] if parts_v is None else [p + [x] for p, x in zip(parts_v, vv)]
+    full_k = [torch.cat(p) for p in parts_k]
+    full_v = [torch.cat(p) for p in parts_v]
+    return full_k, full_v, same
+
+
+def verify_sharded_agg(name, ctx, dev, rank, world, dist, gen, own, aggs, threads, budget, with_oracle=True):
+    """One more sharded call of the config's query (+ count(), so that group sizes are compared too), its result slabs
+    gathered on rank 0 and compared with the SINGLE-GPU call over the rebuilt frame, which verify_agg() compares with the
+    OpenMP oracle on all rows.  Collective; returns the verdict on every rank."""
+    import numpy as np
+    import torch
+    from datatable_amd.torch_bridge import devcol, ST2T
+    t0 = time.perf_counter()
+    skip = torch.tensor([0 if budget.ok(60) else 1], dtype=torch.int64)
+    dist.broadcast(skip, src=0)
+    if int(skip.item()):
+        return {"skipped": "time budget (%.0f s) spent" % budget.seconds}
+    keys, vals = own
+    n = keys[0].numel()
+    vaggs = list(aggs) + ([] if ("count0", None) in aggs else [("count0", None)])
+    r = ctx.sharded_groupby_agg([devcol(k) for k in keys], [devcol(v) for v in vals], vaggs, nrows=n)
+    ngl = r.ngroups
+    slabs = []
+    for i, k in enumerate(keys):
+        t = torch.empty(ngl, dtype=k.dtype, device=dev)
+        if ngl:
+            r.key_into(i, t.data_ptr())
+        slabs.append(t)
+    for a in range(len(vaggs)):
+        t = torch.empty(ngl, dtype=ST2T[r.agg_stype(a)], device=dev)
+        if ngl:
+            r.agg_into(a, t.data_ptr())
+        slabs.append(t)
+    torch.cuda.synchronize()
+    r.free()
+    got = [gather_to_rank0(dist, rank, world, t) for t in slabs]
+    del slabs
+    sums = [None] * world
+    dist.all_gather_object(sums, tensor_checksum(keys + vals))
+    verdict = None
+    if rank == 0:
+        full_k, full_v, same = rebuild_frame(gen, dev, rank, world, own, sums)
+        keep = {}
+        if with_oracle:
+            par, _host = verify_agg(ctx, name, full_k, full_v, vaggs, threads, keep=keep)
+            del _host
+        else:
+            par = None
+            rr = ctx.groupby_agg([devcol(k) for k in full_k], [devcol(v) for v in full_v], vaggs, nrows=full_k[0].numel())
+            keep["keys"] = [rr.key(i) for i in range(len(full_k))]; keep["aggs"] = [rr.agg(a) for a in range(len(vaggs))]
+            rr.free()
+        del full_k, full_v
+        torch.cuda.empty_cache(); ctx.trim()
+        nk = len(keys)
+        keys_ok = all(_cmp_exact(got[i][0], keep["keys"][i]) for i in range(nk))
+        verdict = {"against": "the single-GPU path (dthip_groupby_agg) over ALL rows, rebuilt on rank 0's GPU from the ranks' seeds",
+                   "groups": int(len(keep["keys"][0])), "groups_per_rank": got[0][1], "inputs_rebuilt_identical": bool(same),
+                   "keys_bit_exact": bool(keys_ok), "single_gpu_vs_oracle_all_rows": par}
+        ok = bool(keys_ok and same and (par is None or par["ok"]))
+        wa, wr = 0.0, 0.0
+        for a, (op, c) in enumerate(vaggs):
+            if not keys_ok:
+                break
+            g_, e_ = got[nk + a][0], keep["aggs"][a]
+            if e_.dtype.kind == "f" and op in ("sum", "mean"):
+                o_, ma, mr = sums_close(g_, e_)
+                wa, wr = max(wa, ma), max(wr, mr)
+            else:
+                o_ = _cmp_exact(g_, e_)
+            verdict["%s(%s)" % (op, "" if c is None else "v%d" % c)] = bool(o_)
+            ok = ok and bool(o_)
+        verdict.update(ok=ok, sum_max_abs_err=wa, sum_max_rel_err=wr, rtol=RTOL, atol=ATOL, seconds=time.perf_counter() - t0)
+    return agree(dist, rank, verdict)
+
+
+def verify_sharded_c5(ctx, dev, rank, world, dist, n_total, own, threads, budget):
+    """config 5 sharded vs single GPU: every rank's slab of V[:, :, by(f.k)] -- group sizes, key and x columns and the
+    composed RowIndex (first row of the source rank's shard + the filter's RowIndex that travelled with the row) -- gathered
+    on rank 0 and compared bit for bit with the single-GPU filter -> rows-in-grouped-order over the rebuilt frame, which
+    verify_c5() compares with the OpenMP oracle on all rows."""
+    import numpy as np
+    import torch
+    from datatable_amd.torch_bridge import devcol
+    t0 = time.perf_counter()
+    skip = torch.tensor([0 if budget.ok(120) else 1], dtype=torch.int64)
+    dist.broadcast(skip, src=0)
+    if int(skip.item()):
+        return {"skipped": "time budget (%.0f s) spent" % budget.seconds}
+    (k,), (x,) = own
+    n = k.numel()
+    lo = shard_bounds(rank, world, n_total)[0]
+    ri = torch.empty(n, dtype=torch.int32, device=dev)
+    kb = torch.empty(n, dtype=torch.int64, device=dev)
+    xb = torch.empty(n, dtype=torch.float64, device=dev)
+    npass = ctx.filter_take_dev(devcol(x), ">", 0.0, [devcol(k), devcol(x)], n, ri.data_ptr(), [kb.data_ptr(), xb.data_ptr()])
+    r = ctx.sharded_groupby_rows([devcol(kb[:npass])], [devcol(kb[:npass]), devcol(xb[:npass]), devcol(ri[:npass])],
+                                 row_offset=lo, nrows=npass)
+    nr, ngl = r.nrows, r.ngroups
+    off = torch.empty(ngl + 1, dtype=torch.int32, device=dev)
+    ck = torch.empty(nr, dtype=torch.int64, device=dev); cx = torch.empty(nr, dtype=torch.float64, device=dev)
+    cri = torch.empty(nr, dtype=torch.int32, device=dev); cid = torch.empty(nr, dtype=torch.int64, device=dev)
+    r.offsets_into(off.data_ptr())
+    if nr:
+        r.col_into(0, ck.data_ptr()); r.col_into(1, cx.data_ptr()); r.col_into(2, cri.data_ptr()); r.col_into(3, cid.data_ptr())
+    torch.cuda.synchronize()
+    r.free()
+    del ri, kb, xb
+    # global row id = (first row of the SOURCE rank's shard) + (position among that rank's passing rows): the source rank
+    # is the shard the id falls into, and the row's place in the unfiltered frame is that shard's start + the filter's RowIndex
+    los = torch.tensor([shard_bounds(q, world, n_total)[0] for q in range(world)], dtype=torch.int64, device=dev)
+    src = torch.searchsorted(los, cid, right=True) - 1
+    comp = (los[src] + cri.to(torch.int64)).to(torch.int32)
+    sizes = (off[1:] - off[:-1]).contiguous()
+    del src, cri, cid, off
+    got = {nm: gather_to_rank0(dist, rank, world, t) for nm, t in (("sizes", sizes), ("k", ck), ("x", cx), ("ri", comp))}
+    del sizes, ck, cx, comp
+    sums = [None] * world
+    dist.all_gather_object(sums, tensor_checksum([k, x]))
+    torch.cuda.empty_cache(); ctx.trim()
+    verdict = None
+    if rank == 0:
+        full_k, full_v, same = rebuild_frame(lambda q: gen_c5(dev, q, world, n_total), dev, rank, world, own, sums)
+        keep = {}
+        par, _host = verify_c5(ctx, full_k[0], full_v[0], threads, keep=keep)
+        del _host, full_k, full_v
+        torch.cuda.empty_cache(); ctx.trim()
+        exp_sizes = np.diff(keep["offsets"]).astype(np.int32)
+        verdict = {"against": "the single-GPU path (dthip_filter_take + dthip_groupby_rows) over ALL rows, rebuilt on rank 0's GPU "
+                              "from the ranks' seeds",
+                   "rows_passing": int(len(keep["ri"])), "groups": int(len(exp_sizes)), "rows_per_rank": got["k"][1],
+                   "inputs_rebuilt_identical": bool(same), "single_gpu_vs_oracle_all_rows": par,
+                   "group_sizes_bit_exact": _cmp_exact(got["sizes"][0], exp_sizes),
+                   "composed_rowindex_bit_exact": _cmp_exact(got["ri"][0], keep["ri"]),
+                   "key_column_bit_exact": _cmp_exact(got["k"][0], keep["k"]),
+                   "x_column_bit_exact": _cmp_exact(got["x"][0], keep["x"])}
+        verdict["ok"] = bool(same and par["ok"] and all(v for kk, v in verdict.items() if kk.endswith("bit_exact")))
+        verdict["seconds"] = time.perf_counter() - t0
+    return agree(dist, rank, verdict)
+
+
+def sharded_config_legs(ctx, dev, rank, world, n_total, steps, dist, verify=True, threads=16, budget=None):
     """--gpus N: BASELINE configs 4 and 5 through the sharded entry points, row-block shards like C3's.  Per config: wall
     time (barrier, max over ranks), rows/s, bytes every rank sent to its peers in the all-to-all-v and what that is of the
     xGMI bound, and the wall-clock phases of one profiled call."""
@@ -582,19 +829,17 @@ def sharded_config_legs(ctx, dev, rank, world, n_total, steps, dist):
                 "phases_ms_rank0": phases, "kernel_ms_rank0": dict(list(kern.items())[:8])}
 
     # C4: DT[:, [count(), sum(f.v)], by(f.a, f.b)]
-    g.manual_seed(1238 + 1000 * rank)
-    a = torch.randint(0, 3163, (n,), dtype=torch.int32, device=dev, generator=g)
-    b = torch.randint(0, 3163, (n,), dtype=torch.int32, device=dev, generator=g)
-    v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    (a, b), (v,) = gen_c4(dev, rank, world, n_total)
     out["C4"] = timed(lambda: ctx.sharded_groupby_agg([devcol(a), devcol(b)], [devcol(v)], [("count0", None), ("sum", 0)], nrows=n),
                       n_total * 16 + 10_004_569 * 24)
     out["C4"]["query"] = "DT[:, [count(), sum(f.v)], by(f.a, f.b)], %d rows over %d ranks" % (n_total, world)
+    if verify:
+        out["C4"]["parity"] = verify_sharded_agg("C4", ctx, dev, rank, world, dist, lambda q: gen_c4(dev, q, world, n_total),
+                                                 ([a, b], [v]), [("count0", None), ("sum", 0)], threads, budget)
     del a, b, v
     torch.cuda.empty_cache(); ctx.trim()
     # C5: V = DT[f.x > 0, :] on the shard (local: a filter needs no exchange), then V[:, :, by(f.k)] sharded
-    g.manual_seed(1239 + 1000 * rank)
-    k = torch.randint(0, 100_000_000, (n,), dtype=torch.int64, device=dev, generator=g)
-    x = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+    (k,), (x,) = gen_c5(dev, rank, world, n_total)
     ri = torch.empty(n, dtype=torch.int32, device=dev)
     kb = torch.empty(n, dtype=torch.int64, device=dev)
     xb = torch.empty(n, dtype=torch.float64, device=dev)
@@ -605,7 +850,11 @@ def sharded_config_legs(ctx, dev, rank, world, n_total, steps, dist):
                                         row_offset=lo, nrows=npass)
     out["C5"] = timed(c5, int(n_total * 30.4))
     out["C5"]["query"] = "V = DT[f.x > 0, :] per shard; V[:, :, by(f.k)] sharded (rows + the filter's RowIndex travel), %d rows over %d ranks" % (n_total, world)
-    del k, x, ri, kb, xb
+    del ri, kb, xb
+    torch.cuda.empty_cache(); ctx.trim()
+    if verify:
+        out["C5"]["parity"] = verify_sharded_c5(ctx, dev, rank, world, dist, n_total, ([k], [x]), threads, budget)
+    del k, x
     torch.cuda.empty_cache(); ctx.trim()
     return out
 
@@ -749,10 +998,7 @@ def main():
     n_total = args.rows
     lo, hi = rank * n_total // world, (rank + 1) * n_total // world
     n_local = hi - lo
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + 3 + 1000 * rank)
-    keys = torch.randint(0, args.groups, (n_local,), dtype=torch.int64, device=dev, generator=g)
-    vals = torch.randn(n_local, dtype=torch.float64, device=dev, generator=g)
+    (keys,), (vals,) = gen_c3(dev, rank, world, n_total, args.groups)
     torch.cuda.synchronize()
     aggs = [("sum", 0)]
     kcol, vcol = devcol(keys), devcol(vals)
@@ -868,6 +1114,19 @@ def main():
                          "allgathers": st["allgathers"], "xgmi_peak_GBs_per_gpu": XGMI_GBS_PER_GPU,
                          "xgmi_frac_of_step": mxb.item() / (dt / args.steps) / 1e9 / XGMI_GBS_PER_GPU,
                          "xgmi_frac_of_exchange": (st["bytes_to_peers"] / (a2a * 1e-3) / 1e9 / XGMI_GBS_PER_GPU) if a2a else None}
+    ranks_seen = None
+    if sharded:
+        # who took part, as the LIBRARY's communicator sees it (dthip_comm_rank / dthip_comm_world) and on which device
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            devid = "%s %s" % (pr.name, getattr(pr, "pci_bus_id", "?"))
+        except Exception:
+            devid = "?"
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "comm_rank": int(ctx.comm_rank), "comm_world": int(ctx.comm_world),
+                                      "device": local_rank, "gpu": devid, "pid": os.getpid()})
+        ranks_seen = seen
+        assert sorted(x["comm_rank"] for x in seen) == list(range(world)) and all(x["comm_world"] == world for x in seen), seen
     line = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -909,6 +1168,18 @@ def main():
             "kernels": per_kernel,
             "cpu_baseline": None,
         }
+        if sharded and not args.no_cpu_baseline:
+            # N > 1: the reference's CPU path, timed on rank 0's host cores on the first rows of rank 0's shard (= the first
+            # rows of the frame) while the other ranks sleep in a gloo barrier; GPU-vs-reference parity on that sample too
+            try:
+                base, par = reference_leg(ctx, keys, vals, min(args.cpu_sample, n_local), [int(t) for t in args.ref_threads.split(",") if t != ""])
+            except Exception as e:
+                base, par = None, None
+                parity["vs_reference"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            if base is not None:
+                line["cpu_baseline"] = base
+                parity["vs_reference"] = par
+                assert par["keys_bit_exact"] and par["sums_within_tol"], par
         if world == 1 and not sharded and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 64)
             try:
@@ -929,6 +1200,9 @@ def main():
                 else:
                     line["cpu_baseline"]["port"] = port
         line["parity"] = parity or None
+        if ranks_seen is not None:
+            line["ranks_seen"] = sorted(x["comm_rank"] for x in ranks_seen)
+            line["ranks"] = ranks_seen
         if sharded_extra:
             line["exchange"] = sharded_extra
             if line.get("roofline"):
@@ -948,15 +1222,29 @@ def main():
             and line["cpu_baseline"].get("kind") == "reference":
         ref_full_inputs = (to_host(keys), to_host(vals))
     raw_c3_ms = dt / args.steps * 1e3
+    verify_sharded = sharded and not (args.no_check or args.no_verify_configs)
+    if sharded:
+        dist.barrier()                  # (the other ranks waited here, in gloo, while rank 0 timed the reference)
+    if verify_sharded:
+        # the timed query's sharded result vs the single-GPU path over ALL rows (itself vs the OpenMP oracle): see
+        # verify_sharded_agg; a mismatch aborts every rank
+        par3 = verify_sharded_agg("C3", ctx, dev, rank, world, dist, lambda q: gen_c3(dev, q, world, n_total, args.groups),
+                                  ([keys], [vals]), aggs, threads, budget, with_oracle=not args.no_full_parity)
+        if rank == 0:
+            line["parity"] = line.get("parity") or {}
+            line["parity"]["sharded_vs_single_gpu"] = par3
+            line["parity"]["configs"] = {"C3": par3.get("ok", par3.get("skipped"))}
     del keys, vals, kcol, vcol
     torch.cuda.empty_cache(); ctx.trim()
     if sharded and world > 1 and not args.no_sharded_configs:
-        try:
-            cfgs = sharded_config_legs(ctx, dev, rank, world, int(n_total * args.config_scale), max(1, min(args.steps, 5)), dist)
-        except Exception as e:
-            cfgs = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        cfgs = sharded_config_legs(ctx, dev, rank, world, int(n_total * args.config_scale), max(1, min(args.steps, 5)), dist,
+                                   verify=verify_sharded, threads=threads, budget=budget)
         if rank == 0:
             line["configs"] = cfgs
+            if verify_sharded:
+                for c in ("C4", "C5"):
+                    pc = cfgs[c].get("parity") or {}
+                    line["parity"]["configs"][c] = pc.get("ok", pc.get("skipped"))
     if rank == 0 and world == 1 and not sharded:
         which = [c for c in args.configs.split(",") if c]
         if which:

@@ -36,6 +36,7 @@ class Agg(C.Structure):
 # name -> (restype, argtypes); must list every symbol include/dthip.h declares
 SIGNATURES = {
     "dthip_abi_version": (C.c_int, []),
+    "dthip_build_id": (C.c_char_p, []),
     "dthip_last_error": (C.c_char_p, []),
     "dthip_device_count": (C.c_int, []),
     "dthip_init": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -100,6 +101,7 @@ SIGNATURES = {
     "dthip_filter_cmp": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int64, C.c_int, C.c_double, C.c_int64, C.c_int,
                                    C.c_void_p, C.POINTER(C.c_int64)]),
     "dthip_gather": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "dthip_from_arrow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     # multi-GPU (comm.hip)
     "dthip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "dthip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -138,8 +140,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dthip_abi_version() != 4:
-        raise ImportError("libdthip.so ABI version %d != 4" % lib.dthip_abi_version())
+    if lib.dthip_abi_version() != 5:
+        raise ImportError("libdthip.so ABI version %d != 5" % lib.dthip_abi_version())
     _lib = lib
     return lib
 

@@ -191,9 +191,15 @@ int dev_trim(dthip_ctx* ctx) {
 
 int read_back(dthip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
   if (bytes > ctx->pinned_bytes) {
+#ifdef DTHIP_REPRO_UAF
+    // `make uaf` only: the round-4 defect put back -- the mapped words of the small-table path freed
+    // with the read-back buffer, their pointers left behind -- to show that it is what made ranks die of "Memory access
+    // fault" on some boxes (profiles/r05_fault_hunt.txt).  Never in the product library.
     if (ctx->host_words) (void)hipHostFree(ctx->host_words);
-  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+#endif
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     ctx->pinned = nullptr;
+    ctx->pinned_bytes = 0;
     size_t nb = std::max<size_t>(bytes, 1 << 16);
     DTHIP_CHECK_HIP(hipHostMalloc(&ctx->pinned, nb, hipHostMallocDefault));
     ctx->pinned_bytes = nb;
@@ -420,7 +426,7 @@ static MsdPlan msd_plan(const dthip_ctx* ctx, int64_t n, int bits, int key64, ui
   // measured (C5, 5e8 rows, 27 bits, MI355X, one box): levels 4.3 + 4.5 + final 4.4 ms (windows of whole buckets) and two
   // histogram passes against 3 x 4.7 ms of LSD passes and three: ~1 ms per call, more when the final level also writes the
   // original key column.  Below msd_min_rows the LSD passes are quick and the final buckets would be tiny.
-  if (ctx->sort_path == 1 || key64 || n < ctx->msd_min_rows) return MsdPlan();
+  if (ctx->sort_path == 1 || key64 || (ctx->sort_path != 2 && n < ctx->msd_min_rows)) return MsdPlan();
   static const int rbmax = getenv("DTHIP_MSD_RBMAX") ? atoi(getenv("DTHIP_MSD_RBMAX")) : 9;
   return msd_split(n, bits, tile, ctx->msd_bucket_rows, rbmax);       // (host logic: csrc/msd_plan.hpp, tests/test_msd_plan.py)
 }
@@ -1526,6 +1532,12 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
 extern "C" {
 
 int dthip_abi_version(void) { return DTHIP_ABI_VERSION; }
+const char* dthip_build_id(void) {
+  static const char id[] =
+#include "build_id.inc"
+      ;
+  return id;
+}
 const char* dthip_last_error(void) { return g_err; }
 
 int dthip_device_count(void) {
@@ -1586,6 +1598,9 @@ int dthip_destroy(dthip_ctx* ctx) {
             (long long)ctx->guard_allocs, (long long)ctx->guard_launches);
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->host_words) (void)hipHostFree(ctx->host_words);   // the mapped words of the small-table path: freed here and only here
+  ctx->host_words = nullptr;
+  ctx->host_words_dev = nullptr;
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

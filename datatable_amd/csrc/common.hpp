@@ -91,7 +91,7 @@ struct dthip_ctx {
   int filter_path = 1;       // row filters: 1 count pass + write pass (default: 1.3 + 5.8 ms per 1e9 float64 rows with two 8-byte columns
                              // taken); 0 ONE pass, tile offsets by decoupled look-back (measured 8.6-9.2 ms: the look-back chain costs
                              // more than the second read of the predicate column; kept selectable)
-  int sort_path = 0;         // 0: MSD levels (two scatter levels + final buckets ordered in LDS) from msd_min_rows rows on where their preconditions hold, else LSD passes; 1: LSD passes only; 2: as 0 (kept for scripts)
+  int sort_path = 0;         // 0: MSD levels (two scatter levels + final buckets ordered in LDS) from msd_min_rows rows on where their preconditions hold, else LSD passes; 1: LSD passes only; 2: MSD levels whenever their preconditions hold, whatever msd_min_rows says (A/B runs, tests)
   int64_t msd_min_rows = 1 << 26;    // below this the LSD passes are quick enough (and the final buckets would be tiny)
   int msd_bucket_rows = 2048;        // target size of a final bucket (sorted in LDS: at most one radix tile)
   // multi-GPU (comm.hip): the communicator this context is a rank of

@@ -299,11 +299,13 @@ __global__ void __launch_bounds__(HIST_STRIDE) msd_scan_kernel(uint32_t* __restr
     const uint32_t fs = pstart[b] + excl;
     fstart[(size_t)b * bins + d] = fs;
     for (uint32_t g = g0; g < g1; g++) gtot[(size_t)g * bins + d] += fs;
-    uint32_t m = run;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)m, o, 64); m = x > m ? x : m; }
-    if ((d & 63u) == 0 && m) atomicMax(maxsize, m);
   }
+  // largest child bucket: the wave maximum is taken by ALL lanes (lanes past the last digit contribute 0 -- run is 0
+  // there), never inside the divergent branch
+  uint32_t m = run;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)m, o, 64); m = x > m ? x : m; }
+  if ((d & 63u) == 0 && m) atomicMax(maxsize, m);
   if (b + 1 == nb && d == 0) fstart[(size_t)nb * bins] = n;
 }
 

@@ -331,6 +331,33 @@ class Context(_ShardMixin):
             L.check(self._lib.dthip_memcpy_h2d(self._h, p, a.ctypes.data, a.nbytes))
         return DevCol(p.value, col.stype, keepalive=buf)
 
+    def from_arrow(self, values, validity, nrows, stype, device=False):
+        """Arrow-layout column (values buffer + validity bitmap, LSB first; validity None = no nulls; stype BOOL: values are
+        Arrow's bit-packed booleans) -> a DevCol in the sentinel layout, converted on the device (dthip_from_arrow).
+        values / validity: numpy arrays (host) or, with device=True, raw HBM addresses."""
+        st = int(stype)
+        nbytes = nrows * ST2NP[st].itemsize
+        p = C.c_void_p()
+        L.check(self._lib.dthip_malloc(self._h, max(nbytes, 1), C.byref(p)))
+        buf = _DevBuf(self, p.value)
+        if device:
+            vp, bp, keep = int(values), (int(validity) if validity else None), None
+        else:
+            va = np.ascontiguousarray(values)
+            ba = np.ascontiguousarray(validity, np.uint8) if validity is not None else None
+            vp, bp, keep = va.ctypes.data, (ba.ctypes.data if ba is not None else None), (va, ba)
+        L.check(self._lib.dthip_from_arrow(self._h, C.c_void_p(vp), C.c_void_p(bp) if bp else None, int(nrows), st,
+                                           L.DEVICE if device else L.HOST, p))
+        del keep
+        return DevCol(p.value, st, keepalive=buf)
+
+    def download(self, col, nrows):
+        """DevCol -> numpy (one device->host copy)"""
+        out = np.empty(nrows, ST2NP[col.stype])
+        if out.nbytes:
+            L.check(self._lib.dthip_memcpy_d2h(self._h, out.ctypes.data, C.c_void_p(col.ptr), out.nbytes))
+        return out
+
     def host_register(self, a):
         """page-lock a numpy array's buffer so DTHIP_HOST calls DMA from it directly (dthip_host_register)"""
         L.check(self._lib.dthip_host_register(self._h, a.ctypes.data, a.nbytes))

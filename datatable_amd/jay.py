@@ -177,21 +177,11 @@ def open_jay(path, strings="error"):
     return fr
 
 
-def to_device(path, device=0, strings="error"):
-    """Jay -> HBM: {name: CUDA tensor}, one host->device copy per column straight from the mapped file"""
-    import warnings
-    import torch
-    from .torch_bridge import ST2T
+def to_device(path, ctx=None, strings="error"):
+    """Jay -> HBM without a parsed copy and without torch: ({name: DevCol}, nrows) -- one dthip_malloc + one host->device
+    copy per column straight from the mapped file (the pages are read-only and only read).  The DevCols own their
+    buffers and go into any DTHIP_DEVICE call of `ctx` (default: the calling thread's default context)."""
+    from .engine import default_context
+    ctx = ctx or default_context()
     cols, _ = jay_columns(path, strings)
-    out = {}
-    with torch.cuda.device(device):
-        for nm, st, a in cols:
-            t = torch.empty(len(a), dtype=ST2T[st], device="cuda:%d" % device)
-            if len(a):
-                # the mapped pages are read-only: view them without asking numpy for a writable array
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore", UserWarning)       # "buffer is not writable": it is only read
-                    src = torch.frombuffer(memoryview(a).cast("B"), dtype=ST2T[st])
-                t.copy_(src)
-            out[nm] = t
-    return out
+    return {nm: ctx.upload(a, st) for nm, st, a in cols}, (len(cols[0][2]) if cols else 0)

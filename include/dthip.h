@@ -52,10 +52,11 @@
 extern "C" {
 #endif
 
-#define DTHIP_ABI_VERSION 4   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10
+#define DTHIP_ABI_VERSION 5   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10
                                  3: + dthip_comm_*, dthip_sharded_groupby_* (multi-GPU inside the library), DTHIP_FLAG_NONA,
                                     dthip_host_register / dthip_host_unregister
-                                 4: + dthip_comm_last_stats; options sort_path, msd_min_rows, msd_bucket_rows, filter_path */
+                                 4: + dthip_comm_last_stats; options sort_path, msd_min_rows, msd_bucket_rows, filter_path
+                                 5: + dthip_build_id, dthip_from_arrow (Arrow-layout columns: validity bitmap -> sentinels on the device) */
 
 /* error codes */
 #define DTHIP_OK        0
@@ -141,6 +142,9 @@ typedef struct dthip_result dthip_result; /* device-resident result of a groupby
 
 /* ---- library / context -------------------------------------------------- */
 int         dthip_abi_version(void);
+/* 12 hex digits: a hash of the SOURCES of the library (every .hip / .hpp file of csrc and this header) taken by the build -- what a profile or
+ * a counter record was taken on (profiles/pmc_traffic.json "build_id"; bench.py drops a traffic record of another build) */
+const char* dthip_build_id(void);
 const char* dthip_last_error(void);
 int         dthip_device_count(void);
 /* stream: a hipStream_t to launch on (e.g. the caller's current stream), or NULL
@@ -165,7 +169,8 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    MSD levels -- two stable scatter levels, then every final bucket (about "msd_bucket_rows" rows; windows of
  *                    whole buckets fill a tile) ordered in LDS and written in place -- and fall back to the LSD passes when
  *                    a final bucket would not fit a tile (heavy duplicates over a wide range); everything else takes stable
- *                    LSD radix passes; 1: LSD passes only.  Same results, bit for bit
+ *                    LSD radix passes; 1: LSD passes only; 2: the MSD levels whenever their other preconditions hold, without
+ *                    the "msd_min_rows" test (A/B runs, tests).  Same results, bit for bit
  *   "small_path"     2 (default): a groupby_agg whose keys fit ONE table of <= 8192 slots runs a launch-lean sequence (tables
  *                    initialised by the plan kernel; group list + offsets + count from one single-workgroup kernel, which
  *                    writes its counts into mapped host memory -- no copy command); 1: the counts are copied back instead;
@@ -405,6 +410,18 @@ int  dthip_filter_cmp(dthip_ctx* ctx, const dthip_col* col, int64_t n, int cmp,
 int  dthip_filter_take(dthip_ctx* ctx, const dthip_col* col, int cmp, double scalar_f, int64_t scalar_i,
                        const dthip_col* cols, int ncols, int64_t n, int mem,
                        int32_t* out_rowindex /* nullable */, void* const* out_cols, int64_t* nout);
+
+/* An Arrow-layout fixed-width column -> the sentinel layout every other entry point takes, written to the DEVICE buffer
+ * dst (nrows elements of `stype`, 16-byte aligned, e.g. from dthip_malloc; DTHIP_BOOL: one int8 per row).
+ *   values    the Arrow data buffer: T[nrows]; for DTHIP_BOOL Arrow's bit-packed booleans (bit i = values[i/8] >> (i&7) & 1)
+ *   validity  the Arrow validity bitmap, bit i set = row i valid (LSB first); NULL = no nulls
+ *   mem       where values / validity live.  DTHIP_HOST: the two buffers cross PCIe as they are (a column without nulls
+ *             is copied straight into dst) and one kernel writes NA sentinels at the invalid rows -- the reference's
+ *             element-by-element CPU materialisation of an Arrow column never runs.  DTHIP_DEVICE: nothing is copied.
+ * Replaces ArrowFw_ColumnImpl::_get / ArrowBool_ColumnImpl::get_element read by a materialising loop
+ * (src/core/column/arrow_fw.cc:63-72, column/arrow_bool.cc, Column::from_arrow column_from_arrow.cc:40-59). */
+int  dthip_from_arrow(dthip_ctx* ctx, const void* values, const uint8_t* validity, int64_t nrows, int stype, int mem,
+                      void* dst);
 
 /* out[i] = rowindex[i] < 0 ? NA : col[rowindex[i]] */
 int  dthip_gather(dthip_ctx* ctx, const dthip_col* col, const int32_t* rowindex,

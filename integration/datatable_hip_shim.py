@@ -44,6 +44,7 @@ reference does.
 """
 import os
 import re
+import threading
 import warnings
 
 import numpy as np
@@ -51,7 +52,7 @@ import numpy as np
 import datatable as dt
 
 from datatable_amd import _lib as L
-from datatable_amd.engine import ST2NP, _DevBuf, default_context
+from datatable_amd.engine import ST2NP, Context, _DevBuf
 
 
 class _Options:
@@ -74,6 +75,20 @@ class _Options:
 
 
 options = _Options()
+stats = {"arrow_uploads": 0}      # columns that went to HBM in Arrow layout (dthip_from_arrow), for tests and curiosity
+
+
+_tls = threading.local()
+
+
+def default_context():
+    """The binding's OWN context of the calling thread -- not datatable_amd.engine.default_context(): the options set in
+    _context() (agg_offsets = 0, f32_sum) would otherwise change what every other user of that shared context gets
+    (engine.groupby_agg(...).offsets(), torch_bridge) merely because this module was imported."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None:
+        ctx = _tls.ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return ctx
 
 
 def _context(ctx=None):
@@ -106,10 +121,43 @@ def _dev_alloc(ctx, nbytes):
     return _DevBuf(ctx, p.value)
 
 
+def _arrow_buffers(frame, c):
+    """(validity address or 0, values address, owner) when column c can be handed over in Arrow layout WITHOUT the
+    reference's materialisation pass, else None.  A column that came from an Arrow table is two buffers -- validity bitmap
+    and values (ArrowFw_ColumnImpl / ArrowBool_ColumnImpl, column_from_arrow.cc:40-59) -- and is reported `virtual`;
+    `frame_column_data_r` would first rewrite it element by element into a sentinel column on the CPU
+    (arrow_fw.cc:63-72 read by _materialize_fw).  Its Arrow export is zero-copy (Column::to_arrow hands out the column's own
+    buffers, frame/to_arrow.cc:85-118), so the two addresses go to dthip_from_arrow and the NA sentinels are written by a
+    kernel on the device.  Needs pyarrow (the reference's own to_arrow() does)."""
+    try:
+        if not dt.internal.frame_columns_virtual(frame)[c]:
+            return None
+        import pyarrow  # noqa: F401
+        col = dt.Frame.__getitem__(frame, (slice(None), c)).to_arrow().column(0)
+    except Exception:
+        return None
+    if col.num_chunks != 1:
+        return None
+    a = col.chunk(0)
+    bufs = a.buffers()
+    if a.offset != 0 or len(bufs) != 2 or bufs[1] is None or len(a) != frame.nrows:
+        return None
+    return (bufs[0].address if bufs[0] is not None else 0), bufs[1].address, a
+
+
 def _upload_column(ctx, frame, c):
     import ctypes as C
     st = frame.stypes[c].value
     n = frame.nrows
+    ab = _arrow_buffers(frame, c) if st in _ACCEL_STYPES and n else None
+    if ab is not None:
+        nbytes = n * ST2NP[st].itemsize
+        buf = _dev_alloc(ctx, nbytes)
+        L.check(ctx._lib.dthip_from_arrow(ctx._h, C.c_void_p(ab[1]), C.c_void_p(ab[0]) if ab[0] else None, n, st, L.HOST, C.c_void_p(buf.ptr)))
+        stats["arrow_uploads"] += 1
+        # (no host pointer to re-validate against: asking the reference for one would materialise the column after all;
+        # every mutating Frame call drops the cache, and row count / stype are compared on every use)
+        return _DevColumn(buf.ptr, nbytes, None, n, st, buf)
     hp = dt.internal.frame_column_data_r(frame, c).value or 0
     nbytes = n * ST2NP[st].itemsize
     buf = _dev_alloc(ctx, nbytes)

@@ -242,3 +242,23 @@ def join_index(xkeys, jkeys, xstypes=None, jstypes=None):
     if rc != 0:
         raise ValueError("dto_join_index failed")
     return out
+
+
+def arrow_to_sentinel(values, validity, nrows, stype):
+    """The column an Arrow-layout column materialises to in the reference: element i is valid when there is no validity
+    bitmap or bit `validity[i / 8] & (1 << (i & 7))` is set (ArrowFw_ColumnImpl::_get, src/core/column/arrow_fw.cc:63-72);
+    booleans are bit-packed the same way (ArrowBool_ColumnImpl::get_element, column/arrow_bool.cc); an invalid element
+    reads as the stype's NA sentinel once materialised (ColumnImpl::_materialize_fw, column_impl.cc:78-101 writes
+    GETNA<T>(), stype.h:186-197).  numpy restatement; TEST INFRASTRUCTURE ONLY."""
+    i = np.arange(nrows)
+    valid = np.ones(nrows, bool) if validity is None else ((np.asarray(validity, np.uint8)[i >> 3] >> (i & 7)) & 1).astype(bool)
+    if stype == BOOL:
+        data = ((np.asarray(values, np.uint8)[i >> 3] >> (i & 7)) & 1).astype(np.int8)
+    else:
+        data = np.asarray(values)[:nrows].astype(_ST2NP[stype], copy=True)
+    out = data.copy()
+    if stype in (FLOAT32, FLOAT64):
+        out[~valid] = np.nan
+    else:
+        out[~valid] = np.iinfo(_ST2NP[stype]).min
+    return out

@@ -88,6 +88,20 @@ class StandinLib:
     def dthip_set_option(self, h, name, v):
         return 0
 
+    def dthip_from_arrow(self, h, values, validity, nrows, st, mem, dst):
+        # Arrow layout -> sentinel column (oracle.arrow_to_sentinel restates arrow_fw.cc:63-72); counted as one upload
+        self.uploads += 1
+        self.calls.append("from_arrow")
+        n = int(nrows)
+        nb = (n + 7) // 8
+        bm = np.frombuffer((C.c_char * nb).from_address(_addr(validity)), np.uint8).copy() if _addr(validity) else None
+        if st == L.BOOL:
+            vals = np.frombuffer((C.c_char * nb).from_address(_addr(values)), np.uint8).copy()
+        else:
+            vals = _view(values, n, st)
+        _store(dst, o.arrow_to_sentinel(vals, bm, n, st))
+        return 0
+
     # ---- queries ----------------------------------------------------------------------------------------------------
     def _group(self, karr, nkeys, n, na_pos):
         keys = [_view(karr[i].data, n, karr[i].stype) for i in range(nkeys)]

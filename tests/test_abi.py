@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libdthip.so does not export %s" % s
         assert s in _lib.SIGNATURES, "%s has no ctypes signature in datatable_amd/_lib.py" % s
     assert set(_lib.SIGNATURES) == set(declared_symbols())
-    assert lib.dthip_abi_version() == 4
+    assert lib.dthip_abi_version() == 5
+    bid = lib.dthip_build_id().decode()
+    assert len(bid) == 12 and all(ch in "0123456789abcdef" for ch in bid)
 
 
 def test_reduce_out_stype_rules():

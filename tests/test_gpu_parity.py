@@ -41,7 +41,9 @@ def check_agg(got, exp, opn, v, ri, off, what):
 # ---- golden fixtures (reference outputs) -----------------------------------------------
 
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_groupby(ctx, gold, name):
+def test_golden_groupby(routed_ctx, gold, name):
+    """the reference's RowIndex / offsets / group keys, on BOTH routes of the sort path (LSD passes; MSD levels forced)"""
+    ctx = routed_ctx
     c = gold.by_name[name]
     keys = gold.keys(name)
     r = ctx.groupby(keys, stypes=c["key_stypes"])
@@ -54,7 +56,8 @@ def test_golden_groupby(ctx, gold, name):
 
 
 @pytest.mark.parametrize("name", golden_names())
-def test_golden_fused_agg(ctx, gold, name):
+def test_golden_fused_agg(routed_ctx, gold, name):
+    ctx = routed_ctx
     c = gold.by_name[name]
     keys, vals = gold.keys(name), gold.vals(name)
     aggs = [(opn, vi) for opn, vi, _ in c["aggs"]] + [("count0", None)]
@@ -979,3 +982,39 @@ def test_small_table_sequence(ctx, small_path):
         ctx.profile(False)
         ctx.set_option("small_path", 2)
         ctx.set_option("spec_min_rows", 1 << 23)
+
+
+def test_small_path_mapped_words_survive_read_back():
+    """read_back() used to free the mapped host words of the small-table path whenever its own pinned
+    buffer grew -- the FIRST read_back of a context always did -- and left the stale pointers behind: the next small call
+    wrote through a freed mapping (GPU fault / garbage group count).  The sequence that exposed it: a bool-key
+    groupby_agg as the first call of a fresh context (no read_back before the words are allocated), an int-key call (its
+    planning reads the range back), a second small call; then a read-back that makes the pinned buffer grow again."""
+    from datatable_amd.engine import Context
+    rng = np.random.default_rng(4242)
+    for rounds in range(3):
+        c = Context(0)
+        try:
+            n = 50_000
+            kb = (rng.random(n) < 0.4)
+            v = rng.standard_normal(n)
+            ki = rng.integers(-5, 90, n).astype(np.int64)
+            for k in (kb, ki, kb, ki):
+                ri, off = o.group([k])
+                r = c.groupby_agg([k], [v], [("sum", 0), ("count0", None)])
+                assert_same(r.offsets(), off, "offsets")
+                assert_same(r.key(0), k[ri[off[:-1]]], "keys")
+                assert_same(r.agg(1), np.diff(off).astype(np.int64), "count()")
+                check_agg(r.agg(0), o.reduce("sum", v, ri, off), "sum", v, ri, off, "sum")
+                r.free()
+            # a big read-back (the pinned buffer grows a second time), then small calls again
+            big = rng.integers(0, 3_000_000, 4_000_000).astype(np.int64)
+            g = c.groupby([big]); ri, off = o.group([big])
+            assert_same(g.rowindex(), ri, "rowindex"); assert_same(g.offsets(), off, "offsets"); g.free()
+            for k in (kb, ki):
+                ri, off = o.group([k])
+                r = c.groupby_agg([k], [v], [("sum", 0), ("count0", None)])
+                assert_same(r.offsets(), off, "offsets"); assert_same(r.agg(1), np.diff(off).astype(np.int64), "count()")
+                r.free()
+        finally:
+            c.close()

@@ -119,7 +119,7 @@ def test_bench_two_ranks_end_to_end(fake_rccl):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(DTHIP_RCCL_LIB=fake_rccl, DTHIP_BENCH_ONE_GPU="1", FAKE_RCCL_DIR=os.path.dirname(fake_rccl))
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rows", "20000000", "--groups", "200000", "--steps", "2",
-                          "--warmup", "1", "--config-scale", "0.2"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+                          "--warmup", "1", "--config-scale", "0.2"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
     assert out.returncode == 0, out.stderr.decode(errors="replace")[-3000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
@@ -128,7 +128,22 @@ def test_bench_two_ranks_end_to_end(fake_rccl):
     assert line["config"]["rows"] == 20_000_000 and line["config"]["rows_per_gpu"] == 10_000_000
     p = line["parity"]["properties"]
     assert p["groups"] == 200_000 and p["keys_strictly_ascending_within_and_across_ranks"] and p["sum_of_group_sums_equals_sum_of_values"]
-    assert line["roofline"]["kernel"] and line["cpu_baseline"] is None
+    assert line["roofline"]["kernel"]
+    # round 5: the N > 1 line is COMPLETE and SELF-VERIFYING -- the reference's CPU path timed on rank 0 (cpu_baseline), the
+    # ranks as the library's communicator saw them, and every sharded result (C3, C4, C5) compared with the single-GPU
+    # path over all rows (rebuilt on rank 0 from the ranks' seeds), which in turn is compared with the OpenMP oracle
+    cb = line["cpu_baseline"]
+    assert cb and cb["kind"] == "reference" and cb["value"] > 0 and cb["cores"] >= 1, cb
+    assert line["ranks_seen"] == [0, 1] and [x["comm_world"] for x in line["ranks"]] == [2, 2]
+    assert line["parity"]["configs"] == {"C3": True, "C4": True, "C5": True}, line["parity"]
+    sv = line["parity"]["sharded_vs_single_gpu"]
+    assert sv["ok"] and sv["keys_bit_exact"] and sv["inputs_rebuilt_identical"] and sv["count()"] and sv["sum(v0)"], sv
+    assert sv["single_gpu_vs_oracle_all_rows"]["ok"] and sv["groups"] == 200_000 and sum(sv["groups_per_rank"]) == 200_000
+    assert line["parity"]["vs_reference"]["keys_bit_exact"] and line["parity"]["vs_reference"]["sums_within_tol"]
+    p4, p5 = line["configs"]["C4"]["parity"], line["configs"]["C5"]["parity"]
+    assert p4["ok"] and p4["count()"] and p4["sum(v0)"] and p4["single_gpu_vs_oracle_all_rows"]["ok"], p4
+    assert p5["ok"] and p5["composed_rowindex_bit_exact"] and p5["group_sizes_bit_exact"] and p5["key_column_bit_exact"] \
+        and p5["x_column_bit_exact"] and p5["single_gpu_vs_oracle_all_rows"]["ok"] and min(p5["rows_per_rank"]) > 0, p5
     # round 4: the N > 1 line says what crossed the fabric and where the time went, for all three multi-GPU configs
     ex = line["exchange"]
     assert ex["bytes_to_peers_max"] > 0 and ex["allgathers"] == 2 and 0 < ex["xgmi_frac_of_step"] < 1      # samples, counts + status

@@ -68,19 +68,24 @@ def test_jay_bad_files(tmp_path):
 @pytest.mark.gpu
 def test_jay_to_device_and_groupby():
     """Jay -> HBM -> the hot path, never through a parsed copy"""
-    import torch
-    from datatable_amd import torch_bridge as tb
+    from datatable_amd import _lib as L
+    from datatable_amd.engine import Context
     from datatable_amd.frame import by, f, sum, count
-    t = jay.to_device(os.path.join(JDIR, "big.jay"))
+    ctx = Context(0)
+    cols, nrows = jay.to_device(os.path.join(JDIR, "big.jay"), ctx)          # dthip_malloc + dthip_memcpy_h2d, no torch
     e = EXP["big"]
-    assert t["k"].dtype == torch.int32 and t["k"].cpu().tolist() == e["columns"][0]
-    ctx = tb.context_for_current_stream(0)
-    off, gk, out = tb.groupby_agg_tensors(ctx, [t["k"]], [t["v"]], [("sum", 0), ("count0", None)])
+    assert nrows == len(e["columns"][0]) and cols["k"].stype == L.INT32
+    r = ctx.groupby_agg([cols["k"]], [cols["v"]], [("sum", 0), ("count0", None)], nrows=nrows)
     DT = jay.open_jay(os.path.join(JDIR, "big.jay"))
     R = DT[:, [sum(f.v), count()], by(f.k)]
-    assert gk[0].cpu().tolist() == R.to_list()[0]
-    assert np.allclose(out[0].cpu().numpy(), np.array(R.to_list()[1]))
-    assert out[1].cpu().tolist() == R.to_list()[2]
+    assert r.key(0).tolist() == R.to_list()[0]
+    assert np.allclose(r.agg(0), np.array(R.to_list()[1]))
+    assert r.agg(1).tolist() == R.to_list()[2]
+    g = ctx.groupby([cols["k"]], nrows=nrows)
+    assert np.array_equal(np.array(e["columns"][0], np.int32)[g.rowindex()[g.offsets()[:-1]]], r.key(0))
+    r.free(); g.free()
+    del cols
+    ctx.close()
     K = jay.open_jay(os.path.join(JDIR, "keyed.jay"))
     assert K.key == ("k",)
     X = type(K)(k=[3, 4, 9])

@@ -15,10 +15,16 @@ pytestmark = pytest.mark.gpu
 builtins_sum, builtins_min = builtins.sum, builtins.min
 
 
-@pytest.fixture(scope="module")
-def dt():
+@pytest.fixture(scope="module", params=["lsd", "msd"])
+def dt(request):
+    """datatable_amd.frame on the calling thread's default context, once per route of the sort path: LSD radix passes, and
+    the MSD levels forced onto every input (conftest.set_sort_route) -- the ported reference cases must hold on both"""
+    from conftest import set_sort_route
     from datatable_amd import frame
-    return frame
+    from datatable_amd.engine import default_context
+    set_sort_route(default_context(), request.param)
+    yield frame
+    set_sort_route(default_context(), "default")
 
 
 def assert_equals(A, B):
