@@ -43,6 +43,20 @@ ALG_BYTES_PER_ROW = 16         # key 8 B + value 8 B read once 
 RTOL, ATOL = 1e-6, 1e-9        # float64 sums: BASELINE.json's tolerance (+ an absolute floor for sums near 0)
 
 
+def pmc_records():
+    """(profiles/pmc_traffic.json, None) -- or ({}, why) when the counter passes were recorded on ANOTHER build of the library:
+    the file carries dthip_build_id() of the library that was profiled (scripts/prof.sh), a hash of the library's sources"""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception as e:
+        return {}, "no profiles/pmc_traffic.json (%s)" % type(e).__name__
+    from datatable_amd import _lib
+    bid = _lib.load().dthip_build_id().decode()
+    if doc.get("_build_id") != bid:
+        return {}, "stale: recorded on library build %s, this library is build %s -- re-run scripts/prof.sh" % (doc.get("_build_id"), bid)
+    return doc, None
+
+
 def to_host(t, chunk=1 << 27):
     """device tensor -> numpy, through a pinned bounce buffer (the inputs of the CPU legs are the GPU leg's)"""
     import numpy as np
@@ -223,14 +237,36 @@ def verify_c5(ctx, k_t, x_t, threads, keep=None):
     t0 = time.perf_counter()
     n = k_t.numel()
     dev = k_t.device
+    # (1) the TIMED form: one call, dthip_filter_groupby_rows (fused route: filter + key transform + first sort level in one
+    # sweep, csrc/tlsort.hip)
+    rf = ctx.filter_groupby_rows(devcol(x_t), ">", 0.0, [devcol(k_t)], [devcol(k_t), devcol(x_t)], nrows=n, want_rowindex=True)
+    npf = rf.nrows
+    f_off = torch.empty(rf.ngroups + 1, dtype=torch.int32, device=dev); rf.offsets_into(f_off.data_ptr())
+    f_k = torch.empty(npf, dtype=torch.int64, device=dev); f_x = torch.empty(npf, dtype=torch.float64, device=dev)
+    f_ri = torch.empty(npf, dtype=torch.int32, device=dev)
+    rf.col_into(0, f_k.data_ptr()); rf.col_into(1, f_x.data_ptr()); rf.rowindex_into(f_ri.data_ptr())
+    torch.cuda.synchronize()
+    rf.free()
+    # (2) the two statements as two calls (round 4's form): filter -> RowIndex + the view's columns, then the rows in grouped
+    # order with the filter's RowIndex riding along
     ri_t = torch.empty(n, dtype=torch.int32, device=dev)
     kb = torch.empty(n, dtype=torch.int64, device=dev)
     xb = torch.empty(n, dtype=torch.float64, device=dev)
     npass = ctx.filter_take_dev(devcol(x_t), ">", 0.0, [devcol(k_t), devcol(x_t)], n, ri_t.data_ptr(), [kb.data_ptr(), xb.data_ptr()])
     r = ctx.groupby_rows([devcol(kb[:npass])], [devcol(kb[:npass]), devcol(xb[:npass]), devcol(ri_t[:npass])], nrows=npass, want_rowindex=False)
-    g_off = r.offsets()
-    g_k, g_x, g_ri = r.col(0), r.col(1), r.col(2)
+    t_off = torch.empty(r.ngroups + 1, dtype=torch.int32, device=dev); r.offsets_into(t_off.data_ptr())
+    t_k = torch.empty(npass, dtype=torch.int64, device=dev); t_x = torch.empty(npass, dtype=torch.float64, device=dev)
+    t_ri = torch.empty(npass, dtype=torch.int32, device=dev)
+    r.col_into(0, t_k.data_ptr()); r.col_into(1, t_x.data_ptr()); r.col_into(2, t_ri.data_ptr())
+    torch.cuda.synchronize()
     r.free()
+    one_call_equals_two_calls = bool(npf == npass and torch.equal(f_off, t_off) and torch.equal(f_ri, t_ri) and torch.equal(f_k, t_k)
+                                     and torch.equal(f_x.view(torch.int64), t_x.view(torch.int64)))
+    # ... and the filter's own RowIndex is the composed RowIndex sorted ascending
+    filter_is_sorted_composed = bool(torch.equal(torch.sort(f_ri).values, ri_t[:npass])) if npf == npass else False
+    del t_off, t_k, t_x, t_ri
+    g_off, g_k, g_x, g_ri = to_host(f_off), to_host(f_k), to_host(f_x), to_host(f_ri)
+    del f_off, f_k, f_x, f_ri
     if keep is not None:
         keep.update(offsets=g_off, k=g_k, x=g_x, ri=g_ri)
     g_filter = to_host(ri_t[:npass])
@@ -246,6 +282,8 @@ def verify_c5(ctx, k_t, x_t, threads, keep=None):
         comp = fri[p]                                  # RowIndex composition ab*bc (rowindex_array.cc:258-269)
         res = {"against": "oracle/dt_oracle.c, %d OpenMP threads" % threads, "rows": int(n), "rows_passing": int(len(fri)),
                "groups": int(len(off) - 1), "filter_rowindex_bit_exact": filter_ok,
+               "one_call_equals_two_calls_bit_exact": one_call_equals_two_calls,
+               "sorted_composed_rowindex_is_filter_rowindex_bit_exact": filter_is_sorted_composed,
                "offsets_bit_exact": _cmp_exact(g_off, off), "composed_rowindex_bit_exact": _cmp_exact(g_ri, comp),
                "key_column_bit_exact": _cmp_exact(g_k, hk[comp]), "x_column_bit_exact": _cmp_exact(g_x, hx[comp])}
     finally:
@@ -280,10 +318,10 @@ def run_configs(ctx, dev, which, steps, scale, verify, cpu_sample, ref_threads, 
                      "kernel_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]}}
         # HBM bytes of one whole query from the rocprofv3 PMC passes recorded under profiles/ (scripts/prof_r04.sh):
         # FETCH_SIZE x 2 + WRITE_SIZE over every kernel of the query; amplification = traffic / algorithmic bytes
-        try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("_configs", {}).get(name)
-        except Exception:
-            rec = None
+        doc, why = pmc_records()
+        rec = doc.get("_configs", {}).get(name)
+        if why:
+            out[name]["traffic_note"] = why
         if rec and rec.get("rows") == n:
             out[name]["traffic"] = rec["hbm_bytes_per_query"]
             out[name]["amplification"] = rec["hbm_bytes_per_query"] / alg_bytes
@@ -381,16 +419,26 @@ def run_configs(ctx, dev, which, steps, scale, verify, cpu_sample, ref_threads, 
             ri = torch.empty(n, dtype=torch.int32, device=dev)
             kbuf = torch.empty(n, dtype=torch.int64, device=dev)
             xbuf = torch.empty(n, dtype=torch.float64, device=dev)
-            def run():
-                # V = DT[f.x > 0, :]; V[:, :, by(f.k)] (two-step form): filter -> RowIndex + the view's
-                # columns in one sweep, then the rows in grouped order (key, x and the RowIndex ride through the sort)
+            def run_two_calls():
+                # V = DT[f.x > 0, :]; V[:, :, by(f.k)] (two-step form) as TWO calls (round 4): filter -> RowIndex +
+                # the view's columns in one sweep, then the rows in grouped order (key, x and the RowIndex ride through the sort)
                 npass = ctx.filter_take_dev(devcol(x), ">", 0.0, [devcol(k), devcol(x)], n, ri.data_ptr(),
                                             [kbuf.data_ptr(), xbuf.data_ptr()])
                 kv, xv = kbuf[:npass], xbuf[:npass]
                 r = ctx.groupby_rows([devcol(kv)], [devcol(kv), devcol(xv), devcol(ri[:npass])], nrows=npass, want_rowindex=False)
                 ng = r.ngroups; r.free(); return ng
-            measure(c, n, int(n * 30.4), run, "V = DT[f.x > 0, :]; V[:, :, by(f.k)], int64 key in [0,1e8), float64 x, ~50% pass")
+            def run():
+                # the same two statements as ONE call (round 5, dthip_filter_groupby_rows): same outputs -- offsets, key and x
+                # columns in grouped order, the composed RowIndex -- the filter fused into the first sort level
+                r = ctx.filter_groupby_rows(devcol(x), ">", 0.0, [devcol(k)], [devcol(k), devcol(x)], nrows=n, want_rowindex=True)
+                ng = r.ngroups; r.free(); return ng
+            measure("C5_two_calls", n, int(n * 30.4), run_two_calls, "config 5 as dthip_filter_take + dthip_groupby_rows (round 4's form)")
+            two = out.pop("C5_two_calls")
             del ri, kbuf, xbuf
+            torch.cuda.empty_cache(); ctx.trim()
+            measure(c, n, int(n * 30.4), run, "V = DT[f.x > 0, :]; V[:, :, by(f.k)], int64 key in [0,1e8), float64 x, ~50% pass; ONE call "
+                                               "(dthip_filter_groupby_rows): offsets, key and x columns in grouped order, composed RowIndex")
+            out[c]["two_calls"] = {"ms": two["ms"], "kernel_ms": two["kernel_ms"], "what": two["workload"]}
             torch.cuda.empty_cache(); ctx.trim()
             host = check(c, lambda: verify_c5(ctx, k, x, port_threads))
             if host:
@@ -1139,15 +1187,12 @@ def main():
             per_step = max(1, round(rp_n / args.steps))
             avg_s = rp_ms / rp_n * per_step * 1e-3
             ach = alg_bytes_launch / avg_s / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc) and not sharded:
-                try:
-                    traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch_at_rows", {}).get(str(n_local))
-                except Exception:
-                    traffic = None
+            traffic, traffic_note = None, None
+            if not sharded:
+                doc, traffic_note = pmc_records()
+                traffic = (doc.get(dom) or {}).get("hbm_bytes_per_launch_at_rows", {}).get(str(n_local))
             roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launches": rp_n, "launches_per_step": per_step,
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "launches": rp_n, "launches_per_step": per_step,
                     "avg_launch_ms": rp_ms / rp_n * per_step,
                     "alg_bytes_per_launch": alg_bytes_launch,
                     "note": "achieved = 16 B/row (SURVEY 8d, C3) x rows of one launch / HIP-event time of that launch; "
@@ -1166,6 +1211,7 @@ def main():
                                        "(RCCL inside libdthip.so), merge on the owner" % world) if sharded else "single GPU"},
             "roofline": roof,
             "kernels": per_kernel,
+            "library_build_id": __import__("datatable_amd._lib", fromlist=["load"]).load().dthip_build_id().decode(),
             "cpu_baseline": None,
         }
         if sharded and not args.no_cpu_baseline:

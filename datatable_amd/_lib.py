@@ -101,6 +101,8 @@ SIGNATURES = {
     "dthip_filter_cmp": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int64, C.c_int, C.c_double, C.c_int64, C.c_int,
                                    C.c_void_p, C.POINTER(C.c_int64)]),
     "dthip_gather": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "dthip_filter_groupby_rows": (C.c_int, [C.c_void_p, C.POINTER(Col), C.c_int, C.c_double, C.c_int64, C.POINTER(Col), C.c_int,
+                                            C.POINTER(Col), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "dthip_from_arrow": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     # multi-GPU (comm.hip)
     "dthip_comm_unique_id": (C.c_int, [C.c_void_p]),

@@ -1644,6 +1644,11 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
     return DTHIP_OK;
   }
   if (!strcmp(name, "spec_min_rows")) { ctx->spec_min_rows = value; return DTHIP_OK; }
+  if (!strcmp(name, "filter_rows_fused")) {
+    if (value < 0 || value > 1) { set_error("filter_rows_fused must be 0 or 1"); return DTHIP_EINVAL; }
+    ctx->filter_rows_fused = (int)value;
+    return DTHIP_OK;
+  }
   if (!strcmp(name, "sort_path")) {
     if (value < 0 || value > 2) { set_error("sort_path must be 0 (auto), 1 (LSD passes only) or 2 (MSD levels whenever they apply)"); return DTHIP_EINVAL; }
     ctx->sort_path = (int)value;
@@ -1948,6 +1953,303 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
       if (want_rowindex) { result_adopt(sc, res, g.rowindex); res->rowindex = g.rowindex; }
     }
     res->nrows = nrows; res->ngroups = g.ngroups; res->offsets = g.offsets;
+  } while (0);
+  if (rc != DTHIP_OK) { result_destroy(ctx, res); return rc; }
+  *out = res;
+  return DTHIP_OK;
+}
+
+// ---- V = DT[f.x <cmp> c, :]; V[:, cols, by(key)] in one call ----------------------------------------------------------
+// The fused route (tlsort.hip): ONE sweep over the unfiltered rows evaluates the predicate, transforms the key and orders
+// every tile's passing rows by the top digit inside the tile's own row range (sequential writes + a 16-bit directory);
+// level 2 collects every bucket's rows from those segments and scatters them to their final buckets, which the final
+// level orders in LDS and writes in place (the last two as in sort_stage's MSD levels).  DTHIP_NOT_APPLICABLE: the query
+// does not fit (the caller then runs filter_take + groupby_rows); DTHIP_RETRY_EXACT: a guessed key range was wrong.
+static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthip_col& pred, int cmp, double cf, int64_t ci,
+                             const dthip_col* keys_orig, const std::vector<dthip_col>& kd, const dthip_col* cols_orig,
+                             const std::vector<dthip_col>& cd, int ncols, int64_t n, int na_pos, int want_rowindex, bool speculative) {
+  if (ctx->sort_path == 1 || (ctx->sort_path != 2 && n < ctx->msd_min_rows)) return DTHIP_NOT_APPLICABLE;
+  if (kd.size() != 1 || (kd[0].stype != DTHIP_INT32 && kd[0].stype != DTHIP_INT64)) return DTHIP_NOT_APPLICABLE;
+  if (stype_size(pred.stype) != 8) return DTHIP_NOT_APPLICABLE;
+  // riding columns (requested columns that are not the key column) and the row number: <= 2, an 8-byte one first
+  std::vector<int> is_key(ncols, 0), slot(ncols, -1);
+  int ride[2] = {-1, -1}, nride = 0;
+  for (int c = 0; c < ncols; c++) {
+    if (cols_orig[c].data == keys_orig[0].data && cols_orig[c].stype == keys_orig[0].stype) { is_key[c] = 1; continue; }
+    for (int c2 = 0; c2 < c; c2++) if (!is_key[c2] && cols_orig[c2].data == cols_orig[c].data && cols_orig[c2].stype == cols_orig[c].stype) slot[c] = slot[c2];
+    if (slot[c] >= 0) continue;
+    if (nride == 2) return DTHIP_NOT_APPLICABLE;
+    const int w = stype_size(cd[c].stype);
+    if (w != 4 && w != 8) return DTHIP_NOT_APPLICABLE;
+    slot[c] = nride; ride[nride++] = c;
+  }
+  if (nride == 2 && stype_size(cd[ride[0]].stype) == 4 && stype_size(cd[ride[1]].stype) == 8) {
+    std::swap(ride[0], ride[1]);
+    for (int c = 0; c < ncols; c++) if (slot[c] >= 0) slot[c] ^= 1;
+  }
+  int npay = nride, rid_slot = -1;
+  int payw[2] = {nride > 0 ? stype_size(cd[ride[0]].stype) : 0, nride > 1 ? stype_size(cd[ride[1]].stype) : 0};
+  if (want_rowindex) {
+    if (npay == 2) return DTHIP_NOT_APPLICABLE;
+    rid_slot = npay; payw[npay++] = 4;
+  }
+  if (npay == 0) return DTHIP_NOT_APPLICABLE;
+  if (npay == 2 && payw[0] == 4) return DTHIP_NOT_APPLICABLE;              // (4, 4): not a variant of the gather pass
+  KeyPlan plan;
+  DTHIP_TRY(plan_keys(ctx, sc, kd.data(), 1, n, na_pos, &plan, speculative, true));
+  if (plan.nstages != 1 || plan.stage_bits[0] > 32 || plan.stage_bits[0] < 3) return DTHIP_NOT_APPLICABLE;
+  const int bits = plan.stage_bits[0];
+  const uint32_t tile = tl_tile_rows();
+  PredArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.data = pred.data; pa.stype = pred.stype; pa.cmp = cmp; pa.cf = cf; pa.ci = ci; pa.is_mask = 0;
+  // passing rows, estimated from 65536 evenly spaced rows: sizes the digits (a final bucket should hold ~msd_bucket_rows rows)
+  uint32_t* d_cnt = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>(1, &d_cnt));
+  DTHIP_CHECK_HIP(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), ctx->stream));
+  const uint32_t nsamp = (uint32_t)std::min<int64_t>(n, 65536);
+  DTHIP_TRY(launch_tl_pred_sample(ctx, pa, (uint32_t)n, nsamp, d_cnt));
+  uint32_t scnt = 0;
+  DTHIP_TRY(read_back(ctx, &scnt, d_cnt, sizeof(scnt)));
+  const int64_t est = std::max<int64_t>(2, (int64_t)((double)n * ((double)scnt + 0.5) / (double)nsamp));
+  static const int rbmax = getenv("DTHIP_MSD_RBMAX") ? atoi(getenv("DTHIP_MSD_RBMAX")) : 9;
+  const MsdPlan msd = msd_split(est, bits, tile, ctx->msd_bucket_rows, rbmax > 9 ? 9 : rbmax);
+  if (!msd.ok) return DTHIP_NOT_APPLICABLE;
+  const uint32_t nb1 = 1u << msd.s1, bins2 = 1u << msd.s2;
+  // ---- level 1: filter + key transform + top digit, tile-local ------------------------------------------------------------
+  const uint32_t ntiles1 = (uint32_t)((n + tile - 1) / tile);
+  const uint32_t ntb = (ntiles1 + 63) / 64, dstride = ntb * 64;
+  uint32_t* k1 = nullptr; uint16_t* dir = nullptr; uint16_t* dirT = nullptr; uint32_t* cc = nullptr; uint32_t* tot = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)n, &k1));
+  DTHIP_TRY(sc.get<uint16_t>((size_t)ntiles1 * (nb1 + 1), &dir));
+  DTHIP_TRY(sc.get<uint16_t>((size_t)(nb1 + 1) * dstride, &dirT));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)nb1 * ntb, &cc));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)nb1 + 1, &tot));
+  DTHIP_CHECK_HIP(hipMemsetAsync(tot + nb1, 0, sizeof(uint32_t), ctx->stream));
+  void* l1[2] = {nullptr, nullptr};
+  for (int q = 0; q < npay; q++) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)n * payw[q], &b)); l1[q] = b; }
+  TL1Args ta;
+  memset(&ta, 0, sizeof(ta));
+  ta.pred = pa; ta.key = plan.col[0]; ta.key.shift = 0;
+  ta.n = (uint32_t)n; ta.shift = msd.rb + msd.s2; ta.bits = msd.s1;
+  ta.kout = k1; ta.dir = dir; ta.rowid = rid_slot >= 0 ? static_cast<uint32_t*>(l1[rid_slot]) : nullptr;
+  ta.keepx = -1; ta.pay.n = nride;
+  for (int q = 0; q < nride; q++) {
+    ta.pay.in[q] = cd[ride[q]].data; ta.pay.out[q] = l1[q]; ta.pay.width[q] = payw[q];
+    if (cd[ride[q]].data == pred.data && payw[q] == 8) ta.keepx = q;
+  }
+  ta.bad = plan.speculative ? tot + nb1 : nullptr;
+  DTHIP_TRY(launch_tl_level1(ctx, ta));
+  DTHIP_TRY(launch_tl_directory(ctx, dir, ntiles1, nb1, dirT, dstride, cc, ntb, tot));
+  std::vector<uint32_t> htot((size_t)nb1 + 1);
+  DTHIP_TRY(read_back(ctx, htot.data(), tot, htot.size() * sizeof(uint32_t)));
+  if (plan.speculative && htot[nb1]) return DTHIP_RETRY_EXACT;
+  int64_t npass = 0;
+  for (uint32_t b = 0; b < nb1; b++) npass += htot[b];
+  if (npass == 0) { DTHIP_TRY(empty_result(ctx, res)); return DTHIP_OK; }
+  // ---- level 2: ragged tiles inside the level-1 buckets, planned on the host (msd_plan.hpp), rows read through the directory
+  BucketGeom hg;
+  memset(&hg, 0, sizeof(hg));
+  {
+    const uint32_t gmax = (uint32_t)ctx->num_cus * 4, nt = (uint32_t)((npass + tile - 1) / tile);
+    hg.tpg = (nt + gmax - 1) / gmax; if (hg.tpg == 0) hg.tpg = 1;
+  }
+  std::vector<uint32_t> tdesc, gdesc, gfirst, pstart((size_t)nb1 + 1, 0);
+  msd_level2_tiles(htot.data(), nb1, tile, hg.tpg, &tdesc, &gdesc, &gfirst);
+  for (uint32_t b = 0; b < nb1; b++) pstart[b + 1] = pstart[b] + htot[b];
+  const uint32_t ntiles2 = (uint32_t)(tdesc.size() / 4), G2 = (uint32_t)(gdesc.size() / 2);
+  uint32_t* d_plan = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>(tdesc.size() + gdesc.size() + gfirst.size() + pstart.size() + 4, &d_plan));
+  uint32_t* d_tdesc = d_plan; uint32_t* d_gdesc = d_tdesc + tdesc.size(); uint32_t* d_gfirst = d_gdesc + gdesc.size();
+  uint32_t* d_pstart = d_gfirst + gfirst.size(); uint32_t* d_max = d_pstart + pstart.size();
+  DTHIP_CHECK_HIP(hipMemcpyAsync(d_tdesc, tdesc.data(), tdesc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  DTHIP_CHECK_HIP(hipMemcpyAsync(d_gdesc, gdesc.data(), gdesc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  DTHIP_CHECK_HIP(hipMemcpyAsync(d_gfirst, gfirst.data(), gfirst.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  DTHIP_CHECK_HIP(hipMemcpyAsync(d_pstart, pstart.data(), pstart.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  DTHIP_CHECK_HIP(hipMemsetAsync(d_max, 0, 4, ctx->stream));
+  DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));            // (the host vectors above go out of use only at the end; pageable copies)
+  uint32_t* P = nullptr; uint32_t* gtot2 = nullptr; uint32_t* fstart = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)(ntiles2 ? ntiles2 : 1) * bins2, &P));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)(G2 ? G2 : 1) * bins2, &gtot2));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)nb1 * bins2 + 1, &fstart));
+  TLGatherHistArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.keys = k1; ga.shift = msd.rb; ga.bits = msd.s2; ga.tdesc = d_tdesc; ga.gdesc = d_gdesc; ga.pstart = d_pstart;
+  ga.dirT = dirT; ga.dstride = dstride; ga.cc = cc; ga.ntb = ntb; ga.ntiles1 = ntiles1; ga.T1 = tile; ga.P = P; ga.gtot = gtot2;
+  DTHIP_TRY(launch_tl_gather_hist(ctx, ga, G2));
+  DTHIP_TRY(launch_msd_scan(ctx, gtot2, d_gfirst, d_pstart, msd.s2, nb1, (uint32_t)npass, fstart, d_max));
+  const uint32_t nbk = nb1 * bins2;
+  const uint32_t nwmax = (uint32_t)(npass / (tile / 2)) + 2;
+  uint32_t* wplan = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)2 * (nwmax + 2) + 4, &wplan));
+  uint32_t* wbounds = wplan; uint32_t* wfirst = wplan + nwmax + 2; uint32_t* winfo = wfirst + nwmax + 2;
+  DTHIP_CHECK_HIP(hipMemsetAsync(winfo, 0, 4 * sizeof(uint32_t), ctx->stream));
+  DTHIP_TRY(launch_msd_windows(ctx, fstart, nbk, (uint32_t)npass, d_max, tile, nwmax, wbounds, wfirst, winfo));
+  uint32_t wi[4] = {0, 0, 0, 0};
+  DTHIP_TRY(read_back(ctx, wi, winfo, sizeof(wi)));
+  uint32_t maxsize = 0;
+  DTHIP_TRY(read_back(ctx, &maxsize, d_max, sizeof(maxsize)));
+  int wbits2 = 1;
+  while ((1u << wbits2) < wi[2]) wbits2++;
+  int maxw_w = 4;
+  for (int q = 0; q < npay; q++) maxw_w = std::max(maxw_w, payw[q]);
+  const bool windows = wi[0] > 0 && wi[2] >= 1 && wi[2] <= 16 &&
+                       (size_t)2 * ((size_t)1 << wbits2) * ((size_t)1 << msd.rb) * 4 <= (size_t)tile * maxw_w;
+  if (getenv("DTHIP_MSD_DEBUG"))
+    fprintf(stderr, "[dthip fused] n=%lld est=%lld pass=%lld bits=%d s1=%d s2=%d rb=%d tiles1=%u tiles2=%u groups2=%u largest bucket=%u windows=%u max buckets/window=%u -> %s\n",
+            (long long)n, (long long)est, (long long)npass, bits, msd.s1, msd.s2, msd.rb, ntiles1, ntiles2, G2, maxsize, wi[0], wi[2],
+            windows ? "windows" : (maxsize <= tile ? "per bucket" : "not applicable"));
+  if (!(windows || maxsize <= tile)) return DTHIP_NOT_APPLICABLE;       // a final bucket outgrows a tile (heavy duplicates)
+  unsigned char* kA = nullptr; unsigned char* kB = nullptr;
+  DTHIP_TRY(sc.get<unsigned char>((size_t)npass * 4, &kA));
+  DTHIP_TRY(sc.get<unsigned char>((size_t)npass * 4, &kB));
+  void* pb[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  for (int q = 0; q < npay; q++)
+    for (int h = 0; h < 2; h++) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)npass * payw[q], &b)); pb[h][q] = b; }
+  RadixPass rp;
+  memset(&rp, 0, sizeof(rp));
+  rp.kin = k1; rp.kout = kA; rp.key64 = 0; rp.n = (uint32_t)npass;
+  rp.shift = msd.rb; rp.bits = msd.s2; rp.P = P; rp.gpre = gtot2; rp.tpg = hg.tpg; rp.iota = 0;
+  rp.ntiles = ntiles2; rp.tdesc = d_tdesc;
+  rp.pay.n = npay;
+  for (int q = 0; q < npay; q++) { rp.pay.in[q] = l1[q]; rp.pay.out[q] = pb[0][q]; rp.pay.width[q] = payw[q]; }
+  rp.g_dirT = dirT; rp.g_dstride = dstride; rp.g_cc = cc; rp.g_ntb = ntb; rp.g_ntiles1 = ntiles1; rp.g_T1 = tile; rp.g_pstart = d_pstart;
+  rp.label = "tl_level2_kernel";
+  DTHIP_TRY(launch_radix_pass(ctx, rp));
+  // ---- final level: every bucket (window of buckets) ordered by the remaining bits in LDS, written over its own rows
+  rp.g_dirT = nullptr; rp.g_cc = nullptr; rp.g_pstart = nullptr;
+  rp.kin = kA; rp.kout = kB; rp.shift = 0; rp.bits = msd.rb; rp.P = nullptr; rp.gpre = nullptr;
+  rp.ntiles = nbk; rp.tdesc = nullptr; rp.bounds = fstart;
+  rp.block = (maxsize <= tile / 2) ? 256 : 0;
+  if (windows) {
+    rp.ntiles = wi[0]; rp.bounds = wbounds; rp.wfirst = wfirst; rp.block = 0;
+    rp.bits2 = 1;
+    while ((1u << rp.bits2) < wi[2]) rp.bits2++;
+  }
+  for (int q = 0; q < npay; q++) { rp.pay.in[q] = pb[0][q]; rp.pay.out[q] = pb[1][q]; }
+  void* ukey_out = nullptr;
+  for (int c = 0; c < ncols; c++) if (is_key[c]) { DTHIP_TRY(result_alloc(ctx, res, (size_t)npass * stype_size(kd[0].stype), &ukey_out)); break; }
+  if (ukey_out) {
+    const KeyColDev& kc = plan.col[0];
+    rp.ukout = ukey_out; rp.uk_stype = kc.stype; rp.uk_desc = kc.desc; rp.uk_bits = bits;
+    rp.uk_edge = kc.edge; rp.uk_na_repl = kc.na_repl; rp.uk_inc = kc.inc;
+  }
+  rp.label = "msd_final_kernel";
+  DTHIP_TRY(launch_radix_pass(ctx, rp));
+  Grouping g;
+  if (ukey_out) DTHIP_TRY(heads_to_offsets(ctx, sc, res, ukey_out, kd[0].stype == DTHIP_INT64, nullptr, npass, &g));
+  else DTHIP_TRY(heads_to_offsets(ctx, sc, res, kB, 0, nullptr, npass, &g));
+  bool first_key = true;
+  for (int c = 0; c < ncols; c++) {
+    if (is_key[c]) {
+      if (first_key) { res->col[c] = ukey_out; first_key = false; continue; }
+      void* q = nullptr;
+      const size_t bytes = (size_t)npass * stype_size(kd[0].stype);
+      DTHIP_TRY(result_alloc(ctx, res, bytes, &q));
+      DTHIP_CHECK_HIP(hipMemcpyAsync(q, ukey_out, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      res->col[c] = q;
+      continue;
+    }
+    void* p = pb[1][slot[c]];
+    bool dup = false;
+    for (int c2 = 0; c2 < c; c2++) if (!is_key[c2] && slot[c2] == slot[c]) dup = true;
+    if (!dup) { result_adopt(sc, res, p); res->col[c] = p; continue; }
+    void* q = nullptr;
+    const size_t bytes = (size_t)npass * stype_size(cd[c].stype);
+    DTHIP_TRY(result_alloc(ctx, res, bytes, &q));
+    DTHIP_CHECK_HIP(hipMemcpyAsync(q, p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    res->col[c] = q;
+  }
+  if (rid_slot >= 0) { result_adopt(sc, res, pb[1][rid_slot]); res->rowindex = static_cast<int32_t*>(pb[1][rid_slot]); }
+  res->nrows = npass; res->ngroups = g.ngroups; res->offsets = g.offsets;
+  return DTHIP_OK;
+}
+
+int dthip_filter_groupby_rows(dthip_ctx* ctx, const dthip_col* pred, int cmp, double cf, int64_t ci, const dthip_col* keys, int nkeys,
+                              const dthip_col* cols, int ncols, int64_t nrows, int na_pos, int mem, int want_rowindex,
+                              dthip_result** out) {
+  DTHIP_TRY(check_common(ctx, nrows, mem));
+  if (!pred || !keys || !out || nkeys < 1 || nkeys > MAX_KEYCOLS || ncols < 0 || (ncols > 0 && !cols)) { set_error("bad filter_groupby_rows arguments"); return DTHIP_EINVAL; }
+  if (cmp < DTHIP_GT || cmp > DTHIP_ISNA) { set_error("bad comparison %d", cmp); return DTHIP_EINVAL; }
+  if (na_pos != DTHIP_NA_FIRST && na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", na_pos); return DTHIP_ENOTIMPL; }
+  if (!stype_size(pred->stype) || (nrows > 0 && !pred->data)) { set_error("unsupported predicate column"); return DTHIP_ENOTIMPL; }
+  dthip_result* res = new dthip_result();
+  res->nkeys = nkeys;
+  res->col.assign(ncols, nullptr); res->col_stype.assign(ncols, 0);
+  for (int c = 0; c < ncols; c++) res->col_stype[c] = cols[c].stype;
+  int rc = DTHIP_OK;
+  do {
+    Scratch sc(ctx);
+    std::vector<dthip_col> pd, kd, cd;
+    if ((rc = stage_cols(ctx, sc, pred, 1, nrows, mem, &pd)) != DTHIP_OK) break;
+    if ((rc = stage_cols(ctx, sc, keys, nkeys, nrows, mem, &kd)) != DTHIP_OK) break;
+    if ((rc = stage_cols(ctx, sc, cols, ncols, nrows, mem, &cd)) != DTHIP_OK) break;
+    if (nrows == 0) { rc = empty_result(ctx, res); break; }
+    if (mem == DTHIP_HOST) {
+      // staged copies of one host column are different device buffers: the same-column tests below compare the CALLER's
+      // pointers, and a staged column that is also the predicate column is mapped back onto it
+      for (int c = 0; c < ncols; c++) if (cols[c].data == pred->data && cols[c].stype == pred->stype) cd[c].data = pd[0].data;
+    }
+    // fused route first (twice at most: a guessed key range, then the exact one)
+    rc = DTHIP_NOT_APPLICABLE;
+    static const bool fused_on = !(getenv("DTHIP_FILTER_ROWS_FUSED") && atoi(getenv("DTHIP_FILTER_ROWS_FUSED")) == 0);
+    if (fused_on && ctx->filter_rows_fused) {
+      for (int attempt = 0; attempt < 2; attempt++) {
+        Scratch fs(ctx);
+        rc = filter_rows_fused(ctx, fs, res, pd[0], cmp, cf, ci, keys, kd, cols, cd, ncols, nrows, na_pos, want_rowindex, attempt == 0);
+        if (rc != DTHIP_RETRY_EXACT) break;
+      }
+      if (rc == DTHIP_RETRY_EXACT) { set_error("filter_groupby_rows: exact key range violated"); rc = DTHIP_EDEVICE; }
+    }
+    if (rc != DTHIP_NOT_APPLICABLE) break;
+    // ---- the two-call sequence: filter (RowIndex + the view's columns in one sweep), then the rows in grouped order ------
+    for (void* p : res->owned) dev_release(ctx, p);          // (anything a fused attempt set aside before it gave up)
+    res->owned.clear();
+    res->col.assign(ncols, nullptr);
+    std::vector<const void*> uniq;                          // distinct source columns: keys first, then the requested columns
+    std::vector<int> uniq_st, kmap(nkeys, -1), cmap(ncols, -1);
+    auto add = [&](const dthip_col& orig, const dthip_col& dev) -> int {
+      for (size_t u = 0; u < uniq.size(); u++) if (uniq[u] == dev.data && uniq_st[u] == orig.stype) return (int)u;
+      uniq.push_back(dev.data); uniq_st.push_back(orig.stype);
+      return (int)uniq.size() - 1;
+    };
+    for (int k = 0; k < nkeys; k++) kmap[k] = add(keys[k], kd[k]);
+    for (int c = 0; c < ncols; c++) {
+      bool same_key = false;
+      for (int k = 0; k < nkeys; k++) if (cols[c].data == keys[k].data && cols[c].stype == keys[k].stype) { cmap[c] = kmap[k]; same_key = true; break; }
+      if (!same_key) cmap[c] = add(cols[c], cd[c]);
+    }
+    if (uniq.size() > 8) { set_error("filter_groupby_rows: more than 8 distinct columns"); rc = DTHIP_ENOTIMPL; break; }
+    PredArgs p;
+    memset(&p, 0, sizeof(p));
+    p.data = pd[0].data; p.stype = pred->stype; p.cmp = cmp; p.cf = cf; p.ci = ci; p.is_mask = 0;
+    TakeCols tc;
+    memset(&tc, 0, sizeof(tc));
+    tc.n = (int)uniq.size();
+    std::vector<void*> fbuf(uniq.size(), nullptr);
+    for (size_t u = 0; u < uniq.size() && rc == DTHIP_OK; u++) {
+      const int w = stype_size(uniq_st[u]);
+      unsigned char* b = nullptr;
+      if ((rc = sc.get<unsigned char>((size_t)nrows * w, &b)) != DTHIP_OK) break;
+      fbuf[u] = b; tc.in[u] = uniq[u]; tc.out[u] = b; tc.width[u] = w;
+    }
+    if (rc != DTHIP_OK) break;
+    int32_t* fri = nullptr;
+    if (want_rowindex && (rc = sc.get<int32_t>((size_t)nrows, &fri)) != DTHIP_OK) break;
+    int64_t npass = 0;
+    if ((rc = launch_compact_take(ctx, p, nrows, fri, tc, &npass)) != DTHIP_OK) break;
+    if (npass == 0) { rc = empty_result(ctx, res); break; }
+    std::vector<dthip_col> fk(nkeys), fc(ncols + (want_rowindex ? 1 : 0));
+    for (int k = 0; k < nkeys; k++) { fk[k] = keys[k]; fk[k].data = fbuf[kmap[k]]; }
+    for (int c = 0; c < ncols; c++) { fc[c] = cols[c]; fc[c].data = fbuf[cmap[c]]; }
+    if (want_rowindex) { fc[ncols].data = fri; fc[ncols].stype = DTHIP_INT32; fc[ncols].flags = 0; }
+    dthip_result* tmp = nullptr;
+    if ((rc = dthip_groupby_rows(ctx, fk.data(), nkeys, fc.data(), (int)fc.size(), npass, na_pos, DTHIP_DEVICE, 0, &tmp)) != DTHIP_OK) break;
+    res->owned = tmp->owned; tmp->owned.clear();
+    for (int c = 0; c < ncols; c++) res->col[c] = tmp->col[c];
+    if (want_rowindex) res->rowindex = static_cast<int32_t*>(tmp->col[ncols]);      // the COMPOSED RowIndex (rowindex_array.cc:258-269)
+    res->nrows = tmp->nrows; res->ngroups = tmp->ngroups; res->offsets = tmp->offsets;
+    delete tmp;
   } while (0);
   if (rc != DTHIP_OK) { result_destroy(ctx, res); return rc; }
   *out = res;

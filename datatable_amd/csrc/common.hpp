@@ -91,6 +91,7 @@ struct dthip_ctx {
   int filter_path = 1;       // row filters: 1 count pass + write pass (default: 1.3 + 5.8 ms per 1e9 float64 rows with two 8-byte columns
                              // taken); 0 ONE pass, tile offsets by decoupled look-back (measured 8.6-9.2 ms: the look-back chain costs
                              // more than the second read of the predicate column; kept selectable)
+  int filter_rows_fused = 1; // dthip_filter_groupby_rows: 1 (default) the fused route of tlsort.hip where it applies, 0 always filter_take + groupby_rows
   int sort_path = 0;         // 0: MSD levels (two scatter levels + final buckets ordered in LDS) from msd_min_rows rows on where their preconditions hold, else LSD passes; 1: LSD passes only; 2: MSD levels whenever their preconditions hold, whatever msd_min_rows says (A/B runs, tests)
   int64_t msd_min_rows = 1 << 26;    // below this the LSD passes are quick enough (and the final buckets would be tiny)
   int msd_bucket_rows = 2048;        // target size of a final bucket (sorted in LDS: at most one radix tile)
@@ -257,6 +258,12 @@ struct RadixPass {
   void* ukout; int uk_stype; int uk_desc; int uk_bits;
   unsigned long long uk_edge, uk_na_repl, uk_inc;
   uint32_t* headbits;            // final MSD level only: 1 bit per row, set where a run of equal keys starts (zeroed by the caller)
+  // gather mode (tlsort.hip; g_dirT != null): the level ABOVE wrote its rows tile-locally (rows of digit b of tile t at
+  // [t * g_T1 + dirT[b][t], t * g_T1 + dirT[b + 1][t]) of kin / pay.in), so tile t of THIS level -- tdesc[4 t ..] = {first
+  // row of the bucket-ordered sequence, rows, histogram group, bucket} -- collects its rows from those segments
+  // (radix_dev.hpp tl_build_src).  Needs tdesc, 4-byte keys, and every payload column prefetched (<= 2, widths 8 / 4).
+  const uint16_t* g_dirT; uint32_t g_dstride; const uint32_t* g_cc; uint32_t g_ntb, g_ntiles1, g_T1;
+  const uint32_t* g_pstart;      // [buckets]: first row of every bucket in the bucket-ordered sequence
 };
 uint32_t radix_tile_items(int key64, int maxpaywidth);
 int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t n, int shift, int bits,
@@ -444,5 +451,32 @@ int launch_range_bucket(dthip_ctx* ctx, const void* keys, int stype, int64_t n, 
                         int8_t* out);
 int launch_firstlast(dthip_ctx* ctx, const void* data, int stype, const int32_t* ri, const int32_t* offsets,
                      int64_t ngroups, int last, void* out);
+
+// tlsort.hip: filter + key transform + first sort level in one sweep, tile-local output (see the file's header)
+struct TL1Args {
+  PredArgs pred;            // 8-byte predicate column (float64 / int64) <cmp> scalar
+  KeyColDev key;            // ONE int32 / int64 key column; the packed key is its transformed value (<= 32 bits)
+  uint32_t n;               // unfiltered rows
+  int shift, bits;          // the level's digit of the transformed key
+  uint32_t* kout;           // [n] transformed keys of the passing rows, tile t's at [t * tile, t * tile + count)
+  uint16_t* dir;            // [ntiles][bins + 1] first place of every digit inside the tile; [bins] = the tile's count
+  uint32_t* rowid;          // [n] original row numbers, same layout (nullable)
+  PayCols pay;              // riding columns: in = the unfiltered columns, out = same layout as kout
+  int keepx;                // index of the riding column that IS the predicate column (-1: none)
+  uint32_t* bad;            // set when a passing row's key lies outside the (guessed) key range
+};
+uint32_t tl_tile_rows();
+int launch_tl_pred_sample(dthip_ctx* ctx, const PredArgs& p, uint32_t n, uint32_t nsamp, uint32_t* count);   // *count += passing sample rows
+int launch_tl_level1(dthip_ctx* ctx, const TL1Args& a);
+// dir -> dirT[bins + 1][dstride], cc[bins][ntb] = rows of digit b before tile block tb (64 tiles per block), tot[bins]
+int launch_tl_directory(dthip_ctx* ctx, const uint16_t* dir, uint32_t ntiles, uint32_t F, uint16_t* dirT, uint32_t dstride, uint32_t* cc,
+                        uint32_t ntb, uint32_t* tot);
+struct TLGatherHistArgs {
+  const uint32_t* keys; int shift, bits;
+  const uint32_t* tdesc; const uint32_t* gdesc; const uint32_t* pstart;
+  const uint16_t* dirT; uint32_t dstride; const uint32_t* cc; uint32_t ntb, ntiles1, T1;
+  uint32_t* P; uint32_t* gtot;
+};
+int launch_tl_gather_hist(dthip_ctx* ctx, const TLGatherHistArgs& a, uint32_t G);
 
 }  // namespace dthip

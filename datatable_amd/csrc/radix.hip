@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "keyxform.hpp"
+#include "radix_dev.hpp"
 
 namespace dthip {
 
@@ -185,16 +186,6 @@ int launch_hist_scan(dthip_ctx* ctx, const uint32_t* hist, uint32_t* base, int n
 // order (one extra 4/8-byte read per row and pass) and bucket_gscan_kernel turns the counts into
 // positions -- so the pass needs no inter-workgroup communication: no decoupled look-back, no
 // tickets, no spinning (measured at 1e9 rows: 7.2 ms per pass with look-back, 5.6 + 0.8 ms without).
-#ifndef DTHIP_RP_BLOCK
-#define DTHIP_RP_BLOCK 512
-#endif
-#ifndef DTHIP_RP_ITEMS
-#define DTHIP_RP_ITEMS 16
-#endif
-#ifndef DTHIP_RP_WAVES
-#define DTHIP_RP_WAVES 4
-#endif
-constexpr int RP_BLOCK = DTHIP_RP_BLOCK, RP_ITEMS = DTHIP_RP_ITEMS, RP_TILE = RP_BLOCK * RP_ITEMS;
 
 template <typename KeyT>
 struct PassArgsT {
@@ -219,6 +210,8 @@ struct PassArgsT {
   unsigned long long uk_edge, uk_na_repl, uk_inc;
   uint32_t* headbits;       // final MSD level: head bitmap of the sorted order (the tile's keys sit in LDS in sorted order anyway)
   uint32_t hw_off;          // byte offset of the head-bitmap words inside the workgroup's LDS
+  // gather mode (GATH): see RadixPass::g_dirT
+  const uint16_t* dirT; uint32_t dstride; const uint32_t* cc; uint32_t ntb, ntiles1, T1; const uint32_t* pstart;
   PayCols pay;
 };
 
@@ -371,132 +364,6 @@ int launch_msd_scan(dthip_ctx* ctx, uint32_t* gtot, const uint32_t* gfirst, cons
   return DTHIP_OK;
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-B access
-
-// build-time experiments (A/B through DTHIP_LIB): streaming hints on the pass' loads / stores
-#ifdef DTHIP_RP_NT
-#define RP_LD(p) __builtin_nontemporal_load(p)
-#else
-#define RP_LD(p) (*(p))
-#endif
-#ifdef DTHIP_RP_NTS
-#define RP_ST(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define RP_ST(p, v) (*(p) = (v))
-#endif
-
-// store 4 values of tile-sorted slots s0..s0+3 to their global positions: one 16-B
-// (or two, for 8-byte elements) store when the four land on consecutive addresses
-template <typename T>
-__device__ __forceinline__ void store_group4(T* __restrict__ out, const uint32_t (&gp)[4], const T (&v)[4], uint32_t nv) {
-  const bool run = nv == 4 && gp[1] == gp[0] + 1 && gp[2] == gp[0] + 2 && gp[3] == gp[0] + 3;
-  if (run) {
-    if (sizeof(T) == 4) {
-      u32x4 w;
-      w.x = (uint32_t)v[0]; w.y = (uint32_t)v[1]; w.z = (uint32_t)v[2]; w.w = (uint32_t)v[3];
-      RP_ST(reinterpret_cast<u32x4_u*>(out + gp[0]), w);
-    } else {
-      u32x4 w0, w1;
-      w0.x = (uint32_t)v[0]; w0.y = (uint32_t)((unsigned long long)v[0] >> 32);
-      w0.z = (uint32_t)v[1]; w0.w = (uint32_t)((unsigned long long)v[1] >> 32);
-      w1.x = (uint32_t)v[2]; w1.y = (uint32_t)((unsigned long long)v[2] >> 32);
-      w1.z = (uint32_t)v[3]; w1.w = (uint32_t)((unsigned long long)v[3] >> 32);
-      u32x4_u* o = reinterpret_cast<u32x4_u*>(out + gp[0]);
-      RP_ST(&o[0], w0); RP_ST(&o[1], w1);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; j++) if ((uint32_t)j < nv) RP_ST(&out[gp[j]], v[j]);
-  }
-}
-
-// One STABLE ranking round over the workgroup's rows (the lane-mask ranking of the pass kernel as a function): on entry
-// pos is don't-care, on exit pos[i] = number of rows of the tile that precede row i in the order (digit, current row
-// order).  wh / bin_excl / misc / exch as in the pass kernel; contains barriers, all threads must call.
-// nbal > 0: the lanes of an item that share a digit are found with nbal ballot rounds instead of the LDS lane masks --
-// for a digit of FEW values (the bucket number inside a window: ~3) dozens of lanes would pile their ds_or onto one
-// address and serialise (measured: the windowed final level 5.8 ms instead of 3.8).
-// (the digit of item i is dig(i): recomputed where it is needed instead of held in ITEMS more registers -- the two-round
-// final level was register-starved: 6.4 ms for its first round alone against 3.85 for the one-round kernel)
-template <int BLOCK, int ITEMS, int RBMAX, typename DigF>
-__device__ __forceinline__ void rank_round(DigF dig, uint32_t vmask, int bins, uint16_t* wh, uint32_t* bin_excl,
-                                           uint32_t* misc, unsigned char* exch, uint32_t slice_bytes, uint32_t (&pos)[ITEMS], int nbal = 0) {
-  constexpr int WAVES = BLOCK / 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < WAVES * bins / 2; i += BLOCK) reinterpret_cast<uint32_t*>(wh)[i] = 0;
-  unsigned long long* mk = reinterpret_cast<unsigned long long*>(exch + (size_t)wave * slice_bytes);
-  for (int b = lane; b < bins; b += 64) mk[b] = 0ULL;
-  __syncthreads();
-  uint16_t* mywh = wh + wave * bins;
-  const unsigned long long mybit = 1ULL << lane;
-  if (nbal > 0) {
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-      const bool valid = (vmask >> i) & 1u;
-      const uint32_t d = dig(i);
-      unsigned long long m = __ballot(valid);
-      for (int b = 0; b < nbal; b++) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
-      }
-      const uint32_t below = mbcnt64(m);
-      uint32_t prev = 0;
-      __builtin_amdgcn_wave_barrier();
-      if (valid) prev = __hip_atomic_load(&mywh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      pos[i] = prev + below;
-      if (valid && below == 0) __hip_atomic_store(&mywh[d], (uint16_t)(prev + (uint32_t)__popcll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
-  } else
-#pragma unroll
-  for (int i = 0; i < ITEMS; i++) {
-    pos[i] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if ((vmask >> i) & 1u) {
-      const uint32_t d = dig(i);
-      __hip_atomic_fetch_or(&mk[d], mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      const unsigned long long m = __hip_atomic_load(&mk[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      const uint32_t prev = __hip_atomic_load(&mywh[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      const uint32_t below = mbcnt64(m);
-      pos[i] = prev + below;
-      if (below == 0) {
-        __hip_atomic_store(&mk[d], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_store(&mywh[d], (uint16_t)(prev + (uint32_t)__popcll(m)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      }
-    }
-  }
-  __syncthreads();
-  constexpr int KB = ((1 << RBMAX) + BLOCK - 1) / BLOCK;
-  uint32_t tc[KB], tsum = 0;
-#pragma unroll
-  for (int k = 0; k < KB; k++) {
-    const int b = tid * KB + k;
-    tc[k] = 0;
-    if (b < bins) {
-      uint32_t sum = 0;
-#pragma unroll
-      for (int w = 0; w < WAVES; w++) {
-        const uint32_t c = wh[w * bins + b];
-        wh[w * bins + b] = (uint16_t)sum;
-        sum += c;
-      }
-      tc[k] = sum;
-    }
-    tsum += tc[k];
-  }
-  uint32_t excl = block_excl_scan_u32<BLOCK>(tsum, misc, nullptr);
-#pragma unroll
-  for (int k = 0; k < KB; k++) {
-    const int b = tid * KB + k;
-    if (b < bins) { bin_excl[b] = excl; excl += tc[k]; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < ITEMS; i++)
-    if ((vmask >> i) & 1u) { const uint32_t d = dig(i); pos[i] += bin_excl[d] + wh[wave * bins + d]; }
-}
-
 // RB   = number of ballot rounds (>= bits of every pass run with this instance)
 // P0W  = byte width of payload column 0 when it is prefetched with the keys (0: none / iota)
 // P1W  = the same for payload column 1 (only with P0W == 8): both columns' loads are in flight before the ranking
@@ -513,7 +380,9 @@ __device__ __forceinline__ void rank_round(DigF dig, uint32_t vmask, int bins, u
 // R2   = final MSD level over WINDOWS (whole consecutive buckets of the last scatter level, together at most one tile):
 //        two ranking rounds in LDS -- by the low a.bits bits, then by the bucket (key >> a.bits) - wfirst[tile], a.bits2 bits
 //        -- give every row its place in the window; rows, ordered, go back over the window's own row range
-template <typename KeyT, int RB, int P0W, int P1W = 0, int RK = 0, int BLK = RP_BLOCK, bool R2 = false>
+// GATH = the tile's rows are gathered from the segments of a tile-local level above (RadixPass::g_dirT): their global rows
+//        are listed in LDS first (in the exchange buffer, free until the ranking), every load goes through that list
+template <typename KeyT, int RB, int P0W, int P1W = 0, int RK = 0, int BLK = RP_BLOCK, bool R2 = false, bool GATH = false>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) radix_pass_kernel(PassArgsT<KeyT> a) {
   constexpr int BLOCK = BLK, ITEMS = RP_ITEMS;
   constexpr int WAVES = BLOCK / 64, TILE = BLOCK * ITEMS;
@@ -556,6 +425,14 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
   const uint32_t chunk = full ? 64u * ITEMS : ((((nvalid + WAVES - 1) / WAVES) + 63u) & ~63u);
   const uint32_t wbase = (uint32_t)wave * chunk + (uint32_t)lane;
 #define RP_VALID(i) (64u * (uint32_t)(i) < chunk && wbase + 64u * (uint32_t)(i) < nvalid)
+  const uint32_t* gsrc_rows = reinterpret_cast<const uint32_t*>(exch);       // GATH: global row of the tile's v-th row
+  if (GATH) {
+    const uint32_t bkt = a.tdesc[4 * tile + 3];
+    tl_build_src<BLOCK>(reinterpret_cast<uint32_t*>(exch), a.dirT, a.dstride, a.cc, a.ntb, a.ntiles1, a.T1, bkt,
+                        tile_base - a.pstart[bkt], nvalid);
+    __syncthreads();
+  }
+#define RP_SRC(loc) (GATH ? gsrc_rows[(loc)] : tile_base + (loc))
 
   // ---- load keys (and payload column 0) -----------------------------------
   // Full tiles: 16-byte coalesced loads of the wave's 1024 consecutive keys, transposed
@@ -568,7 +445,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
       const uint32_t loc = wbase + 64u * i;
-      pay0[i] = RP_VALID(i) ? RP_LD(&pin[tile_base + loc]) : P0T(0);
+      pay0[i] = RP_VALID(i) ? RP_LD(&pin[RP_SRC(loc)]) : P0T(0);
     }
   }
   typedef typename std::conditional<P1W == 8, unsigned long long, uint32_t>::type P1T;
@@ -578,10 +455,10 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
       const uint32_t loc = wbase + 64u * i;
-      pay1[i] = RP_VALID(i) ? RP_LD(&pin[tile_base + loc]) : P1T(0);
+      pay1[i] = RP_VALID(i) ? RP_LD(&pin[RP_SRC(loc)]) : P1T(0);
     }
   }
-  if (full) {
+  if (full && !GATH) {
     constexpr int NV = ITEMS * (int)sizeof(KeyT) / 16;
     const u32x4_u* gsrc = reinterpret_cast<const u32x4_u*>(a.kin + tile_base + (uint32_t)wave * 64u * ITEMS);   // ragged tiles start at any row
     u32x4* wl = reinterpret_cast<u32x4*>(exch) + (size_t)wave * 64 * NV;
@@ -598,8 +475,9 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
       const uint32_t loc = wbase + 64u * i;
-      key[i] = RP_VALID(i) ? RP_LD(&a.kin[tile_base + loc]) : KeyT(0);
+      key[i] = RP_VALID(i) ? RP_LD(&a.kin[RP_SRC(loc)]) : KeyT(0);
     }
+    if (GATH) __syncthreads();      // every wave has read its rows' places: the list makes room for the lane-mask tables
   }
 
   uint32_t pos[ITEMS];
@@ -917,6 +795,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
 }
 
 #undef RP_VALID
+#undef RP_SRC
 
 uint32_t radix_tile_items(int, int) { return (uint32_t)RP_TILE; }
 
@@ -933,9 +812,10 @@ int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t
   return DTHIP_OK;
 }
 
-template <typename KeyT, int RB, int P0W, int P1W, int RK, int BLK = RP_BLOCK, bool R2 = false>
+template <typename KeyT, int RB, int P0W, int P1W, int RK, int BLK = RP_BLOCK, bool R2 = false, bool GATH = false>
 static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
   PassArgsT<KeyT> a;
+  a.dirT = p.g_dirT; a.dstride = p.g_dstride; a.cc = p.g_cc; a.ntb = p.g_ntb; a.ntiles1 = p.g_ntiles1; a.T1 = p.g_T1; a.pstart = p.g_pstart;
   a.kin = static_cast<const KeyT*>(p.kin); a.kout = static_cast<KeyT*>(p.kout);
   a.n = p.n; a.shift = p.shift; a.bits = p.bits; a.P = p.P; a.gpre = p.gpre; a.tpg = p.tpg;
   a.iota = p.iota; a.pay = p.pay;
@@ -959,7 +839,7 @@ static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
     const size_t need = (size_t)((BLK * RP_ITEMS) / 32 + 4) * 4;
     if ((size_t)(BLK / 64) * bins * 2 < need) { a.hw_off = (uint32_t)lds; lds += need; }
   }
-  auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W, RK, BLK, R2>;
+  auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W, RK, BLK, R2, GATH>;
   DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
   const uint32_t ntiles = p.ntiles ? p.ntiles : (p.n + RP_TILE - 1) / RP_TILE;
   DTHIP_LAUNCH(ctx, (p.label ? p.label : "radix_pass_kernel"), kfn, ntiles, BLK, lds, a);
@@ -1017,9 +897,31 @@ static int launch_pass_k(dthip_ctx* ctx, const RadixPass& p) {
   return launch_pass_t<KeyT, 8, 0>(ctx, p);
 }
 
+// gather mode: 4-byte keys, ragged tiles, every payload column prefetched (the list of rows lives in the exchange buffer
+// only until the ranking starts)
+static int launch_pass_gather(dthip_ctx* ctx, const RadixPass& p) {
+  const int w0 = p.pay.n > 0 ? p.pay.width[0] : 0, w1 = p.pay.n > 1 ? p.pay.width[1] : 0;
+  if (p.key64 || !p.tdesc || p.bounds || p.wfirst || p.iota || p.pay.n < 1 || p.pay.n > 2 || p.bits > 9 || !p.g_cc || !p.g_pstart ||
+      !((w0 == 8 && (w1 == 0 || w1 == 4 || w1 == 8)) || (w0 == 4 && w1 == 0))) {
+    set_error("radix pass: gather mode takes 4-byte keys, ragged tiles and payload widths 8 / 8+4 / 8+8 / 4");
+    return DTHIP_EINVAL;
+  }
+  if (p.bits > 8) {
+    if (w0 == 8 && w1 == 4) return launch_pass_r<uint32_t, 9, 8, 4, 1, RP_BLOCK, false, true>(ctx, p);
+    if (w0 == 8 && w1 == 8) return launch_pass_r<uint32_t, 9, 8, 8, 1, RP_BLOCK, false, true>(ctx, p);
+    if (w0 == 8) return launch_pass_r<uint32_t, 9, 8, 0, 1, RP_BLOCK, false, true>(ctx, p);
+    return launch_pass_r<uint32_t, 9, 4, 0, 1, RP_BLOCK, false, true>(ctx, p);
+  }
+  if (w0 == 8 && w1 == 4) return launch_pass_r<uint32_t, 8, 8, 4, 1, RP_BLOCK, false, true>(ctx, p);
+  if (w0 == 8 && w1 == 8) return launch_pass_r<uint32_t, 8, 8, 8, 1, RP_BLOCK, false, true>(ctx, p);
+  if (w0 == 8) return launch_pass_r<uint32_t, 8, 8, 0, 1, RP_BLOCK, false, true>(ctx, p);
+  return launch_pass_r<uint32_t, 8, 4, 0, 1, RP_BLOCK, false, true>(ctx, p);
+}
+
 int launch_radix_pass(dthip_ctx* ctx, const RadixPass& p) {
   if (p.n == 0) return DTHIP_OK;
   if (p.bits < 1 || p.bits > 10) { set_error("radix pass: bad digit width %d", p.bits); return DTHIP_EINVAL; }
+  if (p.g_dirT) return launch_pass_gather(ctx, p);
   if (p.key64) return launch_pass_k<unsigned long long>(ctx, p);
   return launch_pass_k<uint32_t>(ctx, p);
 }

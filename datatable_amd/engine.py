@@ -336,7 +336,7 @@ class Context(_ShardMixin):
         Arrow's bit-packed booleans) -> a DevCol in the sentinel layout, converted on the device (dthip_from_arrow).
         values / validity: numpy arrays (host) or, with device=True, raw HBM addresses."""
         st = int(stype)
-        nbytes = nrows * ST2NP[st].itemsize
+        nbytes = max(int(nrows), 0) * (ST2NP[st].itemsize if st in ST2NP else 8)      # (an unknown stype is the library's to refuse)
         p = C.c_void_p()
         L.check(self._lib.dthip_malloc(self._h, max(nbytes, 1), C.byref(p)))
         buf = _DevBuf(self, p.value)
@@ -414,6 +414,23 @@ class Context(_ShardMixin):
         L.check(self._lib.dthip_groupby_rows(self._h, karr, len(keys), carr, len(cols), nrows,
                                              L.NA_LAST if na_last else L.NA_FIRST, kmem, 1 if want_rowindex else 0,
                                              C.byref(h)))
+        return Result(self, h, [karr[i].stype for i in range(len(keys))], 0, [carr[i].stype for i in range(len(cols))])
+
+    def filter_groupby_rows(self, pred, cmp, scalar, keys, cols, nrows=None, pred_stype=None, key_stypes=None, col_stypes=None,
+                            desc=None, na_last=False, want_rowindex=True):
+        """V = DT[pred <cmp> scalar, :]; V[:, cols, by(keys)] in one call (dthip_filter_groupby_rows): the passing rows in
+        grouped order; result.rowindex() = the composed RowIndex (original row numbers in grouped order)"""
+        parr, pmem, pkeep = _cols([pred], [pred_stype] if pred_stype is not None else None)
+        karr, kmem, kkeep = _cols(keys, key_stypes, desc)
+        carr, cmem, ckeep = _cols(cols, col_stypes)
+        if kmem != pmem or (cols and cmem != pmem):
+            raise ValueError("predicate, keys and columns must live in the same memory space")
+        if nrows is None:
+            nrows = len(pkeep[0])
+        code, cf, ci = _cmp_args(cmp, scalar, parr[0].stype)
+        h = C.c_void_p()
+        L.check(self._lib.dthip_filter_groupby_rows(self._h, parr, code, cf, ci, karr, len(keys), carr, len(cols), nrows,
+                                                    L.NA_LAST if na_last else L.NA_FIRST, pmem, 1 if want_rowindex else 0, C.byref(h)))
         return Result(self, h, [karr[i].stype for i in range(len(keys))], 0, [carr[i].stype for i in range(len(cols))])
 
     def groupby_agg(self, keys, values, aggs, nrows=None, key_stypes=None, value_stypes=None, desc=None,

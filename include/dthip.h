@@ -56,7 +56,8 @@ extern "C" {
                                  3: + dthip_comm_*, dthip_sharded_groupby_* (multi-GPU inside the library), DTHIP_FLAG_NONA,
                                     dthip_host_register / dthip_host_unregister
                                  4: + dthip_comm_last_stats; options sort_path, msd_min_rows, msd_bucket_rows, filter_path
-                                 5: + dthip_build_id, dthip_from_arrow (Arrow-layout columns: validity bitmap -> sentinels on the device) */
+                                 5: + dthip_build_id, dthip_from_arrow (Arrow-layout columns: validity bitmap -> sentinels on the device),
+                                    dthip_filter_groupby_rows (config 5 in one call); option filter_rows_fused */
 
 /* error codes */
 #define DTHIP_OK        0
@@ -171,6 +172,8 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    a final bucket would not fit a tile (heavy duplicates over a wide range); everything else takes stable
  *                    LSD radix passes; 1: LSD passes only; 2: the MSD levels whenever their other preconditions hold, without
  *                    the "msd_min_rows" test (A/B runs, tests).  Same results, bit for bit
+ *   "filter_rows_fused" 1 (default): dthip_filter_groupby_rows takes its fused route where it applies; 0: always the
+ *                    two-call sequence (A/B runs, tests).  Same results, bit for bit
  *   "small_path"     2 (default): a groupby_agg whose keys fit ONE table of <= 8192 slots runs a launch-lean sequence (tables
  *                    initialised by the plan kernel; group list + offsets + count from one single-workgroup kernel, which
  *                    writes its counts into mapped host memory -- no copy command); 1: the counts are copied back instead;
@@ -422,6 +425,23 @@ int  dthip_filter_take(dthip_ctx* ctx, const dthip_col* col, int cmp, double sca
  * (src/core/column/arrow_fw.cc:63-72, column/arrow_bool.cc, Column::from_arrow column_from_arrow.cc:40-59). */
 int  dthip_from_arrow(dthip_ctx* ctx, const void* values, const uint8_t* validity, int64_t nrows, int stype, int mem,
                       void* dst);
+
+/* V = DT[pred <cmp> scalar, :]; V[:, cols, by(keys)] -- BASELINE config 5's two statements (the reference refuses the
+ * one-statement form DT[i, j, by()], fexpr_func.cc:76-78) -- in ONE call: the rows that pass, in grouped order.
+ * Result: offsets, cols[c] of the passing rows in grouped order (dthip_result_col(c)), nrows = passing rows, and with
+ * want_rowindex the COMPOSED RowIndex of filter and grouping (dthip_result_rowindex: ORIGINAL row numbers in grouped
+ * order -- RowIndex composition ab*bc, rowindex_array.cc:258-269; sorted ascending it is the filter's own RowIndex).
+ * Identical, bit for bit, to dthip_filter_take + dthip_groupby_rows over the filter's outputs (the route this call takes
+ * itself when the fused one does not apply: several keys, keys wider than 32 bits, fewer than "msd_min_rows" rows, a
+ * predicate column that is not 8 bytes wide, more than two riding columns; option "filter_rows_fused" = 0 forces it).
+ * Fused route (csrc/tlsort.hip): one sweep over the unfiltered rows evaluates the predicate, transforms the key and
+ * orders every 8192-row tile's passing rows by the top digit inside the tile's own row range -- no count pass, no
+ * compaction, no key-transform pass, no histogram pass, sequential writes -- then two more levels finish the order.
+ * Replaces init_from_boolean_column (rowindex_array.cc:130-170) + the view's columns (view.cc:140-145) + group()
+ * (sort.cc:1411-1495) + _materialize_fw (column_impl.cc:78-101). */
+int  dthip_filter_groupby_rows(dthip_ctx* ctx, const dthip_col* pred, int cmp, double scalar_f, int64_t scalar_i,
+                               const dthip_col* keys, int nkeys, const dthip_col* cols, int ncols, int64_t nrows,
+                               int na_pos, int mem, int want_rowindex, dthip_result** out);
 
 /* out[i] = rowindex[i] < 0 ? NA : col[rowindex[i]] */
 int  dthip_gather(dthip_ctx* ctx, const dthip_col* col, const int32_t* rowindex,

@@ -1003,7 +1003,7 @@ def test_small_path_mapped_words_survive_read_back():
                 ri, off = o.group([k])
                 r = c.groupby_agg([k], [v], [("sum", 0), ("count0", None)])
                 assert_same(r.offsets(), off, "offsets")
-                assert_same(r.key(0), k[ri[off[:-1]]], "keys")
+                assert_same(r.key(0), k[ri[off[:-1]]].view(np.int8) if k.dtype == np.bool_ else k[ri[off[:-1]]], "keys")
                 assert_same(r.agg(1), np.diff(off).astype(np.int64), "count()")
                 check_agg(r.agg(0), o.reduce("sum", v, ri, off), "sum", v, ri, off, "sum")
                 r.free()

@@ -137,11 +137,11 @@ def test_bench_two_ranks_end_to_end(fake_rccl):
     assert line["ranks_seen"] == [0, 1] and [x["comm_world"] for x in line["ranks"]] == [2, 2]
     assert line["parity"]["configs"] == {"C3": True, "C4": True, "C5": True}, line["parity"]
     sv = line["parity"]["sharded_vs_single_gpu"]
-    assert sv["ok"] and sv["keys_bit_exact"] and sv["inputs_rebuilt_identical"] and sv["count()"] and sv["sum(v0)"], sv
+    assert sv["ok"] and sv["keys_bit_exact"] and sv["inputs_rebuilt_identical"] and sv["count0()"] and sv["sum(v0)"], sv
     assert sv["single_gpu_vs_oracle_all_rows"]["ok"] and sv["groups"] == 200_000 and sum(sv["groups_per_rank"]) == 200_000
     assert line["parity"]["vs_reference"]["keys_bit_exact"] and line["parity"]["vs_reference"]["sums_within_tol"]
     p4, p5 = line["configs"]["C4"]["parity"], line["configs"]["C5"]["parity"]
-    assert p4["ok"] and p4["count()"] and p4["sum(v0)"] and p4["single_gpu_vs_oracle_all_rows"]["ok"], p4
+    assert p4["ok"] and p4["count0()"] and p4["sum(v0)"] and p4["single_gpu_vs_oracle_all_rows"]["ok"], p4
     assert p5["ok"] and p5["composed_rowindex_bit_exact"] and p5["group_sizes_bit_exact"] and p5["key_column_bit_exact"] \
         and p5["x_column_bit_exact"] and p5["single_gpu_vs_oracle_all_rows"]["ok"] and min(p5["rows_per_rank"]) > 0, p5
     # round 4: the N > 1 line says what crossed the fabric and where the time went, for all three multi-GPU configs
