@@ -1644,6 +1644,11 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
     return DTHIP_OK;
   }
   if (!strcmp(name, "spec_min_rows")) { ctx->spec_min_rows = value; return DTHIP_OK; }
+  if (!strcmp(name, "tl_level2")) {
+    if (value < 0 || value > 2) { set_error("tl_level2 must be 0, 1 or 2"); return DTHIP_EINVAL; }
+    ctx->tl_level2 = (int)value;
+    return DTHIP_OK;
+  }
   if (!strcmp(name, "filter_rows_fused")) {
     if (value < 0 || value > 1) { set_error("filter_rows_fused must be 0 or 1"); return DTHIP_EINVAL; }
     ctx->filter_rows_fused = (int)value;
@@ -2017,7 +2022,11 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
   if (!msd.ok) return DTHIP_NOT_APPLICABLE;
   const uint32_t nb1 = 1u << msd.s1, bins2 = 1u << msd.s2;
   // ---- level 1: filter + key transform + top digit, tile-local ------------------------------------------------------------
-  const uint32_t ntiles1 = (uint32_t)((n + tile - 1) / tile);
+  // first-level tiles: 512 threads x 16 rows, two workgroups per CU -- or (DTHIP_TL_BLOCK=1024, A/B) 16384-row tiles, whose
+  // segments are twice as long for the level that gathers them, one workgroup per CU
+  static const int tl_block = (getenv("DTHIP_TL_BLOCK") && atoi(getenv("DTHIP_TL_BLOCK")) == 1024) ? 1024 : 512;
+  const uint32_t T1 = (uint32_t)tl_block * 16u;
+  const uint32_t ntiles1 = (uint32_t)((n + T1 - 1) / T1);
   const uint32_t ntb = (ntiles1 + 63) / 64, dstride = ntb * 64;
   uint32_t* k1 = nullptr; uint16_t* dir = nullptr; uint16_t* dirT = nullptr; uint32_t* cc = nullptr; uint32_t* tot = nullptr;
   DTHIP_TRY(sc.get<uint32_t>((size_t)n, &k1));
@@ -2031,7 +2040,7 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
   TL1Args ta;
   memset(&ta, 0, sizeof(ta));
   ta.pred = pa; ta.key = plan.col[0]; ta.key.shift = 0;
-  ta.n = (uint32_t)n; ta.shift = msd.rb + msd.s2; ta.bits = msd.s1;
+  ta.n = (uint32_t)n; ta.block = tl_block; ta.shift = msd.rb + msd.s2; ta.bits = msd.s1;
   ta.kout = k1; ta.dir = dir; ta.rowid = rid_slot >= 0 ? static_cast<uint32_t*>(l1[rid_slot]) : nullptr;
   ta.keepx = -1; ta.pay.n = nride;
   for (int q = 0; q < nride; q++) {
@@ -2068,17 +2077,60 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
   DTHIP_CHECK_HIP(hipMemcpyAsync(d_pstart, pstart.data(), pstart.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   DTHIP_CHECK_HIP(hipMemsetAsync(d_max, 0, 4, ctx->stream));
   DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));            // (the host vectors above go out of use only at the end; pageable copies)
+  // Level 2 writes tile-locally as well (default): no histogram pass, sequential writes, the final level gathers its
+  // buckets' segments.  DTHIP_TL_LEVEL2=0: level 2 scatters to exact positions (a gathering histogram pass first) and the
+  // final level runs in place, as in sort_stage -- kept for A/B runs.
+  // (the gathering final level works on windows of <= 16 whole buckets whose (bucket, digit) counts fit the exchange buffer:
+  // tiny final buckets -- tests forcing the levels onto small inputs -- take the scatter form)
+  int maxw_p = 4;
+  for (int q = 0; q < npay; q++) maxw_p = std::max(maxw_p, payw[q]);
+  const int64_t win_buckets = std::min<int64_t>(16, (int64_t)tile * maxw_p / ((int64_t)8 << msd.rb));
+  static const int tl2_env = getenv("DTHIP_TL_LEVEL2") ? atoi(getenv("DTHIP_TL_LEVEL2")) : -1;
+  const int tl2_opt = tl2_env >= 0 ? tl2_env : ctx->tl_level2;
+  const bool tl2 = tl2_opt == 2 || (tl2_opt == 1 && (npass >> (msd.s1 + msd.s2)) * win_buckets * 4 >= (int64_t)tile * 5);
   uint32_t* P = nullptr; uint32_t* gtot2 = nullptr; uint32_t* fstart = nullptr;
-  DTHIP_TRY(sc.get<uint32_t>((size_t)(ntiles2 ? ntiles2 : 1) * bins2, &P));
-  DTHIP_TRY(sc.get<uint32_t>((size_t)(G2 ? G2 : 1) * bins2, &gtot2));
   DTHIP_TRY(sc.get<uint32_t>((size_t)nb1 * bins2 + 1, &fstart));
-  TLGatherHistArgs ga;
-  memset(&ga, 0, sizeof(ga));
-  ga.keys = k1; ga.shift = msd.rb; ga.bits = msd.s2; ga.tdesc = d_tdesc; ga.gdesc = d_gdesc; ga.pstart = d_pstart;
-  ga.dirT = dirT; ga.dstride = dstride; ga.cc = cc; ga.ntb = ntb; ga.ntiles1 = ntiles1; ga.T1 = tile; ga.P = P; ga.gtot = gtot2;
-  DTHIP_TRY(launch_tl_gather_hist(ctx, ga, G2));
-  DTHIP_TRY(launch_msd_scan(ctx, gtot2, d_gfirst, d_pstart, msd.s2, nb1, (uint32_t)npass, fstart, d_max));
   const uint32_t nbk = nb1 * bins2;
+  unsigned char* kA = nullptr; unsigned char* kB = nullptr;
+  DTHIP_TRY(sc.get<unsigned char>((size_t)npass * 4, &kA));
+  DTHIP_TRY(sc.get<unsigned char>((size_t)npass * 4, &kB));
+  void* pb[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  for (int q = 0; q < npay; q++)
+    for (int h = 0; h < 2; h++) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)npass * payw[q], &b)); pb[h][q] = b; }
+  RadixPass rp;
+  memset(&rp, 0, sizeof(rp));
+  rp.kin = k1; rp.kout = kA; rp.key64 = 0; rp.n = (uint32_t)npass;
+  rp.shift = msd.rb; rp.bits = msd.s2; rp.tpg = hg.tpg; rp.iota = 0;
+  rp.ntiles = ntiles2; rp.tdesc = d_tdesc;
+  rp.pay.n = npay;
+  for (int q = 0; q < npay; q++) { rp.pay.in[q] = l1[q]; rp.pay.out[q] = pb[0][q]; rp.pay.width[q] = payw[q]; }
+  rp.g_dirT = dirT; rp.g_dstride = dstride; rp.g_cc = cc; rp.g_ntb = ntb; rp.g_ntiles1 = ntiles1; rp.g_T1 = T1; rp.g_pstart = d_pstart;
+  rp.label = "tl_level2_kernel";
+  uint16_t* dirT2 = nullptr; uint32_t* d_pfirst = nullptr;
+  const uint32_t dstride2 = ((ntiles2 + 63) / 64) * 64;
+  if (tl2) {
+    uint16_t* dir2 = nullptr;
+    DTHIP_TRY(sc.get<uint16_t>((size_t)(ntiles2 ? ntiles2 : 1) * (bins2 + 1), &dir2));
+    DTHIP_TRY(sc.get<uint16_t>((size_t)(bins2 + 1) * dstride2, &dirT2));
+    DTHIP_TRY(sc.get<uint32_t>((size_t)nb1 + 1, &d_pfirst));
+    std::vector<uint32_t> pfirst((size_t)nb1 + 1, ntiles2);           // first level-2 tile of every parent bucket
+    for (uint32_t t = ntiles2; t-- > 0;) pfirst[tdesc[4 * (size_t)t + 3]] = t;
+    for (uint32_t b = nb1; b-- > 0;) if (htot[b] == 0) pfirst[b] = pfirst[b + 1];
+    DTHIP_CHECK_HIP(hipMemcpyAsync(d_pfirst, pfirst.data(), pfirst.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    rp.tl_dir2 = dir2;
+    DTHIP_TRY(launch_radix_pass(ctx, rp));
+    DTHIP_TRY(launch_tl_final_plan(ctx, dir2, ntiles2, nb1, msd.s2, d_pfirst, d_pstart, dirT2, dstride2, fstart, d_max));
+  } else {
+    DTHIP_TRY(sc.get<uint32_t>((size_t)(ntiles2 ? ntiles2 : 1) * bins2, &P));
+    DTHIP_TRY(sc.get<uint32_t>((size_t)(G2 ? G2 : 1) * bins2, &gtot2));
+    TLGatherHistArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.keys = k1; ga.shift = msd.rb; ga.bits = msd.s2; ga.tdesc = d_tdesc; ga.gdesc = d_gdesc; ga.pstart = d_pstart;
+    ga.dirT = dirT; ga.dstride = dstride; ga.cc = cc; ga.ntb = ntb; ga.ntiles1 = ntiles1; ga.T1 = T1; ga.P = P; ga.gtot = gtot2;
+    DTHIP_TRY(launch_tl_gather_hist(ctx, ga, G2));
+    DTHIP_TRY(launch_msd_scan(ctx, gtot2, d_gfirst, d_pstart, msd.s2, nb1, (uint32_t)npass, fstart, d_max));
+  }
   const uint32_t nwmax = (uint32_t)(npass / (tile / 2)) + 2;
   uint32_t* wplan = nullptr;
   DTHIP_TRY(sc.get<uint32_t>((size_t)2 * (nwmax + 2) + 4, &wplan));
@@ -2099,28 +2151,18 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
     fprintf(stderr, "[dthip fused] n=%lld est=%lld pass=%lld bits=%d s1=%d s2=%d rb=%d tiles1=%u tiles2=%u groups2=%u largest bucket=%u windows=%u max buckets/window=%u -> %s\n",
             (long long)n, (long long)est, (long long)npass, bits, msd.s1, msd.s2, msd.rb, ntiles1, ntiles2, G2, maxsize, wi[0], wi[2],
             windows ? "windows" : (maxsize <= tile ? "per bucket" : "not applicable"));
-  if (!(windows || maxsize <= tile)) return DTHIP_NOT_APPLICABLE;       // a final bucket outgrows a tile (heavy duplicates)
-  unsigned char* kA = nullptr; unsigned char* kB = nullptr;
-  DTHIP_TRY(sc.get<unsigned char>((size_t)npass * 4, &kA));
-  DTHIP_TRY(sc.get<unsigned char>((size_t)npass * 4, &kB));
-  void* pb[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-  for (int q = 0; q < npay; q++)
-    for (int h = 0; h < 2; h++) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)npass * payw[q], &b)); pb[h][q] = b; }
-  RadixPass rp;
-  memset(&rp, 0, sizeof(rp));
-  rp.kin = k1; rp.kout = kA; rp.key64 = 0; rp.n = (uint32_t)npass;
-  rp.shift = msd.rb; rp.bits = msd.s2; rp.P = P; rp.gpre = gtot2; rp.tpg = hg.tpg; rp.iota = 0;
-  rp.ntiles = ntiles2; rp.tdesc = d_tdesc;
-  rp.pay.n = npay;
-  for (int q = 0; q < npay; q++) { rp.pay.in[q] = l1[q]; rp.pay.out[q] = pb[0][q]; rp.pay.width[q] = payw[q]; }
-  rp.g_dirT = dirT; rp.g_dstride = dstride; rp.g_cc = cc; rp.g_ntb = ntb; rp.g_ntiles1 = ntiles1; rp.g_T1 = tile; rp.g_pstart = d_pstart;
-  rp.label = "tl_level2_kernel";
-  DTHIP_TRY(launch_radix_pass(ctx, rp));
-  // ---- final level: every bucket (window of buckets) ordered by the remaining bits in LDS, written over its own rows
-  rp.g_dirT = nullptr; rp.g_cc = nullptr; rp.g_pstart = nullptr;
+  // a final bucket outgrows a tile (heavy duplicates) -- or, with the gathering final level, there are no windows
+  if (!(windows || (!tl2 && maxsize <= tile))) return DTHIP_NOT_APPLICABLE;
+  if (!tl2) { rp.P = P; rp.gpre = gtot2; DTHIP_TRY(launch_radix_pass(ctx, rp)); }
+  // ---- final level: every bucket (window of buckets) ordered by the remaining bits in LDS, written to its rows of the result
+  rp.g_dirT = nullptr; rp.g_cc = nullptr; rp.g_pstart = nullptr; rp.tl_dir2 = nullptr;
   rp.kin = kA; rp.kout = kB; rp.shift = 0; rp.bits = msd.rb; rp.P = nullptr; rp.gpre = nullptr;
   rp.ntiles = nbk; rp.tdesc = nullptr; rp.bounds = fstart;
   rp.block = (maxsize <= tile / 2) ? 256 : 0;
+  if (tl2) {
+    rp.tdesc = d_tdesc;
+    rp.g2_dirT = dirT2; rp.g2_dstride = dstride2; rp.g2_pfirst = d_pfirst; rp.g2_fstart = fstart; rp.g2_s2bits = msd.s2; rp.g2_nbk = nbk;
+  }
   if (windows) {
     rp.ntiles = wi[0]; rp.bounds = wbounds; rp.wfirst = wfirst; rp.block = 0;
     rp.bits2 = 1;
@@ -2203,6 +2245,7 @@ int dthip_filter_groupby_rows(dthip_ctx* ctx, const dthip_col* pred, int cmp, do
     }
     if (rc != DTHIP_NOT_APPLICABLE) break;
     // ---- the two-call sequence: filter (RowIndex + the view's columns in one sweep), then the rows in grouped order ------
+    rc = DTHIP_OK;
     for (void* p : res->owned) dev_release(ctx, p);          // (anything a fused attempt set aside before it gave up)
     res->owned.clear();
     res->col.assign(ncols, nullptr);

@@ -91,6 +91,8 @@ struct dthip_ctx {
   int filter_path = 1;       // row filters: 1 count pass + write pass (default: 1.3 + 5.8 ms per 1e9 float64 rows with two 8-byte columns
                              // taken); 0 ONE pass, tile offsets by decoupled look-back (measured 8.6-9.2 ms: the look-back chain costs
                              // more than the second read of the predicate column; kept selectable)
+  int tl_level2 = 1;         // fused filter -> group-rows route: 1 (default) the second level writes tile-locally too when the final buckets
+                             // are expected to fill windows, 0 never (exact-position scatter after a gathering histogram), 2 always (tests)
   int filter_rows_fused = 1; // dthip_filter_groupby_rows: 1 (default) the fused route of tlsort.hip where it applies, 0 always filter_take + groupby_rows
   int sort_path = 0;         // 0: MSD levels (two scatter levels + final buckets ordered in LDS) from msd_min_rows rows on where their preconditions hold, else LSD passes; 1: LSD passes only; 2: MSD levels whenever their preconditions hold, whatever msd_min_rows says (A/B runs, tests)
   int64_t msd_min_rows = 1 << 26;    // below this the LSD passes are quick enough (and the final buckets would be tiny)
@@ -264,6 +266,14 @@ struct RadixPass {
   // (radix_dev.hpp tl_build_src).  Needs tdesc, 4-byte keys, and every payload column prefetched (<= 2, widths 8 / 4).
   const uint16_t* g_dirT; uint32_t g_dstride; const uint32_t* g_cc; uint32_t g_ntb, g_ntiles1, g_T1;
   const uint32_t* g_pstart;      // [buckets]: first row of every bucket in the bucket-ordered sequence
+  // ... and may write ITS rows tile-locally as well (tl_dir2 != null; no P / gpre, no histogram pass): tile t's rows, ordered
+  // by the level's digit, over the tile's own rows [tdesc[4 t], + rows) of kout / pay.out, tl_dir2[t][d] = first place of
+  // digit d inside the tile ([bins] = the tile's rows)
+  uint16_t* tl_dir2;
+  // final level over windows reading such a level (g2_dirT != null): bucket c = (parent b1 = c >> g2_s2bits, digit d2) is
+  // the concatenation, over the parent's tiles [g2_pfirst[b1], g2_pfirst[b1 + 1]), of the segments
+  // [tdesc[4 p] + dirT[d2][p], tdesc[4 p] + dirT[d2 + 1][p]); it goes to rows [g2_fstart[c], g2_fstart[c + 1]) of the output
+  const uint16_t* g2_dirT; uint32_t g2_dstride; const uint32_t* g2_pfirst; const uint32_t* g2_fstart; int g2_s2bits; uint32_t g2_nbk;
 };
 uint32_t radix_tile_items(int key64, int maxpaywidth);
 int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t n, int shift, int bits,
@@ -457,6 +467,7 @@ struct TL1Args {
   PredArgs pred;            // 8-byte predicate column (float64 / int64) <cmp> scalar
   KeyColDev key;            // ONE int32 / int64 key column; the packed key is its transformed value (<= 32 bits)
   uint32_t n;               // unfiltered rows
+  int block;                // threads per workgroup, 512 | 1024: tile = block * 16 rows
   int shift, bits;          // the level's digit of the transformed key
   uint32_t* kout;           // [n] transformed keys of the passing rows, tile t's at [t * tile, t * tile + count)
   uint16_t* dir;            // [ntiles][bins + 1] first place of every digit inside the tile; [bins] = the tile's count
@@ -478,5 +489,9 @@ struct TLGatherHistArgs {
   uint32_t* P; uint32_t* gtot;
 };
 int launch_tl_gather_hist(dthip_ctx* ctx, const TLGatherHistArgs& a, uint32_t G);
+// second tile-local level: dir2[ntiles2][bins2 + 1] -> dirT2[bins2 + 1][dstride2], fstart[nbk + 1] = first row of every final
+// bucket (parent-major: c = b1 * bins2 + d2; pfirst[b1] = first level-2 tile of parent b1), *maxsize = largest final bucket
+int launch_tl_final_plan(dthip_ctx* ctx, const uint16_t* dir2, uint32_t ntiles2, uint32_t nb1, int s2bits, const uint32_t* pfirst,
+                         const uint32_t* pstart, uint16_t* dirT2, uint32_t dstride2, uint32_t* fstart, uint32_t* maxsize);
 
 }  // namespace dthip

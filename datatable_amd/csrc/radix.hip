@@ -212,6 +212,9 @@ struct PassArgsT {
   uint32_t hw_off;          // byte offset of the head-bitmap words inside the workgroup's LDS
   // gather mode (GATH): see RadixPass::g_dirT
   const uint16_t* dirT; uint32_t dstride; const uint32_t* cc; uint32_t ntb, ntiles1, T1; const uint32_t* pstart;
+  uint16_t* dir2;           // GATH == 1: tile-local output + directory instead of P / gpre (RadixPass::tl_dir2)
+  // GATH == 2 (final level over windows of a tile-local level): RadixPass::g2_*
+  const uint16_t* dirT2; uint32_t dstride2; const uint32_t* pfirst; const uint32_t* gfstart; int s2bits; uint32_t nbk;
   PayCols pay;
 };
 
@@ -382,7 +385,8 @@ int launch_msd_scan(dthip_ctx* ctx, uint32_t* gtot, const uint32_t* gfirst, cons
 //        -- give every row its place in the window; rows, ordered, go back over the window's own row range
 // GATH = the tile's rows are gathered from the segments of a tile-local level above (RadixPass::g_dirT): their global rows
 //        are listed in LDS first (in the exchange buffer, free until the ranking), every load goes through that list
-template <typename KeyT, int RB, int P0W, int P1W = 0, int RK = 0, int BLK = RP_BLOCK, bool R2 = false, bool GATH = false>
+//        (1: a level reading the first, tile-local level; 2: the final level over windows reading a tile-local second level)
+template <typename KeyT, int RB, int P0W, int P1W = 0, int RK = 0, int BLK = RP_BLOCK, bool R2 = false, int GATH = 0>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) radix_pass_kernel(PassArgsT<KeyT> a) {
   constexpr int BLOCK = BLK, ITEMS = RP_ITEMS;
   constexpr int WAVES = BLOCK / 64, TILE = BLOCK * ITEMS;
@@ -426,10 +430,15 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
   const uint32_t wbase = (uint32_t)wave * chunk + (uint32_t)lane;
 #define RP_VALID(i) (64u * (uint32_t)(i) < chunk && wbase + 64u * (uint32_t)(i) < nvalid)
   const uint32_t* gsrc_rows = reinterpret_cast<const uint32_t*>(exch);       // GATH: global row of the tile's v-th row
-  if (GATH) {
+  if (GATH == 1) {
     const uint32_t bkt = a.tdesc[4 * tile + 3];
     tl_build_src<BLOCK>(reinterpret_cast<uint32_t*>(exch), a.dirT, a.dstride, a.cc, a.ntb, a.ntiles1, a.T1, bkt,
                         tile_base - a.pstart[bkt], nvalid);
+    __syncthreads();
+  }
+  if (GATH == 2) {
+    tl_build_src_final<BLOCK>(reinterpret_cast<uint32_t*>(exch), a.dirT2, a.dstride2, a.tdesc, a.pfirst, a.gfstart, a.s2bits, a.nbk,
+                              a.wfirst ? a.wfirst[tile] : tile, tile_base, nvalid);
     __syncthreads();
   }
 #define RP_SRC(loc) (GATH ? gsrc_rows[(loc)] : tile_base + (loc))
@@ -638,6 +647,12 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     const int b = tid * KB + k;
     if (b < bins) {
       bin_excl[b] = excl;
+      if (GATH == 1 && a.dir2) {
+        // second tile-local level: the tile's rows go over its own rows of the outputs, the directory says where digit b starts
+        bin_delta[b] = tile_base;
+        a.dir2[(size_t)tile * (uint32_t)(bins + 1) + b] = (uint16_t)excl;
+        if (b == bins - 1) a.dir2[(size_t)tile * (uint32_t)(bins + 1) + bins] = (uint16_t)nvalid;
+      } else
       bin_delta[b] = a.seq ? tile_base : a.gpre[(size_t)grp * bins + b] + a.P[(size_t)tile * bins + b] - excl;
       excl += tc[k];
     }
@@ -812,10 +827,12 @@ int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t
   return DTHIP_OK;
 }
 
-template <typename KeyT, int RB, int P0W, int P1W, int RK, int BLK = RP_BLOCK, bool R2 = false, bool GATH = false>
+template <typename KeyT, int RB, int P0W, int P1W, int RK, int BLK = RP_BLOCK, bool R2 = false, int GATH = 0>
 static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
   PassArgsT<KeyT> a;
   a.dirT = p.g_dirT; a.dstride = p.g_dstride; a.cc = p.g_cc; a.ntb = p.g_ntb; a.ntiles1 = p.g_ntiles1; a.T1 = p.g_T1; a.pstart = p.g_pstart;
+  a.dir2 = p.tl_dir2;
+  a.dirT2 = p.g2_dirT; a.dstride2 = p.g2_dstride; a.pfirst = p.g2_pfirst; a.gfstart = p.g2_fstart; a.s2bits = p.g2_s2bits; a.nbk = p.g2_nbk;
   a.kin = static_cast<const KeyT*>(p.kin); a.kout = static_cast<KeyT*>(p.kout);
   a.n = p.n; a.shift = p.shift; a.bits = p.bits; a.P = p.P; a.gpre = p.gpre; a.tpg = p.tpg;
   a.iota = p.iota; a.pay = p.pay;
@@ -902,26 +919,42 @@ static int launch_pass_k(dthip_ctx* ctx, const RadixPass& p) {
 static int launch_pass_gather(dthip_ctx* ctx, const RadixPass& p) {
   const int w0 = p.pay.n > 0 ? p.pay.width[0] : 0, w1 = p.pay.n > 1 ? p.pay.width[1] : 0;
   if (p.key64 || !p.tdesc || p.bounds || p.wfirst || p.iota || p.pay.n < 1 || p.pay.n > 2 || p.bits > 9 || !p.g_cc || !p.g_pstart ||
+      (!p.tl_dir2 && (!p.P || !p.gpre)) ||
       !((w0 == 8 && (w1 == 0 || w1 == 4 || w1 == 8)) || (w0 == 4 && w1 == 0))) {
     set_error("radix pass: gather mode takes 4-byte keys, ragged tiles and payload widths 8 / 8+4 / 8+8 / 4");
     return DTHIP_EINVAL;
   }
   if (p.bits > 8) {
-    if (w0 == 8 && w1 == 4) return launch_pass_r<uint32_t, 9, 8, 4, 1, RP_BLOCK, false, true>(ctx, p);
-    if (w0 == 8 && w1 == 8) return launch_pass_r<uint32_t, 9, 8, 8, 1, RP_BLOCK, false, true>(ctx, p);
-    if (w0 == 8) return launch_pass_r<uint32_t, 9, 8, 0, 1, RP_BLOCK, false, true>(ctx, p);
-    return launch_pass_r<uint32_t, 9, 4, 0, 1, RP_BLOCK, false, true>(ctx, p);
+    if (w0 == 8 && w1 == 4) return launch_pass_r<uint32_t, 9, 8, 4, 1, RP_BLOCK, false, 1>(ctx, p);
+    if (w0 == 8 && w1 == 8) return launch_pass_r<uint32_t, 9, 8, 8, 1, RP_BLOCK, false, 1>(ctx, p);
+    if (w0 == 8) return launch_pass_r<uint32_t, 9, 8, 0, 1, RP_BLOCK, false, 1>(ctx, p);
+    return launch_pass_r<uint32_t, 9, 4, 0, 1, RP_BLOCK, false, 1>(ctx, p);
   }
-  if (w0 == 8 && w1 == 4) return launch_pass_r<uint32_t, 8, 8, 4, 1, RP_BLOCK, false, true>(ctx, p);
-  if (w0 == 8 && w1 == 8) return launch_pass_r<uint32_t, 8, 8, 8, 1, RP_BLOCK, false, true>(ctx, p);
-  if (w0 == 8) return launch_pass_r<uint32_t, 8, 8, 0, 1, RP_BLOCK, false, true>(ctx, p);
-  return launch_pass_r<uint32_t, 8, 4, 0, 1, RP_BLOCK, false, true>(ctx, p);
+  if (w0 == 8 && w1 == 4) return launch_pass_r<uint32_t, 8, 8, 4, 1, RP_BLOCK, false, 1>(ctx, p);
+  if (w0 == 8 && w1 == 8) return launch_pass_r<uint32_t, 8, 8, 8, 1, RP_BLOCK, false, 1>(ctx, p);
+  if (w0 == 8) return launch_pass_r<uint32_t, 8, 8, 0, 1, RP_BLOCK, false, 1>(ctx, p);
+  return launch_pass_r<uint32_t, 8, 4, 0, 1, RP_BLOCK, false, 1>(ctx, p);
+}
+
+// the final level over windows, reading a tile-local second level (RadixPass::g2_dirT)
+static int launch_pass_gather_final(dthip_ctx* ctx, const RadixPass& p) {
+  const int w0 = p.pay.n > 0 ? p.pay.width[0] : 0, w1 = p.pay.n > 1 ? p.pay.width[1] : 0;
+  if (p.key64 || !p.tdesc || !p.bounds || !p.wfirst || p.iota || p.pay.n < 1 || p.pay.n > 2 || p.bits > 9 || !p.g2_pfirst || !p.g2_fstart ||
+      !((w0 == 8 && (w1 == 0 || w1 == 4 || w1 == 8)) || (w0 == 4 && w1 == 0))) {
+    set_error("radix pass: the gathering final level takes windows, 4-byte keys and payload widths 8 / 8+4 / 8+8 / 4");
+    return DTHIP_EINVAL;
+  }
+  if (w0 == 8 && w1 == 4) return launch_pass_r<uint32_t, 9, 8, 4, 1, RP_BLOCK, true, 2>(ctx, p);
+  if (w0 == 8 && w1 == 8) return launch_pass_r<uint32_t, 9, 8, 8, 1, RP_BLOCK, true, 2>(ctx, p);
+  if (w0 == 8) return launch_pass_r<uint32_t, 9, 8, 0, 1, RP_BLOCK, true, 2>(ctx, p);
+  return launch_pass_r<uint32_t, 9, 4, 0, 1, RP_BLOCK, true, 2>(ctx, p);
 }
 
 int launch_radix_pass(dthip_ctx* ctx, const RadixPass& p) {
   if (p.n == 0) return DTHIP_OK;
   if (p.bits < 1 || p.bits > 10) { set_error("radix pass: bad digit width %d", p.bits); return DTHIP_EINVAL; }
   if (p.g_dirT) return launch_pass_gather(ctx, p);
+  if (p.g2_dirT) return launch_pass_gather_final(ctx, p);
   if (p.key64) return launch_pass_k<unsigned long long>(ctx, p);
   return launch_pass_k<uint32_t>(ctx, p);
 }

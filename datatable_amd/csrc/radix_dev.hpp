@@ -190,4 +190,56 @@ __device__ __forceinline__ void tl_build_src(uint32_t* src, const uint16_t* __re
   }
 }
 
+// The same for the FINAL level over a second tile-local level (RadixPass::g2_dirT): the rows [row0, row0 + nrows) of the
+// final order are whole final buckets c0, c0 + 1, ... (a window); bucket c = (parent b1, digit d2) is the concatenation over
+// the parent's tiles p of the segments [dirT2[d2][p], dirT2[d2 + 1][p]) at base tdesc[4 p].  A parent has ~n / 2^s1 / tile
+// tiles (two 64-tile blocks for config 5): every wave walks all of a bucket's blocks to keep the running offset and writes
+// the rows of the blocks that are its share.
+template <int BLOCK>
+__device__ __forceinline__ void tl_build_src_final(uint32_t* src, const uint16_t* __restrict__ dirT2, uint32_t dstride2,
+                                                   const uint32_t* __restrict__ tdesc, const uint32_t* __restrict__ pfirst,
+                                                   const uint32_t* __restrict__ fstart, int s2bits, uint32_t nbk, uint32_t c0,
+                                                   uint32_t row0, uint32_t nrows) {
+  constexpr int WAVES = BLOCK / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t vend = row0 + nrows, dmask2 = (1u << s2bits) - 1u;
+  for (uint32_t c = c0; c < nbk; c++) {
+    const uint32_t fs = fstart[c];
+    if (fs >= vend) break;
+    const uint32_t fe = fstart[c + 1];
+    if (fe <= row0 || fe == fs) continue;            // before the window / empty
+    const uint32_t b1 = c >> s2bits, d2 = c & dmask2;
+    const uint32_t p0 = pfirst[b1], p1 = pfirst[b1 + 1];
+    const uint16_t* r0 = dirT2 + (size_t)d2 * dstride2;
+    const uint16_t* r1 = r0 + dstride2;
+    uint32_t run = fs;
+    uint32_t blk = 0;
+    for (uint32_t pb = p0; pb < p1; pb += 64u, blk++) {
+      const uint32_t p = pb + (uint32_t)lane;
+      uint32_t st = 0, len = 0, base = 0;
+      if (p < p1) { st = r0[p]; len = (uint32_t)r1[p] - st; base = tdesc[4 * p]; }
+      const uint32_t incl = wave_incl_scan_u32(len);
+      const uint32_t tot = (uint32_t)__shfl((int)incl, 63, 64);
+      if ((blk % (uint32_t)WAVES) == (uint32_t)wave) {
+        const uint32_t vs = run + incl - len;
+        const uint32_t g0 = base + st;
+        uint32_t jlo = vs < row0 ? row0 - vs : 0u;
+        uint32_t jhi = vs >= vend ? 0u : (vend - vs < len ? vend - vs : len);
+        if (jlo > jhi) jlo = jhi;
+        const bool big = jhi - jlo > 32u;
+        if (!big) for (uint32_t j = jlo; j < jhi; j++) src[vs + j - row0] = g0 + j;
+        unsigned long long lm = __ballot(big);
+        while (lm) {
+          const int l = __ffsll((long long)lm) - 1;
+          lm &= lm - 1ULL;
+          const uint32_t G0 = (uint32_t)__shfl((int)g0, l, 64), VS = (uint32_t)__shfl((int)vs, l, 64);
+          const uint32_t JLO = (uint32_t)__shfl((int)jlo, l, 64), JHI = (uint32_t)__shfl((int)jhi, l, 64);
+          for (uint32_t j = JLO + (uint32_t)lane; j < JHI; j += 64u) src[VS + j - row0] = G0 + j;
+        }
+      }
+      run += tot;
+    }
+  }
+}
+
 }  // namespace dthip

@@ -24,10 +24,12 @@ namespace dthip {
 
 // KT = the key column's element type (int32_t / long long); KEEPX = the predicate column (8 bytes wide) is one of the
 // riding columns: its loaded values stay in registers instead of being read a second time
-template <typename KT, int RB, bool KEEPX>
-__global__ void __launch_bounds__(RP_BLOCK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) tl_level1_kernel(TL1Args a) {
+// BLK = threads per workgroup: 512 (8192-row tiles, two workgroups per CU) or 1024 (16384-row tiles, one per CU: segments
+// twice as long for the level that gathers them)
+template <typename KT, int RB, bool KEEPX, int BLK>
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) tl_level1_kernel(TL1Args a) {
   typedef unsigned long long u64;
-  constexpr int BLOCK = RP_BLOCK, ITEMS = RP_ITEMS, WAVES = BLOCK / 64, TILE = BLOCK * ITEMS, GROUPS = ITEMS / 4;
+  constexpr int BLOCK = BLK, ITEMS = RP_ITEMS, WAVES = BLOCK / 64, TILE = BLOCK * ITEMS, GROUPS = ITEMS / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int bins = 1 << a.bits;
   const uint32_t dmask = (uint32_t)bins - 1u;
@@ -171,34 +173,42 @@ int launch_tl_pred_sample(dthip_ctx* ctx, const PredArgs& p, uint32_t n, uint32_
   return DTHIP_OK;
 }
 
-template <typename KT, int RB>
+template <typename KT, int RB, int BLK>
 static int launch_tl1_t(dthip_ctx* ctx, const TL1Args& a, uint32_t ntiles, size_t lds) {
   if (a.keepx >= 0) {
-    auto kfn = tl_level1_kernel<KT, RB, true>;
+    auto kfn = tl_level1_kernel<KT, RB, true, BLK>;
     DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
-    DTHIP_LAUNCH(ctx, "tl_level1_kernel", kfn, ntiles, RP_BLOCK, lds, a);
+    DTHIP_LAUNCH(ctx, "tl_level1_kernel", kfn, ntiles, BLK, lds, a);
   } else {
-    auto kfn = tl_level1_kernel<KT, RB, false>;
+    auto kfn = tl_level1_kernel<KT, RB, false, BLK>;
     DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
-    DTHIP_LAUNCH(ctx, "tl_level1_kernel", kfn, ntiles, RP_BLOCK, lds, a);
+    DTHIP_LAUNCH(ctx, "tl_level1_kernel", kfn, ntiles, BLK, lds, a);
   }
   return DTHIP_OK;
 }
 
 uint32_t tl_tile_rows() { return (uint32_t)RP_TILE; }
 
+// a.block = 512 | 1024 threads: tiles of a.block * 16 rows
 int launch_tl_level1(dthip_ctx* ctx, const TL1Args& a) {
   if (a.n == 0) return DTHIP_OK;
   if (a.bits < 1 || a.bits > 9) { set_error("tile-local level: bad digit width %d", a.bits); return DTHIP_EINVAL; }
+  if (a.block != 512 && a.block != 1024) { set_error("tile-local level: 512 or 1024 threads"); return DTHIP_EINVAL; }
   if (stype_size(a.pred.stype) != 8 || a.pred.is_mask) { set_error("tile-local level: the predicate column must be 8 bytes wide"); return DTHIP_EINVAL; }
   if (a.key.stype != DTHIP_INT32 && a.key.stype != DTHIP_INT64) { set_error("tile-local level: int32 / int64 keys"); return DTHIP_EINVAL; }
   for (int c = 0; c < a.pay.n; c++)
     if (a.pay.width[c] != 4 && a.pay.width[c] != 8) { set_error("tile-local level: riding columns are 4 or 8 bytes wide"); return DTHIP_EINVAL; }
   const int bins = 1 << a.bits;
-  const uint32_t ntiles = (a.n + RP_TILE - 1) / RP_TILE;
-  const size_t lds = (size_t)(RP_BLOCK / 64) * bins * 2 + (size_t)(bins + 16) * 4 + (size_t)RP_TILE * 8;
-  if (a.key.stype == DTHIP_INT64) return a.bits > 8 ? launch_tl1_t<long long, 9>(ctx, a, ntiles, lds) : launch_tl1_t<long long, 8>(ctx, a, ntiles, lds);
-  return a.bits > 8 ? launch_tl1_t<int32_t, 9>(ctx, a, ntiles, lds) : launch_tl1_t<int32_t, 8>(ctx, a, ntiles, lds);
+  const uint32_t trows = (uint32_t)a.block * RP_ITEMS;
+  const uint32_t ntiles = (a.n + trows - 1) / trows;
+  const size_t lds = (size_t)(a.block / 64) * bins * 2 + (size_t)(bins + 16) * 4 + (size_t)trows * 8;
+  const bool k64 = a.key.stype == DTHIP_INT64, b9 = a.bits > 8;
+  if (a.block == 1024) {
+    if (k64) return b9 ? launch_tl1_t<long long, 9, 1024>(ctx, a, ntiles, lds) : launch_tl1_t<long long, 8, 1024>(ctx, a, ntiles, lds);
+    return b9 ? launch_tl1_t<int32_t, 9, 1024>(ctx, a, ntiles, lds) : launch_tl1_t<int32_t, 8, 1024>(ctx, a, ntiles, lds);
+  }
+  if (k64) return b9 ? launch_tl1_t<long long, 9, 512>(ctx, a, ntiles, lds) : launch_tl1_t<long long, 8, 512>(ctx, a, ntiles, lds);
+  return b9 ? launch_tl1_t<int32_t, 9, 512>(ctx, a, ntiles, lds) : launch_tl1_t<int32_t, 8, 512>(ctx, a, ntiles, lds);
 }
 
 // ---- directory: transpose, rows per (digit, tile block), their prefix over the blocks, rows per digit ------------------
@@ -252,6 +262,40 @@ int launch_tl_directory(dthip_ctx* ctx, const uint16_t* dir, uint32_t ntiles, ui
   DTHIP_LAUNCH(ctx, "tl_dir_transpose_kernel", tl_dir_transpose_kernel, grid, 256, 0, dir, ntiles, F + 1, dirT, dstride);
   DTHIP_LAUNCH(ctx, "tl_blocksum_kernel", tl_blocksum_kernel, ntb, 256, 0, dir, ntiles, F, ntb, cc);
   DTHIP_LAUNCH(ctx, "tl_blockscan_kernel", tl_blockscan_kernel, F, 256, 0, cc, ntb, tot);
+  return DTHIP_OK;
+}
+
+// ---- second tile-local level -> the final level's plan ------------------------------------------------------------------
+// fstart[b1 * bins2 + d2] = first row of final bucket (b1, d2) in the result = first row of the parent (pstart[b1], known on
+// the host from the first level's directory) + the rows of the parent's smaller digits; a bucket's rows = the sum over the
+// parent's tiles of their d2 segments.  One workgroup per parent, thread = digit (directory rows read coalesced).
+__global__ void __launch_bounds__(512) tl_final_starts_kernel(const uint16_t* __restrict__ dir2, const uint32_t* __restrict__ pfirst,
+                                                              const uint32_t* __restrict__ pstart, uint32_t bins2, uint32_t nb1,
+                                                              uint32_t* __restrict__ fstart, uint32_t* __restrict__ maxsize) {
+  __shared__ uint32_t scratch[8];
+  const uint32_t b1 = blockIdx.x, p0 = pfirst[b1], p1 = pfirst[b1 + 1];
+  const uint32_t d = threadIdx.x;
+  uint32_t s = 0;
+  if (d < bins2)
+    for (uint32_t p = p0; p < p1; p++) {
+      const uint16_t* row = dir2 + (size_t)p * (bins2 + 1);
+      s += (uint32_t)row[d + 1] - (uint32_t)row[d];
+    }
+  const uint32_t e = block_excl_scan_u32<512>(s, scratch, nullptr);
+  if (d < bins2) fstart[(size_t)b1 * bins2 + d] = pstart[b1] + e;
+  if (b1 + 1 == nb1 && d == 0) fstart[(size_t)nb1 * bins2] = pstart[nb1];
+  uint32_t mx = s;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)mx, o, 64); mx = x > mx ? x : mx; }
+  if ((threadIdx.x & 63) == 0 && mx) atomicMax(maxsize, mx);
+}
+
+int launch_tl_final_plan(dthip_ctx* ctx, const uint16_t* dir2, uint32_t ntiles2, uint32_t nb1, int s2bits, const uint32_t* pfirst,
+                         const uint32_t* pstart, uint16_t* dirT2, uint32_t dstride2, uint32_t* fstart, uint32_t* maxsize) {
+  const uint32_t bins2 = 1u << s2bits;
+  dim3 grid((dstride2 + 63) / 64, (bins2 + 1 + 63) / 64);
+  DTHIP_LAUNCH(ctx, "tl_dir_transpose_kernel", tl_dir_transpose_kernel, grid, 256, 0, dir2, ntiles2, bins2 + 1, dirT2, dstride2);
+  DTHIP_LAUNCH(ctx, "tl_final_starts_kernel", tl_final_starts_kernel, nb1, 512, 0, dir2, pfirst, pstart, bins2, nb1, fstart, maxsize);
   return DTHIP_OK;
 }
 

@@ -174,6 +174,9 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    the "msd_min_rows" test (A/B runs, tests).  Same results, bit for bit
  *   "filter_rows_fused" 1 (default): dthip_filter_groupby_rows takes its fused route where it applies; 0: always the
  *                    two-call sequence (A/B runs, tests).  Same results, bit for bit
+ *   "tl_level2"      the fused route's second level: 1 (default) tile-local output as well (no histogram pass, sequential
+ *                    writes; the final level gathers its buckets' segments) when the final buckets are expected to fill
+ *                    windows, 0 never (exact-position scatter), 2 always (tests).  Same results, bit for bit
  *   "small_path"     2 (default): a groupby_agg whose keys fit ONE table of <= 8192 slots runs a launch-lean sequence (tables
  *                    initialised by the plan kernel; group list + offsets + count from one single-workgroup kernel, which
  *                    writes its counts into mapped host memory -- no copy command); 1: the counts are copied back instead;

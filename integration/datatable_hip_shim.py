@@ -71,11 +71,14 @@ class _Options:
     f32_sum    True: sum(float32 column) accumulates in float32 row by row like the reference (dthip option f32_sum = 1,
                column/sumprod.h:48-55); default False: float64 accumulation, rounded once.  Environment: DTHIP_SHIM_F32_SUM=1."""
     residency = os.environ.get("DTHIP_SHIM_RESIDENCY", "auto")
+    # residency "lazy" only: V = DT[f.x <cmp> c, cols] stays a pending view until it is used; V[:, cols, by(key)] then runs as
+    # ONE fused library call (BASELINE config 5's two statements).  False: the filter runs at once (round 4's behaviour)
+    defer_filter = os.environ.get("DTHIP_SHIM_DEFER_FILTER", "1") not in ("", "0")
     f32_sum = os.environ.get("DTHIP_SHIM_F32_SUM", "0") not in ("", "0")
 
 
 options = _Options()
-stats = {"arrow_uploads": 0}      # columns that went to HBM in Arrow layout (dthip_from_arrow), for tests and curiosity
+stats = {"arrow_uploads": 0, "fused_filter_rows": 0}      # columns that went to HBM in Arrow layout (dthip_from_arrow), for tests and curiosity
 
 
 _tls = threading.local()
@@ -743,7 +746,7 @@ def match_filter(frame, item):
     return None if th is None else (ci, th, cols)
 
 
-def run_filter(frame, ci, th, cols, ctx=None):
+def run_filter(frame, ci, th, cols, ctx=None, _eager=False):
     """the passing rows of `cols`, materialised in one sweep next to the predicate column (dthip_filter_take)"""
     import ctypes as C
     ctx = _context(ctx)
@@ -761,6 +764,13 @@ def run_filter(frame, ci, th, cols, ctx=None):
     cint = int(th[1]) if len(th) > 1 and not isf else 0
     lcols, mem = _columns(frame, [ci] + list(cols), ctx)
     pcol = lcols[0]
+    if _lazy() and mem == L.DEVICE and options.defer_filter and not _eager:
+        # lazy residency: the result is what it is in the reference -- a VIEW (a RowIndex over the parent's columns,
+        # rowindex_array.cc:130-170: nothing is copied until something reads it).  `V[:, cols, by(key)]` on it runs as ONE
+        # library call (dthip_filter_groupby_rows: the filter fused into the first sort level); anything else makes the view
+        # materialise first (dthip_filter_take, below), exactly as before
+        owners = [frame._cols[c] for c in [ci] + list(cols)] if isinstance(frame, DeviceFrame) else _resident(frame, [ci] + list(cols), ctx)
+        return _PendingFilter(ctx, [frame.names[c] for c in cols], [frame.stypes[c] for c in cols], lcols, (code, cf, cint), n, owners)
     out = _Out(ctx, mem)
     for lo in range(0, len(cols), 8):                       # dthip_filter_take takes up to 8 columns per sweep
         part = cols[lo:lo + 8]
@@ -979,6 +989,95 @@ class DeviceFrame:
 
     def __repr__(self):
         return "<DeviceFrame [%d rows x %d cols] in HBM%s>" % (self._nrows, len(self._names), "" if self._frame is None else " (downloaded)")
+
+
+class _PendingFilter(DeviceFrame):
+    """`V = DT[f.x <cmp> c, cols]` under residency "lazy", not evaluated yet: the parent's device columns (the buffers, not
+    the Frame: a later change of the parent cannot reach them), the predicate, and the selection.  Names / stypes / ncols
+    answer from metadata; `V[:, j, by(key)]` with plain columns in j evaluates filter + grouping in one library call;
+    every other use (nrows, to_frame, another query, ...) runs the filter first and behaves like any DeviceFrame."""
+
+    def __init__(self, ctx, names, stypes, lcols, pred, nrows_in, owners):
+        DeviceFrame.__init__(self, ctx, names, stypes, -1, [], True)
+        self._pending = (lcols, pred, nrows_in)          # lcols[0] = predicate column, lcols[1:] = the selected columns
+        self._owners = owners                            # the _DevColumn objects behind lcols: they keep the buffers alive
+
+    def _materialise(self):
+        import ctypes as C
+        pend = self.__dict__.get("_pending")
+        if pend is None:
+            return
+        lcols, (code, cf, cint), n = pend
+        ctx, lib = self._ctx, self._ctx._lib
+        out = _Out(ctx, L.DEVICE)
+        ncol = len(lcols) - 1
+        for lo in range(0, ncol, 8):
+            part = lcols[1 + lo:1 + lo + 8]
+            bufs = [out.alloc(n, c.stype) for c in part]
+            optr = (C.c_void_p * len(part))(*[b[0] for b in bufs])
+            k = C.c_int64(0)
+            L.check(lib.dthip_filter_take(ctx._h, C.byref(lcols[0]), code, cf, cint, _carr(part), len(part), n, L.DEVICE, None, optr, C.byref(k)))
+            for i, (c, b) in enumerate(zip(part, bufs)):
+                out.add(b[1], self._names[lo + i], c.stype, nrows=k.value)
+        self._cols = out.cols
+        self._nrows = out.cols[0].nrows if out.cols else 0
+        self._pending = None
+
+    nrows = property(lambda self: (self._materialise(), self._nrows)[1])
+    shape = property(lambda self: (self.nrows, len(self._names)))
+
+    def to_frame(self):
+        self._materialise()
+        return DeviceFrame.to_frame(self)
+
+    def __len__(self):
+        return self.nrows
+
+    def __repr__(self):
+        if self.__dict__.get("_pending") is not None:
+            return "<DeviceFrame [pending row filter x %d cols] in HBM>" % len(self._names)
+        return DeviceFrame.__repr__(self)
+
+    def _fused_rows(self, item):
+        """V[:, j, by(keys)] on the pending view -> one dthip_filter_groupby_rows call, or NotImplemented"""
+        import ctypes as C
+        item, names = _dict_j(item)
+        if not (isinstance(item, tuple) and len(item) == 3 and isinstance(item[2], by) and _is_all(item[0])):
+            return NotImplemented
+        keys = [_colindex(self, c) for c in item[2].cols]
+        if not keys or any(k is None for k in keys) or len(set(keys)) != len(keys) or not _uniform(item[2].cols):
+            return NotImplemented
+        cols = _jcols(self, item[1], exclude=keys)
+        if cols is None or not all(self._stypes[c].value in _ACCEL_STYPES for c in keys + cols):
+            return NotImplemented
+        lcols, (code, cf, cint), n = self._pending
+        ctx, lib = self._ctx, self._ctx._lib
+        allc = list(keys) + list(cols)
+        karr = _carr([lcols[1 + k] for k in keys])
+        carr = _carr([lcols[1 + c] for c in allc])
+        h = C.c_void_p()
+        L.check(lib.dthip_filter_groupby_rows(ctx._h, C.byref(lcols[0]), code, cf, cint, karr, len(keys), carr, len(allc), n,
+                                              L.NA_FIRST, L.DEVICE, 0, C.byref(h)))
+        keep = _ResultKeep(ctx, h)
+        m = lib.dthip_result_nrows(h)
+        out = _Out(ctx, L.DEVICE)
+        for i, c in enumerate(allc):
+            out.borrowed(lib.dthip_result_col(h, i), m, self._stypes[c].value, keep, self._names[c])
+        stats["fused_filter_rows"] += 1
+        res = out.finish(self, wrap=True)
+        if names is not None:
+            res = _renamed(res, names, len(keys))
+            if res is None:
+                return NotImplemented
+        return res
+
+    def __getitem__(self, item):
+        if self.__dict__.get("_pending") is not None and self._frame is None:
+            r = self._fused_rows(item)
+            if r is not NotImplemented:
+                return r
+            self._materialise()
+        return DeviceFrame.__getitem__(self, item)
 
 
 class Frame(dt.Frame):

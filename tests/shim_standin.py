@@ -149,16 +149,40 @@ class StandinLib:
             r.rowindex = np.ascontiguousarray(ri, np.int32)
         return self._new(r, out)
 
-    def dthip_filter_take(self, h, pcol, code, cf, cint, carr, ncols, n, mem, out_ri, optr, k):
-        self.calls.append(("filter_take", mem))
-        p = pcol._obj
+    @staticmethod
+    def _mask(p, code, cf, cint, n):
         x = _view(p.data, n, p.stype)
         isf = p.stype in (L.FLOAT32, L.FLOAT64)
         na = np.isnan(x) if isf else x == np.iinfo(x.dtype).min
         c = NP[p.stype](cf) if isf else int(cint)
         with np.errstate(invalid="ignore"):
-            m = {L.GT: lambda: ~na & (x > c), L.GE: lambda: ~na & (x >= c), L.LT: lambda: ~na & (x < c), L.LE: lambda: ~na & (x <= c),
-                 L.EQ: lambda: ~na & (x == c), L.NE: lambda: na | (x != c), L.NOTNA: lambda: ~na, L.ISNA: lambda: na}[code]()
+            return {L.GT: lambda: ~na & (x > c), L.GE: lambda: ~na & (x >= c), L.LT: lambda: ~na & (x < c), L.LE: lambda: ~na & (x <= c),
+                    L.EQ: lambda: ~na & (x == c), L.NE: lambda: na | (x != c), L.NOTNA: lambda: ~na, L.ISNA: lambda: na}[code]()
+
+    def dthip_filter_groupby_rows(self, h, pcol, code, cf, cint, karr, nkeys, carr, ncols, n, na_pos, mem, want_ri, out):
+        # V = DT[pred, :]; V[:, cols, by(keys)] in one call: filter -> gather -> group (the oracle's), composed RowIndex
+        self.calls.append(("filter_groupby_rows", mem))
+        fri = np.flatnonzero(self._mask(pcol._obj, code, cf, cint, n)).astype(np.int32)
+        r = _Res()
+        if len(fri) == 0:
+            r.nrows, r.ngroups = 0, 0
+            r.cols = [np.empty(0, NP[carr[i].stype]) for i in range(ncols)]
+            r.offsets = np.zeros(1, np.int32); r.rowindex = np.empty(0, np.int32)
+            return self._new(r, out)
+        keys = [_view(karr[i].data, n, karr[i].stype)[fri] for i in range(nkeys)]
+        p, off = o.group(keys, stypes=[karr[i].stype for i in range(nkeys)],
+                         desc=[bool(karr[i].flags & L.FLAG_DESCENDING) for i in range(nkeys)], na_last=na_pos == L.NA_LAST)
+        comp = fri[p]
+        r.nrows, r.ngroups = len(comp), len(off) - 1
+        r.cols = [np.ascontiguousarray(_view(carr[i].data, n, carr[i].stype)[comp]) for i in range(ncols)]
+        r.offsets = np.ascontiguousarray(off, np.int32)
+        if want_ri:
+            r.rowindex = np.ascontiguousarray(comp, np.int32)
+        return self._new(r, out)
+
+    def dthip_filter_take(self, h, pcol, code, cf, cint, carr, ncols, n, mem, out_ri, optr, k):
+        self.calls.append(("filter_take", mem))
+        m = self._mask(pcol._obj, code, cf, cint, n)
         for i in range(ncols):
             _store(optr[i], _view(carr[i].data, n, carr[i].stype)[m])
         if _addr(out_ri):

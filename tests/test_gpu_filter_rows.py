@@ -34,22 +34,28 @@ def expected(x, cmp, scalar, keys, cols, **kw):
     return comp, off, [c[comp] for c in cols]
 
 
-def run(ctx, x, cmp, scalar, keys, cols, expect_fused, want_rowindex=True, **kw):
+def run(ctx, x, cmp, scalar, keys, cols, expect_fused, want_rowindex=True, expect_tl2=None, **kw):
+    """the query on three routes -- fused with a tile-local second level (tl_level2 = 2), fused with a scattering second
+    level (0), the two calls (filter_rows_fused = 0) -- against the oracle.  expect_fused: the scatter form must run to the
+    end (True) / must not (False) / may (None); expect_tl2: the same for the tile-local form"""
     comp, off, ecols = expected(x, cmp, scalar, keys, cols, **kw)
     ekw = {k: v for k, v in kw.items() if k in ("desc", "na_last")}
-    for route in (1, 0):
-        ctx.set_option("filter_rows_fused", route)
+    for route, tl2, want in (("fused, tile-local level 2", 2, expect_tl2), ("fused, scatter level 2", 0, expect_fused), ("two calls", None, False)):
+        ctx.set_option("filter_rows_fused", 0 if tl2 is None else 1)
+        ctx.set_option("tl_level2", tl2 or 0)
         ctx.profile_reset(); ctx.profile(True)
         try:
             r = ctx.filter_groupby_rows(x, cmp, scalar, keys, cols, want_rowindex=want_rowindex, **ekw)
         finally:
             ctx.profile(False)
-        ran = ctx.profile_get("tl_level1_kernel")[1] > 0 and ctx.profile_get("tl_level2_kernel")[1] > 0
-        tag = " [%s route]" % ("fused" if route else "two-call")
-        if route == 1 and expect_fused is not None:
-            assert ran == expect_fused, "the fused route %s" % ("did not run" if expect_fused else "ran unexpectedly")
-        if route == 0:
-            assert not ran
+        # the fused route ran TO THE END: its first level and the final level, and no fall-back to the filter's take kernel
+        ran = ctx.profile_get("tl_level1_kernel")[1] > 0 and ctx.profile_get("msd_final_kernel")[1] > 0 and \
+            ctx.profile_get("compact_take_kernel")[1] == 0
+        tag = " [%s]" % route
+        if want is not None:
+            assert ran == want, "the fused route %s%s" % ("did not run" if want else "ran unexpectedly", tag)
+        if tl2 == 2 and ran:
+            assert ctx.profile_get("tl_gather_hist_kernel")[1] == 0 and ctx.profile_get("tl_final_starts_kernel")[1] > 0, tag
         assert r.nrows == len(comp), "rows" + tag
         assert_same(r.offsets(), off, "offsets" + tag)
         if want_rowindex:
@@ -62,16 +68,19 @@ def run(ctx, x, cmp, scalar, keys, cols, expect_fused, want_rowindex=True, **kw)
             else:
                 assert_same(got, exp, "column %d%s" % (c, tag))
         r.free()
-    ctx.set_option("filter_rows_fused", 1)
+    ctx.set_option("filter_rows_fused", 1); ctx.set_option("tl_level2", 1)
 
 
 # (the levels need  significant key bits - scatter bits <= 9  with scatter bits ~ log2(passing rows / msd_bucket_rows): the
 # shapes below are chosen so that the fused route applies; wider keys take the two-call route, tested further down)
-@pytest.mark.parametrize("n,hi,bucket_rows", [(1, 5, 64), (100, 50, 64), (5000, 3000, 64), (8191, 20_000, 64), (8192, 20_000, 64),
-                                              (8193, 20_000, 64), (100_003, 60_000, 512), (1_000_003, 2_000_000, 64),
-                                              (3_000_000, 10_000_000, 64), (2_500_001, 300_000, 64), (3_000_000, 500_000, 2048),
-                                              (2_000_000, 100_000, 1024)])
-def test_config5_shape(fused, n, hi, bucket_rows):
+@pytest.mark.parametrize("n,hi,bucket_rows,tl2", [(1, 5, 64, None), (100, 50, 64, None), (5000, 3000, 64, None), (8191, 20_000, 64, None),
+                                                  (8192, 20_000, 64, None), (8193, 20_000, 64, None), (100_003, 60_000, 512, None),
+                                                  (1_000_003, 2_000_000, 64, None), (3_000_000, 10_000_000, 64, None),
+                                                  (2_500_001, 300_000, 64, None), (3_000_000, 500_000, 2048, True),
+                                                  (2_000_000, 100_000, 1024, True), (100_003, 30_000, 1024, True),
+                                                  (1_000_003, 100_000, 2048, True), (600_000, 60_000, 2048, True),
+                                                  (5_000_000, 1_000_000, 2048, True)])
+def test_config5_shape(fused, n, hi, bucket_rows, tl2):
     """int64 key, float64 predicate column riding along, the key column rebuilt by the final level, the composed RowIndex"""
     rng = np.random.default_rng(n)
     fused.set_option("msd_bucket_rows", bucket_rows)
@@ -79,8 +88,8 @@ def test_config5_shape(fused, n, hi, bucket_rows):
     x = rng.standard_normal(n)
     if n > 1000:
         x[rng.random(n) < 0.01] = np.nan
-        k[rng.random(n) < 0.01] = -2**63
-    run(fused, x, ">", 0.0, [k], [k, x], expect_fused=None if n < 5000 else True)
+        k[rng.integers(0, n, 7)] = -2**63           # (a FEW NA keys: thousands of them are one big group, see the test below)
+    run(fused, x, ">", 0.0, [k], [k, x], expect_fused=None if n < 5000 else True, expect_tl2=tl2)
 
 
 @pytest.mark.parametrize("cmp,scalar", [(">", 0.25), (">=", -0.5), ("<", 0.0), ("<=", 1.0), ("==", 0.0), ("!=", 0.0), ("==", None), ("!=", None)])
@@ -93,14 +102,16 @@ def test_predicates_float64_and_int64(fused, cmp, scalar):
     xi = rng.integers(-3, 4, n).astype(np.int64); xi[rng.random(n) < 0.05] = -2**63
     w = rng.integers(-10**6, 10**6, n).astype(np.int32)
     run(fused, x, cmp, scalar, [k], [x, k], expect_fused=True)
-    run(fused, xi, cmp, None if scalar is None else int(scalar), [k], [w], expect_fused=True)
+    run(fused, xi, cmp, None if scalar is None else int(scalar), [k], [w], expect_fused=True, want_rowindex=False)
 
 
-def test_column_sets_and_orders(fused):
+@pytest.mark.parametrize("bucket_rows", [256, 2048])           # 2048: the final buckets fill windows -> tile-local level 2 too
+def test_column_sets_and_orders(fused, bucket_rows):
     rng = np.random.default_rng(6)
     n = 600_000
-    fused.set_option("msd_bucket_rows", 256)
-    k = rng.integers(0, 200_000, n).astype(np.int64); k[rng.random(n) < 0.02] = -2**63
+    fused.set_option("msd_bucket_rows", bucket_rows)
+    T = True if bucket_rows == 2048 else None
+    k = rng.integers(0, 100_000, n).astype(np.int64); k[rng.integers(0, n, 40)] = -2**63
     x = rng.standard_normal(n)
     y = rng.standard_normal(n)
     w = rng.integers(-99, 99, n).astype(np.int32)
@@ -108,10 +119,10 @@ def test_column_sets_and_orders(fused):
     for cols, ri, fusedp in (([k, x], True, True), ([x], True, True), ([], True, True), ([k], True, True), ([x, k, x, k], True, True),
                              ([w], True, False), ([w], False, True), ([w, x], False, True), ([x, y], False, True), ([f32, x], False, True),
                              ([x, y], True, False), ([w, f32], False, False), ([x, y, w], False, False), ([k], False, False)):
-        run(fused, x, ">", 0.0, [k], cols, expect_fused=fusedp, want_rowindex=ri)
-    run(fused, x, "<", 0.3, [k], [x, k], expect_fused=True, na_last=True)
-    run(fused, x, "<", 0.3, [k], [x, k], expect_fused=True, desc=[True])
-    run(fused, y, ">", 0.0, [k], [x], expect_fused=True)                         # the predicate column does not ride
+        run(fused, x, ">", 0.0, [k], cols, expect_fused=fusedp, want_rowindex=ri, expect_tl2=(T if fusedp else False))
+    run(fused, x, "<", 0.3, [k], [x, k], expect_fused=True, expect_tl2=T, na_last=True)
+    run(fused, x, "<", 0.3, [k], [x, k], expect_fused=True, expect_tl2=T, desc=[True])
+    run(fused, y, ">", 0.0, [k], [x], expect_fused=True, expect_tl2=T)           # the predicate column does not ride
 
 
 def test_queries_outside_the_fused_route(fused):
@@ -132,24 +143,38 @@ def test_queries_outside_the_fused_route(fused):
     run(fused, x, ">", 5.0e9, [a], [x, a], expect_fused=None)                    # nothing passes
 
 
-def test_clustered_sorted_and_duplicate_keys(fused):
+@pytest.mark.parametrize("bucket_rows", [64, 2048])
+def test_clustered_sorted_and_duplicate_keys(fused, bucket_rows):
     """long segments (a tile's rows all in one or two level-1 buckets: the whole-wave branch of the segment loader), a
     constant top digit, and keys with so many duplicates that a final bucket outgrows a tile (the call falls back)"""
     rng = np.random.default_rng(9)
     n = 2_000_000
-    fused.set_option("msd_bucket_rows", 64)
+    fused.set_option("msd_bucket_rows", bucket_rows)
+    T = True if bucket_rows == 2048 else None
     x = rng.standard_normal(n)
-    ks = np.sort(rng.integers(0, 5_000_000, n)).astype(np.int64)
-    run(fused, x, ">", 0.0, [ks], [ks, x], expect_fused=True)
-    run(fused, x, ">", 0.0, [ks[::-1].copy()], [x], expect_fused=True)
+    ks = np.sort(rng.integers(0, 5_000_000 if bucket_rows == 64 else 250_000, n)).astype(np.int64)
+    run(fused, x, ">", 0.0, [ks], [ks, x], expect_fused=True, expect_tl2=T)
+    run(fused, x, ">", 0.0, [ks[::-1].copy()], [x], expect_fused=True, expect_tl2=T)
     kc = (np.arange(n) // 50_000 * 1000 + rng.integers(0, 1000, n)).astype(np.int64)      # clustered in blocks of 50000 rows
-    run(fused, x, ">", -0.5, [kc], [kc, x], expect_fused=True)
+    run(fused, x, ">", -0.5, [kc], [kc, x], expect_fused=True, expect_tl2=T)
     klow = rng.integers(0, 2000, n).astype(np.int64) + 10_000_000; klow[0] = 0          # top digits constant but for one row
     run(fused, x, ">", 0.0, [klow], [klow, x], expect_fused=None)
     kdup = (rng.integers(0, 12, n) * 100_000_000 // 12).astype(np.int64)                  # 12 distinct keys over a wide range
     run(fused, x, ">", 0.0, [kdup], [kdup, x], expect_fused=None)
     kone = np.full(n, 7, np.int64)
     run(fused, x, ">", 0.0, [kone], [kone, x], expect_fused=None)
+
+
+def test_a_big_na_group_falls_back(fused):
+    """1 % NA keys are ONE group of thousands of rows: the final bucket holding it outgrows a tile, the fused route gives up
+    after its levels' plan and the call takes the two-call route -- same results"""
+    rng = np.random.default_rng(12)
+    n = 2_000_000
+    fused.set_option("msd_bucket_rows", 64)
+    k = rng.integers(0, 300_000, n).astype(np.int64); k[rng.random(n) < 0.02] = -2**63
+    x = rng.standard_normal(n)
+    run(fused, x, ">", 0.0, [k], [k, x], expect_fused=False)
+    run(fused, x, ">", 0.0, [k], [k, x], expect_fused=False, na_last=True)
 
 
 def test_guessed_key_range_violated_by_a_passing_row(fused):

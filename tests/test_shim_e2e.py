@@ -299,7 +299,7 @@ def test_every_route_in_every_residency_mode(env, residency, mode):
         assert_frames_equal(dt, _host(shim, got), exp)
         assert DT.is_resident == (mode != "off")
         V = DT[f.f8 > 0.1, [f.k, f.f8, f["i1"], f.b]]
-        assert (type(V) is shim.DeviceFrame) == (mode == "lazy")
+        assert isinstance(V, shim.DeviceFrame) == (mode == "lazy")
         Vr = dt.Frame.__getitem__(DT, (f.f8 > 0.1, [f.k, f.f8, f["i1"], f.b]))
         assert V.shape == Vr.shape and V.names == Vr.names and tuple(V.stypes) == tuple(Vr.stypes)
         R = V[:, :, shim.by(f.k)]                                             # lazy: runs on the DeviceFrame's columns
@@ -347,10 +347,12 @@ def test_config5_never_leaves_the_gpu_when_lazy(env, residency, monkeypatch):
 
     monkeypatch.setattr(shim, "_upload_column", up)
     monkeypatch.setattr(ctx, "_lib", LibSpy(ctx._lib))
+    fused0 = shim.stats["fused_filter_rows"]
     V = DT[f.x > 0, :]
-    R = V[:, :, shim.by(f.k)]
-    A = V[:, [sum(f.x), count()], shim.by(f.k)]
-    assert all(type(x) is shim.DeviceFrame for x in (V, R, A))
+    R = V[:, :, shim.by(f.k)]                          # the pending view + by(): ONE dthip_filter_groupby_rows call
+    assert shim.stats["fused_filter_rows"] == fused0 + 1
+    A = V[:, [sum(f.x), count()], shim.by(f.k)]        # anything else evaluates the view's filter first
+    assert all(isinstance(x, shim.DeviceFrame) for x in (V, R, A))
     assert moved == {"h2d": 0, "d2h": 0}, moved
     monkeypatch.undo()
     Vr = dt.Frame.__getitem__(DT, (f.x > 0, slice(None)))

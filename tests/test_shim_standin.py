@@ -7,6 +7,8 @@ lazy DeviceFrame results, result assembly and names.  The kernels themselves are
 import math
 
 import numpy as np
+
+from datatable_amd import _lib as L
 import pytest
 
 from oracle import ref
@@ -96,17 +98,30 @@ def test_config5_two_steps_stay_resident(env):
     DT = shim.Frame(k=k, x=x)
     lib = ctx._lib
     V = DT[f.x > 0, :]
+    assert isinstance(V, shim.DeviceFrame) and "pending" in repr(V) and V.names == ("k", "x")     # a view, like the reference's
     R = V[:, :, shim.by(f.k)]
-    assert type(V) is shim.DeviceFrame and type(R) is shim.DeviceFrame
+    assert type(R) is shim.DeviceFrame
+    # round 5: the two statements ran as ONE library call (the filter fused into the grouping), the filter alone never ran
+    assert [c[0] for c in lib.calls if isinstance(c, tuple)] == ["filter_groupby_rows"], lib.calls
     assert lib.uploads == 2 and lib.downloads == 0
     assert R.names == ("k", "x") and R.nrows == V.nrows == int((x > 0).sum())
+    assert ("filter_take", L.DEVICE) in lib.calls              # V.nrows made the pending view evaluate its filter
     V2 = DT[f.x > 0, :]                                        # the columns are resident: nothing is uploaded again
     assert lib.uploads == 2
+    # the view used for anything else first, then grouped: the ordinary two calls, same rows
+    assert V2.shape == (V.nrows, 2)
+    R2 = V2[:, :, shim.by(f.k)]
+    shim.options.defer_filter = False
+    try:
+        R3 = DT[f.x > 0, :][:, :, shim.by(f.k)]                # round 4's behaviour: filter at once
+    finally:
+        shim.options.defer_filter = True
     exp = dt.Frame.__getitem__(dt.Frame.__getitem__(DT, (f.x > 0, slice(None))), (slice(None), slice(None), dt.by(f.k)))
     assert_rows_equal(dt, R.to_frame(), exp)
     assert lib.downloads == 2                                  # the two result columns, once
     R.to_frame()
     assert lib.downloads == 2
+    assert_rows_equal(dt, R2.to_frame(), exp); assert_rows_equal(dt, R3.to_frame(), exp)
     assert V2.nrows == V.nrows
     # a mutation of DT drops its device copies: the next query uploads the NEW values
     DT[0, "x"] = 1e9
