@@ -14,14 +14,15 @@
 //     reference's permutation exactly (global row ids travel as a payload column);
 //   * key-range (not hash) partitioning keeps the global group order = concatenation of the ranks' results in rank
 //     order -- what the reference returns (groups ascending, NA group first / last);
-//   * the splitters balance the destinations: a 4096-bin histogram of the order-preserving 64-bit image of the first
-//     key, min-subtracted, summed over all ranks, is cut at the world-quantiles (a plain even split of [min, max]
-//     sends skewed keys to one rank).
+//   * the splitters balance the destinations: every rank contributes quantiles of the order-preserving 64-bit image of
+//     its first key -- exact ones on the aggregate path (its partial groups ascend), a stratified random sample's on the
+//     rows path -- and the weighted union is cut at the world-quantiles (a plain even split of [min, max] sends skewed
+//     keys to one rank).
 // Collectives per call.  Aggregates: the partial groups of a rank are ASCENDING in the first key, so 1024 of them at
 // evenly spaced positions are exact local quantiles: one all-gather of those samples gives every rank the same
 // splitters (no key-image pass, no histogram over the partials), one all-gather carries the send counts, one 16-byte
-// all-gather agrees on the status before the data moves.  Rows: key range (24 B), 4096-bin histogram (32 KB), send
-// counts, status.  Then one grouped all-to-all-v over all columns: xGMI is point-to-point, the grouped send/recv keeps
+// all-gather agrees on the status before the data moves.  Rows (round 5): 4096 sampled key images (32 KB), then send
+// counts + status; a status-only round only when a share exceeds the receive bound.  Then one grouped all-to-all-v over all columns: xGMI is point-to-point, the grouped send/recv keeps
 // all 7 links of a GPU busy at once.
 // Failure handling: every all-gathered blob starts with {status, query signature, rows}; a rank whose local work failed
 // keeps taking part in the all-gathers (with empty data), and after each of them ALL ranks see the failure and return
@@ -170,19 +171,6 @@ __global__ void __launch_bounds__(256) key_image_kernel(const void* data, int st
 }
 
 
-// histogram of the valid images over [gmin, gmax] in SPLIT_BINS bins of 2^shift
-__global__ void __launch_bounds__(256) image_hist_kernel(const u64* img, uint32_t n, u64 na_img, u64 gmin, int shift, u64* hist) {
-  __shared__ uint32_t h[SPLIT_BINS];
-  for (int b = threadIdx.x; b < SPLIT_BINS; b += 256) h[b] = 0;
-  __syncthreads();
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const u64 v = img[i];
-    if (v != na_img) atomicAdd(&h[(uint32_t)((v - gmin) >> shift)], 1u);
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < SPLIT_BINS; b += 256) if (h[b]) atomicAdd(&hist[b], (u64)h[b]);
-}
-
 // cuts[j] = first position of the key column (ASCENDING images) whose image is >= bounds[j]
 __global__ void lower_bound_kernel(const void* data, int stype, uint32_t n, u64 na_img, const u64* bounds, int nb, uint32_t* cuts) {
   const int j = threadIdx.x;
@@ -197,6 +185,12 @@ __global__ void lower_bound_kernel(const void* data, int stype, uint32_t n, u64 
 __global__ void __launch_bounds__(256) sample_image_kernel(const void* data, int stype, uint32_t n, uint32_t q, u64 na_img, u64* out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < q) out[i] = key_image(data, stype, (uint32_t)(((u64)i * n) / q), na_img);
+}
+
+// out[i] = img[pos[i]]: the rows path's stratified sample of key images (positions from split_plan.hpp::row_sample_pos)
+__global__ void __launch_bounds__(256) row_sample_kernel(const u64* __restrict__ img, const uint32_t* __restrict__ pos, uint32_t q, u64* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < q) out[i] = img[pos[i]];
 }
 
 // destination rank of every row: number of boundaries <= image (int8: world <= 127)
@@ -394,7 +388,7 @@ static int agree_round(dthip_comm* comm, std::vector<Job>& jobs, const char* sta
 
 // ---- shared phases (rows) -----------------------------------------------------------------------------
 // images of the first key of the rows + local range; the blob of the first all-gather
-static int phase_images(Job& j, const void* key0, int stype, int64_t n, int na_pos) {
+static int phase_images(Job& j, const void* key0, int stype, int64_t n, int na_pos, std::vector<u64>* samples = nullptr) {
   dthip_ctx* ctx = j.ctx;
   j.na_img = (na_pos == DTHIP_NA_LAST) ? ~0ULL : 0ULL;
   j.nimg = n;
@@ -405,36 +399,24 @@ static int phase_images(Job& j, const void* key0, int stype, int64_t n, int na_p
     DTHIP_TRY(j.sc->get<RangeAcc>(1, &d_acc));
     DTHIP_CHECK_HIP(hipMemcpyAsync(d_acc, &j.range, sizeof(RangeAcc), hipMemcpyHostToDevice, ctx->stream));
     DTHIP_LAUNCH(ctx, "key_image_kernel", key_image_kernel, (unsigned)std::min<int64_t>((n + 255) / 256, 4096), 256, 0, key0, stype, (uint32_t)n, j.na_img, j.img, d_acc);
-    DTHIP_TRY(read_back(ctx, &j.range, d_acc, sizeof(RangeAcc)));
+    if (samples) {
+      // round 5: the rank's stratified sample of ROW_SAMPLES images, sorted = its approximate quantiles (the key range and
+      // the histogram over it -- two all-gathers -- are not needed any more)
+      std::vector<uint32_t> pos(ROW_SAMPLES);
+      for (int i = 0; i < ROW_SAMPLES; i++) pos[i] = (uint32_t)row_sample_pos((unsigned)i, (unsigned long long)n);
+      uint32_t* d_pos = nullptr; u64* d_s = nullptr;
+      DTHIP_TRY(j.sc->get<uint32_t>(ROW_SAMPLES, &d_pos));
+      DTHIP_TRY(j.sc->get<u64>(ROW_SAMPLES, &d_s));
+      DTHIP_CHECK_HIP(hipMemcpyAsync(d_pos, pos.data(), sizeof(uint32_t) * ROW_SAMPLES, hipMemcpyHostToDevice, ctx->stream));
+      DTHIP_LAUNCH(ctx, "row_sample_kernel", row_sample_kernel, ROW_SAMPLES / 256, 256, 0, j.img, d_pos, (uint32_t)ROW_SAMPLES, d_s);
+      samples->resize(ROW_SAMPLES);
+      DTHIP_TRY(read_back(ctx, samples->data(), d_s, sizeof(u64) * ROW_SAMPLES));
+      std::sort(samples->begin(), samples->end());
+    } else {
+      DTHIP_TRY(read_back(ctx, &j.range, d_acc, sizeof(RangeAcc)));
+    }
   }
   return DTHIP_OK;
-}
-
-static GlobalRange reduce_ranges(const Job& j, int world) {
-  std::vector<RangeAcc> r(world);
-  for (int k = 0; k < world; k++) memcpy(&r[k], blob_of(j, k), sizeof(RangeAcc));
-  return reduce_key_ranges(r.data(), world);
-}
-
-static int phase_hist(Job& j, const GlobalRange& g, std::vector<u64>* hist) {
-  dthip_ctx* ctx = j.ctx;
-  hist->assign(SPLIT_BINS, 0);
-  if (j.nimg > 0 && g.nvalid > 0) {
-    u64* d_hist = nullptr;
-    DTHIP_TRY(j.sc->get<u64>(SPLIT_BINS, &d_hist));
-    DTHIP_CHECK_HIP(hipMemsetAsync(d_hist, 0, sizeof(u64) * SPLIT_BINS, ctx->stream));
-    const unsigned grid = (unsigned)std::min<int64_t>((j.nimg + 255) / 256, 2048);
-    DTHIP_LAUNCH(ctx, "image_hist_kernel", image_hist_kernel, grid, 256, 0, j.img, (uint32_t)j.nimg, j.na_img, g.gmin, g.shift, d_hist);
-    DTHIP_TRY(read_back(ctx, hist->data(), d_hist, sizeof(u64) * SPLIT_BINS));
-  }
-  return DTHIP_OK;
-}
-
-// world-1 ascending boundary images from the summed histogram (split_plan.hpp)
-static void splitters(Job& j, const GlobalRange& g, int world) {
-  std::vector<u64> h((size_t)world * SPLIT_BINS);
-  for (int r = 0; r < world; r++) memcpy(&h[(size_t)r * SPLIT_BINS], blob_of(j, r), sizeof(u64) * SPLIT_BINS);
-  split_bounds(h.data(), world, g, &j.bounds);
 }
 
 static void layout_from_counts(Job& j, int world) {
@@ -713,18 +695,20 @@ struct RowsArgs {
   int64_t nrows; int64_t row_offset; int na_pos; int mem;
 };
 
-// Phases: 1 key images + local range -> all-gather A;  2 4096-bin histogram over the global range -> all-gather B;
-// 3 splitters, destination of every row, stable partition by destination -> all-gather C (send counts);
-// 4 receive buffers -> all-gather D (status only);  5 all-to-all-v, one stable local grouping.
+// Phases (round 5: two all-gathers instead of four): 1 key images + a stratified sample of them -> all-gather A (the samples);
+// 2 splitters from the weighted union of the samples, destination of every row, stable partition by destination, receive
+// buffers of the common bound -> all-gather B (send counts + status);  [a share above the bound: exact buffers + a status
+// round];  3 all-to-all-v, one stable local grouping.
 static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std::vector<RowsArgs>& args) {
   const int world = comm->world;
   const int nkeys = args[0].nkeys, ncols = args[0].ncols;
   std::vector<std::vector<dthip_col>> kd(jobs.size()), cd(jobs.size());
   std::vector<long long*> rowid(jobs.size(), nullptr);
   PhaseClock clock(jobs);
-  // ---- 1
+  // ---- 1: key images + the rank's stratified sample of them (its approximate quantiles)
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const RowsArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
+    std::vector<u64> smp(ROW_SAMPLES, 0);
     auto local = [&]() -> int {
       DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
       kd[q].resize(nkeys); cd[q].resize(ncols);
@@ -734,34 +718,38 @@ static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std:
         DTHIP_TRY(j.sc->get<long long>((size_t)a.nrows, &rowid[q]));
         DTHIP_LAUNCH(ctx, "iota64_kernel", iota64_kernel, (unsigned)((a.nrows + 255) / 256), 256, 0, rowid[q], (uint32_t)a.nrows, (long long)a.row_offset);
       }
-      return phase_images(j, kd[q][0].data, kd[q][0].stype, a.nrows, a.na_pos);
+      return phase_images(j, kd[q][0].data, kd[q][0].stype, a.nrows, a.na_pos, &smp);
     };
     if (j.rc == DTHIP_OK) j.rc = local();
-    if (j.rc != DTHIP_OK) { j.range = RangeAcc{~0ULL, 0ULL, 0ULL}; j.nimg = 0; }
-    blob_set(j, j.nimg, &j.range, sizeof(RangeAcc));
+    if (j.rc != DTHIP_OK) j.nimg = 0;
+    smp.resize(ROW_SAMPLES, 0);
+    blob_set(j, j.nimg, smp.data(), sizeof(u64) * ROW_SAMPLES);
   }
   clock.lap("phase_local");
   DTHIP_TRY(exchange_allgather(comm, jobs));
-  DTHIP_TRY(agree(comm, jobs, "the key range scan"));
+  DTHIP_TRY(agree(comm, jobs, "the key images"));
   clock.lap("phase_allgather");
-  // ---- 2
-  const GlobalRange g = reduce_ranges(jobs[0], world);
-  for (auto& j : jobs) {
-    std::vector<u64> hist;
-    auto local = [&]() -> int { DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device)); return phase_hist(j, g, &hist); };
-    j.rc = local();
-    hist.resize(SPLIT_BINS, 0);
-    blob_set(j, j.nimg, hist.data(), sizeof(u64) * SPLIT_BINS);
-  }
-  clock.lap("phase_local");
-  DTHIP_TRY(exchange_allgather(comm, jobs));
-  DTHIP_TRY(agree(comm, jobs, "the key histogram"));
-  clock.lap("phase_allgather");
-  // ---- 3: destination of every row, slabs in sender row order
+  // ---- 2: splitters from the weighted union of the samples, destination of every row, slabs in sender row order;
+  // receive buffers of the bound every rank computes alike (fair share + 1/8 of all rows) BEFORE the counts travel
   const int npay = nkeys + ncols + 1;                 // keys, columns, global row id
+  int64_t recv_bound = 0;
+  {
+    long long total = 0;
+    for (int r = 0; r < world; r++) total += hdr_of(jobs[0], r).n;
+    recv_bound = rows_recv_bound(total, world);
+  }
+  auto alloc_recv = [&](Job& j, int64_t rows) -> int {
+    for (auto& c : j.cols) { unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)rows * c.elem + 16, &r)); c.recv = r; }
+    return DTHIP_OK;
+  };
   for (size_t q = 0; q < jobs.size(); q++) {
     Job& j = jobs[q]; const RowsArgs& a = args[q]; dthip_ctx* ctx = j.ctx;
-    splitters(j, g, world);
+    {
+      std::vector<u64> all((size_t)world * ROW_SAMPLES);
+      std::vector<long long> cnt(world);
+      for (int r = 0; r < world; r++) { memcpy(&all[(size_t)r * ROW_SAMPLES], blob_of(j, r), sizeof(u64) * ROW_SAMPLES); cnt[r] = hdr_of(j, r).n; }
+      sample_bounds_q(all.data(), cnt.data(), world, ROW_SAMPLES, &j.bounds);
+    }
     j.send_cnt.assign(world, 0); j.send_off.assign(world, 0);
     auto local = [&]() -> int {
       DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
@@ -794,7 +782,7 @@ static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std:
       } else if (world == 1) {
         j.send_cnt[0] = a.nrows;
       }
-      return DTHIP_OK;
+      return alloc_recv(j, recv_bound);
     };
     j.rc = local();
     j.nsend = a.nrows;
@@ -802,21 +790,26 @@ static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std:
   }
   clock.lap("phase_local");
   DTHIP_TRY(exchange_allgather(comm, jobs));
-  DTHIP_TRY(agree(comm, jobs, "the partition of the rows"));
+  DTHIP_TRY(agree(comm, jobs, "the partition of the rows / the allocation of the receive buffers"));
   clock.lap("phase_allgather");
-  // ---- 4
-  for (auto& j : jobs) {
-    layout_from_counts(j, world);
-    auto local = [&]() -> int {
-      DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device));
-      for (auto& c : j.cols) { unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)j.nrecv * c.elem + 16, &r)); c.recv = r; }
-      return DTHIP_OK;
-    };
-    j.rc = local();
+  // ---- 3: exact receive layout; every rank sees the whole count matrix, so all ranks agree WITHOUT another round on whether
+  // somebody's share exceeds the bound (one key holding most of the rows: then exact buffers and a status round)
+  bool exceeded = false;
+  for (auto& j : jobs) layout_from_counts(j, world);
+  for (int r = 0; r < world; r++) {
+    int64_t recv_r = 0;
+    for (int s_ = 0; s_ < world; s_++) { int64_t c = 0; memcpy(&c, blob_of(jobs[0], s_) + sizeof(int64_t) * (size_t)r, sizeof(c)); recv_r += c; }
+    if (recv_r > recv_bound) exceeded = true;
   }
-  clock.lap("phase_plan");
-  DTHIP_TRY(agree_round(comm, jobs, "the allocation of the receive buffers"));
-  clock.lap("phase_allgather");
+  if (exceeded) {
+    for (auto& j : jobs) {
+      auto local = [&]() -> int { DTHIP_CHECK_HIP(hipSetDevice(j.ctx->device)); return alloc_recv(j, j.nrecv); };
+      j.rc = local();
+    }
+    clock.lap("phase_plan");
+    DTHIP_TRY(agree_round(comm, jobs, "the allocation of the receive buffers"));
+    clock.lap("phase_allgather");
+  }
   // ---- 5
   DTHIP_TRY(exchange_alltoallv(comm, jobs));
   clock.lap("phase_alltoallv");

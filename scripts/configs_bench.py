@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--once", action="store_true", help="evaluate every query exactly once (rocprofv3 PMC passes: counters per query)")
     ap.add_argument("--agg-path", type=int, default=0)
     ap.add_argument("--bucket-variant", type=int, default=0)
+    ap.add_argument("--c5-two-calls", action="store_true", help="config 5 as dthip_filter_take + dthip_groupby_rows (round 4's form)")
     ap.add_argument("--c5-unfused", action="store_true", help="config 5 with filter_cmp + two gathers instead of filter_take")
     args = ap.parse_args()
     import torch
@@ -122,8 +123,14 @@ def main():
             kbuf = torch.empty(n, dtype=torch.int64, device=dev)
             xbuf = torch.empty(n, dtype=torch.float64, device=dev)
             def run():
-                # V = DT[f.x > 0, :]; V[:, :, by(f.k)]: filter -> RowIndex -> view gather (ascending) ->
-                # group, the key, the value and the filter's RowIndex riding through the sort
+                # V = DT[f.x > 0, :]; V[:, :, by(f.k)]: round 5 = ONE call (dthip_filter_groupby_rows: the filter fused into the
+                # first sort level, tile-local levels); --c5-two-calls = round 4's filter_take + groupby_rows with the filter's
+                # RowIndex riding through the sort; --c5-unfused = round 1's filter_cmp + two gathers
+                if not (args.c5_unfused or args.c5_two_calls):
+                    r = ctx.filter_groupby_rows(devcol(x), ">", 0.0, [devcol(k)], [devcol(k), devcol(x)], nrows=n, want_rowindex=True)
+                    ng = r.ngroups
+                    r.free()
+                    return ng
                 if args.c5_unfused:
                     npass = ctx.filter_cmp_dev(devcol(x), n, ">", 0.0, ri.data_ptr())
                     kv = torch.empty(npass, dtype=torch.int64, device=dev)

@@ -26,9 +26,15 @@ def main(fetch_txt, write_txt, rows, out_path):
         b = f.get(k, 0.0) * 2 * 1024 + w.get(k, 0.0) * 1024
         res[k] = {"fetch_KB_raw": f.get(k), "write_KB_raw": w.get(k),
                   "hbm_bytes_per_launch_at_rows": {str(rows): b}}
+    # the library build the counters were taken on (bench.py drops the record when it runs on another build)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from datatable_amd import _lib
+    res["_build_id"] = _lib.load().dthip_build_id().decode()
     json.dump(res, open(out_path, "w"), indent=1)
     for k, v in res.items():
-        print("%-32s %.3f GB / launch" % (k, v["hbm_bytes_per_launch_at_rows"][str(rows)] / 1e9))
+        if not k.startswith("_"):
+            print("%-32s %.3f GB / launch" % (k, v["hbm_bytes_per_launch_at_rows"][str(rows)] / 1e9))
 
 
 if __name__ == "__main__":

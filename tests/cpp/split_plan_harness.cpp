@@ -90,3 +90,29 @@ extern "C" int sp_bounds_from_hist(const unsigned long long* ranges3, const unsi
   for (size_t k = 0; k < b.size(); k++) bounds[k] = b[k];
   return 0;
 }
+
+// the rows path (round 5): every rank's slice imgs[cuts[r] .. cuts[r+1]) in ROW order; samples at row_sample_pos, sorted
+// per rank (what comm.hip's row_sample_kernel + the host's std::sort produce), then sample_bounds_q
+extern "C" int sp_row_sample_bounds(const unsigned long long* imgs, const long long* cuts, int world, unsigned long long* bounds) {
+  using namespace dthip;
+  std::vector<unsigned long long> smp((size_t)world * ROW_SAMPLES, 0);
+  std::vector<long long> n(world);
+  for (int r = 0; r < world; r++) {
+    n[r] = cuts[r + 1] - cuts[r];
+    if (n[r] <= 0) continue;
+    for (int i = 0; i < ROW_SAMPLES; i++) smp[(size_t)r * ROW_SAMPLES + i] = imgs[cuts[r] + (long long)row_sample_pos((unsigned)i, (unsigned long long)n[r])];
+    std::sort(smp.begin() + (size_t)r * ROW_SAMPLES, smp.begin() + (size_t)(r + 1) * ROW_SAMPLES);
+  }
+  std::vector<unsigned long long> b;
+  sample_bounds_q(smp.data(), n.data(), world, ROW_SAMPLES, &b);
+  for (size_t k = 0; k < b.size(); k++) bounds[k] = b[k];
+  return ROW_SAMPLES;
+}
+extern "C" unsigned long long sp_row_sample_pos(unsigned i, unsigned long long n) { return dthip::row_sample_pos(i, n); }
+extern "C" int sp_bounds_from_row_samples(const unsigned long long* samples, const long long* n, int world, unsigned long long* bounds) {
+  std::vector<unsigned long long> b;
+  dthip::sample_bounds_q(samples, n, world, dthip::ROW_SAMPLES, &b);
+  for (size_t k = 0; k < b.size(); k++) bounds[k] = b[k];
+  return dthip::ROW_SAMPLES;
+}
+extern "C" long long sp_rows_recv_bound(long long total, int world) { return dthip::rows_recv_bound(total, world); }

@@ -2,8 +2,9 @@
 process per rank, with the CPU oracle standing in for the per-rank HIP kernels.  What it shares with the product is the
 host-side planning code itself -- csrc/split_plan.hpp compiled by g++ (tests/cpp/split_plan_harness.cpp): quantile
 splitters (sample_bounds), histogram splitters (reduce_key_ranges / split_bounds), the {status, signature, n} header of
-every all-gathered blob and first_failure -- and the phase order: all-gather A (samples | range), [B histogram], send
-counts, status, all-to-all-v, merge.  Used by tests/test_dist_gloo.py (world_size 2)."""
+every all-gathered blob and first_failure -- and the phase order: all-gather A (quantile samples: exact on the aggregate
+path, a stratified random sample on the rows path), B (send counts + status), [C status when a share exceeds the receive
+bound], all-to-all-v, merge.  Used by tests/test_dist_gloo.py (world_size 2)."""
 import ctypes as C
 import os
 import struct
@@ -152,34 +153,44 @@ def sharded_groupby_agg(local_agg, keys, values, aggs, sig=1, fail=False, na_las
     return mk, out
 
 
-def sharded_groupby_rows(local_rows, keys, cols, row_offset, sig=2, na_last=False):
-    """rows in grouped order: range (A), histogram (B), counts (C), status (D), all-to-all-v, one stable local grouping.
-    local_rows(keys, cols) -> (offsets, cols in grouped order)."""
+ROW_Q = 4096
+
+
+def sharded_groupby_rows(local_rows, keys, cols, row_offset, sig=2, na_last=False, stats=None):
+    """rows in grouped order (round 5: TWO all-gathers): A = every rank's stratified sample of ROW_Q key images, sorted
+    (positions: split_plan.hpp row_sample_pos); splitters from the weighted union (sample_bounds_q); B = send counts +
+    status, receive buffers sized by rows_recv_bound beforehand; a status-only round C only when a share exceeds that bound;
+    all-to-all-v; one stable local grouping.  local_rows(keys, cols) -> (offsets, cols in grouped order)."""
     world = dist.get_world_size()
+    H = harness()
+    H.sp_row_sample_pos.restype = C.c_ulonglong
+    H.sp_rows_recv_bound.restype = C.c_longlong
     n = len(keys[0])
     img = image(keys[0], na_last)
-    na_img = np.uint64(2**64 - 1) if na_last else np.uint64(0)
-    valid = img != na_img
-    rng = np.array([img[valid].min() if valid.any() else 2**64 - 1, img[valid].max() if valid.any() else 0, int(valid.sum())], np.uint64)
-    blobs = allgather_blob(0, sig, n, rng.tobytes())                                     # A
+    smp = np.zeros(ROW_Q, np.uint64)
+    if n:
+        pos = np.array([H.sp_row_sample_pos(C.c_uint(i), C.c_ulonglong(n)) for i in range(ROW_Q)], np.int64)
+        smp = np.sort(img[pos])                                                            # row_sample_kernel + std::sort
+    blobs = allgather_blob(0, sig, n, smp.tobytes())                                      # A
     _check(blobs)
-    ranges = np.concatenate([np.frombuffer(b[3], np.uint64) for b in blobs])
-    gmin, shift, nvalid = C.c_ulonglong(0), C.c_int(0), C.c_ulonglong(0)
-    assert harness().sp_range(ranges.ctypes.data_as(C.c_void_p), world, C.byref(gmin), C.byref(shift), C.byref(nvalid)) == BINS
-    hist = np.zeros(BINS, np.uint64)
-    if nvalid.value and valid.any():
-        hist = np.bincount(((img[valid] - np.uint64(gmin.value)) >> np.uint64(shift.value)).astype(np.int64), minlength=BINS).astype(np.uint64)
-    blobs = allgather_blob(0, sig, n, hist.tobytes())                                    # B
-    _check(blobs)
-    allhist = np.concatenate([np.frombuffer(b[3], np.uint64) for b in blobs])
+    allsmp = np.concatenate([np.frombuffer(b[3], np.uint64) for b in blobs])
+    ns = (C.c_longlong * world)(*[b[2] for b in blobs])
     bounds = np.zeros(max(world - 1, 1), np.uint64)
-    harness().sp_bounds_from_hist(ranges.ctypes.data_as(C.c_void_p), allhist.ctypes.data_as(C.c_void_p), world,
-                                  bounds.ctypes.data_as(C.c_void_p))
+    assert H.sp_bounds_from_row_samples(allsmp.ctypes.data_as(C.c_void_p), ns, world, bounds.ctypes.data_as(C.c_void_p)) == ROW_Q
     dest = np.searchsorted(bounds[:world - 1], img, side="right")                         # image_dest_kernel
     order = np.argsort(dest, kind="stable")                                               # stable partition by destination
     send_cnt = np.bincount(dest, minlength=world)
-    recv_cnt = _exchange_counts(send_cnt, sig)                                            # C
-    _check(allgather_blob(0, sig, 0, b""))                                                # D
+    bound = H.sp_rows_recv_bound(C.c_longlong(sum(b[2] for b in blobs)), world)
+    blobs = allgather_blob(0, sig, n, send_cnt.astype(np.int64).tobytes())                # B: counts + status
+    _check(blobs)
+    mat = np.stack([np.frombuffer(b[3], np.int64) for b in blobs])                       # [sender][receiver]
+    recv_cnt = mat[:, dist.get_rank()].copy()
+    rounds = 2
+    if (mat.sum(axis=0) > bound).any():                                                   # every rank sees the same matrix
+        _check(allgather_blob(0, sig, 0, b""))                                            # C: exact buffers allocated
+        rounds = 3
+    if stats is not None:
+        stats["allgathers"] = rounds
     rowid = np.arange(row_offset, row_offset + n, dtype=np.int64)
     rk = [_a2av(torch.from_numpy(np.ascontiguousarray(k[order])), send_cnt, recv_cnt).numpy() for k in keys]
     rc = [_a2av(torch.from_numpy(np.ascontiguousarray(c[order])), send_cnt, recv_cnt).numpy() for c in list(cols) + [rowid]]

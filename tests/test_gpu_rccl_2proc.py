@@ -146,3 +146,5 @@ def test_bench_two_ranks_end_to_end(fake_rccl):
         assert set(r["phases_ms_rank0"]) >= {"local", "allgather", "alltoallv", "merge"}, (c, r)
         assert 0 < r["xgmi_frac_of_step"] < 1 and r["hbm_frac"] > 0
     assert 3_000_000 < line["configs"]["C4"]["groups"] <= 3163 * 3163        # 4e6 rows over 1e7 possible (a, b) pairs
+    # round 5: the rows path (C5) needs two all-gather rounds too (sampled key images; send counts + status)
+    assert line["configs"]["C5"]["allgathers"] == 2 and line["configs"]["C4"]["allgathers"] == 2

@@ -147,6 +147,83 @@ def test_sample_splitters_balance(lib, world, kind):
         assert abs(int(got[:kk].sum()) - total * kk / world) <= slack, (kk, got, slack)
 
 
+# ---- the rows path (round 5): splitters from every rank's stratified random sample of 4096 row images ---------------------
+def row_sample_plan(lib, slices):
+    """slices: one uint64 image array per rank, in ROW order (unsorted)"""
+    world = len(slices)
+    imgs = np.ascontiguousarray(np.concatenate(slices) if slices else np.zeros(0, np.uint64), np.uint64)
+    cuts = np.array([0] + list(np.cumsum([len(s) for s in slices])), np.int64)
+    bounds = np.zeros(max(world - 1, 1), np.uint64)
+    assert lib.sp_row_sample_bounds(imgs.ctypes.data_as(C.c_void_p), cuts.ctypes.data_as(C.c_void_p), world,
+                                    bounds.ctypes.data_as(C.c_void_p)) == 4096
+    return bounds[:world - 1]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8, 64])
+@pytest.mark.parametrize("kind", ["uniform", "skew", "wide", "uneven", "sorted", "periodic", "clustered"])
+def test_row_sample_splitters_balance(lib, world, kind):
+    """shares within a few standard errors of a random sample (sqrt(p (1 - p) / samples) of the total), whatever the row
+    order: random, sorted (every rank holds its own key range), periodic with a period that divides the strata, clustered"""
+    rng = np.random.default_rng(world * 17 + len(kind))
+    n = 600_000
+    if kind == "skew":
+        k = (rng.random(n) ** 8 * 1e12).astype(np.int64)
+    elif kind == "wide":
+        k = rng.integers(-2**62, 2**62, n)
+    elif kind == "periodic":
+        k = (np.arange(n) % 4096) * 1000 + rng.integers(0, 10, n)
+    elif kind == "clustered":
+        k = (np.arange(n) // 5000) * 10_000 + rng.integers(0, 100, n)
+    else:
+        k = rng.integers(0, 10**7, n)
+    if kind == "sorted":
+        k = np.sort(k)
+    if kind == "uneven":
+        cuts = [0] + sorted(rng.integers(0, n + 1, world - 1).tolist()) + [n]
+    else:
+        cuts = [r * n // world for r in range(world + 1)]
+    slices = [image_i64(k[cuts[r]:cuts[r + 1]]) for r in range(world)]
+    b = row_sample_plan(lib, slices)
+    assert np.all(b[1:] >= b[:-1])
+    allimg = np.concatenate(slices)
+    got = np.bincount(dest(b, allimg), minlength=world)
+    assert got.sum() == n
+    # destinations are monotone in the key
+    order = np.argsort(allimg, kind="stable")
+    assert np.all(np.diff(dest(b, allimg)[order]) >= 0)
+    lib.sp_rows_recv_bound.restype = C.c_longlong
+    bound = lib.sp_rows_recv_bound(C.c_longlong(n), world)
+    nsamp = 4096 * sum(1 for s in slices if len(s))
+    heavy = int(np.unique(allimg, return_counts=True)[1].max())           # one key is never cut: the granularity of any splitter
+    for kk in range(1, world):
+        p = kk / world
+        se = n * (p * (1 - p) / nsamp) ** 0.5
+        assert abs(int(got[:kk].sum()) - n * p) <= 6 * se + 4 * n / 4096 / world + 64 + heavy, (kind, kk, got[:kk].sum(), n * p, se)
+    assert got.max() <= bound + heavy, "a share above the receive bound on well-behaved keys"
+
+
+def test_row_sample_positions_and_heavy_keys(lib):
+    lib.sp_row_sample_pos.restype = C.c_ulonglong
+    for n in (1, 2, 100, 4095, 4096, 4097, 10**6, 2**31 - 1):
+        pos = np.array([lib.sp_row_sample_pos(C.c_uint(i), C.c_ulonglong(n)) for i in range(4096)], np.int64)
+        assert pos.min() >= 0 and pos.max() < n and np.all(np.diff(pos) >= 0)
+        if n >= 4096:
+            assert np.all(np.diff(pos) >= 0) and len(np.unique(pos)) == 4096          # one row per stratum
+    # one key holding 70 % of the rows is never cut: its owner's share exceeds the bound, which the count matrix shows to
+    # every rank (comm.hip then allocates exactly and runs the status round)
+    rng = np.random.default_rng(3)
+    n = 200_000
+    k = np.where(rng.random(n) < 0.7, 5_000_000, rng.integers(0, 10**7, n))
+    slices = [image_i64(k[r * n // 4:(r + 1) * n // 4]) for r in range(4)]
+    b = row_sample_plan(lib, slices)
+    got = np.bincount(dest(b, np.concatenate(slices)), minlength=4)
+    lib.sp_rows_recv_bound.restype = C.c_longlong
+    assert got.max() >= 0.7 * n and got.max() > lib.sp_rows_recv_bound(C.c_longlong(n), 4)
+    # empty ranks and a rank with fewer rows than samples
+    b = row_sample_plan(lib, [np.zeros(0, np.uint64), image_i64(rng.integers(0, 1000, 50)), image_i64(rng.integers(0, 1000, 100_000))])
+    assert np.all(b[1:] >= b[:-1])
+
+
 def test_sample_splitters_edge_cases(lib):
     # no partial groups anywhere; one rank only; a single distinct key; the NA image (0) next to valid ones
     assert list(sample_plan(lib, [np.zeros(0, np.uint64)] * 4)) == [2**64 - 1] * 3
