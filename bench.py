@@ -316,7 +316,7 @@ def run_configs(ctx, dev, which, steps, scale, verify, cpu_sample, ref_threads, 
                      "alg_bytes": alg_bytes, "alg_GBs": alg_bytes / sec / 1e9, "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS,
                      "dominant_kernel": dom, "dominant_ms": prof[dom][0] if dom else None,
                      "kernel_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]}}
-        # HBM bytes of one whole query from the rocprofv3 PMC passes recorded under profiles/ (scripts/prof_r04.sh):
+        # HBM bytes of one whole query from the rocprofv3 PMC passes recorded under profiles/ (scripts/prof.sh):
         # FETCH_SIZE x 2 + WRITE_SIZE over every kernel of the query; amplification = traffic / algorithmic bytes
         doc, why = pmc_records()
         rec = doc.get("_configs", {}).get(name)

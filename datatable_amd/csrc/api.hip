@@ -2045,7 +2045,8 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
   ta.keepx = -1; ta.pay.n = nride;
   for (int q = 0; q < nride; q++) {
     ta.pay.in[q] = cd[ride[q]].data; ta.pay.out[q] = l1[q]; ta.pay.width[q] = payw[q];
-    if (cd[ride[q]].data == pred.data && payw[q] == 8) ta.keepx = q;
+    static const bool keepx_on = !(getenv("DTHIP_TL_KEEPX") && atoi(getenv("DTHIP_TL_KEEPX")) == 0);     // (A/B: re-read the predicate column instead)
+    if (keepx_on && cd[ride[q]].data == pred.data && payw[q] == 8) ta.keepx = q;
   }
   ta.bad = plan.speculative ? tot + nb1 : nullptr;
   DTHIP_TRY(launch_tl_level1(ctx, ta));

@@ -385,7 +385,12 @@ int launch_msd_scan(dthip_ctx* ctx, uint32_t* gtot, const uint32_t* gfirst, cons
 //        -- give every row its place in the window; rows, ordered, go back over the window's own row range
 // GATH = the tile's rows are gathered from the segments of a tile-local level above (RadixPass::g_dirT): their global rows
 //        are listed in LDS first (in the exchange buffer, free until the ranking), every load goes through that list
-//        (1: a level reading the first, tile-local level; 2: the final level over windows reading a tile-local second level)
+//        (1: a level reading the first, tile-local level and scattering to exact positions; 3: the same level writing its
+//        rows tile-locally again + a directory; 2: the final level over windows reading a tile-local second level)
+// A tile whose rows go back over ONE contiguous row range -- the windowed final level (R2) and GATH == 3 -- knows its global
+// positions at compile time (first row + slot): no per-row position array, no digit recomputation for the stores.  PMC showed
+// why that matters (profiles/r05_c5_pmc.txt): the 26-28 spilled VGPRs of these instances were 3.6 + 5.1 GB of scratch
+// WRITES per config-5 query, a quarter of what the two kernels wrote.
 template <typename KeyT, int RB, int P0W, int P1W = 0, int RK = 0, int BLK = RP_BLOCK, bool R2 = false, int GATH = 0>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) radix_pass_kernel(PassArgsT<KeyT> a) {
   constexpr int BLOCK = BLK, ITEMS = RP_ITEMS;
@@ -430,7 +435,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
   const uint32_t wbase = (uint32_t)wave * chunk + (uint32_t)lane;
 #define RP_VALID(i) (64u * (uint32_t)(i) < chunk && wbase + 64u * (uint32_t)(i) < nvalid)
   const uint32_t* gsrc_rows = reinterpret_cast<const uint32_t*>(exch);       // GATH: global row of the tile's v-th row
-  if (GATH == 1) {
+  constexpr bool SEQOUT = R2 || GATH == 3;       // the tile's rows go back, in tile-sorted order, over [tile_base, tile_base + nvalid)
+  if (GATH == 1 || GATH == 3) {
     const uint32_t bkt = a.tdesc[4 * tile + 3];
     tl_build_src<BLOCK>(reinterpret_cast<uint32_t*>(exch), a.dirT, a.dstride, a.cc, a.ntb, a.ntiles1, a.T1, bkt,
                         tile_base - a.pstart[bkt], nvalid);
@@ -647,9 +653,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     const int b = tid * KB + k;
     if (b < bins) {
       bin_excl[b] = excl;
-      if (GATH == 1 && a.dir2) {
+      if (GATH == 3) {
         // second tile-local level: the tile's rows go over its own rows of the outputs, the directory says where digit b starts
-        bin_delta[b] = tile_base;
         a.dir2[(size_t)tile * (uint32_t)(bins + 1) + b] = (uint16_t)excl;
         if (b == bins - 1) a.dir2[(size_t)tile * (uint32_t)(bins + 1) + bins] = (uint16_t)nvalid;
       } else
@@ -714,7 +719,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
   }
 #endif
   // thread owns slots (g*BLOCK + tid)*4 .. +3 for g in [0, GROUPS)
-  uint32_t gpos[ITEMS];
+  uint32_t gpos[SEQOUT ? 1 : ITEMS];
 #pragma unroll
   for (int g = 0; g < GROUPS; g++) {
     const uint32_t s0 = ((uint32_t)g * BLOCK + tid) * 4u;
@@ -724,9 +729,13 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       kk[j] = ek[s0 + j];     // slots beyond nvalid hold stale data, never stored
-      const uint32_t d = (uint32_t)(kk[j] >> a.shift) & dmask;
-      gp[j] = bin_delta[d] + s0 + j;
-      gpos[g * 4 + j] = gp[j];
+      if (SEQOUT) {
+        gp[j] = tile_base + s0 + j;
+      } else {
+        const uint32_t d = (uint32_t)(kk[j] >> a.shift) & dmask;
+        gp[j] = bin_delta[d] + s0 + j;
+        gpos[g * 4 + j] = gp[j];
+      }
     }
     if (a.ukout) {
       // inverse of the integer key transform (sort.cc:728-776), as in group.hip's untransform_kernel
@@ -776,7 +785,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
         const uint32_t nv = s0 < nvalid ? (nvalid - s0 < 4u ? nvalid - s0 : 4u) : 0u;
         uint32_t vv[4], gp[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { vv[j] = e4[s0 + j]; gp[j] = gpos[g * 4 + j]; }
+        for (int j = 0; j < 4; j++) { vv[j] = e4[s0 + j]; gp[j] = SEQOUT ? tile_base + s0 + j : gpos[g * 4 + j]; }
         if (nv) store_group4<uint32_t>(pout, gp, vv, nv);
       }
     } else {
@@ -802,7 +811,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
         unsigned long long vv[4];
         uint32_t gp[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { vv[j] = e8[s0 + j]; gp[j] = gpos[g * 4 + j]; }
+        for (int j = 0; j < 4; j++) { vv[j] = e8[s0 + j]; gp[j] = SEQOUT ? tile_base + s0 + j : gpos[g * 4 + j]; }
         if (nv) store_group4<unsigned long long>(pout, gp, vv, nv);
       }
     }
@@ -923,6 +932,18 @@ static int launch_pass_gather(dthip_ctx* ctx, const RadixPass& p) {
       !((w0 == 8 && (w1 == 0 || w1 == 4 || w1 == 8)) || (w0 == 4 && w1 == 0))) {
     set_error("radix pass: gather mode takes 4-byte keys, ragged tiles and payload widths 8 / 8+4 / 8+8 / 4");
     return DTHIP_EINVAL;
+  }
+  if (p.tl_dir2) {                // tile-local output + directory
+    if (p.bits > 8) {
+      if (w0 == 8 && w1 == 4) return launch_pass_r<uint32_t, 9, 8, 4, 1, RP_BLOCK, false, 3>(ctx, p);
+      if (w0 == 8 && w1 == 8) return launch_pass_r<uint32_t, 9, 8, 8, 1, RP_BLOCK, false, 3>(ctx, p);
+      if (w0 == 8) return launch_pass_r<uint32_t, 9, 8, 0, 1, RP_BLOCK, false, 3>(ctx, p);
+      return launch_pass_r<uint32_t, 9, 4, 0, 1, RP_BLOCK, false, 3>(ctx, p);
+    }
+    if (w0 == 8 && w1 == 4) return launch_pass_r<uint32_t, 8, 8, 4, 1, RP_BLOCK, false, 3>(ctx, p);
+    if (w0 == 8 && w1 == 8) return launch_pass_r<uint32_t, 8, 8, 8, 1, RP_BLOCK, false, 3>(ctx, p);
+    if (w0 == 8) return launch_pass_r<uint32_t, 8, 8, 0, 1, RP_BLOCK, false, 3>(ctx, p);
+    return launch_pass_r<uint32_t, 8, 4, 0, 1, RP_BLOCK, false, 3>(ctx, p);
   }
   if (p.bits > 8) {
     if (w0 == 8 && w1 == 4) return launch_pass_r<uint32_t, 9, 8, 4, 1, RP_BLOCK, false, 1>(ctx, p);

@@ -1,8 +1,11 @@
 #!/bin/bash
-# integration/build_dt_hip.sh -- the IN-TREE S-grp binding, built: the reference (h2oai/datatable, /root/reference) with
-# integration/patches/s_grp_sort_cc.patch applied, so that its own `group()` (src/core/sort.cc:1411) hands fixed-width key
-# columns to libdthip.so's dthip_groupby when DTHIP_LIB points at the library (dlopen: no link dependency; everything the
-# library does not take falls through to the reference's own code).  Every `by()`, `sort()`, `Frame.sort`, `unique`, set
+# integration/build_dt_hip.sh -- the IN-TREE bindings, built: the reference (h2oai/datatable, /root/reference) with
+# integration/patches/*.patch applied --
+#   s_grp_sort_cc.patch              S-grp: `group()` (src/core/sort.cc:1411) hands fixed-width key columns to dthip_groupby
+#   s_red_fexpr_reduce_unary_cc.patch  S-red: FExpr_ReduceUnary::evaluate_n (expr/fexpr_reduce_unary.cc:32) computes the
+#                                    sum / mean / min / max / count columns with dthip_reduce
+# -- when DTHIP_LIB points at libdthip.so (dlopen: no link dependency; everything the library does not take falls through
+# to the reference's own code).  Every `by()`, `sort()`, `Frame.sort`, `unique`, set
 # function, `Frame.key = ...` and join of the patched build then runs its grouping on the MI355X -- and the reference's OWN
 # test-suite becomes a parity suite of the HIP path (scripts/run_ref_suite.sh, summary under profiles/).
 #
@@ -23,14 +26,14 @@ FORCE=0; [ "${1:-}" = "--force" ] && FORCE=1
 if [ ! -d "$SRC/src/core" ]; then
   echo "build_dt_hip: $SRC not present (GPU box?) -- using the prebuilt integration/_dt_hip as is" >&2; exit 0
 fi
-if ls "$OUT"/datatable/lib/_datatable*.so >/dev/null 2>&1 && [ $FORCE -eq 0 ] && [ "$OUT/PROVENANCE.txt" -nt "$HERE/patches/s_grp_sort_cc.patch" ]; then
+if ls "$OUT"/datatable/lib/_datatable*.so >/dev/null 2>&1 && [ $FORCE -eq 0 ] && [ -z "$(find "$HERE/patches" -name "*.patch" -newer "$OUT/PROVENANCE.txt")" ]; then
   echo "build_dt_hip: integration/_dt_hip already built (use --force to rebuild)"; exit 0
 fi
 rm -rf "$WORK"; mkdir -p "$WORK"
 if [ -d "$BASE/build" ]; then cp -r "$BASE"/. "$WORK"/; else cp -r "$SRC"/. "$WORK"/; fi
 chmod -R u+w "$WORK"
-cp "$SRC/src/core/sort.cc" "$WORK/src/core/sort.cc"                 # (the unpatched file, whatever the base held)
-( cd "$WORK" && patch -p1 --no-backup-if-mismatch < "$HERE/patches/s_grp_sort_cc.patch" )
+for f in src/core/sort.cc src/core/expr/fexpr_reduce_unary.cc; do cp "$SRC/$f" "$WORK/$f"; done      # (the unpatched files, whatever the base held)
+for pf in "$HERE"/patches/*.patch; do ( cd "$WORK" && patch -p1 --no-backup-if-mismatch < "$pf" ); done
 ( cd "$WORK" && python ci/ext.py build > "$WORK/build_hip.log" 2>&1 ) || { tail -30 "$WORK/build_hip.log"; exit 1; }
 SO=$(ls "$WORK"/src/datatable/lib/_datatable*.so | head -1)
 rm -rf "$OUT"; mkdir -p "$OUT"
@@ -45,7 +48,7 @@ cp "$SRC/tests/__init__.py" "$SRC/tests/conftest.py" "$SRC/tests/test-groups.py"
    "$SRC/tests/test-sets.py" "$SRC/tests/test-join.py" "$OUT/ref/tests/"
 cp -r "$SRC/tests/ijby" "$SRC/tests/dt" "$OUT/ref/tests/"
 {
-  echo "reference: $SRC + integration/patches/s_grp_sort_cc.patch ($(sha256sum "$HERE/patches/s_grp_sort_cc.patch" | cut -c1-16))"
+  echo "reference: $SRC + integration/patches/*.patch ($(cat "$HERE"/patches/*.patch | sha256sum | cut -c1-16))"
   echo "built: $(date -u +%Y-%m-%dT%H:%M:%SZ) by integration/build_dt_hip.sh"
 } > "$OUT/PROVENANCE.txt"
 PYTHONPATH="$OUT" python -c "import datatable as dt; print('build_dt_hip: integration/_dt_hip ok, datatable', dt.__version__)"

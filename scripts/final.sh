@@ -1,9 +1,8 @@
 #!/bin/bash
-# round-end evidence: default bench line (with cpu baseline), rocprofv3 stats + PMC
-TAG=${1:-r01c}
-mkdir -p gpurun_out
-( time python bench.py ) > gpurun_out/bench_default_$TAG.log 2>&1
-grep '^{' gpurun_out/bench_default_$TAG.log | tail -1 > gpurun_out/bench_default_$TAG.json
-tail -4 gpurun_out/bench_default_$TAG.log | cut -c1-600
-bash scripts/prof.sh $TAG > gpurun_out/prof_$TAG.log 2>&1
-tail -30 gpurun_out/prof_$TAG.log
+# end-of-round evidence in one GPU call: the whole GPU suite, the default bench line, the rocprofv3 profiles
+export TMPDIR=/tmp
+OUT=gpurun_out/final; rm -rf $OUT; mkdir -p $OUT
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=15 > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log
+tail -6 $OUT/pytest.log
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+timeout 2400 bash scripts/prof.sh r05 > $OUT/prof.log 2>&1; tail -40 $OUT/prof.log
