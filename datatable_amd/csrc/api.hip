@@ -431,6 +431,40 @@ static MsdPlan msd_plan(const dthip_ctx* ctx, int64_t n, int bits, int key64, ui
   return msd_split(n, bits, tile, ctx->msd_bucket_rows, rbmax);       // (host logic: csrc/msd_plan.hpp, tests/test_msd_plan.py)
 }
 
+// ---- windows of the final MSD level (whole buckets, together at most one tile of rows), planned on the device ----------
+// Round 5: packed greedily per parent bucket (radix.hip msd_window_greedy_kernel; DTHIP_MSD_GREEDY=0: round 4's equal-step
+// windows, kept for A/B).  ok = the windowed final level can run; maxsize = the largest final bucket either way.
+struct WindowPlan { bool ok = false; uint32_t nwin = 0; const uint32_t* bounds = nullptr; const uint32_t* wfirst = nullptr;
+                    int bits2 = 1; int pairs = 0; uint32_t maxsize = 0, span = 0, step = 0; };
+static int plan_windows(dthip_ctx* ctx, Scratch& sc, const uint32_t* fstart, uint32_t nb1, uint32_t bins2, int64_t n, const uint32_t* d_max,
+                        uint32_t tile, int maxw, int rb, WindowPlan* wp) {
+  static const bool greedy = !(getenv("DTHIP_MSD_GREEDY") && atoi(getenv("DTHIP_MSD_GREEDY")) == 0);
+  const uint32_t nbk = nb1 * bins2;
+  // the (bucket, digit) counts of a window and their prefix live in the tile's exchange buffer: 2 x buckets x bins words
+  uint32_t maxspan = 16;
+  while (maxspan > 1 && (size_t)2 * maxspan * ((size_t)1 << rb) * 4 > (size_t)tile * maxw) maxspan >>= 1;
+  const uint32_t nwmax = greedy ? (uint32_t)(2 * (n / tile)) + nb1 + 8 : (uint32_t)(n / (tile / 2)) + 2;
+  uint32_t* wplan = nullptr;
+  DTHIP_TRY(sc.get<uint32_t>((size_t)3 * (nwmax + 2) + 4, &wplan));
+  uint32_t* wbounds = wplan; uint32_t* wfirst = wplan + 2 * (nwmax + 2); uint32_t* winfo = wfirst + nwmax + 2;
+  DTHIP_CHECK_HIP(hipMemsetAsync(winfo, 0, 4 * sizeof(uint32_t), ctx->stream));
+  if (greedy) DTHIP_TRY(launch_msd_windows_greedy(ctx, fstart, nb1, bins2, tile, maxspan, nwmax, wbounds, wfirst, winfo));
+  else DTHIP_TRY(launch_msd_windows(ctx, fstart, nbk, (uint32_t)n, d_max, tile, nwmax, wbounds, wfirst, winfo));
+  uint32_t wi[4] = {0, 0, 0, 0};                     // equal-step: {windows, rows per step, largest span, -}; greedy: {~0 = infeasible, -, span, windows}
+  DTHIP_TRY(read_back(ctx, wi, winfo, sizeof(wi)));
+  DTHIP_TRY(read_back(ctx, &wp->maxsize, d_max, sizeof(uint32_t)));
+  wp->bounds = wbounds; wp->wfirst = wfirst; wp->pairs = greedy ? 1 : 0; wp->span = wi[2];
+  wp->nwin = greedy ? wi[3] : wi[0];
+  wp->step = greedy ? 0 : wi[1];
+  wp->bits2 = 1;
+  while ((1u << wp->bits2) < wi[2]) wp->bits2++;
+  wp->ok = wp->nwin > 0 && wp->nwin <= nwmax && wi[2] >= 1 && wi[2] <= maxspan && !(greedy && wi[0] == 0xFFFFFFFFu) &&
+           (size_t)2 * ((size_t)1 << wp->bits2) * ((size_t)1 << rb) * 4 <= (size_t)tile * maxw;
+  static const int win_env = getenv("DTHIP_MSD_WINDOWS") ? atoi(getenv("DTHIP_MSD_WINDOWS")) : 1;   // 0: one workgroup per bucket (A/B)
+  if (win_env == 0) wp->ok = false;
+  return DTHIP_OK;
+}
+
 // Stable sort of rows by one stage of packed keys, moving the payload columns along.
 // `order` (nullable): the key columns are read through this ordering (later stages).
 static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stage, int64_t n,
@@ -583,28 +617,15 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
     DTHIP_TRY(launch_radix_tile_hist(ctx, kB, key64, (uint32_t)n, xa.pshift[p2], xa.pbits[p2], ntiles2, hg.tpg, G2, P, gtot2, d_tdesc, d_gdesc));
     DTHIP_TRY(launch_msd_scan(ctx, gtot2, d_gfirst, base + (size_t)p1 * HIST_STRIDE, msd.s2, nb1, (uint32_t)n, fstart, d_max));
     // windows of the final level (whole buckets, together at most one tile of rows), planned on the device
-    const uint32_t nbk = nb1 * bins2;
-    const uint32_t nwmax = (uint32_t)(n / (tile / 2)) + 2;
-    uint32_t* wplan = nullptr;
-    DTHIP_TRY(sc.get<uint32_t>((size_t)2 * (nwmax + 2) + 4, &wplan));
-    uint32_t* wbounds = wplan; uint32_t* wfirst = wplan + nwmax + 2; uint32_t* winfo = wfirst + nwmax + 2;
-    DTHIP_CHECK_HIP(hipMemsetAsync(winfo, 0, 4 * sizeof(uint32_t), ctx->stream));
-    DTHIP_TRY(launch_msd_windows(ctx, fstart, nbk, (uint32_t)n, d_max, tile, nwmax, wbounds, wfirst, winfo));
-    uint32_t wi[4] = {0, 0, 0, 0};                     // {windows, rows per window step, most buckets in a window, -}
-    DTHIP_TRY(read_back(ctx, wi, winfo, sizeof(wi)));
-    uint32_t maxsize = 0;
-    DTHIP_TRY(read_back(ctx, &maxsize, d_max, sizeof(maxsize)));
-    static const int win_env = getenv("DTHIP_MSD_WINDOWS") ? atoi(getenv("DTHIP_MSD_WINDOWS")) : 1;   // 0: one workgroup per bucket (A/B)
-    // the (bucket, digit) counts of a window and their prefix live in the tile's exchange buffer: 2 x buckets x bins words
-    int wbits2 = 1;
-    while ((1u << wbits2) < wi[2]) wbits2++;
     int maxw_w = 4;
     for (int c = 0; c < pay.n; c++) maxw_w = std::max(maxw_w, pay.width[c]);
-    const bool windows = win_env != 0 && wi[0] > 0 && wi[2] >= 1 && wi[2] <= 16 &&
-                         (size_t)2 * ((size_t)1 << wbits2) * ((size_t)1 << msd.rb) * 4 <= (size_t)tile * maxw_w;
+    WindowPlan wp;
+    DTHIP_TRY(plan_windows(ctx, sc, fstart, nb1, bins2, n, d_max, tile, maxw_w, msd.rb, &wp));
+    const bool windows = wp.ok;
+    const uint32_t maxsize = wp.maxsize;
     if (getenv("DTHIP_MSD_DEBUG"))
       fprintf(stderr, "[dthip msd] n=%lld s1=%d s2=%d rb=%d tiles2=%u groups2=%u largest bucket=%u windows=%u step=%u max buckets/window=%u -> %s\n",
-              (long long)n, msd.s1, msd.s2, msd.rb, ntiles2, G2, maxsize, wi[0], wi[1], wi[2], windows ? "windows" : (maxsize <= tile ? "per bucket" : "LSD"));
+              (long long)n, msd.s1, msd.s2, msd.rb, ntiles2, G2, maxsize, wp.nwin, wp.step, wp.span, windows ? "windows" : (maxsize <= tile ? "per bucket" : "LSD"));
     if (windows || maxsize <= tile) {
       rp.kin = kB; rp.kout = kA;
       rp.shift = xa.pshift[p2]; rp.bits = xa.pbits[p2];
@@ -623,9 +644,8 @@ static int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stag
       if (windows) {
         // a bucket of ~2000 rows per workgroup leaves a CU with too few rows in flight (5.9 ms for C5's 5e8 rows); windows
         // of several whole buckets fill the tile (3.8 ms at ~6000 rows) at the price of a second ranking round in LDS
-        rp.ntiles = wi[0]; rp.bounds = wbounds; rp.wfirst = wfirst; rp.block = 0;
-        rp.bits2 = 1;
-        while ((1u << rp.bits2) < wi[2]) rp.bits2++;
+        rp.ntiles = wp.nwin; rp.bounds = wp.bounds; rp.wfirst = wp.wfirst; rp.block = 0;
+        rp.bits2 = wp.bits2; rp.wpairs = wp.pairs;
 #ifdef DTHIP_RP_EXPERIMENT
         if (getenv("DTHIP_MSD_R1ONLY")) rp.bits2 = 99;        // timing experiment: wrong results
         if (getenv("DTHIP_MSD_WIN_NOR2")) rp.wfirst = nullptr; // timing experiment: the one-round kernel over the real windows
@@ -2021,6 +2041,15 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
   const MsdPlan msd = msd_split(est, bits, tile, ctx->msd_bucket_rows, rbmax > 9 ? 9 : rbmax);
   if (!msd.ok) return DTHIP_NOT_APPLICABLE;
   const uint32_t nb1 = 1u << msd.s1, bins2 = 1u << msd.s2;
+  // Level 2 writes tile-locally as well (default) -- decided HERE, from the estimate, because level 1's output format
+  // depends on it: (the gathering final level works on windows of <= 16 whole buckets whose (bucket, digit) counts fit the
+  // exchange buffer: tiny final buckets -- tests forcing the levels onto small inputs -- take the scatter form)
+  int maxw_p = 4;
+  for (int q = 0; q < npay; q++) maxw_p = std::max(maxw_p, payw[q]);
+  const int64_t win_buckets = std::min<int64_t>(16, (int64_t)tile * maxw_p / ((int64_t)8 << msd.rb));
+  static const int tl2_env = getenv("DTHIP_TL_LEVEL2") ? atoi(getenv("DTHIP_TL_LEVEL2")) : -1;
+  const int tl2_opt = tl2_env >= 0 ? tl2_env : ctx->tl_level2;
+  const bool tl2 = tl2_opt == 2 || (tl2_opt == 1 && (est >> (msd.s1 + msd.s2)) * win_buckets * 4 >= (int64_t)tile * 5);
   // ---- level 1: filter + key transform + top digit, tile-local ------------------------------------------------------------
   // first-level tiles: 512 threads x 16 rows, two workgroups per CU -- or (DTHIP_TL_BLOCK=1024, A/B) 16384-row tiles, whose
   // segments are twice as long for the level that gathers them, one workgroup per CU
@@ -2028,15 +2057,22 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
   const uint32_t T1 = (uint32_t)tl_block * 16u;
   const uint32_t ntiles1 = (uint32_t)((n + T1 - 1) / T1);
   const uint32_t ntb = (ntiles1 + 63) / 64, dstride = ntb * 64;
+  // Level 1 writes RECORDS {key, 4-byte riding value, 8-byte riding value} when a tile-local level 2 will gather them (one
+  // 16-byte piece per row instead of three places: level 2's over-fetch 3.2x -> ~1.4x); separate arrays otherwise
+  static const bool aos_env = !(getenv("DTHIP_TL_RECORDS") && atoi(getenv("DTHIP_TL_RECORDS")) == 0);
+  const bool use_rec = aos_env && tl2 && tl_block == 512 && !(npay == 2 && payw[1] == 8);
   uint32_t* k1 = nullptr; uint16_t* dir = nullptr; uint16_t* dirT = nullptr; uint32_t* cc = nullptr; uint32_t* tot = nullptr;
-  DTHIP_TRY(sc.get<uint32_t>((size_t)n, &k1));
+  unsigned char* rec = nullptr;
+  if (use_rec) DTHIP_TRY(sc.get<unsigned char>((size_t)n * 16, &rec));
+  else DTHIP_TRY(sc.get<uint32_t>((size_t)n, &k1));
   DTHIP_TRY(sc.get<uint16_t>((size_t)ntiles1 * (nb1 + 1), &dir));
   DTHIP_TRY(sc.get<uint16_t>((size_t)(nb1 + 1) * dstride, &dirT));
   DTHIP_TRY(sc.get<uint32_t>((size_t)nb1 * ntb, &cc));
   DTHIP_TRY(sc.get<uint32_t>((size_t)nb1 + 1, &tot));
   DTHIP_CHECK_HIP(hipMemsetAsync(tot + nb1, 0, sizeof(uint32_t), ctx->stream));
   void* l1[2] = {nullptr, nullptr};
-  for (int q = 0; q < npay; q++) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)n * payw[q], &b)); l1[q] = b; }
+  if (!use_rec)
+    for (int q = 0; q < npay; q++) { unsigned char* b = nullptr; DTHIP_TRY(sc.get<unsigned char>((size_t)n * payw[q], &b)); l1[q] = b; }
   TL1Args ta;
   memset(&ta, 0, sizeof(ta));
   ta.pred = pa; ta.key = plan.col[0]; ta.key.shift = 0;
@@ -2049,6 +2085,12 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
     if (keepx_on && cd[ride[q]].data == pred.data && payw[q] == 8) ta.keepx = q;
   }
   ta.bad = plan.speculative ? tot + nb1 : nullptr;
+  ta.rec = rec; ta.rec4 = -1; ta.rec8 = -1;
+  if (use_rec)
+    for (int q = 0; q < npay; q++) {
+      if (payw[q] == 8) ta.rec8 = q;
+      else ta.rec4 = (q == rid_slot) ? -2 : q;
+    }
   DTHIP_TRY(launch_tl_level1(ctx, ta));
   DTHIP_TRY(launch_tl_directory(ctx, dir, ntiles1, nb1, dirT, dstride, cc, ntb, tot));
   std::vector<uint32_t> htot((size_t)nb1 + 1);
@@ -2078,17 +2120,10 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
   DTHIP_CHECK_HIP(hipMemcpyAsync(d_pstart, pstart.data(), pstart.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   DTHIP_CHECK_HIP(hipMemsetAsync(d_max, 0, 4, ctx->stream));
   DTHIP_CHECK_HIP(hipStreamSynchronize(ctx->stream));            // (the host vectors above go out of use only at the end; pageable copies)
-  // Level 2 writes tile-locally as well (default): no histogram pass, sequential writes, the final level gathers its
-  // buckets' segments.  DTHIP_TL_LEVEL2=0: level 2 scatters to exact positions (a gathering histogram pass first) and the
-  // final level runs in place, as in sort_stage -- kept for A/B runs.
-  // (the gathering final level works on windows of <= 16 whole buckets whose (bucket, digit) counts fit the exchange buffer:
-  // tiny final buckets -- tests forcing the levels onto small inputs -- take the scatter form)
-  int maxw_p = 4;
-  for (int q = 0; q < npay; q++) maxw_p = std::max(maxw_p, payw[q]);
-  const int64_t win_buckets = std::min<int64_t>(16, (int64_t)tile * maxw_p / ((int64_t)8 << msd.rb));
-  static const int tl2_env = getenv("DTHIP_TL_LEVEL2") ? atoi(getenv("DTHIP_TL_LEVEL2")) : -1;
-  const int tl2_opt = tl2_env >= 0 ? tl2_env : ctx->tl_level2;
-  const bool tl2 = tl2_opt == 2 || (tl2_opt == 1 && (npass >> (msd.s1 + msd.s2)) * win_buckets * 4 >= (int64_t)tile * 5);
+  // Level 2, tile-local (tl2, decided above): no histogram pass, sequential writes, the final level gathers its buckets'
+  // segments.  tl_level2 = 0: level 2 scatters to exact positions (a gathering histogram pass first) and the final level
+  // runs in place, as in sort_stage -- kept for A/B runs and for tiny final buckets.
+
   uint32_t* P = nullptr; uint32_t* gtot2 = nullptr; uint32_t* fstart = nullptr;
   DTHIP_TRY(sc.get<uint32_t>((size_t)nb1 * bins2 + 1, &fstart));
   const uint32_t nbk = nb1 * bins2;
@@ -2106,6 +2141,7 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
   rp.pay.n = npay;
   for (int q = 0; q < npay; q++) { rp.pay.in[q] = l1[q]; rp.pay.out[q] = pb[0][q]; rp.pay.width[q] = payw[q]; }
   rp.g_dirT = dirT; rp.g_dstride = dstride; rp.g_cc = cc; rp.g_ntb = ntb; rp.g_ntiles1 = ntiles1; rp.g_T1 = T1; rp.g_pstart = d_pstart;
+  rp.g_rec = rec;
   rp.label = "tl_level2_kernel";
   uint16_t* dirT2 = nullptr; uint32_t* d_pfirst = nullptr;
   const uint32_t dstride2 = ((ntiles2 + 63) / 64) * 64;
@@ -2132,31 +2168,21 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
     DTHIP_TRY(launch_tl_gather_hist(ctx, ga, G2));
     DTHIP_TRY(launch_msd_scan(ctx, gtot2, d_gfirst, d_pstart, msd.s2, nb1, (uint32_t)npass, fstart, d_max));
   }
-  const uint32_t nwmax = (uint32_t)(npass / (tile / 2)) + 2;
-  uint32_t* wplan = nullptr;
-  DTHIP_TRY(sc.get<uint32_t>((size_t)2 * (nwmax + 2) + 4, &wplan));
-  uint32_t* wbounds = wplan; uint32_t* wfirst = wplan + nwmax + 2; uint32_t* winfo = wfirst + nwmax + 2;
-  DTHIP_CHECK_HIP(hipMemsetAsync(winfo, 0, 4 * sizeof(uint32_t), ctx->stream));
-  DTHIP_TRY(launch_msd_windows(ctx, fstart, nbk, (uint32_t)npass, d_max, tile, nwmax, wbounds, wfirst, winfo));
-  uint32_t wi[4] = {0, 0, 0, 0};
-  DTHIP_TRY(read_back(ctx, wi, winfo, sizeof(wi)));
-  uint32_t maxsize = 0;
-  DTHIP_TRY(read_back(ctx, &maxsize, d_max, sizeof(maxsize)));
-  int wbits2 = 1;
-  while ((1u << wbits2) < wi[2]) wbits2++;
   int maxw_w = 4;
   for (int q = 0; q < npay; q++) maxw_w = std::max(maxw_w, payw[q]);
-  const bool windows = wi[0] > 0 && wi[2] >= 1 && wi[2] <= 16 &&
-                       (size_t)2 * ((size_t)1 << wbits2) * ((size_t)1 << msd.rb) * 4 <= (size_t)tile * maxw_w;
+  WindowPlan wp;
+  DTHIP_TRY(plan_windows(ctx, sc, fstart, nb1, bins2, npass, d_max, tile, maxw_w, msd.rb, &wp));
+  const bool windows = wp.ok;
+  const uint32_t maxsize = wp.maxsize;
   if (getenv("DTHIP_MSD_DEBUG"))
-    fprintf(stderr, "[dthip fused] n=%lld est=%lld pass=%lld bits=%d s1=%d s2=%d rb=%d tiles1=%u tiles2=%u groups2=%u largest bucket=%u windows=%u max buckets/window=%u -> %s\n",
-            (long long)n, (long long)est, (long long)npass, bits, msd.s1, msd.s2, msd.rb, ntiles1, ntiles2, G2, maxsize, wi[0], wi[2],
+    fprintf(stderr, "[dthip fused] n=%lld est=%lld pass=%lld bits=%d s1=%d s2=%d rb=%d tiles1=%u tiles2=%u groups2=%u largest bucket=%u windows=%u max buckets/window=%u records=%d -> %s\n",
+            (long long)n, (long long)est, (long long)npass, bits, msd.s1, msd.s2, msd.rb, ntiles1, ntiles2, G2, maxsize, wp.nwin, wp.span, use_rec ? 1 : 0,
             windows ? "windows" : (maxsize <= tile ? "per bucket" : "not applicable"));
   // a final bucket outgrows a tile (heavy duplicates) -- or, with the gathering final level, there are no windows
   if (!(windows || (!tl2 && maxsize <= tile))) return DTHIP_NOT_APPLICABLE;
   if (!tl2) { rp.P = P; rp.gpre = gtot2; DTHIP_TRY(launch_radix_pass(ctx, rp)); }
   // ---- final level: every bucket (window of buckets) ordered by the remaining bits in LDS, written to its rows of the result
-  rp.g_dirT = nullptr; rp.g_cc = nullptr; rp.g_pstart = nullptr; rp.tl_dir2 = nullptr;
+  rp.g_dirT = nullptr; rp.g_cc = nullptr; rp.g_pstart = nullptr; rp.tl_dir2 = nullptr; rp.g_rec = nullptr;
   rp.kin = kA; rp.kout = kB; rp.shift = 0; rp.bits = msd.rb; rp.P = nullptr; rp.gpre = nullptr;
   rp.ntiles = nbk; rp.tdesc = nullptr; rp.bounds = fstart;
   rp.block = (maxsize <= tile / 2) ? 256 : 0;
@@ -2165,9 +2191,8 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
     rp.g2_dirT = dirT2; rp.g2_dstride = dstride2; rp.g2_pfirst = d_pfirst; rp.g2_fstart = fstart; rp.g2_s2bits = msd.s2; rp.g2_nbk = nbk;
   }
   if (windows) {
-    rp.ntiles = wi[0]; rp.bounds = wbounds; rp.wfirst = wfirst; rp.block = 0;
-    rp.bits2 = 1;
-    while ((1u << rp.bits2) < wi[2]) rp.bits2++;
+    rp.ntiles = wp.nwin; rp.bounds = wp.bounds; rp.wfirst = wp.wfirst; rp.block = 0;
+    rp.bits2 = wp.bits2; rp.wpairs = wp.pairs;
   }
   for (int q = 0; q < npay; q++) { rp.pay.in[q] = pb[0][q]; rp.pay.out[q] = pb[1][q]; }
   void* ukey_out = nullptr;

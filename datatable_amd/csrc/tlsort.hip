@@ -26,7 +26,8 @@ namespace dthip {
 // riding columns: its loaded values stay in registers instead of being read a second time
 // BLK = threads per workgroup: 512 (8192-row tiles, two workgroups per CU) or 1024 (16384-row tiles, one per CU: segments
 // twice as long for the level that gathers them)
-template <typename KT, int RB, bool KEEPX, int BLK>
+// AOS = the passing rows are written as 16-byte records {key, 4-byte riding value, 8-byte riding value} (TL1Args::rec)
+template <typename KT, int RB, bool KEEPX, int BLK, bool AOS = false>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_RP_WAVES, DTHIP_RP_WAVES))) tl_level1_kernel(TL1Args a) {
   typedef unsigned long long u64;
   constexpr int BLOCK = BLK, ITEMS = RP_ITEMS, WAVES = BLOCK / 64, TILE = BLOCK * ITEMS, GROUPS = ITEMS / 4;
@@ -86,6 +87,52 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     if (tid == 0) drow[bins] = (uint16_t)total;
   }
 
+  if (AOS) {
+    // ---- records: {key, 4-byte value} pairs through LDS first, kept in registers; then the 8-byte values; every thread owns 4
+    // consecutive places per group = 64 contiguous bytes of records, written with four 16-byte stores
+    u64* e8 = reinterpret_cast<u64*>(exch);
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      if ((vmask >> i) & 1u) {
+        uint32_t v4 = 0;
+        if (a.rec4 == -2) v4 = tile_base + wbase + 64u * i;
+        else if (a.rec4 >= 0) v4 = RP_LD(&static_cast<const uint32_t*>(a.pay.in[a.rec4])[tile_base + wbase + 64u * i]);
+        e8[pos[i]] = (u64)key[i] | ((u64)v4 << 32);
+      }
+    }
+    __syncthreads();
+    u64 kr[ITEMS];
+#pragma unroll
+    for (int g = 0; g < GROUPS; g++) {
+      const uint32_t s0 = ((uint32_t)g * BLOCK + tid) * 4u;
+#pragma unroll
+      for (int j = 0; j < 4; j++) kr[g * 4 + j] = e8[s0 + j];
+    }
+    __syncthreads();
+    if (a.rec8 >= 0) {
+      const u64* pin = static_cast<const u64*>(a.pay.in[a.rec8]);
+      const bool isx = KEEPX && a.rec8 == a.keepx;
+#pragma unroll
+      for (int i = 0; i < ITEMS; i++)
+        if ((vmask >> i) & 1u) e8[pos[i]] = (KEEPX && isx) ? xv[i] : RP_LD(&pin[tile_base + wbase + 64u * i]);
+      __syncthreads();
+    }
+    u32x4* rec = static_cast<u32x4*>(a.rec);
+#pragma unroll
+    for (int g = 0; g < GROUPS; g++) {
+      const uint32_t s0 = ((uint32_t)g * BLOCK + tid) * 4u;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (s0 + j < total) {
+          const u64 x8 = a.rec8 >= 0 ? e8[s0 + j] : 0ULL;
+          u32x4 r;
+          r.x = (uint32_t)kr[g * 4 + j]; r.y = (uint32_t)(kr[g * 4 + j] >> 32); r.z = (uint32_t)x8; r.w = (uint32_t)(x8 >> 32);
+          RP_ST(&rec[tile_base + s0 + j], r);
+        }
+      }
+    }
+    return;
+  }
   // ---- transformed keys, row numbers, riding columns: registers -> LDS in (digit, row) order -> the tile's own rows -----
   uint32_t* e4 = reinterpret_cast<uint32_t*>(exch);
 #pragma unroll
@@ -175,6 +222,19 @@ int launch_tl_pred_sample(dthip_ctx* ctx, const PredArgs& p, uint32_t n, uint32_
 
 template <typename KT, int RB, int BLK>
 static int launch_tl1_t(dthip_ctx* ctx, const TL1Args& a, uint32_t ntiles, size_t lds) {
+  if (a.rec && BLK == 512) {
+    if (a.keepx >= 0) {
+      auto kfn = tl_level1_kernel<KT, RB, true, 512, true>;
+      DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
+      DTHIP_LAUNCH(ctx, "tl_level1_kernel", kfn, ntiles, 512, lds, a);
+    } else {
+      auto kfn = tl_level1_kernel<KT, RB, false, 512, true>;
+      DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
+      DTHIP_LAUNCH(ctx, "tl_level1_kernel", kfn, ntiles, 512, lds, a);
+    }
+    return DTHIP_OK;
+  }
+  if (a.rec) { set_error("tile-local level: records need 512-thread tiles"); return DTHIP_EINVAL; }
   if (a.keepx >= 0) {
     auto kfn = tl_level1_kernel<KT, RB, true, BLK>;
     DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
