@@ -21,7 +21,8 @@
 
 namespace {
 
-constexpr size_t OUTBOX_BYTES = 96u << 20;      // per rank
+// per rank; FAKE_RCCL_OUTBOX_MB widens it (every rank must see the same value)
+static const size_t OUTBOX_BYTES = [] { const char* e = getenv("FAKE_RCCL_OUTBOX_MB"); size_t mb = e ? strtoull(e, nullptr, 10) : 0; return (mb ? mb : 96) << 20; }();
 constexpr int MAX_RANKS = 16, MAX_MSGS = 4096;
 
 struct Msg { int dst; size_t off, bytes; };
