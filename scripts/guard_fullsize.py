@@ -108,6 +108,18 @@ def main():
             r = ctx.groupby_rows([kb], [kb, xb, ri], nrows=npass, want_rowindex=False)
             ng = r.ngroups; cnt = int(r.offsets()[-1]); r.free(); free(k, x, ri, kb, xb)
             assert cnt == npass
+        elif c == "C5f":
+            # round 5: the same query as ONE call (dthip_filter_groupby_rows: tile-local levels, records, windows); the sort
+            # route can be forced through DTHIP_TL_LEVEL2 / DTHIP_FILTER_ROWS_FUSED like everywhere else
+            n = int(1e9 * args.scale); g.manual_seed(1239)
+            k = guarded(torch.randint(0, 100_000_000, (n,), dtype=torch.int64, device=dev, generator=g))
+            xt = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            npass_exp = int((xt > 0).sum().item())
+            x = guarded(xt); del xt
+            torch.cuda.empty_cache()
+            r = ctx.filter_groupby_rows(x, ">", 0.0, [k], [k, x], nrows=n, want_rowindex=True)
+            ng = r.ngroups; cnt = int(r.offsets()[-1]); r.free(); free(k, x)
+            assert cnt == npass_exp
         else:
             raise SystemExit("unknown config " + c)
         ctx.sync()
