@@ -34,7 +34,7 @@ def expected(x, cmp, scalar, keys, cols, **kw):
     return comp, off, [c[comp] for c in cols]
 
 
-def run(ctx, x, cmp, scalar, keys, cols, expect_fused, want_rowindex=True, expect_tl2=None, **kw):
+def run(ctx, x, cmp, scalar, keys, cols, expect_fused, want_rowindex=True, expect_tl2=None, stats=None, **kw):
     """the query on three routes -- fused with a tile-local second level (tl_level2 = 2), fused with a scattering second
     level (0), the two calls (filter_rows_fused = 0) -- against the oracle.  expect_fused: the scatter form must run to the
     end (True) / must not (False) / may (None); expect_tl2: the same for the tile-local form"""
@@ -52,6 +52,8 @@ def run(ctx, x, cmp, scalar, keys, cols, expect_fused, want_rowindex=True, expec
         ran = ctx.profile_get("tl_level1_kernel")[1] > 0 and ctx.profile_get("msd_final_kernel")[1] > 0 and \
             ctx.profile_get("compact_take_kernel")[1] == 0
         tag = " [%s]" % route
+        if stats is not None and ran:
+            stats[route] = stats.get(route, 0) + 1
         if want is not None:
             assert ran == want, "the fused route %s%s" % ("did not run" if want else "ran unexpectedly", tag)
         if tl2 == 2 and ran:
