@@ -184,7 +184,7 @@ def _cmp_exact(got, exp):
     return bool(got.dtype == exp.dtype and got.shape == exp.shape and np.array_equal(got, exp, equal_nan=(exp.dtype.kind == "f")))
 
 
-def verify_agg(ctx, name, keys_t, vals_t, aggs, threads, keep=None):
+def verify_agg(ctx, name, keys_t, vals_t, aggs, threads, keep=None, host=None):
     """GPU result of DT[:, aggs, by(keys)] on ALL rows of the config vs the OpenMP oracle (oracle/dt_oracle.c): group
     keys, counts, min / max bit-exact, float64 sums / means within RTOL (+ATOL); raises on mismatch.
     keep (dict): receives the single-GPU result arrays ("keys", "aggs") for the sharded-vs-single-GPU comparison"""
@@ -198,8 +198,7 @@ def verify_agg(ctx, name, keys_t, vals_t, aggs, threads, keep=None):
     r.free()
     if keep is not None:
         keep["keys"], keep["aggs"] = gk, ga
-    hk = [to_host(k) for k in keys_t]
-    hv = [to_host(v) for v in vals_t]
+    hk, hv = host if host is not None else ([to_host(k) for k in keys_t], [to_host(v) for v in vals_t])
     o.lib(); o.set_threads(threads)
     try:
         ri, off = o.group(hk)
@@ -291,6 +290,124 @@ def verify_c5(ctx, k_t, x_t, threads, keep=None):
     res["ok"] = all(v for k, v in res.items() if k.endswith("bit_exact"))
     res["seconds"] = time.perf_counter() - t0
     return res, (hk, hx)
+
+
+def verify_sgrp(ctx, k_t, v_t, threads):
+    """the LITERAL seam on ALL rows: dthip_groupby's RowIndex and offsets bit-exact against the oracle's group()
+    (sort.cc:1411-1495), dthip_reduce(SUM) THROUGH that RowIndex within RTOL of the oracle's reducer (column/sumprod.h:34-59)"""
+    import numpy as np
+    import torch
+    from oracle import oracle as o
+    from datatable_amd.torch_bridge import devcol
+    t0 = time.perf_counter()
+    n = k_t.numel()
+    r = ctx.groupby([devcol(k_t)], nrows=n, want_rowindex=True)
+    ng = r.ngroups
+    sums = torch.empty(ng, dtype=torch.float64, device=k_t.device)
+    ctx.reduce_dev("sum", devcol(v_t), r.rowindex_ptr, r.offsets_ptr, ng, n, sums.data_ptr())
+    g_ri = torch.empty(n, dtype=torch.int32, device=k_t.device); r.rowindex_into(g_ri.data_ptr())
+    g_off = torch.empty(ng + 1, dtype=torch.int32, device=k_t.device); r.offsets_into(g_off.data_ptr())
+    torch.cuda.synchronize()
+    r.free()
+    h_ri, h_off, h_s = to_host(g_ri), to_host(g_off), sums.cpu().numpy()
+    del g_ri, g_off, sums
+    hk, hv = to_host(k_t), to_host(v_t)
+    o.lib(); o.set_threads(threads)
+    try:
+        ri, off = o.group([hk])
+        es = o.reduce("sum", hv, ri, off)
+    finally:
+        o.set_threads(1)
+    ri_ok, off_ok = _cmp_exact(h_ri, ri), _cmp_exact(h_off, off)
+    s_ok, ma, mr = sums_close(h_s, es) if (ri_ok and off_ok) else (False, None, None)
+    res = {"against": "oracle/dt_oracle.c, %d OpenMP threads" % threads, "rows": int(n), "groups": int(len(off) - 1),
+           "rowindex_bit_exact": ri_ok, "offsets_bit_exact": off_ok, "sums_within_tol": s_ok, "sum_max_abs_err": ma,
+           "sum_max_rel_err": mr, "rtol": RTOL, "atol": ATOL, "ok": bool(ri_ok and off_ok and s_ok), "seconds": time.perf_counter() - t0}
+    return res, None
+
+
+def adversarial_legs(ctx, dev, n, groups, steps, verify, threads, budget, c3_ms):
+    """Inputs the DEFAULT path's guesses do not like: the key range and NA-freeness are guessed from
+    samples and verified on every row, so one outlier key / one NA costs a second sweep; sorted and hot keys serialise LDS
+    atomics.  Every variant of C3 is timed, its retries counted (dthip_last_call_stats) and its result verified on ALL rows."""
+    import numpy as np
+    import torch
+    from datatable_amd.torch_bridge import devcol
+    (k,), (v,) = gen_c3(dev, 0, 1, n, groups)
+    out = {}
+
+    def timed(name, keys, vals, aggs, desc, host=None):
+        kc, vc = devcol(keys), devcol(vals)
+        def run():
+            r = ctx.groupby_agg([kc], [vc], aggs, nrows=n); ng = r.ngroups; r.free(); return ng
+        run(); torch.cuda.synchronize()
+        st = ctx.last_call_stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ng = run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        ctx.profile_reset(); ctx.profile(True); run(); torch.cuda.synchronize(); ctx.profile(False)
+        prof = {nm: ctx.profile_get(nm) for nm in ctx.profile_names()}
+        out[name] = {"workload": desc, "rows": n, "groups": int(ng), "ms": ms, "rows_s": n / (ms * 1e-3), "x_C3": (ms / c3_ms) if c3_ms else None,
+                     "retries": {"key_range": st["retries_key_range"], "na_guess": st["retries_na_guess"]}, "path": st["path"],
+                     "kernel_ms": {q: round(w[0], 4) for q, w in sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]}}
+        if verify and budget.ok(40):
+            par, _ = verify_agg(ctx, name, [keys], [vals], aggs + ([("count0", None)] if ("count0", None) not in aggs else []), threads, host=host)
+            out[name]["parity"] = par
+            out[name]["ok"] = par["ok"]
+            assert par["ok"], (name, par)
+        elif verify:
+            out[name]["parity"] = {"skipped": "time budget (%.0f s) spent" % budget.seconds}
+        torch.cuda.empty_cache(); ctx.trim()
+
+    hk = hv = None
+    if verify:
+        hk, hv = to_host(k), to_host(v)
+    # (1) ONE key outside the range the 2^17-piece sample sees (widened by 1/64): the partition's per-row check raises the
+    # flag, the query runs again with the exact range (DTHIP_RETRY_EXACT).  A row the sample does not visit is looked for.
+    outlier_val = 3 * groups
+    for row in (n // 3 + 7, n // 3 + 100_003, n // 5 + 11):
+        old = int(k[row].item()); k[row] = outlier_val
+        r = ctx.groupby_agg([devcol(k)], [devcol(v)], [("sum", 0)], nrows=n); r.free()
+        hit = ctx.last_call_stats()["retries_key_range"] > 0
+        if hit:
+            break
+        k[row] = old
+    if hk is not None:
+        hk_old = int(hk[row]); hk[row] = outlier_val
+    timed("C3_outlier", k, v, [("sum", 0)], "C3 with ONE key = %d at row %d (sampled range [0,%d) violated -> second sweep with the exact range)" % (outlier_val, row, groups),
+          host=([hk], [hv]) if hk is not None else None)
+    out["C3_outlier"]["sample_missed_the_outlier"] = bool(hit)
+    k[row] = old
+    if hk is not None:
+        hk[row] = hk_old
+    # (2) ONE NA in a value column whose 65536-row sample shows none, under a reducer that needs valid counts (mean): the
+    # aggregation runs again with counters (DTHIP_RETRY_NA); the same query without the NA is timed beside it
+    aggs2 = [("sum", 0), ("mean", 0)]
+    timed("C3_mean_clean", k, v, aggs2, "DT[:, [sum(f.v), mean(f.v)], by(f.k)] on C3's rows, no NA", host=([hk], [hv]) if hk is not None else None)
+    rowv = n // 2 + 12_345
+    oldv = float(v[rowv].item()); v[rowv] = float("nan")
+    if hv is not None:
+        hv[rowv] = np.nan
+    timed("C3_na_planted", k, v, aggs2, "the same with ONE NaN planted at row %d (value column guessed NA-free -> aggregated again with valid counts)" % rowv,
+          host=([hk], [hv]) if hk is not None else None)
+    out["C3_na_planted"]["x_clean"] = out["C3_na_planted"]["ms"] / out["C3_mean_clean"]["ms"]
+    v[rowv] = oldv
+    if hv is not None:
+        hv[rowv] = oldv
+    # (3) sorted keys: whole waves address one bucket / one slot (cluster variants, DESIGN 3.1)
+    ks = torch.sort(k).values
+    timed("C3_sorted", ks, v, [("sum", 0)], "C3 with the key column sorted ascending", host=([to_host(ks)], [hv]) if hk is not None else None)
+    del ks
+    torch.cuda.empty_cache()
+    # (4) one hot key: 7 % of the rows
+    g = torch.Generator(device=dev); g.manual_seed(4242)
+    kh = torch.where(torch.rand(n, device=dev, generator=g) < 0.07, torch.tensor(12_345, dtype=torch.int64, device=dev), k)
+    timed("C3_hotkey", kh, v, [("sum", 0)], "C3 with 7 % of the rows in ONE key", host=([to_host(kh)], [hv]) if hk is not None else None)
+    del kh, k, v, hk, hv
+    torch.cuda.empty_cache(); ctx.trim()
+    return out
 
 
 def run_configs(ctx, dev, which, steps, scale, verify, cpu_sample, ref_threads, port_threads, budget):
@@ -397,6 +514,23 @@ def run_configs(ctx, dev, which, steps, scale, verify, cpu_sample, ref_threads, 
                 S = min(n, cpu_sample)
                 cpu(c, S, lambda: ref.groupby_agg({"k": host[0][0][:S], "v": host[1][0][:S]}, ["k"], [("sum", "v")], nthreads=ref_threads)[1])
             del k, v, host
+        elif c == "C3_sgrp":
+            # the LITERAL seam north_star names (VERDICT r05 missing 2): group() -> RowIndex + Groupby (S-grp, sort.h:56-58,
+            # sort.cc:1411-1495), then the reducer gathering value[rowindex[i]] per group (S-red, column/sumprod.h:34-59) --
+            # two calls, the RowIndex materialised in HBM, on the C3 tensors.  Algorithmic bytes: key 8 + value 8 read,
+            # RowIndex 4 written per row ("+ n x 4 B when the RowIndex is a requested output"), offsets + sums per group
+            n = int(1e9 * scale)
+            (k,), (v,) = gen_c3(dev, 0, 1, n, 10_000_000)
+            sums = torch.empty(min(n, 10_000_000) + 16, dtype=torch.float64, device=dev)
+            def run():
+                r = ctx.groupby([devcol(k)], nrows=n, want_rowindex=True)
+                ng = r.ngroups
+                ctx.reduce_dev("sum", devcol(v), r.rowindex_ptr, r.offsets_ptr, ng, n, sums.data_ptr())
+                r.free(); return ng
+            measure(c, n, n * 20 + 10_000_000 * 12, run, "C3 as TWO calls: dthip_groupby(want_rowindex=1) -> RowIndex + offsets in HBM, then "
+                                                       "dthip_reduce(SUM, v, rowindex, offsets): the S-grp -> S-red seam of the in-tree binding")
+            check(c, lambda: verify_sgrp(ctx, k, v, port_threads))
+            del k, v, sums
         elif c == "C4":
             n = int(1e9 * scale); g.manual_seed(1238)
             a = torch.randint(0, 3163, (n,), dtype=torch.int32, device=dev, generator=g)
@@ -960,7 +1094,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-parity", action="store_true", help="skip the all-rows GPU vs OpenMP-port comparison")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the OpenMP port (0: min(host cores, 64))")
-    ap.add_argument("--configs", default="C1,C2,C4,C5,C3_hard", help="other BASELINE configs to time after C3 ('' = none)")
+    ap.add_argument("--configs", default="C1,C2,C4,C5,C3_hard,C3_sgrp,C3_adv",
+                    help="other BASELINE configs to time after C3 ('' = none); C3_sgrp = C3 as dthip_groupby + dthip_reduce (the literal "
+                         "S-grp -> S-red seam); C3_adv = adversarial variants of C3 (outlier key, planted NA, sorted keys, hot key)")
     ap.add_argument("--config-steps", type=int, default=3)
     ap.add_argument("--config-scale", type=float, default=1.0)
     ap.add_argument("--no-verify-configs", action="store_true", help="time the other configs only (no full-size oracle check, no CPU sample)")
@@ -1301,6 +1437,8 @@ def main():
                     line["parity"]["configs"][c] = pc.get("ok", pc.get("skipped"))
     if rank == 0 and world == 1 and not sharded:
         which = [c for c in args.configs.split(",") if c]
+        adv = "C3_adv" in which
+        which = [c for c in which if c != "C3_adv"]
         if which:
             best_threads = int(line["cpu_baseline"]["cores"]) if line.get("cpu_baseline") and line["cpu_baseline"].get("kind") == "reference" else 16
             cfg = run_configs(ctx, dev, which, args.config_steps, args.config_scale,
@@ -1310,6 +1448,18 @@ def main():
             line["configs"] = cfg
             line["parity"] = line.get("parity") or {}
             line["parity"]["configs"] = {c: (v["parity"].get("ok", v["parity"].get("skipped")) if "parity" in v else None) for c, v in cfg.items()}
+        if adv:
+            try:
+                acfg = adversarial_legs(ctx, dev, int(n_total * args.config_scale), args.groups, args.config_steps,
+                                        not (args.no_verify_configs or args.no_check), threads, budget, raw_c3_ms * args.config_scale)
+            except AssertionError:
+                raise
+            except Exception as e:
+                acfg = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            line.setdefault("configs", {}).update(acfg)
+            line["parity"] = line.get("parity") or {}
+            line["parity"].setdefault("configs", {}).update(
+                {c: (v["parity"].get("ok", v["parity"].get("skipped")) if isinstance(v, dict) and "parity" in v else None) for c, v in acfg.items() if c != "error"})
         if ref_full_inputs is not None:
             # the reference's CPU path on the WHOLE workload, once, at the thread count the sample leg found best
             # (sort.cc:1243-1282: past ~1e7 groups it pays a thread-team wake-up per tiny radix bucket -- the "cliff")

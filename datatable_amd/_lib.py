@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DTHIP_LIB") or os.path.join(_HERE, "libdthip.so")   #
 # stype codes == the reference's SType values (src/core/stype.h:41-62)
 BOOL, INT8, INT16, INT32, INT64, FLOAT32, FLOAT64 = 1, 2, 3, 4, 5, 6, 7
 SUM, MEAN, MIN, MAX, COUNT, COUNT0, FIRST, LAST = 0, 1, 2, 3, 4, 5, 6, 7
-SD, MEDIAN, NUNIQUE = 8, 9, 10                      # dthip_reduce only
+SD, MEDIAN, NUNIQUE, PROD, COUNTNA = 8, 9, 10, 11, 12   # dthip_reduce only
 COV, CORR = 0, 1                                    # enum dthip_op2
 CUMSUM, CUMPROD, CUMMIN, CUMMAX, CUMCOUNT, NGROUP = 0, 1, 2, 3, 4, 5   # enum dthip_cumop
 UNION, INTERSECT, SETDIFF, SYMDIFF = 0, 1, 2, 3     # enum dthip_setfn
@@ -53,6 +53,7 @@ SIGNATURES = {
     "dthip_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dthip_timer_start": (C.c_int, [C.c_void_p]),
     "dthip_timer_stop": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "dthip_last_call_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "dthip_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dthip_profile_reset": (C.c_int, [C.c_void_p]),
     "dthip_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -821,7 +821,7 @@ static int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthi
       if (rc != DTHIP_OK) break;
       order = static_cast<const int32_t*>(so.pay[0]);
     }
-    if (rc == DTHIP_RETRY_EXACT && attempt == 0) continue;
+    if (rc == DTHIP_RETRY_EXACT && attempt == 0) { ctx->call_stats[0]++; continue; }
     if (rc == DTHIP_RETRY_EXACT) { set_error("group: exact key range violated"); return DTHIP_EDEVICE; }
     DTHIP_TRY(rc);
     break;
@@ -864,6 +864,13 @@ static int check_common(dthip_ctx* ctx, int64_t nrows, int mem) {
   DTHIP_CHECK_HIP(hipSetDevice(ctx->device));
   return DTHIP_OK;
 }
+
+// dthip_last_call_stats: the outermost query entry point starts the record, nested ones add to it
+struct CallScope {
+  dthip_ctx* c;
+  explicit CallScope(dthip_ctx* ctx) : c(ctx) { if (c->call_depth++ == 0) memset(c->call_stats, 0, sizeof(c->call_stats)); }
+  ~CallScope() { c->call_depth--; }
+};
 
 static int stage_cols(dthip_ctx* ctx, Scratch& sc, const dthip_col* cols, int ncols, int64_t nrows, int mem,
                       std::vector<dthip_col>* out) {
@@ -1454,7 +1461,7 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
     DTHIP_TRY(launch_hash_agg(ctx, ha));
     uint32_t hn[2] = {0, 0};
     DTHIP_TRY(read_back(ctx, hn, d_outn, sizeof(hn)));       // {number of partial groups, overflow bits}
-    if (hn[1]) return DTHIP_NOT_APPLICABLE;                    // a table filled up: the sort path takes over
+    if (hn[1]) { ctx->call_stats[2]++; return DTHIP_NOT_APPLICABLE; }      // a table filled up: the sort path takes over
     const int64_t np = hn[0];
 
     // typed columns of the partial groups
@@ -1770,6 +1777,12 @@ int dthip_timer_stop(dthip_ctx* ctx, float* ms) {
   return DTHIP_OK;
 }
 
+int dthip_last_call_stats(const dthip_ctx* ctx, int64_t* out, int n) {
+  if (!ctx || !out || n < 0) { set_error("null argument"); return DTHIP_EINVAL; }
+  for (int i = 0; i < n; i++) out[i] = i < 4 ? ctx->call_stats[i] : 0;
+  return DTHIP_OK;
+}
+
 int dthip_profile_enable(dthip_ctx* ctx, int on) {
   if (!ctx) return DTHIP_EINVAL;
   if (!on) prof_flush(ctx);
@@ -1804,6 +1817,7 @@ int dthip_profile_names(dthip_ctx* ctx, char* buf, size_t buflen) {
 int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrows, int na_pos, int mem,
                   int want_rowindex, dthip_result** out) {
   DTHIP_TRY(check_common(ctx, nrows, mem));
+  CallScope call_scope(ctx);
   if (!keys || !out) { set_error("null argument"); return DTHIP_EINVAL; }
   const bool remove_na = na_pos == DTHIP_NA_REMOVE;
   if (remove_na) na_pos = DTHIP_NA_FIRST;      // sorted first, then cut off the front (sort.cc:598-608)
@@ -1867,6 +1881,7 @@ int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrow
 int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dthip_col* cols, int ncols,
                        int64_t nrows, int na_pos, int mem, int want_rowindex, dthip_result** out) {
   DTHIP_TRY(check_common(ctx, nrows, mem));
+  CallScope call_scope(ctx);
   if (!keys || !out || (ncols > 0 && !cols) || ncols < 0) { set_error("null argument"); return DTHIP_EINVAL; }
   if (na_pos != DTHIP_NA_FIRST && na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", na_pos); return DTHIP_ENOTIMPL; }
   dthip_result* res = new dthip_result();
@@ -1914,6 +1929,7 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
       if ((rc = alloc_head_bitmap(ctx, sc, nrows, &ps.head_bitmap)) != DTHIP_OK) break;
       rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so);
       if (rc == DTHIP_RETRY_EXACT) {
+        ctx->call_stats[0]++;
         // the sampled key range did not hold, so real keys lie OUTSIDE it: the exact range is usually WIDER, and with
         // several keys the packed width may now exceed 64 bits (two stages) -- then the columns cannot ride
         if ((rc = plan_keys(ctx, sc, kd.data(), nkeys, nrows, na_pos, &plan)) != DTHIP_OK) break;
@@ -2179,7 +2195,7 @@ static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, con
             (long long)n, (long long)est, (long long)npass, bits, msd.s1, msd.s2, msd.rb, ntiles1, ntiles2, G2, maxsize, wp.nwin, wp.span, use_rec ? 1 : 0,
             windows ? "windows" : (maxsize <= tile ? "per bucket" : "not applicable"));
   // a final bucket outgrows a tile (heavy duplicates) -- or, with the gathering final level, there are no windows
-  if (!(windows || (!tl2 && maxsize <= tile))) return DTHIP_NOT_APPLICABLE;
+  if (!(windows || (!tl2 && maxsize <= tile))) { ctx->call_stats[2]++; return DTHIP_NOT_APPLICABLE; }
   if (!tl2) { rp.P = P; rp.gpre = gtot2; DTHIP_TRY(launch_radix_pass(ctx, rp)); }
   // ---- final level: every bucket (window of buckets) ordered by the remaining bits in LDS, written to its rows of the result
   rp.g_dirT = nullptr; rp.g_cc = nullptr; rp.g_pstart = nullptr; rp.tl_dir2 = nullptr; rp.g_rec = nullptr;
@@ -2237,6 +2253,7 @@ int dthip_filter_groupby_rows(dthip_ctx* ctx, const dthip_col* pred, int cmp, do
                               const dthip_col* cols, int ncols, int64_t nrows, int na_pos, int mem, int want_rowindex,
                               dthip_result** out) {
   DTHIP_TRY(check_common(ctx, nrows, mem));
+  CallScope call_scope(ctx);
   if (!pred || !keys || !out || nkeys < 1 || nkeys > MAX_KEYCOLS || ncols < 0 || (ncols > 0 && !cols)) { set_error("bad filter_groupby_rows arguments"); return DTHIP_EINVAL; }
   if (cmp < DTHIP_GT || cmp > DTHIP_ISNA) { set_error("bad comparison %d", cmp); return DTHIP_EINVAL; }
   if (na_pos != DTHIP_NA_FIRST && na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", na_pos); return DTHIP_ENOTIMPL; }
@@ -2265,9 +2282,16 @@ int dthip_filter_groupby_rows(dthip_ctx* ctx, const dthip_col* pred, int cmp, do
       for (int attempt = 0; attempt < 2; attempt++) {
         Scratch fs(ctx);
         rc = filter_rows_fused(ctx, fs, res, pd[0], cmp, cf, ci, keys, kd, cols, cd, ncols, nrows, na_pos, want_rowindex, attempt == 0);
+        if (rc == DTHIP_ENOMEM) {             // 16 B per row of records + double buffers did not fit: the two calls need less
+          rc = DTHIP_NOT_APPLICABLE; ctx->call_stats[2]++;
+          dev_trim(ctx);
+          break;
+        }
         if (rc != DTHIP_RETRY_EXACT) break;
+        ctx->call_stats[0]++;
       }
       if (rc == DTHIP_RETRY_EXACT) { set_error("filter_groupby_rows: exact key range violated"); rc = DTHIP_EDEVICE; }
+      if (rc == DTHIP_OK) ctx->call_stats[3] = 4;
     }
     if (rc != DTHIP_NOT_APPLICABLE) break;
     // ---- the two-call sequence: filter (RowIndex + the view's columns in one sweep), then the rows in grouped order ------
@@ -2328,6 +2352,7 @@ int dthip_filter_groupby_rows(dthip_ctx* ctx, const dthip_col* pred, int cmp, do
 int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dthip_col* values, int nvalues,
                       const dthip_agg* aggs, int naggs, int64_t nrows, int na_pos, int mem, dthip_result** out) {
   DTHIP_TRY(check_common(ctx, nrows, mem));
+  CallScope call_scope(ctx);
   if (!keys || !out || (naggs > 0 && !aggs) || (nvalues > 0 && !values)) { set_error("null argument"); return DTHIP_EINVAL; }
   if (na_pos != DTHIP_NA_FIRST && na_pos != DTHIP_NA_LAST) { set_error("na_pos %d not implemented", na_pos); return DTHIP_ENOTIMPL; }
   for (int a = 0; a < naggs; a++) {
@@ -2402,7 +2427,7 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
           full.nsig[0] = 64; full.nstages = 1; full.stage_first[0] = 0; full.stage_last[0] = 0; full.stage_bits[0] = 64;
           hash_tried = true;
           rc = hash_groupby_agg(ctx, sc, res, full, kd, vd, used, aggs, naggs, nrows, na_pos);
-          if (rc == DTHIP_OK) { done = true; break; }
+          if (rc == DTHIP_OK) { done = true; ctx->call_stats[3] = 3; break; }
           if (rc != DTHIP_NOT_APPLICABLE) break;
           rc = DTHIP_OK;
           drop_partial_result(ctx, res);
@@ -2411,18 +2436,20 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
         if (bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &slot_bits, guess_nona)) {
           rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits, guess_nona);
           if (rc == DTHIP_RETRY_NA) {                    // same plan once more, with valid counts
+            ctx->call_stats[1]++;
             guess_nona = false; rc = DTHIP_OK; drop_partial_result(ctx, res); attempt--; continue;
           }
-          if (rc == DTHIP_RETRY_EXACT && attempt == 0) { rc = DTHIP_OK; drop_partial_result(ctx, res); continue; }
+          if (rc == DTHIP_RETRY_EXACT && attempt == 0) { ctx->call_stats[0]++; rc = DTHIP_OK; drop_partial_result(ctx, res); continue; }
           if (rc == DTHIP_RETRY_EXACT) { set_error("bucketed aggregation: exact key range violated"); rc = DTHIP_EDEVICE; }
           done = true;
+          if (rc == DTHIP_OK) ctx->call_stats[3] = 2;
         }
       }
       if (rc != DTHIP_OK || done) break;
       // sparse keys (exact plan at this point): hash combiner + merge, when its tables are large enough
       if (!hash_tried) rc = hash_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, na_pos);
       else rc = DTHIP_NOT_APPLICABLE;
-      if (rc == DTHIP_OK) break;
+      if (rc == DTHIP_OK) { ctx->call_stats[3] = 3; break; }
       if (rc != DTHIP_NOT_APPLICABLE) break;
       rc = DTHIP_OK;
       drop_partial_result(ctx, res);                       // nothing of a half-built attempt survives
@@ -2434,11 +2461,13 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
       ps.n = (int)used.size();
       for (int i = 0; i < ps.n; i++) { ps.in[i] = vd[used[i]].data; ps.width[i] = stype_size(vd[used[i]].stype); }
       SortOut so;
+      ctx->call_stats[3] = 1;
       if ((rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so)) != DTHIP_OK) break;
       for (int i = 0; i < ps.n; i++) sorted_val[used[i]] = so.pay[i];
       g.sorted_keys = so.keys; g.key64 = so.key64;
       if ((rc = heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, nrows, &g)) != DTHIP_OK) break;
     } else {
+      ctx->call_stats[3] = 1;
       if ((rc = group_core(ctx, sc, res, kd.data(), nkeys, nrows, na_pos, &plan, &g)) != DTHIP_OK) break;
       for (int c : used) sorted_val[c] = vd[c].data;
       gather_ri = g.rowindex;
@@ -2578,7 +2607,7 @@ int dthip_result_free(dthip_ctx* ctx, dthip_result* r) {
 
 int dthip_reduce_out_stype(int op, int st) {
   switch (op) {
-    case DTHIP_SUM: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : st == DTHIP_FLOAT64 ? DTHIP_FLOAT64 : DTHIP_INT64;
+    case DTHIP_SUM: case DTHIP_PROD: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : st == DTHIP_FLOAT64 ? DTHIP_FLOAT64 : DTHIP_INT64;
     case DTHIP_MEAN: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : DTHIP_FLOAT64;
     case DTHIP_MIN: case DTHIP_MAX: case DTHIP_FIRST: case DTHIP_LAST: return st;
     case DTHIP_SD: case DTHIP_MEDIAN: return st == DTHIP_FLOAT32 ? DTHIP_FLOAT32 : DTHIP_FLOAT64;   // head_reduce_unary.cc:221-229,484-491
@@ -2672,7 +2701,7 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
   if (ngroups < 0 || ngroups > nrows) { set_error("ngroups=%lld inconsistent with nrows=%lld", (long long)ngroups, (long long)nrows); return DTHIP_EINVAL; }
   if (ngroups == 0) return DTHIP_OK;
   if (!offsets || !out) { set_error("null argument"); return DTHIP_EINVAL; }
-  if (op < DTHIP_SUM || op > DTHIP_NUNIQUE) { set_error("bad reducer op %d", op); return DTHIP_EINVAL; }
+  if (op < DTHIP_SUM || op > DTHIP_COUNTNA) { set_error("bad reducer op %d", op); return DTHIP_EINVAL; }
   if (op != DTHIP_COUNT0 && (!value || !value->data)) { set_error("reducer needs a value column"); return DTHIP_EINVAL; }
   Scratch sc(ctx);
   const void* d_off = nullptr;
@@ -2698,6 +2727,8 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
       DTHIP_TRY(launch_firstlast(ctx, d_val, value->stype, ri32, off32, ngroups, op == DTHIP_LAST, d_out));
     } else if (op == DTHIP_MEDIAN || op == DTHIP_NUNIQUE) {
       DTHIP_TRY(median_nunique(ctx, sc, op, d_val, value->stype, ri32, off32, ngroups, nrows, d_out));
+    } else if (op == DTHIP_PROD && stype_is_float(value->stype)) {
+      DTHIP_TRY(launch_prod_float_seq(ctx, d_val, value->stype, ri32, off32, ngroups, d_out));
     } else {
       unsigned long long* bitmap = nullptr;
       uint32_t* tile_counts = nullptr;
@@ -2707,6 +2738,13 @@ int dthip_reduce(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t* 
         DTHIP_TRY(grouped_f64(ctx, sc, d_val, value->stype, ri32, nrows, &xg));
         DTHIP_TRY(launch_moments(ctx, xg, nullptr, reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, 0, d_out,
                                  ost == DTHIP_FLOAT32, off32, ngroups));
+      } else if (op == DTHIP_PROD) {
+        DTHIP_TRY(launch_reduce_prod_int(ctx, d_val, value->stype, ri32, reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, d_out));
+      } else if (op == DTHIP_COUNTNA) {
+        ReduceOuts ro;
+        DTHIP_TRY(reduce_outs_for(DTHIP_COUNT, d_out, &ro));
+        DTHIP_TRY(launch_reduce(ctx, d_val, value->stype, ri32, reinterpret_cast<const uint8_t*>(bitmap), tile_counts, nrows, ro));
+        DTHIP_TRY(launch_countna_from_count(ctx, off32, ngroups, static_cast<int64_t*>(d_out)));
       } else {
         ReduceOuts ro;
         DTHIP_TRY(reduce_outs_for(op, d_out, &ro));

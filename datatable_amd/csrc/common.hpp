@@ -97,6 +97,12 @@ struct dthip_ctx {
   int sort_path = 0;         // 0: MSD levels (two scatter levels + final buckets ordered in LDS) from msd_min_rows rows on where their preconditions hold, else LSD passes; 1: LSD passes only; 2: MSD levels whenever their preconditions hold, whatever msd_min_rows says (A/B runs, tests)
   int64_t msd_min_rows = 1 << 26;    // below this the LSD passes are quick enough (and the final buckets would be tiny)
   int msd_bucket_rows = 2048;        // target size of a final bucket (sorted in LDS: at most one radix tile)
+  // what the LAST query entry point did on this context (dthip_last_call_stats): [0] sweeps repeated because a key range
+  // guessed from a sample was wrong, [1] because a value column guessed NA-free held an NA, [2] a route given up after it had
+  // started (fused filter route -> two calls, hash tables full -> sort path), [3] the path that produced the result
+  // (1 sort, 2 bucketed, 3 hash combiner, 4 fused filter route, 5 small table)
+  int64_t call_stats[4] = {0, 0, 0, 0};
+  int call_depth = 0;        // query entry points call each other (fused route -> two calls, hash combiner -> merge): only the outermost resets
   // multi-GPU (comm.hip): the communicator this context is a rank of
   struct dthip_comm* comm = nullptr;
   int comm_rank = 0;
@@ -426,6 +432,10 @@ int launch_reduce(dthip_ctx* ctx, const void* values, int stype, const int32_t* 
                   const uint8_t* bitmap, const uint32_t* tile_first_head, int64_t nrows,
                   const ReduceOuts& outs, int nona = 0);
 int launch_count0(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t* out);
+int launch_reduce_prod_int(dthip_ctx* ctx, const void* values, int stype, const int32_t* rowindex,
+                           const uint8_t* bitmap, const uint32_t* tile_first_head, int64_t nrows, void* out);
+int launch_prod_float_seq(dthip_ctx* ctx, const void* values, int stype, const int32_t* ri, const int32_t* offsets, int64_t ngroups, void* out);
+int launch_countna_from_count(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t* out);
 int launch_sum_f32_seq(dthip_ctx* ctx, const void* values, const int32_t* ri, const int32_t* offsets, int64_t ngroups, void* out);
 
 constexpr int DTHIP_NOT_APPLICABLE = 2;     // internal: this path does not fit, take the next one

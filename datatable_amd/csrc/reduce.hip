@@ -138,6 +138,23 @@ template <typename T> __device__ __forceinline__ void accum(StI& s, T v) {
   s.cnt += 1;
 }
 
+// PROD: the `sum` slot of an INTEGER state carries the wrapping product instead (prod(), column/sumprod.h:34-59 with SUM = false:
+// identity 1, NA skipped; multiplication mod 2^64 is associative, so the segmented scan is exact).  Float products are not
+// re-associated at all (prod_seq_kernel below).
+template <bool PROD> __device__ __forceinline__ StF identP(StF* p) { return ident(p); }
+template <bool PROD> __device__ __forceinline__ StI identP(StI* p) { StI r = ident(p); if (PROD) r.isum = 1ULL; return r; }
+template <bool PROD> __device__ __forceinline__ StF combP(const StF& a, const StF& b) { return comb(a, b); }
+template <bool PROD> __device__ __forceinline__ StI combP(const StI& a, const StI& b) {
+  StI r = comb(a, b);
+  if (PROD) r.isum = a.isum * b.isum;
+  return r;
+}
+template <typename T, bool PROD> __device__ __forceinline__ void accumP(StF& s, T v) { accum<T>(s, v); }
+template <typename T, bool PROD> __device__ __forceinline__ void accumP(StI& s, T v) {
+  if (PROD) { const unsigned long long keep = s.isum; accum<T>(s, v); s.isum = keep * (unsigned long long)(long long)v; }
+  else accum<T>(s, v);
+}
+
 template <typename T>
 struct OutsT {
   typename VT<T>::SumT* sum;
@@ -171,7 +188,7 @@ struct TileSide {
   uint32_t last_gid;   // group of `last`
 };
 
-template <typename T>
+template <typename T, bool PROD>
 __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restrict__ vals, const int32_t* __restrict__ ri,
                                                               const uint8_t* __restrict__ bitmap,
                                                               const uint32_t* __restrict__ tile_first_head,
@@ -237,11 +254,11 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
   }
 
   // thread summary: value of the open segment at the end of the thread's range
-  St cur = ident((St*)nullptr);
+  St cur = identP<PROD>((St*)nullptr);
 #pragma unroll
   for (int j = 0; j < SR_ITEMS; j++) {
-    if ((hb >> j) & 1u) cur = ident((St*)nullptr);
-    if (ok[j]) accum<T>(cur, x[j]);
+    if ((hb >> j) & 1u) cur = identP<PROD>((St*)nullptr);
+    if (ok[j]) accumP<T, PROD>(cur, x[j]);
   }
   const uint32_t nh = (uint32_t)__popc(hb);
   uint32_t flag = nh ? 1u : 0u;
@@ -254,7 +271,7 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
     const uint32_t pf = __shfl_up(sf, o, 64);
     const uint32_t pn = __shfl_up(sn, o, 64);
     if (lane >= o) {
-      if (!sf) sv = comb(pv, sv);
+      if (!sf) sv = combP<PROD>(pv, sv);
       sf |= pf;
       sn += pn;
     }
@@ -262,16 +279,16 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
   if (lane == 63) { w_val[wave] = sv; w_flag[wave] = sf; w_nh[wave] = sn; }
   __syncthreads();
   // exclusive carry for this thread = (carry from earlier waves) (+) (exclusive within wave)
-  St carry = ident((St*)nullptr); uint32_t cflag = 0, hc = 0;
+  St carry = identP<PROD>((St*)nullptr); uint32_t cflag = 0, hc = 0;
   for (int w = 0; w < wave; w++) {
-    if (w_flag[w]) { carry = w_val[w]; cflag = 1; } else { carry = comb(carry, w_val[w]); }
+    if (w_flag[w]) { carry = w_val[w]; cflag = 1; } else { carry = combP<PROD>(carry, w_val[w]); }
     hc += w_nh[w];
   }
   {
     St ev = shfl_up_st(sv, 1);
     uint32_t ef = __shfl_up(sf, 1, 64), en = __shfl_up(sn, 1, 64);
-    if (lane == 0) { ev = ident((St*)nullptr); ef = 0; en = 0; }
-    if (ef) { carry = ev; cflag = 1; } else { carry = comb(carry, ev); }
+    if (lane == 0) { ev = identP<PROD>((St*)nullptr); ef = 0; en = 0; }
+    if (ef) { carry = ev; cflag = 1; } else { carry = combP<PROD>(carry, ev); }
     hc += en;
   }
 
@@ -283,10 +300,10 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
     if ((hb >> j) & 1u) {
       if (k == 0) side[tile].first = acc;           // started in an earlier tile
       else emit<T>(outs, G + k - 1, acc);           // complete group
-      acc = ident((St*)nullptr);
+      acc = identP<PROD>((St*)nullptr);
       k++;
     }
-    if (ok[j]) accum<T>(acc, x[j]);
+    if (ok[j]) accumP<T, PROD>(acc, x[j]);
   }
   if (tid == SR_BLOCK - 1) {
     const bool any = cflag || flag;
@@ -294,7 +311,7 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
       side[tile].last = acc;
     } else {
       side[tile].first = acc;                       // no head in this tile at all
-      side[tile].last = ident((St*)nullptr);
+      side[tile].last = identP<PROD>((St*)nullptr);
     }
     side[tile].has_head = any ? 1u : 0u;
     side[tile].last_gid = G + k - 1;                // meaningful only if any
@@ -304,7 +321,7 @@ __global__ void __launch_bounds__(SR_BLOCK) seg_reduce_kernel(const T* __restric
 // One wave per tile that contains a head: its trailing open segment is
 // completed with the `first` parts of the following tiles up to and including
 // the next tile that has a head, then finalised.
-template <typename T>
+template <typename T, bool PROD>
 __global__ void __launch_bounds__(256) seg_fixup_kernel(const TileSide<typename VT<T>::St>* side, uint32_t ntiles,
                                                         OutsT<T> outs) {
   typedef typename VT<T>::St St;
@@ -318,33 +335,33 @@ __global__ void __launch_bounds__(256) seg_fixup_kernel(const TileSide<typename 
   // common case first: the next tile has a head
   if (!done) {
     const uint32_t hh = side[u].has_head;
-    acc = comb(acc, side[u].first);
+    acc = combP<PROD>(acc, side[u].first);
     u++;
     done = hh || (u >= ntiles);
   }
   while (!done) {
     const uint32_t v = u + lane;
-    St s = ident((St*)nullptr);
+    St s = identP<PROD>((St*)nullptr);
     uint32_t hh = 0;
     if (v < ntiles) { s = side[v].first; hh = side[v].has_head; }
     const unsigned long long bal = __ballot(hh != 0);
     const int stop = bal ? (__ffsll((long long)bal) - 1) : 63;   // last lane that contributes
-    if (lane > stop) s = ident((St*)nullptr);
+    if (lane > stop) s = identP<PROD>((St*)nullptr);
     // ordered inclusive scan, take the value at lane `stop`
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const St pv = shfl_up_st(s, o);
-      if (lane >= o) s = comb(pv, s);
+      if (lane >= o) s = combP<PROD>(pv, s);
     }
     const St tot = shfl_st(s, stop);
-    acc = comb(acc, tot);
+    acc = combP<PROD>(acc, tot);
     u += 64;
     done = (bal != 0) || (u >= ntiles);
   }
   if (lane == 0) emit<T>(outs, side[t].last_gid, acc);
 }
 
-template <typename T>
+template <typename T, bool PROD = false>
 static int reduce_t(dthip_ctx* ctx, const void* values, const int32_t* ri, const uint8_t* bitmap,
                     const uint32_t* tile_first_head, int64_t nrows, const ReduceOuts& o, int nona) {
   typedef typename VT<T>::St St;
@@ -359,9 +376,9 @@ static int reduce_t(dthip_ctx* ctx, const void* values, const int32_t* ri, const
   outs.mn = static_cast<T*>(o.mn);
   outs.mx = static_cast<T*>(o.mx);
   outs.count = reinterpret_cast<long long*>(o.count);
-  DTHIP_LAUNCH(ctx, "seg_reduce_kernel", seg_reduce_kernel<T>, nt, SR_BLOCK, 0,
+  DTHIP_LAUNCH(ctx, "seg_reduce_kernel", (seg_reduce_kernel<T, PROD>), nt, SR_BLOCK, 0,
                static_cast<const T*>(values), ri, bitmap, tile_first_head, (uint32_t)nrows, outs, side, nona);
-  DTHIP_LAUNCH(ctx, "seg_fixup_kernel", seg_fixup_kernel<T>, (nt + 3) / 4, 256, 0, side, nt, outs);
+  DTHIP_LAUNCH(ctx, "seg_fixup_kernel", (seg_fixup_kernel<T, PROD>), (nt + 3) / 4, 256, 0, side, nt, outs);
   return DTHIP_OK;
 }
 
@@ -377,6 +394,33 @@ int launch_reduce(dthip_ctx* ctx, const void* values, int stype, const int32_t* 
     case DTHIP_FLOAT64: return reduce_t<double>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, nona);
     default: set_error("reduce: unsupported stype %d", stype); return DTHIP_ENOTIMPL;
   }
+}
+
+// prod() of an integer column (bool / int8..int64 -> int64, wrapping): outs.sum receives the products
+int launch_reduce_prod_int(dthip_ctx* ctx, const void* values, int stype, const int32_t* rowindex,
+                           const uint8_t* bitmap, const uint32_t* tile_first_head, int64_t nrows, void* out) {
+  ReduceOuts outs;
+  outs.sum = out;
+  switch (stype) {
+    case DTHIP_BOOL: case DTHIP_INT8: return reduce_t<int8_t, true>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, 0);
+    case DTHIP_INT16: return reduce_t<int16_t, true>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, 0);
+    case DTHIP_INT32: return reduce_t<int32_t, true>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, 0);
+    case DTHIP_INT64: return reduce_t<long long, true>(ctx, values, rowindex, bitmap, tile_first_head, nrows, outs, 0);
+    default: set_error("prod: stype %d is not an integer type", stype); return DTHIP_ENOTIMPL;
+  }
+}
+
+// countna(col) = rows of the group - valid rows (count.h:35-58 with COUNTNA = true): `out` holds count(col) on entry
+__global__ void __launch_bounds__(256) countna_kernel(const int32_t* offsets, uint32_t ngroups, long long* out) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g < ngroups) out[g] = (long long)offsets[g + 1] - (long long)offsets[g] - out[g];
+}
+
+int launch_countna_from_count(dthip_ctx* ctx, const int32_t* offsets, int64_t ngroups, int64_t* out) {
+  if (ngroups == 0) return DTHIP_OK;
+  DTHIP_LAUNCH(ctx, "countna_kernel", countna_kernel, (unsigned)((ngroups + 255) / 256), 256, 0,
+               offsets, (uint32_t)ngroups, reinterpret_cast<long long*>(out));
+  return DTHIP_OK;
 }
 
 // count(): rows per group = offsets[g+1] - offsets[g]   (count.h:77-88)
@@ -409,6 +453,36 @@ __global__ void __launch_bounds__(256) sum_f32_seq_kernel(const float* __restric
     if (x == x) s += x;
   }
   out[g] = s;
+}
+
+// prod(float32 / float64 column) in the reference's own order: one T accumulator per group starting at 1, the valid rows
+// multiplied in one by one (SumProd_ColumnImpl<T, false>::get_element, column/sumprod.h:48-55).  A product that overflows
+// or underflows on the way depends on that order, so it is not re-associated: bit-exact, one thread per group.
+template <typename T>
+__global__ void __launch_bounds__(256) prod_seq_kernel(const T* __restrict__ v, const int32_t* __restrict__ ri,
+                                                       const int32_t* __restrict__ offsets, uint32_t ngroups, T* __restrict__ out) {
+#pragma clang fp contract(off)
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  T s = T(1);
+  for (int32_t p = offsets[g]; p < offsets[g + 1]; p++) {
+    const int32_t j = ri ? ri[p] : p;
+    if (j < 0) continue;
+    const T x = v[j];
+    if (x == x) s *= x;
+  }
+  out[g] = s;
+}
+
+int launch_prod_float_seq(dthip_ctx* ctx, const void* values, int stype, const int32_t* ri, const int32_t* offsets, int64_t ngroups, void* out) {
+  if (ngroups == 0) return DTHIP_OK;
+  const unsigned nb = (unsigned)((ngroups + 255) / 256);
+  if (stype == DTHIP_FLOAT32)
+    DTHIP_LAUNCH(ctx, "prod_seq_kernel", prod_seq_kernel<float>, nb, 256, 0, static_cast<const float*>(values), ri, offsets, (uint32_t)ngroups, static_cast<float*>(out));
+  else if (stype == DTHIP_FLOAT64)
+    DTHIP_LAUNCH(ctx, "prod_seq_kernel", prod_seq_kernel<double>, nb, 256, 0, static_cast<const double*>(values), ri, offsets, (uint32_t)ngroups, static_cast<double*>(out));
+  else { set_error("prod: stype %d is not a float type", stype); return DTHIP_ENOTIMPL; }
+  return DTHIP_OK;
 }
 
 int launch_sum_f32_seq(dthip_ctx* ctx, const void* values, const int32_t* ri, const int32_t* offsets, int64_t ngroups, void* out) {

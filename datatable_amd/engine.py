@@ -17,7 +17,8 @@ ST2NP = {L.BOOL: np.dtype(np.int8), L.INT8: np.dtype(np.int8), L.INT16: np.dtype
          L.INT32: np.dtype(np.int32), L.INT64: np.dtype(np.int64),
          L.FLOAT32: np.dtype(np.float32), L.FLOAT64: np.dtype(np.float64)}
 OPS = {"sum": L.SUM, "mean": L.MEAN, "min": L.MIN, "max": L.MAX, "count": L.COUNT, "count0": L.COUNT0,
-       "first": L.FIRST, "last": L.LAST, "sd": L.SD, "median": L.MEDIAN, "nunique": L.NUNIQUE}
+       "first": L.FIRST, "last": L.LAST, "sd": L.SD, "median": L.MEDIAN, "nunique": L.NUNIQUE,
+       "prod": L.PROD, "countna": L.COUNTNA}
 OPS2 = {"cov": L.COV, "corr": L.CORR}
 SETOPS = {"union": L.UNION, "intersect": L.INTERSECT, "setdiff": L.SETDIFF, "symdiff": L.SYMDIFF}
 CUMOPS = {"cumsum": L.CUMSUM, "cumprod": L.CUMPROD, "cummin": L.CUMMIN, "cummax": L.CUMMAX,
@@ -373,6 +374,14 @@ class Context(_ShardMixin):
         ms = C.c_float(0)
         L.check(self._lib.dthip_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+    def last_call_stats(self):
+        """what the last query call did besides its result (dthip_last_call_stats): sweeps repeated after a wrong key-range
+        guess / a wrong NA-free guess, routes given up after they had started, and the path that produced the result"""
+        out = (C.c_int64 * 4)()
+        L.check(self._lib.dthip_last_call_stats(self._h, out, 4))
+        path = {0: None, 1: "sort", 2: "bucketed", 3: "hash", 4: "fused_filter"}.get(int(out[3]), int(out[3]))
+        return {"retries_key_range": int(out[0]), "retries_na_guess": int(out[1]), "routes_abandoned": int(out[2]), "path": path}
 
     def profile(self, on=True):
         L.check(self._lib.dthip_profile_enable(self._h, 1 if on else 0))

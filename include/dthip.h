@@ -52,12 +52,13 @@
 extern "C" {
 #endif
 
-#define DTHIP_ABI_VERSION 5   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10
+#define DTHIP_ABI_VERSION 6   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10
                                  3: + dthip_comm_*, dthip_sharded_groupby_* (multi-GPU inside the library), DTHIP_FLAG_NONA,
                                     dthip_host_register / dthip_host_unregister
                                  4: + dthip_comm_last_stats; options sort_path, msd_min_rows, msd_bucket_rows, filter_path
                                  5: + dthip_build_id, dthip_from_arrow (Arrow-layout columns: validity bitmap -> sentinels on the device),
-                                    dthip_filter_groupby_rows (config 5 in one call); option filter_rows_fused */
+                                    dthip_filter_groupby_rows (config 5 in one call); option filter_rows_fused
+                                 6: + dthip_last_call_stats; reducers DTHIP_PROD, DTHIP_COUNTNA (dthip_reduce) */
 
 /* error codes */
 #define DTHIP_OK        0
@@ -90,7 +91,14 @@ enum dthip_op {
   DTHIP_SD = 8,      /* sd(col): sample standard deviation, NA if < 2 valid rows or a non-finite value
                         (sd_reducer, src/core/expr/head_reduce_unary.cc:194-216) */
   DTHIP_MEDIAN = 9,  /* median(col) of the valid values (Median_ColumnImpl, head_reduce_unary.cc:424-470) */
-  DTHIP_NUNIQUE = 10 /* nunique(col): distinct valid values, int64 (op_nunique, head_reduce_unary.cc:377-387) */
+  DTHIP_NUNIQUE = 10,/* nunique(col): distinct valid values, int64 (op_nunique, head_reduce_unary.cc:377-387) */
+  DTHIP_PROD = 11,   /* prod(col): NA skipped, empty / all-NA group -> 1; output stypes as DTHIP_SUM (FExpr_SumProd<false>,
+                        src/core/expr/fexpr_sumprod.cc:47-82,98-110 registers sum and prod from one template; column/sumprod.h:34-59).
+                        Integers: wrapping int64 product, exact.  float32 / float64: multiplied in the reference's own row
+                        order (one accumulator per group), bit for bit -- a product that overflows or underflows on the way
+                        depends on the order, so it is never re-associated */
+  DTHIP_COUNTNA = 12 /* countna(col): NA rows per group, int64 (CountUnary_ColumnImpl<T, true>, column/count.h:35-58,
+                        fexpr_count.cc:35-90) */
 };
 
 /* binary group reducers, dthip_reduce2 (src/core/expr/head_reduce_binary.cc:113-198) */
@@ -229,6 +237,15 @@ int  dthip_host_unregister(dthip_ctx* ctx, void* ptr);
 /* stream timers (HIP events on the context's stream) */
 int  dthip_timer_start(dthip_ctx* ctx);
 int  dthip_timer_stop(dthip_ctx* ctx, float* elapsed_ms);   /* synchronises */
+/* What the LAST query call on this context (dthip_groupby / _groupby_rows / _groupby_agg / _filter_groupby_rows) did besides
+ * its result -- the default path GUESSES key ranges and NA-freeness from samples and verifies every row, so a wrong guess
+ * costs a second sweep that nothing else reports:
+ *   out[0] sweeps repeated because a guessed integer key range was violated by some row (an outlier key),
+ *   out[1] aggregations repeated because a value column guessed NA-free held an NA,
+ *   out[2] routes given up after they had started (fused filter route -> two calls; hash tables full -> sort path),
+ *   out[3] the path that produced the result: 1 sort path, 2 bucketed aggregation, 3 hash combiner, 4 fused filter route.
+ * n = number of values wanted (<= 4).  The reference has no counterpart (its min / max scan is exact, stats.cc:601-640). */
+int  dthip_last_call_stats(const dthip_ctx* ctx, int64_t* out, int n);
 /* per-kernel accounting: when enabled every launch of the library's kernels is
  * bracketed by HIP events; dthip_profile_get() synchronises and returns the
  * accumulated time and launch count of kernels whose name contains `name`. */

@@ -3,7 +3,11 @@
 # integration/patches/*.patch applied --
 #   s_grp_sort_cc.patch              S-grp: `group()` (src/core/sort.cc:1411) hands fixed-width key columns to dthip_groupby
 #   s_red_fexpr_reduce_unary_cc.patch  S-red: FExpr_ReduceUnary::evaluate_n (expr/fexpr_reduce_unary.cc:32) computes the
-#                                    sum / mean / min / max / count columns with dthip_reduce
+#                                    sum / mean / min / max / count columns with dthip_reduce ON THE DEVICE: the grouped
+#                                    view is peeled into stored column + RowIndex (no CPU gather), and the RowIndex /
+#                                    offsets S-grp produced a moment ago are still in HBM (dthip_seam.h)
+#   s_red_view_peel.patch            the accessor that peeling needs: Column::view_rowindex32() (column.h, column_impl.h,
+#                                    column/view.h: ArrayView_ColumnImpl<int32_t> hands out its RowIndex)
 # -- when DTHIP_LIB points at libdthip.so (dlopen: no link dependency; everything the library does not take falls through
 # to the reference's own code).  Every `by()`, `sort()`, `Frame.sort`, `unique`, set
 # function, `Frame.key = ...` and join of the patched build then runs its grouping on the MI355X -- and the reference's OWN
@@ -26,13 +30,18 @@ FORCE=0; [ "${1:-}" = "--force" ] && FORCE=1
 if [ ! -d "$SRC/src/core" ]; then
   echo "build_dt_hip: $SRC not present (GPU box?) -- using the prebuilt integration/_dt_hip as is" >&2; exit 0
 fi
-if ls "$OUT"/datatable/lib/_datatable*.so >/dev/null 2>&1 && [ $FORCE -eq 0 ] && [ -z "$(find "$HERE/patches" -name "*.patch" -newer "$OUT/PROVENANCE.txt")" ]; then
+PSUM="$(cat "$HERE"/patches/*.patch | sha256sum | cut -c1-16)"
+if ls "$OUT"/datatable/lib/_datatable*.so >/dev/null 2>&1 && [ $FORCE -eq 0 ] && [ -f "$OUT/PROVENANCE.txt" ] \
+   && grep -q "patches/\*.patch ($PSUM)" "$OUT/PROVENANCE.txt"; then
   echo "build_dt_hip: integration/_dt_hip already built (use --force to rebuild)"; exit 0
 fi
 rm -rf "$WORK"; mkdir -p "$WORK"
 if [ -d "$BASE/build" ]; then cp -r "$BASE"/. "$WORK"/; else cp -r "$SRC"/. "$WORK"/; fi
 chmod -R u+w "$WORK"
-for f in src/core/sort.cc src/core/expr/fexpr_reduce_unary.cc; do cp "$SRC/$f" "$WORK/$f"; done      # (the unpatched files, whatever the base held)
+# (the unpatched files, whatever the base held; files a patch ADDS are removed)
+for f in $(grep -h '^+++ b/' "$HERE"/patches/*.patch | sed 's#^+++ b/##; s#\t.*##'); do
+  if [ -f "$SRC/$f" ]; then cp "$SRC/$f" "$WORK/$f"; else rm -f "$WORK/$f"; fi
+done
 for pf in "$HERE"/patches/*.patch; do ( cd "$WORK" && patch -p1 --no-backup-if-mismatch < "$pf" ); done
 ( cd "$WORK" && python ci/ext.py build > "$WORK/build_hip.log" 2>&1 ) || { tail -30 "$WORK/build_hip.log"; exit 1; }
 SO=$(ls "$WORK"/src/datatable/lib/_datatable*.so | head -1)
@@ -48,7 +57,7 @@ cp "$SRC/tests/__init__.py" "$SRC/tests/conftest.py" "$SRC/tests/test-groups.py"
    "$SRC/tests/test-sets.py" "$SRC/tests/test-join.py" "$OUT/ref/tests/"
 cp -r "$SRC/tests/ijby" "$SRC/tests/dt" "$OUT/ref/tests/"
 {
-  echo "reference: $SRC + integration/patches/*.patch ($(cat "$HERE"/patches/*.patch | sha256sum | cut -c1-16))"
+  echo "reference: $SRC + integration/patches/*.patch ($PSUM)"
   echo "built: $(date -u +%Y-%m-%dT%H:%M:%SZ) by integration/build_dt_hip.sh"
 } > "$OUT/PROVENANCE.txt"
 PYTHONPATH="$OUT" python -c "import datatable as dt; print('build_dt_hip: integration/_dt_hip ok, datatable', dt.__version__)"

@@ -66,7 +66,9 @@ int dto_get_threads(void) {
 enum { ST_BOOL = 1, ST_INT8 = 2, ST_INT16 = 3, ST_INT32 = 4, ST_INT64 = 5,
        ST_FLOAT32 = 6, ST_FLOAT64 = 7 };
 /* reducer codes shared with include/dthip.h */
-enum { OP_SUM = 0, OP_MEAN = 1, OP_MIN = 2, OP_MAX = 3, OP_COUNT = 4, OP_COUNT0 = 5 };
+enum { OP_SUM = 0, OP_MEAN = 1, OP_MIN = 2, OP_MAX = 3, OP_COUNT = 4, OP_COUNT0 = 5,
+       OP_PROD = 11,      /* prod(): SumProd_ColumnImpl<T, false>, column/sumprod.h:34-59; registered next to sum, fexpr_sumprod.cc:98-110 */
+       OP_COUNTNA = 12 }; /* countna(col): CountUnary_ColumnImpl<T, true>, column/count.h:35-58 */
 enum { NA_FIRST = 0, NA_LAST = 1 };           /* sort.h NaPosition (REMOVE not restated) */
 enum { FLAG_DESC = 1 };                       /* SortFlag::DESCENDING, sort.h:38-44 */
 
@@ -312,7 +314,7 @@ int dto_gather(const dto_col* col, const int32_t* ri, int64_t nout, void* out)
 int dto_reduce_out_stype(int op, int st)
 {
   switch (op) {
-    case OP_SUM:  return st == ST_FLOAT32 ? ST_FLOAT32 : st == ST_FLOAT64 ? ST_FLOAT64 : ST_INT64;
+    case OP_SUM: case OP_PROD: return st == ST_FLOAT32 ? ST_FLOAT32 : st == ST_FLOAT64 ? ST_FLOAT64 : ST_INT64;
     case OP_MEAN: return st == ST_FLOAT32 ? ST_FLOAT32 : ST_FLOAT64;
     case OP_MIN: case OP_MAX: return st;
     default: return ST_INT64;
@@ -336,6 +338,7 @@ int dto_reduce(int op, const dto_col* col, const int32_t* ri, const int32_t* off
     if (op == OP_COUNT0) { ((int64_t*)out)[g] = i1 - i0; continue; }     /* count.h:77-88 */
     if (isf) {
       double dsum = 0; float fsum = 0; int64_t cnt = 0;
+      double dprod = 1; float fprod = 1;                                   /* sumprod.h:35: result = !SUM */
       double best = 0; int have = 0;
       for (int64_t gi = i0; gi < i1; gi++) {
         int64_t j = ri ? ri[gi] : gi;
@@ -346,12 +349,15 @@ int dto_reduce(int op, const dto_col* col, const int32_t* ri, const int32_t* off
         if (isnan(v)) continue;
         cnt++;
         if (op == OP_SUM) { if (st == ST_FLOAT64) dsum = dsum + v; else fsum = fsum + vf; }  /* sumprod.h:48-55: accumulate in T */
+        else if (op == OP_PROD) { if (st == ST_FLOAT64) dprod = dprod * v; else fprod = fprod * vf; }  /* :51-52 result * value, in T */
         else if (op == OP_MEAN) dsum += v;                                /* mean.h:41-47: double */
         else if (op == OP_MIN) { if (v < best || !have) { best = v; have = 1; } }  /* minmax.h:44-57 */
         else if (op == OP_MAX) { if (v > best || !have) { best = v; have = 1; } }
       }
       switch (op) {
         case OP_SUM: if (st == ST_FLOAT64) ((double*)out)[g] = dsum; else ((float*)out)[g] = fsum; break;
+        case OP_PROD: if (st == ST_FLOAT64) ((double*)out)[g] = dprod; else ((float*)out)[g] = fprod; break;
+        case OP_COUNTNA: ((int64_t*)out)[g] = (i1 - i0) - cnt; break;       /* count.h:52: count += COUNTNA != is_valid */
         case OP_MEAN:
           if (st == ST_FLOAT64) ((double*)out)[g] = cnt ? dsum / (double)cnt : NAN;
           else ((float*)out)[g] = cnt ? (float)(dsum / (double)cnt) : NAN;   /* mean.h:50 static_cast<T>(sum/count) */
@@ -363,7 +369,7 @@ int dto_reduce(int op, const dto_col* col, const int32_t* ri, const int32_t* off
         default: ((int64_t*)out)[g] = cnt; break;                           /* count.h:35-58 */
       }
     } else {
-      uint64_t isum = 0; double dsum = 0; int64_t cnt = 0; int64_t best = 0; int have = 0;
+      uint64_t isum = 0, iprod = 1; double dsum = 0; int64_t cnt = 0; int64_t best = 0; int have = 0;
       for (int64_t gi = i0; gi < i1; gi++) {
         int64_t j = ri ? ri[gi] : gi;
         if (j < 0) continue;
@@ -371,12 +377,15 @@ int dto_reduce(int op, const dto_col* col, const int32_t* ri, const int32_t* off
         if (na) continue;
         cnt++;
         if (op == OP_SUM) isum += (uint64_t)v;             /* int64 accumulate, wraps (fexpr_sumprod.cc:55-60) */
+        else if (op == OP_PROD) iprod *= (uint64_t)v;      /* the same cast to int64, result * value, wraps */
         else if (op == OP_MEAN) dsum += (double)v;         /* cast to double first (fexpr_mean.cc:60-62) */
         else if (op == OP_MIN) { if (v < best || !have) { best = v; have = 1; } }
         else if (op == OP_MAX) { if (v > best || !have) { best = v; have = 1; } }
       }
       switch (op) {
         case OP_SUM: ((int64_t*)out)[g] = (int64_t)isum; break;
+        case OP_PROD: ((int64_t*)out)[g] = (int64_t)iprod; break;
+        case OP_COUNTNA: ((int64_t*)out)[g] = (i1 - i0) - cnt; break;
         case OP_MEAN: ((double*)out)[g] = cnt ? dsum / (double)cnt : NAN; break;
         case OP_MIN: case OP_MAX:
           switch (st) {

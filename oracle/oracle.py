@@ -11,7 +11,8 @@ _SO = os.path.join(_HERE, "libdtoracle.so")
 # reference SType codes (src/core/stype.h:41-62)
 BOOL, INT8, INT16, INT32, INT64, FLOAT32, FLOAT64 = 1, 2, 3, 4, 5, 6, 7
 SUM, MEAN, MIN, MAX, COUNT, COUNT0 = 0, 1, 2, 3, 4, 5
-OPS = {"sum": SUM, "mean": MEAN, "min": MIN, "max": MAX, "count": COUNT, "count0": COUNT0}
+PROD, COUNTNA = 11, 12
+OPS = {"sum": SUM, "mean": MEAN, "min": MIN, "max": MAX, "count": COUNT, "count0": COUNT0, "prod": PROD, "countna": COUNTNA}
 _NP2ST = {np.dtype(np.bool_): BOOL, np.dtype(np.int8): INT8, np.dtype(np.int16): INT16,
           np.dtype(np.int32): INT32, np.dtype(np.int64): INT64,
           np.dtype(np.float32): FLOAT32, np.dtype(np.float64): FLOAT64}
