@@ -18,6 +18,7 @@ COV, CORR = 0, 1                                    # enum dthip_op2
 CUMSUM, CUMPROD, CUMMIN, CUMMAX, CUMCOUNT, NGROUP = 0, 1, 2, 3, 4, 5   # enum dthip_cumop
 UNION, INTERSECT, SETDIFF, SYMDIFF = 0, 1, 2, 3     # enum dthip_setfn
 HOST, DEVICE = 0, 1
+ABI_VERSION = 6                                     # DTHIP_ABI_VERSION of include/dthip.h
 NA_FIRST, NA_LAST, NA_REMOVE = 0, 1, 2
 FLAG_DESCENDING = 1
 GT, GE, LT, LE, EQ, NE, NOTNA, ISNA = 0, 1, 2, 3, 4, 5, 6, 7
@@ -143,8 +144,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.dthip_abi_version() != 5:
-        raise ImportError("libdthip.so ABI version %d != 5" % lib.dthip_abi_version())
+    if lib.dthip_abi_version() != ABI_VERSION:
+        raise ImportError("libdthip.so ABI version %d != %d" % (lib.dthip_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -972,7 +972,11 @@ static bool bucket_eligible(const dthip_ctx* ctx, const KeyPlan& plan, const std
 
 static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const KeyPlan& plan,
                               const std::vector<dthip_col>& kd, const std::vector<dthip_col>& vd,
-                              const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int r, bool guess_nona = false) {
+                              const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int r, bool guess_nona = false,
+                              int r_counting = -1) {
+  // r_counting: the slot bits the same query gets WITHOUT the NA-free guess.  When they equal r, a wrong guess repeats only
+  // the aggregation over the rows already partitioned (the partition's output does not depend on the guess) instead of
+  // the whole query (DTHIP_RETRY_NA): C3 with mean(), one planted NaN: 2.0x -> see DESIGN 6 "adversarial inputs"
   const int nkeys = plan.nkeys;
   const int B = plan.stage_bits[0];
   KeyXform kx;
@@ -999,8 +1003,8 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   // want_offsets: group sizes are part of the result; need_cnt: rows per slot are COUNTED -- also when value columns are
   // guessed NA-free, whose valid counts the row counts then stand for
   const bool want_offsets = bucket_need_counts(ctx, aggs, naggs);
-  const bool need_cnt = want_offsets || guess_nona;
-  const int first_flag = need_cnt ? ACC_CNT : ACC_PRES;
+  bool need_cnt = want_offsets || guess_nona;
+  int first_flag = need_cnt ? ACC_CNT : ACC_PRES;
   // --- partition (skipped when one table holds the whole key range) ---
   uint16_t* kpart = nullptr;
   std::vector<const void*> vsrc(vd.size(), nullptr);
@@ -1060,6 +1064,14 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   const bool tile_local = g.d > 0 && !clustered && ctx->bucket_variant != 2 && g.block == 1024 &&
                           ((n >= (1 << 22) && g.F >= 1024 && even) || ctx->bucket_variant == 3);   // variant 3: forced (tests)
   if (tile_local) {
+    // round 6: 1024 x 16-row tiles (segments of 16 instead of 12 rows: fewer partly used sectors for the aggregation);
+    // DTHIP_TL_ITEMS=12 keeps round 5's tiles (A/B)
+    static const int tl_items = getenv("DTHIP_TL_ITEMS") ? atoi(getenv("DTHIP_TL_ITEMS")) : 16;
+    if (tl_items == 16) {
+      int maxw = 4;
+      for (int c : used) maxw = std::max(maxw, stype_size(vd[c].stype));
+      (void)bucket_tl16_geometry(ctx, n, maxw, &g);
+    }
     uint16_t* dir = nullptr; uint16_t* dT = nullptr; uint32_t* tot = nullptr;
     dstride = (g.ntiles + 63u) & ~63u;
     DTHIP_TRY(sc.get<uint16_t>((size_t)g.ntiles * (g.F + 1) + 8, &dir));
@@ -1106,11 +1118,16 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
 
   // --- dense accumulators + one aggregation launch per value column ---
   uint32_t* d_cnt = nullptr;      // rows per slot, or (no counts wanted) one presence bit per slot
+  std::vector<AggTable> tabs(vd.size());
+  std::vector<int> tflags(vd.size(), 0);
+  int32_t* idx = nullptr;
+  int64_t ng = 0;
+  DTHIP_TRY(sc.get<int32_t>(std::min<size_t>(nslots, (size_t)n) + 1, &idx));
+  for (int round = 0;; round++) {
   const size_t cnt_words = need_cnt ? nslots : (nslots + 31) / 32;
   DTHIP_TRY(sc.get<uint32_t>(cnt_words, &d_cnt));
   DTHIP_TRY(fill(d_cnt, cnt_words * 4, 0));
-  std::vector<AggTable> tabs(vd.size());
-  std::vector<int> tflags(vd.size(), 0);
+  for (auto& t : tabs) t = AggTable();
   bool first = true;
   for (int c : used) {              // tables first (all of them: the small path initialises them in ONE kernel) ...
     AggTable& t = tabs[c];
@@ -1163,12 +1180,10 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   }
 
   // --- groups = non-empty slots in slot order ---
-  int32_t* idx = nullptr;
-  DTHIP_TRY(sc.get<int32_t>(std::min<size_t>(nslots, (size_t)n) + 1, &idx));
   PredArgs pa;
   memset(&pa, 0, sizeof(pa));
   pa.data = d_cnt; pa.stype = DTHIP_INT32; pa.cmp = DTHIP_GT; pa.ci = 0; pa.is_mask = need_cnt ? 0 : 2;
-  int64_t ng = 0;
+  ng = 0;
   if (small) {
     void* off = nullptr;
     if (want_offsets) DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * (nslots + 2), &off));
@@ -1198,8 +1213,20 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
       uint32_t bad = 0;
       DTHIP_TRY(read_back(ctx, &bad, d_bad, sizeof(bad)));
       if (plan.speculative && (bad & 1u)) return DTHIP_RETRY_EXACT;
-      if (bad & 2u) return DTHIP_RETRY_NA;
+      if (bad & 2u) {
+        if (round == 0 && guess_nona && r_counting == r) {
+          // the NA-free guess was wrong, the partitioned rows are still right: aggregate them once more, counting
+          ctx->call_stats[1]++;
+          guess_nona = false;
+          need_cnt = want_offsets; first_flag = need_cnt ? ACC_CNT : ACC_PRES;
+          DTHIP_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
+          continue;
+        }
+        return DTHIP_RETRY_NA;
+      }
     }
+  }
+  break;
   }
   res->nrows = n; res->ngroups = ng;
   if (want_offsets && !small) {
@@ -1375,9 +1402,15 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   // out typed already
   static const bool raw_ok = !(getenv("DTHIP_HASH_RAW") && atoi(getenv("DTHIP_HASH_RAW")) == 0);
   const bool raw_key = raw_ok && nkeys == 1 && kd[0].stype == DTHIP_INT64;
+  // round 6: with a raw key the histogram and partition kernels HASH THE KEY COLUMN ON THE FLY (a two-multiply 24-bit hash,
+  // keyxform.hpp hash_pk24) instead of reading a pseudo-key array that a pass of its own wrote: 12 of the 80 bytes per row
+  // and one sweep less (DTHIP_HASH_FUSED=0: the pseudo-key pass of rounds 3-5, A/B)
+  static const bool fused_ok = !(getenv("DTHIP_HASH_FUSED") && atoi(getenv("DTHIP_HASH_FUSED")) == 0);
+  const bool fused_pk = raw_key && fused_ok;
   unsigned long long* xs = nullptr; int32_t* pk = nullptr;
-  DTHIP_TRY(sc.get<int32_t>((size_t)n + 4, &pk));
-  if (raw_key) {
+  if (!fused_pk) DTHIP_TRY(sc.get<int32_t>((size_t)n + 4, &pk));
+  if (fused_pk) {
+  } else if (raw_key) {
     DTHIP_TRY(launch_hash_pk_raw(ctx, kd[0].data, n, pk));
   } else {
     DTHIP_TRY(sc.get<unsigned long long>((size_t)n + 2, &xs));
@@ -1390,6 +1423,7 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   pkx.cols[0].data = pk; pkx.cols[0].stype = DTHIP_INT32; pkx.cols[0].desc = 0; pkx.cols[0].edge = 0;
   pkx.cols[0].na_repl = 0; pkx.cols[0].inc = 0; pkx.cols[0].xmax = ~0ULL; pkx.cols[0].shift = 0;
   int km = 2;
+  if (fused_pk) { pkx.cols[0].data = kd[0].data; pkx.cols[0].stype = DTHIP_KEY_HASH64; km = 1; }
   for (int c : used) if (reinterpret_cast<uintptr_t>(vd[c].data) & 15) km = 0;
   if (raw_key && (reinterpret_cast<uintptr_t>(kd[0].data) & 15)) km = 0;
   BucketGeom g;
@@ -1814,6 +1848,10 @@ int dthip_profile_names(dthip_ctx* ctx, char* buf, size_t buflen) {
 }
 
 // ---------------------------------------------------------------------------------
+static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthip_col& pred, int cmp, double cf, int64_t ci,
+                             const dthip_col* keys_orig, const std::vector<dthip_col>& kd, const dthip_col* cols_orig,
+                             const std::vector<dthip_col>& cd, int ncols, int64_t n, int na_pos, int want_rowindex, bool speculative);
+
 int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrows, int na_pos, int mem,
                   int want_rowindex, dthip_result** out) {
   DTHIP_TRY(check_common(ctx, nrows, mem));
@@ -1834,8 +1872,33 @@ int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrow
         rc = empty_result(ctx, res);   // Groupby::zero_groups(), sort.cc:1428-1431
       } else {
         KeyPlan plan; Grouping g;
-        rc = group_core(ctx, sc, res, kd.data(), nkeys, nrows, na_pos, &plan, &g);
-        if (rc == DTHIP_OK) {
+        // round 6: ONE big int64 key with the RowIndex wanted runs on the TILE-LOCAL sort levels of dthip_filter_groupby_rows
+        // with a predicate every row passes: the key transform and the first level are one sweep (no transform pass, no
+        // tile-histogram pass), every level writes sequentially, the riding "column" is the row number.  Same RowIndex and
+        // offsets bit for bit (tests/test_gpu_filter_rows.py, tests/test_gpu_msd.py); anything else, and every case the
+        // fused route turns down, takes the levels of group_core.  DTHIP_GROUPBY_TL=0: never (A/B)
+        static const bool tl_ok = !(getenv("DTHIP_GROUPBY_TL") && atoi(getenv("DTHIP_GROUPBY_TL")) == 0);
+        bool tl_done = false;
+        if (tl_ok && ctx->filter_rows_fused && want_rowindex && !remove_na && nkeys == 1 && kd[0].stype == DTHIP_INT64) {
+          const std::vector<dthip_col> none;
+          rc = DTHIP_NOT_APPLICABLE;
+          for (int attempt = 0; attempt < 2; attempt++) {
+            Scratch fs(ctx);
+            rc = filter_rows_fused(ctx, fs, res, kd[0], DTHIP_CMP_ALL, 0.0, 0, keys, kd, nullptr, none, 0, nrows, na_pos, 1, attempt == 0);
+            if (rc == DTHIP_ENOMEM) { rc = DTHIP_NOT_APPLICABLE; ctx->call_stats[2]++; dev_trim(ctx); break; }
+            if (rc != DTHIP_RETRY_EXACT) break;
+            ctx->call_stats[0]++;
+          }
+          if (rc == DTHIP_RETRY_EXACT) { set_error("groupby: exact key range violated"); rc = DTHIP_EDEVICE; }
+          if (rc == DTHIP_OK) { tl_done = true; ctx->call_stats[3] = 4; }
+          else if (rc == DTHIP_NOT_APPLICABLE) {
+            for (void* p : res->owned) dev_release(ctx, p);
+            res->owned.clear(); res->rowindex = nullptr; res->offsets = nullptr; res->col.clear();
+            rc = DTHIP_OK;
+          }
+        }
+        if (rc == DTHIP_OK && !tl_done) rc = group_core(ctx, sc, res, kd.data(), nkeys, nrows, na_pos, &plan, &g);
+        if (rc == DTHIP_OK && !tl_done) {
           res->nrows = nrows; res->ngroups = g.ngroups; res->offsets = g.offsets;
           if (want_rowindex) {
             // the ordering may alias nothing user-owned here: it is always a scratch buffer
@@ -2434,7 +2497,9 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
           continue;
         }
         if (bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &slot_bits, guess_nona)) {
-          rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits, guess_nona);
+          int sb_counting = -1;
+          if (guess_nona && !bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &sb_counting, false)) sb_counting = -1;
+          rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits, guess_nona, sb_counting);
           if (rc == DTHIP_RETRY_NA) {                    // same plan once more, with valid counts
             ctx->call_stats[1]++;
             guess_nona = false; rc = DTHIP_OK; drop_partial_result(ctx, res); attempt--; continue;

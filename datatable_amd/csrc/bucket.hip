@@ -51,6 +51,7 @@ __device__ __forceinline__ uint32_t item_row(int j, int tid) {
 
 // integer key transform (sort.cc:728-776) without branches: ascending u - edge, descending edge - u
 __device__ __forceinline__ uint32_t xf_int(const KeyColDev& c, long long v, long long na, bool& bad) {
+  if (c.stype == DTHIP_KEY_HASH64) return hash_pk24((u64)v);     // (uniform: the descriptor is a kernel argument)
   const u64 m = 0ULL - (u64)c.desc;              // all-ones when descending
   const u64 d0 = (((u64)v - c.edge) ^ m) - m;    // distance from the range's edge: [0, xmax] for a key inside the range
   const u64 t = (v == na) ? c.na_repl : d0 + c.inc;
@@ -431,39 +432,41 @@ struct PartArgs {
   uint16_t* dir; uint32_t* bad;
 };
 
-template <int BLOCK, int ITEMS, int KM, typename PT>
+// SEQ: the tile writes over ONE contiguous row range starting at seq_base (tile-local layout), so the global position of
+// staged row s is seq_base + s and no position array is kept in registers (gpos is a dummy then)
+template <int BLOCK, int ITEMS, int KM, typename PT, bool SEQ = false, int NG = ITEMS>
 __device__ __forceinline__ void place_payload(const PT (&v)[ITEMS], PT* __restrict__ pout, unsigned char* stage,
                                               uint32_t nvalid, bool full, int tid, const uint32_t (&lpos)[ITEMS],
-                                              const uint32_t (&gpos)[ITEMS]) {
+                                              const uint32_t (&gpos)[NG], uint32_t seq_base = 0) {
   PT* st = reinterpret_cast<PT*>(stage);
   __syncthreads();                                   // previous users of `stage` are done
 #pragma unroll
   for (int j = 0; j < ITEMS; j++)
-    if (full || item_row<BLOCK, KM>(j, tid) < nvalid) st[lpos[j]] = v[j];
+    if (SEQ || full || item_row<BLOCK, KM>(j, tid) < nvalid) st[lpos[j]] = v[j];
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
     const uint32_t s = (uint32_t)j * BLOCK + tid;
-    if (s < nvalid) pout[gpos[j]] = st[s];
+    if (s < nvalid) pout[SEQ ? seq_base + s : gpos[SEQ ? 0 : j]] = st[s];
   }
 }
 
-template <int BLOCK, int ITEMS, int KM, typename PT>
+template <int BLOCK, int ITEMS, int KM, typename PT, bool SEQ = false, int NG = ITEMS>
 __device__ __forceinline__ void move_payload(const PT* __restrict__ pin, PT* __restrict__ pout, unsigned char* stage,
                                              uint32_t nvalid, bool full, int tid, const uint32_t (&lpos)[ITEMS],
-                                             const uint32_t (&gpos)[ITEMS]) {
+                                             const uint32_t (&gpos)[NG], uint32_t seq_base = 0) {
   PT v[ITEMS];
   load_tile_vals<BLOCK, ITEMS, KM, PT>(pin, nvalid, full, tid, v);
   PT* st = reinterpret_cast<PT*>(stage);
   __syncthreads();                                   // previous users of `stage` are done
 #pragma unroll
   for (int j = 0; j < ITEMS; j++)
-    if (full || item_row<BLOCK, KM>(j, tid) < nvalid) st[lpos[j]] = v[j];
+    if (SEQ || full || item_row<BLOCK, KM>(j, tid) < nvalid) st[lpos[j]] = v[j];
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
     const uint32_t s = (uint32_t)j * BLOCK + tid;
-    if (s < nvalid) pout[gpos[j]] = st[s];
+    if (s < nvalid) pout[SEQ ? seq_base + s : gpos[SEQ ? 0 : j]] = st[s];
   }
 }
 
@@ -473,7 +476,13 @@ template <int BLOCK, int ITEMS, int KM, bool CL, bool PF>
 __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
   constexpr uint32_t TILE = BLOCK * ITEMS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t F = a.F, Fp = (F + 3u) & ~3u;
+  // TLS: 16-row items (16384-row tiles) exist for the tile-local layout only: the position array goes (compile time), and with
+  // it the registers that kept 1024 x 16 rows from fitting 128 VGPRs; a bucket's segment is 16 rows instead of 12 (C3).
+  // The rows past the end of a ragged last tile are ranked into an extra bin F behind the valid rows (its start is
+  // dir[tile][F] = nvalid anyway) and never written: no per-item "is this row valid" predicate lives across the phases
+  // (16 of them, 64-bit each, overflowed the scalar registers into VGPR lanes and scratch)
+  constexpr bool TLS = ITEMS == 16;
+  const uint32_t F = a.F, Fp = TLS ? ((F + 4u) & ~3u) : ((F + 3u) & ~3u);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);     // [Fp] bucket counts, then tile-local exclusive starts
   uint32_t* delta = cnt + Fp;                            // [Fp] global start - local start
   uint32_t* misc = delta + Fp;                           // [32]
@@ -488,11 +497,11 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
   const uint32_t nvalid = (a.n - tile_base < TILE) ? (a.n - tile_base) : TILE;
   const bool full = nvalid == TILE;
 
-  for (uint32_t b = tid; b < F; b += BLOCK) cnt[b] = 0;
+  for (uint32_t b = tid; b < F + (TLS ? 1u : 0u); b += BLOCK) cnt[b] = 0;
   // global start of this tile's run of every bucket this thread scans below: issued first, needed after the ranking
   const uint32_t K = (F + BLOCK - 1) / BLOCK;            // consecutive bins per thread
   uint32_t gstart[2048 / BLOCK];
-  const bool tl = a.dir != nullptr;
+  const bool tl = TLS || a.dir != nullptr;
   if (!tl) {
     const uint32_t g = tile / a.tpg;
 #pragma unroll
@@ -504,6 +513,10 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
   uint32_t x[ITEMS];
   bool bad = false;     // out-of-range keys were reported by the histogram pass; here they are just key 0 again
   load_tile_x<BLOCK, ITEMS, KM>(a.kx, tile_base, nvalid, full, tid, x, bad);
+  if (TLS && !full) {
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) if (item_row<BLOCK, KM>(j, tid) >= nvalid) x[j] = F << a.r;
+  }
   if (tl && __ballot(bad) && (tid & 63) == 0) atomicOr(a.bad, 1u);
   u64 pv[PF ? ITEMS : 1];
   if (PF) load_tile_vals<BLOCK, ITEMS, KM, u64>(static_cast<const u64*>(a.pay.in[0]) + tile_base, nvalid, full, tid,
@@ -515,8 +528,15 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
     lpos[j] = 0;
-    if (full || item_row<BLOCK, KM>(j, tid) < nvalid)
+    if (TLS || full || item_row<BLOCK, KM>(j, tid) < nvalid)
       lpos[j] = CL ? lds_count_rank(cnt, x[j] >> a.r) : atomicAdd(&cnt[x[j] >> a.r], 1u);
+  }
+  // TLS: the transformed keys wait in the upper half of the stage (the lower half receives them in bucket order) instead of
+  // in 16 registers across the scan: the 16-row instance stays inside 128 VGPRs without spilling
+  uint32_t* xkeep = reinterpret_cast<uint32_t*>(stage) + TILE;
+  if (TLS) {
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) xkeep[(uint32_t)j * BLOCK + tid] = x[j];
   }
   __syncthreads();
 
@@ -541,6 +561,7 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
       }
     }
     if (tl && tid == 0) a.dir[(size_t)tile * (F + 1) + F] = (uint16_t)nvalid;
+    if (TLS && tid == 0) cnt[F] = nvalid;             // the extra bin starts behind the valid rows
   }
   __syncthreads();
 
@@ -548,35 +569,39 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
   uint32_t* st32 = reinterpret_cast<uint32_t*>(stage);
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
-    if (full || item_row<BLOCK, KM>(j, tid) < nvalid) {
-      lpos[j] += cnt[x[j] >> a.r];
-      st32[lpos[j]] = x[j];
+    if (TLS || full || item_row<BLOCK, KM>(j, tid) < nvalid) {
+      const uint32_t xj = TLS ? xkeep[(uint32_t)j * BLOCK + tid] : x[j];
+      lpos[j] += cnt[xj >> a.r];
+      st32[lpos[j]] = xj;
     }
   }
   __syncthreads();
-  uint32_t gpos[ITEMS];
+  constexpr int NG = TLS ? 1 : ITEMS;
+  uint32_t gpos[NG];
   const uint32_t smask = (1u << a.r) - 1u;
 #pragma unroll
   for (int j = 0; j < ITEMS; j++) {
     const uint32_t s = (uint32_t)j * BLOCK + tid;
-    gpos[j] = 0;
+    if (!TLS) gpos[TLS ? 0 : j] = 0;
     if (s < nvalid) {
       const uint32_t xs = st32[s];
-      gpos[j] = delta[xs >> a.r] + s;
-      if (a.kout) a.kout[gpos[j]] = (uint16_t)(xs & smask);      // (hash combiner: no slot keys, the packed key is a payload)
+      const uint32_t gp = TLS ? tile_base + s : delta[xs >> a.r] + s;
+      if (!TLS) gpos[TLS ? 0 : j] = gp;
+      if (a.kout) a.kout[gp] = (uint16_t)(xs & smask);      // (hash combiner: no slot keys, the packed key is a payload)
     }
   }
+  if (TLS) gpos[0] = 0;
 
   // value columns follow the same permutation
-  if (PF) place_payload<BLOCK, ITEMS, KM, u64>(reinterpret_cast<const u64(&)[ITEMS]>(pv), static_cast<u64*>(a.pay.out[0]), stage,
-                                               nvalid, full, tid, lpos, gpos);
+  if (PF) place_payload<BLOCK, ITEMS, KM, u64, TLS, NG>(reinterpret_cast<const u64(&)[ITEMS]>(pv), static_cast<u64*>(a.pay.out[0]), stage,
+                                                        nvalid, full, tid, lpos, gpos, tile_base);
   for (int c = PF ? 1 : 0; c < a.pay.n; c++) {
     if (a.pay.width[c] == 8)
-      move_payload<BLOCK, ITEMS, KM, u64>(static_cast<const u64*>(a.pay.in[c]) + tile_base,
-                                          static_cast<u64*>(a.pay.out[c]), stage, nvalid, full, tid, lpos, gpos);
+      move_payload<BLOCK, ITEMS, KM, u64, TLS, NG>(static_cast<const u64*>(a.pay.in[c]) + tile_base,
+                                                   static_cast<u64*>(a.pay.out[c]), stage, nvalid, full, tid, lpos, gpos, tile_base);
     else
-      move_payload<BLOCK, ITEMS, KM, uint32_t>(static_cast<const uint32_t*>(a.pay.in[c]) + tile_base,
-                                               static_cast<uint32_t*>(a.pay.out[c]), stage, nvalid, full, tid, lpos, gpos);
+      move_payload<BLOCK, ITEMS, KM, uint32_t, TLS, NG>(static_cast<const uint32_t*>(a.pay.in[c]) + tile_base,
+                                                        static_cast<uint32_t*>(a.pay.out[c]), stage, nvalid, full, tid, lpos, gpos, tile_base);
   }
 }
 
@@ -708,8 +733,28 @@ int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const
   int maxw = 4;
   for (int c = 0; c < pay.n; c++) maxw = pay.width[c] > maxw ? pay.width[c] : maxw;
   const uint32_t Fp = (g.F + 3u) & ~3u;
-  const size_t lds = (size_t)(2 * Fp + 32) * 4 + (size_t)g.tile * maxw;
+  size_t lds = (size_t)(2 * Fp + 32) * 4 + (size_t)g.tile * maxw;
+  if (g.items == 16) {          // tile-local layout only (bucket_tl16_geometry); the stage's upper half keeps the keys
+    lds = (size_t)(2 * ((g.F + 4u) & ~3u) + 32) * 4 + (size_t)g.tile * 8;
+    if (!dir || g.block != 1024 || clustered || lds > 160 * 1024 - 256) { set_error("bucket partition: 16-row items need the tile-local layout"); return DTHIP_EINVAL; }
+    BK_DISPATCH_KM(part_t, 1024, 16, false, g, ctx, a, g.ntiles, lds);
+  }
   BK_DISPATCH(part_t, g, clustered, ctx, a, g.ntiles, lds);
+}
+
+// 1024 threads x 16 rows: the tile-local layout's own geometry (its partition instance keeps no position array); false when
+// the staged tile of the widest value column would not fit the LDS
+bool bucket_tl16_geometry(dthip_ctx* ctx, int64_t n, int maxw, BucketGeom* g) {
+  if (g->block != 1024) return false;
+  const uint32_t Fp = (g->F + 4u) & ~3u;
+  if (maxw > 8 || (size_t)(2 * Fp + 32) * 4 + (size_t)16384 * 8 > 160 * 1024 - 256) return false;
+  g->items = 16; g->tile = 16384;
+  g->ntiles = (uint32_t)((n + g->tile - 1) / g->tile);
+  const uint32_t gmax = (uint32_t)ctx->num_cus * 2u;
+  g->tpg = (g->ntiles + gmax - 1) / gmax;
+  if (g->tpg == 0) g->tpg = 1;
+  g->G = (g->ntiles + g->tpg - 1) / g->tpg;
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -212,6 +212,12 @@ int launch_minmax_sample(dthip_ctx* ctx, const void* data, int stype, int64_t n,
 constexpr int MAX_KEYCOLS = 8;
 constexpr int MAX_PASSES = 10;
 constexpr int HIST_STRIDE = 512;
+// internal stype of a key column descriptor: an int64 column whose "transformed key" is a 24-bit HASH of the raw value
+// (hash combiner, one raw int64 key: the partition kernels hash on the fly instead of reading a pseudo-key array)
+constexpr int DTHIP_KEY_HASH64 = 100;
+// internal comparison code of a row predicate: every row passes (dthip_groupby on the fused tile-local sort levels: the
+// "filter" of dthip_filter_groupby_rows that lets all rows through); never accepted from the ABI (enum dthip_cmp ends at 7)
+constexpr int DTHIP_CMP_ALL = 8;
 struct KeyColDev {
   const void* data;
   int stype;
@@ -345,6 +351,7 @@ struct AggTable {
   uint32_t* pres = nullptr;             // 1 bit per slot: some row has this key (when row counts are not wanted)
 };
 void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom* g);
+bool bucket_tl16_geometry(dthip_ctx* ctx, int64_t n, int maxw, BucketGeom* g);
 // *bad is set when a row's transformed key exceeds its column's xmax (such rows are counted as key 0)
 int launch_bucket_hist(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, uint32_t* P, uint32_t* gtot,
                        uint32_t* bad, bool clustered);

@@ -11,10 +11,23 @@ namespace dthip {
 // ---------------------------------------------------------------------------
 // `na` <- the row holds NA (its transformed value is c.na_repl, which a VALID key just outside a guessed range can
 // collide with: range checks must look at non-NA rows only, see xform_in_range)
+// 24-bit pseudo key of a raw 64-bit key: the partition of the hash combiner splits on its top bits.  Two 32-bit multiplies
+// (the two halves by different odd constants, summed): the kernels that evaluate it run one 12288-row tile per workgroup
+// between barriers, where the two 64-bit multiplies of a splitmix round sat on the critical path (round 2: 8.8 -> 12+ ms);
+// the hash tables inside a bucket use their own, full-strength hash, so this one only has to spread keys over buckets
+__device__ __forceinline__ uint32_t hash_pk24(unsigned long long v) {
+  const uint32_t h = (uint32_t)v * 0x9E3779B1u + (uint32_t)(v >> 32) * 0x85EBCA77u;
+  return h >> 8;
+}
+
 __device__ __forceinline__ unsigned long long xform_key_na(const KeyColDev& c, uint32_t row, bool& na) {
   typedef unsigned long long u64;
   na = true;
   switch (c.stype) {
+    case DTHIP_KEY_HASH64: {
+      na = false;                                     // (an NA key is one more raw value here)
+      return (u64)hash_pk24(static_cast<const u64*>(c.data)[row]);
+    }
     case DTHIP_BOOL: {
       const uint8_t t = static_cast<const uint8_t*>(c.data)[row];
       if (t == 128) return c.na_repl;

@@ -68,13 +68,15 @@ class _Options:
                   the GPU this way.
                "off": host pointers in, host buffers out on every call (rounds 1-3; PCIe-bound).
                Environment: DTHIP_SHIM_RESIDENCY.
-    f32_sum    True: sum(float32 column) accumulates in float32 row by row like the reference (dthip option f32_sum = 1,
-               column/sumprod.h:48-55); default False: float64 accumulation, rounded once.  Environment: DTHIP_SHIM_F32_SUM=1."""
+    f32_sum    True (default -- a drop-in binding returns the reference's bits): sum(float32 column) accumulates in float32 row
+               by row like the reference (dthip option f32_sum = 1, column/sumprod.h:48-55: bit for bit, one thread per
+               group); False: float64 accumulation, rounded once (more accurate and faster; differs from the reference by its
+               own float32 rounding, ~1e-7 x sum|v| per group).  Environment: DTHIP_SHIM_F32_SUM=0 / 1."""
     residency = os.environ.get("DTHIP_SHIM_RESIDENCY", "auto")
     # residency "lazy" only: V = DT[f.x <cmp> c, cols] stays a pending view until it is used; V[:, cols, by(key)] then runs as
     # ONE fused library call (BASELINE config 5's two statements).  False: the filter runs at once (round 4's behaviour)
     defer_filter = os.environ.get("DTHIP_SHIM_DEFER_FILTER", "1") not in ("", "0")
-    f32_sum = os.environ.get("DTHIP_SHIM_F32_SUM", "0") not in ("", "0")
+    f32_sum = os.environ.get("DTHIP_SHIM_F32_SUM", "1") not in ("", "0")
 
 
 options = _Options()

@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libdthip.so does not export %s" % s
         assert s in _lib.SIGNATURES, "%s has no ctypes signature in datatable_amd/_lib.py" % s
     assert set(_lib.SIGNATURES) == set(declared_symbols())
-    assert lib.dthip_abi_version() == 5
+    import re
+    hdr = open(os.path.join(ROOT, "include", "dthip.h")).read()
+    assert lib.dthip_abi_version() == int(re.search(r"#define DTHIP_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION == 6
     bid = lib.dthip_build_id().decode()
     assert len(bid) == 12 and all(ch in "0123456789abcdef" for ch in bid)
 

@@ -90,7 +90,9 @@ def test_patched_build_on_gpu_equals_unmodified_build_on_cpu(tmp_path, rows):
     groups, (reds, peeled, kept, mat) = _report(p.stderr)
     # 5 statements: group() served for every by(); 15 + 2 + 4 + 4 + 2 reducer columns over fixed-width columns
     assert groups >= 5 and reds >= 27, (groups, reds)
-    assert peeled >= 15 + 2 + 4 + 2 and kept >= 15 + 2, (peeled, kept)
+    # by_k and by_a_k read their columns through the RowIndex S-grp just produced (peeled, and already on the device); the
+    # filtered frame's columns are views of views (materialised first), sort() + by() hands over views of its own RowIndex
+    assert peeled >= 15 + 2 and kept >= 15 + 2, (peeled, kept, mat)
     env = dict(os.environ); env.pop("DTHIP_LIB", None); env["PYTHONPATH"] = REF
     q = subprocess.run([sys.executable, worker, REF, out_cpu, str(rows)], env=env, capture_output=True, text=True, timeout=900)
     assert q.returncode == 0, q.stderr[-3000:]
