@@ -1848,10 +1848,6 @@ int dthip_profile_names(dthip_ctx* ctx, char* buf, size_t buflen) {
 }
 
 // ---------------------------------------------------------------------------------
-static int filter_rows_fused(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthip_col& pred, int cmp, double cf, int64_t ci,
-                             const dthip_col* keys_orig, const std::vector<dthip_col>& kd, const dthip_col* cols_orig,
-                             const std::vector<dthip_col>& cd, int ncols, int64_t n, int na_pos, int want_rowindex, bool speculative);
-
 int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrows, int na_pos, int mem,
                   int want_rowindex, dthip_result** out) {
   DTHIP_TRY(check_common(ctx, nrows, mem));
@@ -1872,33 +1868,11 @@ int dthip_groupby(dthip_ctx* ctx, const dthip_col* keys, int nkeys, int64_t nrow
         rc = empty_result(ctx, res);   // Groupby::zero_groups(), sort.cc:1428-1431
       } else {
         KeyPlan plan; Grouping g;
-        // round 6: ONE big int64 key with the RowIndex wanted runs on the TILE-LOCAL sort levels of dthip_filter_groupby_rows
-        // with a predicate every row passes: the key transform and the first level are one sweep (no transform pass, no
-        // tile-histogram pass), every level writes sequentially, the riding "column" is the row number.  Same RowIndex and
-        // offsets bit for bit (tests/test_gpu_filter_rows.py, tests/test_gpu_msd.py); anything else, and every case the
-        // fused route turns down, takes the levels of group_core.  DTHIP_GROUPBY_TL=0: never (A/B)
-        static const bool tl_ok = !(getenv("DTHIP_GROUPBY_TL") && atoi(getenv("DTHIP_GROUPBY_TL")) == 0);
-        bool tl_done = false;
-        if (tl_ok && ctx->filter_rows_fused && want_rowindex && !remove_na && nkeys == 1 && kd[0].stype == DTHIP_INT64) {
-          const std::vector<dthip_col> none;
-          rc = DTHIP_NOT_APPLICABLE;
-          for (int attempt = 0; attempt < 2; attempt++) {
-            Scratch fs(ctx);
-            rc = filter_rows_fused(ctx, fs, res, kd[0], DTHIP_CMP_ALL, 0.0, 0, keys, kd, nullptr, none, 0, nrows, na_pos, 1, attempt == 0);
-            if (rc == DTHIP_ENOMEM) { rc = DTHIP_NOT_APPLICABLE; ctx->call_stats[2]++; dev_trim(ctx); break; }
-            if (rc != DTHIP_RETRY_EXACT) break;
-            ctx->call_stats[0]++;
-          }
-          if (rc == DTHIP_RETRY_EXACT) { set_error("groupby: exact key range violated"); rc = DTHIP_EDEVICE; }
-          if (rc == DTHIP_OK) { tl_done = true; ctx->call_stats[3] = 4; }
-          else if (rc == DTHIP_NOT_APPLICABLE) {
-            for (void* p : res->owned) dev_release(ctx, p);
-            res->owned.clear(); res->rowindex = nullptr; res->offsets = nullptr; res->col.clear();
-            rc = DTHIP_OK;
-          }
-        }
-        if (rc == DTHIP_OK && !tl_done) rc = group_core(ctx, sc, res, kd.data(), nkeys, nrows, na_pos, &plan, &g);
-        if (rc == DTHIP_OK && !tl_done) {
+        // (round 6, measured and dropped: this call on the TILE-LOCAL levels of dthip_filter_groupby_rows with a predicate every
+        // row passes -- no transform / tile-histogram passes, sequential writes -- took 6.6 + 5.4 + 6.2 ms for 1e9 rows against
+        // 3.0 + 1.8 + 3.9 + 4.4 + 4.0 here: the gathers cost more than the passes they save, profiles/r06_groupby_tl_ab.txt)
+        rc = group_core(ctx, sc, res, kd.data(), nkeys, nrows, na_pos, &plan, &g);
+        if (rc == DTHIP_OK) {
           res->nrows = nrows; res->ngroups = g.ngroups; res->offsets = g.offsets;
           if (want_rowindex) {
             // the ordering may alias nothing user-owned here: it is always a scratch buffer

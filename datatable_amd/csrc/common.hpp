@@ -215,9 +215,6 @@ constexpr int HIST_STRIDE = 512;
 // internal stype of a key column descriptor: an int64 column whose "transformed key" is a 24-bit HASH of the raw value
 // (hash combiner, one raw int64 key: the partition kernels hash on the fly instead of reading a pseudo-key array)
 constexpr int DTHIP_KEY_HASH64 = 100;
-// internal comparison code of a row predicate: every row passes (dthip_groupby on the fused tile-local sort levels: the
-// "filter" of dthip_filter_groupby_rows that lets all rows through); never accepted from the ABI (enum dthip_cmp ends at 7)
-constexpr int DTHIP_CMP_ALL = 8;
 struct KeyColDev {
   const void* data;
   int stype;

@@ -13,7 +13,6 @@ __device__ __forceinline__ bool pred_at(const PredArgs& p, uint32_t i) {
     const int8_t v = static_cast<const int8_t*>(p.data)[i];
     return v != INT8_MIN && v != 0;
   }
-  if (p.cmp == DTHIP_CMP_ALL) return true;
   bool na; double fv = 0; long long iv = 0; bool isf = false;
   switch (p.stype) {
     case DTHIP_BOOL: case DTHIP_INT8: { int8_t v = static_cast<const int8_t*>(p.data)[i]; na = v == INT8_MIN; iv = v; break; }
@@ -41,7 +40,6 @@ __device__ __forceinline__ bool pred_at(const PredArgs& p, uint32_t i) {
 
 // the predicate on an already loaded element of a float64 / int64 column
 __device__ __forceinline__ bool pred_val8(const PredArgs& p, unsigned long long bitsv) {
-  if (p.cmp == DTHIP_CMP_ALL) return true;
   if (p.stype == DTHIP_FLOAT64) {
     const double d = __longlong_as_double((long long)bitsv);
     const bool na = d != d;
