@@ -1449,27 +1449,30 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   const uint32_t max_items = g.F + (uint32_t)((uint64_t)n / M) + 1;
   WorkItem* items = nullptr;
   DTHIP_TRY(sc.get<WorkItem>(max_items, &items));
-  uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
-  DTHIP_TRY(sc.get<uint32_t>((size_t)g.ntiles * g.F, &P));
-  DTHIP_TRY(sc.get<uint32_t>((size_t)g.G * g.F, &gtot));
-  DTHIP_TRY(sc.get<uint32_t>((size_t)g.F, &tot));
-  DTHIP_TRY(launch_bucket_hist(ctx, pkx, n, g, P, gtot, d_bad, false));
-  DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, nullptr, 0));
-  DTHIP_TRY(launch_bucket_plan(ctx, tot, g.F, 0, M, bbase, items, nitems));
-  DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, bbase, 1));
+  const size_t part_rows = (size_t)n;
   uint16_t* kslot = nullptr;         // not written: the packed key itself travels as payload 0
   unsigned long long* xs_part = nullptr;
-  DTHIP_TRY(sc.get<unsigned long long>((size_t)n + 8, &xs_part));
+  DTHIP_TRY(sc.get<unsigned long long>(part_rows + 8, &xs_part));
   PayCols pc;
   memset(&pc, 0, sizeof(pc));
   pc.in[0] = raw_key ? kd[0].data : static_cast<const void*>(xs); pc.out[0] = xs_part; pc.width[0] = 8; pc.n = 1;
   std::vector<unsigned char*> v_part(std::max<size_t>(used.size(), 1), nullptr);
   for (size_t i = 0; i < used.size(); i++) {
     const int w = stype_size(vd[used[i]].stype);
-    DTHIP_TRY(sc.get<unsigned char>((size_t)n * w + 64, &v_part[i]));
+    DTHIP_TRY(sc.get<unsigned char>(part_rows * w + 64, &v_part[i]));
     pc.in[pc.n] = vd[used[i]].data; pc.out[pc.n] = v_part[i]; pc.width[pc.n] = w; pc.n++;
   }
-  DTHIP_TRY(launch_bucket_partition(ctx, pkx, n, g, P, gtot, kslot, pc, false));
+  {
+    uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
+    DTHIP_TRY(sc.get<uint32_t>((size_t)g.ntiles * g.F, &P));
+    DTHIP_TRY(sc.get<uint32_t>((size_t)g.G * g.F, &gtot));
+    DTHIP_TRY(sc.get<uint32_t>((size_t)g.F, &tot));
+    DTHIP_TRY(launch_bucket_hist(ctx, pkx, n, g, P, gtot, d_bad, false));
+    DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, nullptr, 0));
+    DTHIP_TRY(launch_bucket_plan(ctx, tot, g.F, 0, M, bbase, items, nitems));
+    DTHIP_TRY(launch_bucket_gscan(ctx, g, gtot, tot, bbase, 1));
+    DTHIP_TRY(launch_bucket_partition(ctx, pkx, n, g, P, gtot, kslot, pc, false));
+  }
 
   int64_t ng_all = -1;
   for (int i = 0; i < ncolpass; i++) {

@@ -1382,7 +1382,71 @@ int launch_hash_pk_raw(dthip_ctx* ctx, const void* key, int64_t n, int32_t* pk) 
   return DTHIP_OK;
 }
 
+// Position and double-hashing step of a key inside a workgroup's hash table (C prime): 32-bit arithmetic.  Rounds 2-5 took a
+// splitmix round + two 64-bit Lemire reductions -- five 64 x 64-bit multiplies = ~20 quarter-rate v_mul_lo / v_mul_hi per row,
+// about a third of hash_agg_kernel's time (it is bound by its VALU work: profiles/r06_hash_tl_ab.txt).  Here: the two
+// halves by two odd constants (others than hash_pk24's, which chose the bucket), one xorshift-multiply, two multiply-highs.
+__device__ __forceinline__ void hash_tab_probe0(u64 x, uint32_t C, uint32_t& p, uint32_t& step) {
+#ifdef DTHIP_HASH_MIX64            // (A/B flavour: `make var NAME=mix64 VFILE=bucket FLAGS=-DDTHIP_HASH_MIX64`)
+  const u64 h2 = mix64(x ^ 0x9E3779B97F4A7C15ULL);
+  p = (uint32_t)(((h2 & 0xFFFFFFFFULL) * (u64)C) >> 32);
+  step = 1u + (uint32_t)(((h2 >> 32) * (u64)(C - 1)) >> 32);
+#else
+  uint32_t h = (uint32_t)x * 0xC2B2AE3Du + (uint32_t)(x >> 32) * 0x27D4EB2Fu;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+  p = __umulhi(h, C);
+  step = 1u + __umulhi(h * 0x297A2D39u + 0x165667B1u, C - 1u);
+#endif
+}
+
 constexpr u64 HASH_EMPTY = ~0ULL;
+
+// occupied entries of a workgroup's hash table -> compact partial groups {key, raw accumulators} (unordered)
+__device__ __forceinline__ void hash_tab_flush(const u64* hk, const LdsTab& t, int flags, uint32_t C, uint32_t* s_misc,
+                                               u64* o_key, const AggTable& o_tab, uint32_t* out_n, uint32_t out_cap,
+                                               uint32_t* overflow, int tid) {
+  const uint32_t S = C + 1;
+  uint32_t mine = 0;
+  for (uint32_t s = tid; s < S; s += TA_BLOCK) mine += (s < C ? hk[s] != HASH_EMPTY : s_misc[16] != 0) ? 1u : 0u;
+  uint32_t total;
+  const uint32_t before = block_excl_scan_u32<TA_BLOCK>(mine, s_misc, &total);
+  if (tid == 0) {
+    const uint32_t base = atomicAdd(out_n, total);
+    s_misc[17] = base;
+    if (base + total > out_cap) { atomicOr(overflow, 2u); s_misc[17] = ~0u; }
+  }
+  __syncthreads();
+  const uint32_t base = s_misc[17];
+  if (base == ~0u) return;
+  // block_excl_scan gives each thread the number of occupied entries of LOWER threads; entries of one
+  // thread are strided, so positions are base + before + (rank among the thread's own entries)
+  uint32_t pos = base + before;
+  for (uint32_t s = tid; s < S; s += TA_BLOCK) {
+    const bool occ = s < C ? hk[s] != HASH_EMPTY : s_misc[16] != 0;
+    if (!occ) continue;
+    o_key[pos] = s < C ? hk[s] : HASH_EMPTY;
+    if (flags & ACC_CNT) o_tab.cnt[pos] = t.cnt[s];
+    if (flags & ACC_VCNT) o_tab.vcnt[pos] = t.vcnt[s];
+    if (flags & ACC_SUM) o_tab.sum[pos] = t.sum[s];
+    if (flags & ACC_MIN) o_tab.mn[pos] = t.mn[s];
+    if (flags & ACC_MAX) o_tab.mx[pos] = t.mx[s];
+    if (flags & ACC_FSUM) o_tab.fsum[pos] = t.fsum[s];
+    pos++;
+  }
+}
+
+__device__ __forceinline__ void hash_tab_init(u64* hk, const LdsTab& t, int flags, uint32_t S, uint32_t* s_misc, int tid) {
+  for (uint32_t s = tid; s < S; s += TA_BLOCK) {
+    hk[s] = HASH_EMPTY;
+    if (flags & ACC_SUM) t.sum[s] = 0;
+    if (flags & ACC_MIN) t.mn[s] = ~0ULL;
+    if (flags & ACC_MAX) t.mx[s] = 0;
+    if (flags & ACC_FSUM) t.fsum[s] = 0.0;
+    if (flags & ACC_CNT) t.cnt[s] = 0;
+    if (flags & ACC_VCNT) t.vcnt[s] = 0;
+  }
+  if (tid == 0) s_misc[16] = 0;                      // special entry used?
+}
 
 struct HashAggDev {
   const WorkItem* items; const uint32_t* nitems;
@@ -1406,16 +1470,7 @@ __global__ void __launch_bounds__(TA_BLOCK) hash_agg_kernel(HashAggDev a) {
   u64* hk = reinterpret_cast<u64*>(smem);            // [S] keys
   const LdsTab t = carve_tab(smem + (size_t)S * 8, S, flags);
   __shared__ uint32_t s_misc[20];
-  for (uint32_t s = tid; s < S; s += TA_BLOCK) {
-    hk[s] = HASH_EMPTY;
-    if (flags & ACC_SUM) t.sum[s] = 0;
-    if (flags & ACC_MIN) t.mn[s] = ~0ULL;
-    if (flags & ACC_MAX) t.mx[s] = 0;
-    if (flags & ACC_FSUM) t.fsum[s] = 0.0;
-    if (flags & ACC_CNT) t.cnt[s] = 0;
-    if (flags & ACC_VCNT) t.vcnt[s] = 0;
-  }
-  if (tid == 0) s_misc[16] = 0;                      // special entry used?
+  hash_tab_init(hk, t, flags, S, s_misc, tid);
   __syncthreads();
   const VT* __restrict__ val = static_cast<const VT*>(a.val);
   const bool hasval = (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) != 0;
@@ -1429,9 +1484,8 @@ __global__ void __launch_bounds__(TA_BLOCK) hash_agg_kernel(HashAggDev a) {
       // second hash (independent of the bits that chose the bucket): start by Lemire reduction to [0, C),
       // DOUBLE hashing step in [1, C) -- C is prime, so every step visits all entries.  Linear probing
       // clusters: at load 0.6 the slowest of a wave's 64 lanes needed ~20 probes, and a wave waits for it.
-      const u64 h2 = mix64(x ^ 0x9E3779B97F4A7C15ULL);
-      p = (uint32_t)(((h2 & 0xFFFFFFFFULL) * (u64)C) >> 32);
-      const uint32_t step = 1u + (uint32_t)(((h2 >> 32) * (u64)(C - 1)) >> 32);
+      uint32_t step;
+      hash_tab_probe0(x, C, p, step);
       uint32_t probes = 0;
       // most rows find their key already in the table (rows >> keys): look with a plain DS read first,
       // compare-and-swap only into an empty entry
@@ -1495,9 +1549,7 @@ __global__ void __launch_bounds__(TA_BLOCK) hash_agg_kernel(HashAggDev a) {
             fresh = false; probes = 0;
             if (x == HASH_EMPTY) { p = C; s_misc[16] = 1; resolved = true; }
             else {
-              const u64 h2 = mix64(x ^ 0x9E3779B97F4A7C15ULL);
-              p = (uint32_t)(((h2 & 0xFFFFFFFFULL) * (u64)C) >> 32);
-              step = 1u + (uint32_t)(((h2 >> 32) * (u64)(C - 1)) >> 32);
+              hash_tab_probe0(x, C, p, step);
             }
           }
           if (!resolved) {
@@ -1523,34 +1575,7 @@ __global__ void __launch_bounds__(TA_BLOCK) hash_agg_kernel(HashAggDev a) {
   }
   if (__ballot(full) && (tid & 63) == 0) atomicOr(a.overflow, 1u);
   __syncthreads();
-  // occupied entries -> compact partial groups
-  uint32_t mine = 0;
-  for (uint32_t s = tid; s < S; s += TA_BLOCK) mine += (s < C ? hk[s] != HASH_EMPTY : s_misc[16] != 0) ? 1u : 0u;
-  uint32_t total;
-  const uint32_t before = block_excl_scan_u32<TA_BLOCK>(mine, s_misc, &total);
-  if (tid == 0) {
-    const uint32_t base = atomicAdd(a.out_n, total);
-    s_misc[17] = base;
-    if (base + total > a.out_cap) { atomicOr(a.overflow, 2u); s_misc[17] = ~0u; }
-  }
-  __syncthreads();
-  const uint32_t base = s_misc[17];
-  if (base == ~0u) return;
-  // block_excl_scan gives each thread the number of occupied entries of LOWER threads; entries of one
-  // thread are strided, so positions are base + before + (rank among the thread's own entries)
-  uint32_t pos = base + before;
-  for (uint32_t s = tid; s < S; s += TA_BLOCK) {
-    const bool occ = s < C ? hk[s] != HASH_EMPTY : s_misc[16] != 0;
-    if (!occ) continue;
-    a.o_key[pos] = s < C ? hk[s] : HASH_EMPTY;
-    if (flags & ACC_CNT) a.o_tab.cnt[pos] = t.cnt[s];
-    if (flags & ACC_VCNT) a.o_tab.vcnt[pos] = t.vcnt[s];
-    if (flags & ACC_SUM) a.o_tab.sum[pos] = t.sum[s];
-    if (flags & ACC_MIN) a.o_tab.mn[pos] = t.mn[s];
-    if (flags & ACC_MAX) a.o_tab.mx[pos] = t.mx[s];
-    if (flags & ACC_FSUM) a.o_tab.fsum[pos] = t.fsum[s];
-    pos++;
-  }
+  hash_tab_flush(hk, t, flags, C, s_misc, a.o_key, a.o_tab, a.out_n, a.out_cap, a.overflow, tid);
 }
 
 size_t hash_agg_entry_bytes(int flags) { return 8 + table_agg_slot_bytes(flags); }
@@ -1581,6 +1606,12 @@ int launch_hash_agg(dthip_ctx* ctx, const HashAggArgs& a) {
     default: set_error("hash_agg: unsupported value stype %d", a.vstype); return DTHIP_ENOTIMPL;
   }
 }
+
+// (round 6, measured and dropped: the same tables fed from a TILE-LOCAL partition -- 16384-row tiles, 8-row segments per bucket
+// found through the transposed directory, 8 lanes per segment, every lane walking up to eight rows of eight segments.  The
+// partition took 5.9 ms instead of 8.6 + 1.6 for histogram + exact positions, but this kernel 13.5 instead of 5.8: it is
+// bound by the VALU work of its walk loop, and segments of 8 +- 3 rows fill the lanes' queues unevenly -- three rounds per
+// 64 tiles for what eight full slots do in one.  22.1 ms against 18.5: profiles/r06_hash_tl_ab.txt, r06_hash_tabhash_ab.txt)
 
 // raw accumulators of the partial groups -> typed columns the merge can reduce:
 //   psum  float64 (float values) / int64 (integer values)      pfsum float64 (integer values, for mean)

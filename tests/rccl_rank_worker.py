@@ -1,5 +1,6 @@
 """One rank of tests/test_gpu_rccl_2proc.py: `python rccl_rank_worker.py <rank> <world> <dir>` -- its own process, its own
-HIP context on GPU 0, the library's one-process-per-rank entry points (dthip_comm_init + dthip_sharded_groupby_*)."""
+HIP context on GPU 0 (or, with DTHIP_WORKER_DEVICE_PER_RANK=1 on a multi-GPU box, on GPU <rank>: RCCL's own transport), the
+library's one-process-per-rank entry points (dthip_comm_init + dthip_sharded_groupby_*)."""
 import os
 import sys
 import time
@@ -56,7 +57,7 @@ def main():
                 raise SystemExit("no communicator id after 60 s")
             time.sleep(0.01)
     cid = open(idf, "rb").read()
-    ctx = Context(0)
+    ctx = Context(rank if os.environ.get("DTHIP_WORKER_DEVICE_PER_RANK") else 0)
     ctx.comm_init(rank, world, cid)
     assert ctx.comm_rank == rank and ctx.comm_world == world
     res = {}

@@ -118,18 +118,20 @@ def _vs_oracle(ctx, keys, vals, aggs=OPS, key_stypes=None, check_ri=True):
         r.free()
     # sparse key ranges: the hash combiner (LDS hash tables -> partial groups -> merge), forced on
     # (takes effect where the bucketed path does not apply; several value columns: one pass of hash tables per column)
-    ctx.set_option("hash_mode", 2)
-    try:
-        r = ctx.groupby_agg(keys, vals, alist, key_stypes=key_stypes)
-    finally:
-        ctx.set_option("hash_mode", 0)
-    assert_same(r.offsets(), off, "fused offsets [hash_mode=2]")
-    for i in range(len(keys)):
-        assert_same(r.key(i), gkeys[i], "fused group key %d [hash_mode=2]" % i)
-    for a, (opn, vi) in enumerate(alist[:-1]):
-        check_agg(r.agg(a), expected[a], opn, vals[vi], ri, off, "%s(v%d) [hash_mode=2]" % (opn, vi))
-    assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count() [hash_mode=2]")
-    r.free()
+    for hm in (2,):
+        ctx.set_option("hash_mode", hm)
+        try:
+            r = ctx.groupby_agg(keys, vals, alist, key_stypes=key_stypes)
+        finally:
+            ctx.set_option("hash_mode", 0)
+        tag = " [hash_mode=%d]" % hm
+        assert_same(r.offsets(), off, "fused offsets" + tag)
+        for i in range(len(keys)):
+            assert_same(r.key(i), gkeys[i], "fused group key %d%s" % (i, tag))
+        for a, (opn, vi) in enumerate(alist[:-1]):
+            check_agg(r.agg(a), expected[a], opn, vals[vi], ri, off, "%s(v%d)%s" % (opn, vi, tag))
+        assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count()" + tag)
+        r.free()
     # the same without group sizes in the result (option agg_offsets=0, no count()): the bucketed
     # path then tracks key presence only and uses larger tables / fewer buckets
     ctx.set_option("agg_path", 2)
@@ -308,6 +310,9 @@ def test_hash_combiner_sparse_keys(ctx):
             for val in (v, iv, fv, i32):
                 _vs_oracle(ctx, keys, [val], check_ri=False)
             _vs_oracle(ctx, keys, [], aggs=(), check_ri=False)
+        # several value columns ride through ONE partition
+        _vs_oracle(ctx, [k_int], [v, iv, i32], check_ri=False)
+        _vs_oracle(ctx, [k_skew], [v, fv], check_ri=False)
     finally:
         ctx.set_option("hash_mode", 0)
 

@@ -24,7 +24,7 @@ def fake_rccl(tmp_path_factory):
     return so
 
 
-def run_ranks(world, fake_rccl, d):
+def run_ranks(world, fake_rccl, d, real_rccl=False):
     """Several processes share ONE GPU here, which no deployment does (one process per GPU).  Rounds 3-4 saw a rank die of
     'Memory access fault' on some boxes and ran the ranks a second time; round 5 found the cause -- read_back() freed the
     mapped host words of the small-table path and left the stale pointers behind, and whether the freed mapping still
@@ -32,6 +32,9 @@ def run_ranks(world, fake_rccl, d):
     single process deterministically, the fixed library runs every sequence clean) -- so the retry is gone: a lost rank, a
     wrong result, a Python error or a hang fails the test."""
     env = dict(os.environ, DTHIP_RCCL_LIB=fake_rccl, FAKE_RCCL_DIR=d)
+    if real_rccl:        # one rank per GPU, librccl.so itself (dlopen'ed by dthip_comm_unique_id / dthip_comm_init)
+        env = {k: v for k, v in os.environ.items() if k not in ("DTHIP_RCCL_LIB", "FAKE_RCCL_DIR")}
+        env.update(DTHIP_WORKER_DEVICE_PER_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank_worker.py"), str(r), str(world), d], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
@@ -52,10 +55,28 @@ def run_ranks(world, fake_rccl, d):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_ranks_as_processes(world, fake_rccl, tmp_path):
+    parts, verdicts = run_ranks(world, fake_rccl, str(tmp_path))
+    check_ranks(world, parts, verdicts)
+
+
+def test_ranks_one_per_gpu_over_real_rccl(tmp_path):
+    """The same ranks, ONE PER GPU, over RCCL's own transport (xGMI / PCIe between the devices): enables itself on the first box
+    that shows two devices (dthip_device_count() >= 2) -- the single-GPU boxes of this pool skip it, RCCL refuses two ranks on
+    one device.  Same queries, same assertions: the concatenation of the ranks' results against the oracle, a failure of
+    one rank reaching every rank, the communicator usable afterwards."""
+    from datatable_amd import _lib
+    ndev = _lib.load().dthip_device_count()
+    if ndev < 2:
+        pytest.skip("%d GPU on this box: RCCL's own transport needs one device per rank" % ndev)
+    world = min(ndev, 4)
+    parts, verdicts = run_ranks(world, None, str(tmp_path), real_rccl=True)
+    check_ranks(world, parts, verdicts)
+
+
+def check_ranks(world, parts, verdicts):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import rccl_rank_worker as W
     from oracle import oracle as o
-    parts, verdicts = run_ranks(world, fake_rccl, str(tmp_path))
     cat = lambda key: np.concatenate([p[key] for p in parts])
     for name, (kind, keys, cols, ops, opt) in W.cases(world).items():
         if opt.get("empty_last"):            # the last rank's shard is empty: the frame is what the others hold
