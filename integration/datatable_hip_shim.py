@@ -126,7 +126,7 @@ def _dev_alloc(ctx, nbytes):
     return _DevBuf(ctx, p.value)
 
 
-def _arrow_buffers(frame, c):
+def _arrow_buffers(frame, c, virtual=None):
     """(validity address or 0, values address, owner) when column c can be handed over in Arrow layout WITHOUT the
     reference's materialisation pass, else None.  A column that came from an Arrow table is two buffers -- validity bitmap
     and values (ArrowFw_ColumnImpl / ArrowBool_ColumnImpl, column_from_arrow.cc:40-59) -- and is reported `virtual`;
@@ -134,12 +134,22 @@ def _arrow_buffers(frame, c):
     (arrow_fw.cc:63-72 read by _materialize_fw).  Its Arrow export is zero-copy (Column::to_arrow hands out the column's own
     buffers, frame/to_arrow.cc:85-118), so the two addresses go to dthip_from_arrow and the NA sentinels are written by a
     kernel on the device.  Needs pyarrow (the reference's own to_arrow() does)."""
+    # `virtual`: the frame's virtual-column tuple, asked for ONCE per upload batch by _resident (it is O(ncols) itself).
+    # A virtual column that is not Arrow-backed (a view, a cast, a computed column) would be materialised by to_arrow() on the
+    # CPU and converted a second time on the device: there is no Python-visible mark of an Arrow-backed column, so only frames
+    # whose columns are ALL virtual and that are not views of another frame's rows (what dt.Frame(pyarrow_table) gives) take
+    # this route; everything else keeps frame_column_data_r
+    if virtual is None:
+        virtual = dt.internal.frame_columns_virtual(frame)
+    if not virtual[c] or not all(virtual):
+        return None
     try:
-        if not dt.internal.frame_columns_virtual(frame)[c]:
-            return None
         import pyarrow  # noqa: F401
+    except ImportError:
+        return None
+    try:
         col = dt.Frame.__getitem__(frame, (slice(None), c)).to_arrow().column(0)
-    except Exception:
+    except (TypeError, ValueError, NotImplementedError, RuntimeError):      # stypes / layouts the reference's exporter refuses
         return None
     if col.num_chunks != 1:
         return None
@@ -150,11 +160,11 @@ def _arrow_buffers(frame, c):
     return (bufs[0].address if bufs[0] is not None else 0), bufs[1].address, a
 
 
-def _upload_column(ctx, frame, c):
+def _upload_column(ctx, frame, c, virtual=None):
     import ctypes as C
     st = frame.stypes[c].value
     n = frame.nrows
-    ab = _arrow_buffers(frame, c) if st in _ACCEL_STYPES and n else None
+    ab = _arrow_buffers(frame, c, virtual) if st in _ACCEL_STYPES and n else None
     if ab is not None:
         nbytes = n * ST2NP[st].itemsize
         buf = _dev_alloc(ctx, nbytes)
@@ -181,6 +191,7 @@ def _resident(frame, cols, ctx):
         cache.clear()
     frame.__dict__["_dthip_ctx"] = ctx
     out = []
+    virtual = None
     for c in cols:
         e = cache.get(c)
         st = frame.stypes[c].value
@@ -191,7 +202,9 @@ def _resident(frame, cols, ctx):
         if e is not None and (e.nrows != frame.nrows or e.stype != st):
             e = None
         if e is None:
-            e = cache[c] = _upload_column(ctx, frame, c)
+            if virtual is None:
+                virtual = dt.internal.frame_columns_virtual(frame)
+            e = cache[c] = _upload_column(ctx, frame, c, virtual)
         out.append(e)
     return out
 

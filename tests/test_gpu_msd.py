@@ -1,4 +1,4 @@
-"""The MSD levels of the sort path (round 4: two stable scatter levels + every final bucket ordered in LDS, api.hip
+"""The MSD levels of the sort path (round 4: two stable scatter levels + every final bucket ordered in LDS, plan.hip
 sort_stage / radix.hip) against the oracle, bit for bit, on inputs small enough for the oracle -- the levels are forced on
 with `sort_path` = 2, `msd_min_rows` = 1 and small `msd_bucket_rows` so that a few hundred thousand rows already make
 hundreds of buckets per level, ragged tiles, empty final buckets and buckets of one row.  The same cases run on the LSD
