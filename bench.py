@@ -351,6 +351,7 @@ def adversarial_legs(ctx, dev, n, groups, steps, verify, threads, budget, c3_ms)
         prof = {nm: ctx.profile_get(nm) for nm in ctx.profile_names()}
         out[name] = {"workload": desc, "rows": n, "groups": int(ng), "ms": ms, "rows_s": n / (ms * 1e-3), "x_C3": (ms / c3_ms) if c3_ms else None,
                      "retries": {"key_range": st["retries_key_range"], "na_guess": st["retries_na_guess"]}, "path": st["path"],
+                     "outlier_rows_listed": st["outlier_rows_listed"],
                      "kernel_ms": {q: round(w[0], 4) for q, w in sorted(prof.items(), key=lambda kv: -kv[1][0])[:6]}}
         if verify and budget.ok(40):
             par, _ = verify_agg(ctx, name, [keys], [vals], aggs + ([("count0", None)] if ("count0", None) not in aggs else []), threads, host=host)
@@ -370,13 +371,14 @@ def adversarial_legs(ctx, dev, n, groups, steps, verify, threads, budget, c3_ms)
     for row in (n // 3 + 7, n // 3 + 100_003, n // 5 + 11):
         old = int(k[row].item()); k[row] = outlier_val
         r = ctx.groupby_agg([devcol(k)], [devcol(v)], [("sum", 0)], nrows=n); r.free()
-        hit = ctx.last_call_stats()["retries_key_range"] > 0
+        st0 = ctx.last_call_stats()
+        hit = st0["retries_key_range"] > 0 or st0["outlier_rows_listed"] > 0
         if hit:
             break
         k[row] = old
     if hk is not None:
         hk_old = int(hk[row]); hk[row] = outlier_val
-    timed("C3_outlier", k, v, [("sum", 0)], "C3 with ONE key = %d at row %d (sampled range [0,%d) violated -> second sweep with the exact range)" % (outlier_val, row, groups),
+    timed("C3_outlier", k, v, [("sum", 0)], "C3 with ONE key = %d at row %d (outside the sampled range [0,%d): round 6 lists the row and splices its group in; rounds 2-5 ran a second sweep with the exact range)" % (outlier_val, row, groups),
           host=([hk], [hv]) if hk is not None else None)
     out["C3_outlier"]["sample_missed_the_outlier"] = bool(hit)
     k[row] = old

@@ -68,6 +68,125 @@ static bool bucket_eligible(const dthip_ctx* ctx, const KeyPlan& plan, const std
   return true;
 }
 
+// ---- outlier keys of a guessed range (round 6) ----------------------------------------------------------------------------
+// The range of a big integer key column is guessed from a sample (SPEC_SAMPLES pieces, widened by 1/64) and every row is
+// checked.  Rounds 2-5 answered ONE key outside the guess with a second sweep over all rows (C3, one outlier: 2.1 x).  Now
+// the partition lists such rows (at most OUTLIER_CAP; more than that means the guess was wrong, not that there are
+// outliers) and leaves them out; here they are gathered, grouped by a nested call, and their groups -- all of them below or
+// above every group of the range -- are spliced in: [NA group if NA comes first] [outliers before the range] [range]
+// [outliers behind it] [NA group if NA comes last].  One key column (with several, an outlier in one column interleaves).
+constexpr uint32_t OUTLIER_CAP = 1u << 16;
+
+static int splice_outlier_groups(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const KeyPlan& plan, const std::vector<dthip_col>& kd,
+                                 const std::vector<dthip_col>& vd, const dthip_agg* aggs, int naggs, const uint32_t* ovf_rows,
+                                 uint32_t n_out, const uint32_t* d_cnt, bool cnt_is_counts, bool want_offsets) {
+  const KeyColDev& kc = plan.col[0];
+  const int kst = kd[0].stype, ksz = stype_size(kst);
+  // the listed rows' key and value columns (their order in the list is arbitrary: the nested call orders them)
+  unsigned char* ok = nullptr;
+  DTHIP_TRY(sc.get<unsigned char>((size_t)n_out * ksz + 16, &ok));
+  DTHIP_TRY(launch_gather(ctx, kd[0].data, kst, reinterpret_cast<const int32_t*>(ovf_rows), n_out, ok));
+  std::vector<dthip_col> ov(vd.size());
+  for (size_t c = 0; c < vd.size(); c++) {
+    ov[c] = vd[c];
+    unsigned char* b = nullptr;
+    DTHIP_TRY(sc.get<unsigned char>((size_t)n_out * stype_size(vd[c].stype) + 16, &b));
+    DTHIP_TRY(launch_gather(ctx, vd[c].data, vd[c].stype, reinterpret_cast<const int32_t*>(ovf_rows), n_out, b));
+    ov[c].data = b;
+  }
+  dthip_col k2 = kd[0]; k2.data = ok;
+  const int na_pos = kc.na_repl == 0 ? DTHIP_NA_FIRST : DTHIP_NA_LAST;
+  dthip_result* r2 = nullptr;
+  const int saved_off = ctx->agg_offsets;
+  const bool saved_merge = ctx->in_merge;
+  ctx->agg_offsets = want_offsets ? 1 : 0; ctx->in_merge = true;      // (in_merge: no hash combiner, no list of its own)
+  int rc = dthip_groupby_agg(ctx, &k2, 1, ov.empty() ? nullptr : ov.data(), (int)ov.size(), aggs, naggs, n_out, na_pos, DTHIP_DEVICE, &r2);
+  ctx->agg_offsets = saved_off; ctx->in_merge = saved_merge;
+  if (rc != DTHIP_OK) return rc;
+  const int64_t ng2 = r2->ngroups, ng = res->ngroups;
+  do {
+    // groups of the list that come BEFORE the range: ascending keys below the minimum, descending keys above the maximum
+    std::vector<unsigned char> hk((size_t)ng2 * ksz);
+    if ((rc = read_back(ctx, hk.data(), r2->key[0], hk.size())) != DTHIP_OK) break;
+    int64_t nA = 0;
+    for (int64_t i = 0; i < ng2; i++) {
+      long long v;
+      switch (kst) {
+        case DTHIP_BOOL: case DTHIP_INT8: v = reinterpret_cast<const int8_t*>(hk.data())[i]; break;
+        case DTHIP_INT16: v = reinterpret_cast<const int16_t*>(hk.data())[i]; break;
+        case DTHIP_INT32: v = reinterpret_cast<const int32_t*>(hk.data())[i]; break;
+        default: v = reinterpret_cast<const long long*>(hk.data())[i]; break;
+      }
+      const bool before = kc.desc ? v > (long long)kc.edge : v < (long long)kc.edge;
+      if (before) nA++; else break;          // (r2 is ordered the same way: the groups before the range lead it)
+    }
+    // is the first / last group of the range's result the NA group?
+    bool has_na = false;
+    if (ng > 0) {
+      const size_t na_slot = (size_t)kc.na_repl;
+      uint32_t w = 0;
+      if ((rc = read_back(ctx, &w, d_cnt + (cnt_is_counts ? na_slot : na_slot / 32), sizeof(w))) != DTHIP_OK) break;
+      has_na = cnt_is_counts ? w != 0 : ((w >> (na_slot & 31)) & 1u) != 0;
+    }
+    const int64_t naF = (has_na && na_pos == DTHIP_NA_FIRST) ? 1 : 0, naL = (has_na && na_pos == DTHIP_NA_LAST) ? 1 : 0;
+    const int64_t mid = ng - naF - naL, nB = ng2 - nA, ngT = ng + ng2;
+    // pieces of the spliced result: (source 0 = range result / 1 = outliers, first group, groups)
+    struct Piece { int src; int64_t first, count; };
+    const Piece pieces[5] = {{0, 0, naF}, {1, 0, nA}, {0, naF, mid}, {1, nA, nB}, {0, naF + mid, naL}};
+    auto splice = [&](const void* a0, const void* a1, int elem, void** out) -> int {
+      void* q = nullptr;
+      DTHIP_TRY(result_alloc(ctx, res, (size_t)ngT * elem + 16, &q));
+      size_t at = 0;
+      for (const Piece& pc : pieces) {
+        if (pc.count <= 0) continue;
+        const unsigned char* src = static_cast<const unsigned char*>(pc.src ? a1 : a0) + (size_t)pc.first * elem;
+        DTHIP_CHECK_HIP(hipMemcpyAsync(static_cast<unsigned char*>(q) + at, src, (size_t)pc.count * elem, hipMemcpyDeviceToDevice, ctx->stream));
+        at += (size_t)pc.count * elem;
+      }
+      *out = q;
+      return DTHIP_OK;
+    };
+    void* q = nullptr;
+    if ((rc = splice(res->key[0], r2->key[0], ksz, &q)) != DTHIP_OK) break;
+    res->key[0] = q;
+    for (int a = 0; a < naggs && rc == DTHIP_OK; a++) {
+      if ((rc = splice(res->agg[a], r2->agg[a], stype_size(res->agg_stype[a]), &q)) != DTHIP_OK) break;
+      res->agg[a] = q;
+    }
+    if (rc != DTHIP_OK) break;
+    if (res->offsets && r2->offsets) {
+      // offsets: every piece keeps its group sizes, shifted to where the piece starts.  Piece starts in ROWS need the two
+      // offset arrays at five places: read back those few words
+      int32_t e0[4] = {0, 0, 0, 0}, e1[3] = {0, 0, 0};     // range: at naF, naF + mid, ng; outliers: at nA, ng2
+      const int64_t i0[3] = {naF, naF + mid, ng}, i1[2] = {nA, ng2};
+      for (int t = 0; t < 3 && rc == DTHIP_OK; t++) rc = read_back(ctx, &e0[t], res->offsets + i0[t], sizeof(int32_t));
+      for (int t = 0; t < 2 && rc == DTHIP_OK; t++) rc = read_back(ctx, &e1[t], r2->offsets + i1[t], sizeof(int32_t));
+      if (rc != DTHIP_OK) break;
+      void* no = nullptr;
+      if ((rc = result_alloc(ctx, res, sizeof(int32_t) * ((size_t)ngT + 2), &no)) != DTHIP_OK) break;
+      int32_t* out = static_cast<int32_t*>(no);
+      // rows before each piece in the spliced order
+      const int32_t rows_naF = e0[0], rowsA = e1[0], rows_mid = e0[1] - e0[0], rowsB = e1[1] - e1[0];
+      int64_t gat = 0; int32_t rat = 0;
+      // piece 0: NA group (first)
+      if ((rc = launch_offsets_piece(ctx, res->offsets, naF, 0, out)) != DTHIP_OK) break;
+      gat += naF; rat += rows_naF;
+      if ((rc = launch_offsets_piece(ctx, r2->offsets, nA, rat, out + gat)) != DTHIP_OK) break;
+      gat += nA; rat += rowsA;
+      if ((rc = launch_offsets_piece(ctx, res->offsets + naF, mid, rat - e0[0], out + gat)) != DTHIP_OK) break;
+      gat += mid; rat += rows_mid;
+      if ((rc = launch_offsets_piece(ctx, r2->offsets + nA, nB, rat - e1[0], out + gat)) != DTHIP_OK) break;
+      gat += nB; rat += rowsB;
+      // NA group (last) and the closing entry
+      if ((rc = launch_offsets_piece(ctx, res->offsets + naF + mid, naL + 1, rat - e0[1], out + gat)) != DTHIP_OK) break;
+      res->offsets = out;
+    }
+    res->ngroups = ngT;
+  } while (0);
+  result_destroy(ctx, r2);
+  return rc;
+}
+
 static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const KeyPlan& plan,
                               const std::vector<dthip_col>& kd, const std::vector<dthip_col>& vd,
                               const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int r, bool guess_nona = false,
@@ -156,6 +275,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   // once (16 B/row less HBM traffic for C3).  Random row order only: for sorted / clustered keys a bucket's rows sit in
   // few tiles and the exact-position layout (with its clustered kernel variants and row-range work items) is better.
   const uint16_t* dirT = nullptr; uint32_t dstride = 0;
+  uint32_t* ovf_rows = nullptr; uint32_t* ovf_n = nullptr; uint32_t n_outliers = 0;
   // Worth it when the segments are short and alike: >= 1024 buckets (<= 12 rows of a tile per bucket) and no hot bucket
   // (sampled).  Measured on 1e9 rows: C3 9.5 -> 9.1 ms, C4 11.0 -> 9.4; but 4 x float64 columns over 32 buckets 2.8 -> 3.9
   // and a heavily skewed key 10.6 -> 14.1, which therefore keep the exact-position layout.
@@ -186,7 +306,15 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
       vsrc[c] = vb;
     }
     src = 2;
-    DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, nullptr, nullptr, kpart, pc, false, dir, d_bad));
+    // a guessed key range (one key column): rows outside it are LISTED instead of making the query start over
+    // (DTHIP_OUTLIER_LIST=0: the second sweep of rounds 2-5, A/B)
+    static const bool ovf_ok = !(getenv("DTHIP_OUTLIER_LIST") && atoi(getenv("DTHIP_OUTLIER_LIST")) == 0);
+    if (ovf_ok && plan.speculative && nkeys == 1 && g.items == 16 && !ctx->in_merge) {
+      DTHIP_TRY(sc.get<uint32_t>((size_t)OUTLIER_CAP + 4, &ovf_rows));
+      ovf_n = ovf_rows + OUTLIER_CAP;
+      DTHIP_CHECK_HIP(hipMemsetAsync(ovf_n, 0, sizeof(uint32_t), ctx->stream));
+    }
+    DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, nullptr, nullptr, kpart, pc, false, dir, d_bad, ovf_rows, ovf_n, OUTLIER_CAP));
     DTHIP_TRY(launch_dir_prepare(ctx, dir, g.ntiles, g.F, dT, dstride, tot, M, items, nitems));
     dirT = dT;
   } else if (g.d > 0) {
@@ -311,6 +439,10 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
       uint32_t bad = 0;
       DTHIP_TRY(read_back(ctx, &bad, d_bad, sizeof(bad)));
       if (plan.speculative && (bad & 1u)) return DTHIP_RETRY_EXACT;
+      if (ovf_rows && round == 0) {
+        DTHIP_TRY(read_back(ctx, &n_outliers, ovf_n, sizeof(n_outliers)));
+        if (n_outliers > OUTLIER_CAP) return DTHIP_RETRY_EXACT;      // not a few outliers: the guess was simply wrong
+      }
       if (bad & 2u) {
         if (round == 0 && guess_nona && r_counting == r) {
           // the NA-free guess was wrong, the partitioned rows are still right: aggregate them once more, counting
@@ -373,6 +505,10 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   }
   for (int a = 0; a < naggs; a++)
     if (aggs[a].op == DTHIP_COUNT0) DTHIP_TRY(launch_count0(ctx, res->offsets, ng, static_cast<int64_t*>(res->agg[a])));
+  if (n_outliers) {
+    DTHIP_TRY(splice_outlier_groups(ctx, sc, res, plan, kd, vd, aggs, naggs, ovf_rows, n_outliers, d_cnt, need_cnt, want_offsets));
+    ctx->call_stats[4] += n_outliers;
+  }
   return DTHIP_OK;
 }
 

@@ -564,7 +564,7 @@ int dthip_timer_stop(dthip_ctx* ctx, float* ms) {
 
 int dthip_last_call_stats(const dthip_ctx* ctx, int64_t* out, int n) {
   if (!ctx || !out || n < 0) { set_error("null argument"); return DTHIP_EINVAL; }
-  for (int i = 0; i < n; i++) out[i] = i < 4 ? ctx->call_stats[i] : 0;
+  for (int i = 0; i < n; i++) out[i] = i < 5 ? ctx->call_stats[i] : 0;
   return DTHIP_OK;
 }
 

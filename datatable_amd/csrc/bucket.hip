@@ -426,6 +426,11 @@ struct PartArgs {
   // range of the outputs; dir[tile][b] (b <= F) = first position of bucket b inside the tile.  With no histogram pass
   // before it, this kernel also reports keys outside a guessed key range (*bad).
   uint16_t* dir; uint32_t* bad;
+  // 16-row tile-local instance, ONE key column with a guessed range: a row whose key lies outside the range is not a reason
+  // to start over -- its row number goes to this list (*ovf_n counts; rows past ovf_cap are dropped: the caller retries then)
+  // and the row into the extra bin behind the tile's valid rows, i.e. nowhere.  The caller aggregates the listed rows
+  // separately and splices their groups in front of / behind the others (agg.hip splice_outlier_groups)
+  uint32_t* ovf_rows; uint32_t* ovf_n; uint32_t ovf_cap;
 };
 
 // SEQ: the tile writes over ONE contiguous row range starting at seq_base (tile-local layout), so the global position of
@@ -513,6 +518,23 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) if (item_row<BLOCK, KM>(j, tid) >= nvalid) x[j] = F << a.r;
   }
+  if (TLS && a.ovf_rows && __ballot(bad)) {        // (rare: a wave that holds an outlier key)
+    if (bad) {
+#pragma unroll 1
+      for (int j = 0; j < ITEMS; j++) {
+        const uint32_t rel = item_row<BLOCK, KM>(j, tid);
+        if (rel >= nvalid) continue;
+        bool b = false;
+        (void)packed_key_checked(a.kx.cols, a.kx.ncols, tile_base + rel, b);
+        if (b) {
+          const uint32_t at = atomicAdd(a.ovf_n, 1u);
+          if (at < a.ovf_cap) a.ovf_rows[at] = tile_base + rel;
+          x[j] = F << a.r;
+        }
+      }
+    }
+    bad = false;
+  }
   if (tl && __ballot(bad) && (tid & 63) == 0) atomicOr(a.bad, 1u);
   u64 pv[PF ? ITEMS : 1];
   if (PF) load_tile_vals<BLOCK, ITEMS, KM, u64>(static_cast<const u64*>(a.pay.in[0]) + tile_base, nvalid, full, tid,
@@ -556,8 +578,11 @@ __global__ void __launch_bounds__(BLOCK) bucket_partition_kernel(PartArgs a) {
         e += c[k];
       }
     }
-    if (tl && tid == 0) a.dir[(size_t)tile * (F + 1) + F] = (uint16_t)nvalid;
-    if (TLS && tid == 0) cnt[F] = nvalid;             // the extra bin starts behind the valid rows
+    if (TLS) {
+      // the extra bin (rows past the end of a ragged tile, listed outlier keys) starts behind the rows that count: its
+      // rows take the last places of the tile's stage and are never part of a segment
+      if (tid == 0) { const uint32_t ngood = TILE - cnt[F]; a.dir[(size_t)tile * (F + 1) + F] = (uint16_t)ngood; cnt[F] = ngood; }
+    } else if (tl && tid == 0) a.dir[(size_t)tile * (F + 1) + F] = (uint16_t)nvalid;
   }
   __syncthreads();
 
@@ -722,8 +747,10 @@ static int part_t(dthip_ctx* ctx, const PartArgs& a, uint32_t ntiles, size_t lds
 }
 
 int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
-                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay, bool clustered, uint16_t* dir, uint32_t* bad) {
+                            const uint32_t* gpre, uint16_t* kout, const PayCols& pay, bool clustered, uint16_t* dir, uint32_t* bad,
+                            uint32_t* ovf_rows, uint32_t* ovf_n, uint32_t ovf_cap) {
   PartArgs a;
+  a.ovf_rows = (g.items == 16 && kx.ncols == 1) ? ovf_rows : nullptr; a.ovf_n = ovf_n; a.ovf_cap = ovf_cap;
   a.kx = kx; a.n = (uint32_t)n; a.r = g.r; a.F = g.F; a.tpg = g.tpg; a.P = P; a.gpre = gpre;
   a.kout = kout; a.pay = pay; a.dir = dir; a.bad = bad;
   int maxw = 4;

@@ -101,7 +101,7 @@ struct dthip_ctx {
   // guessed from a sample was wrong, [1] because a value column guessed NA-free held an NA, [2] a route given up after it had
   // started (fused filter route -> two calls, hash tables full -> sort path), [3] the path that produced the result
   // (1 sort, 2 bucketed, 3 hash combiner, 4 fused filter route, 5 small table)
-  int64_t call_stats[4] = {0, 0, 0, 0};
+  int64_t call_stats[5] = {0, 0, 0, 0, 0};     // [4] rows with keys outside a guessed range that were LISTED and grouped apart (no second sweep)
   int call_depth = 0;        // query entry points call each other (fused route -> two calls, hash combiner -> merge): only the outermost resets
   // multi-GPU (comm.hip): the communicator this context is a rank of
   struct dthip_comm* comm = nullptr;
@@ -369,7 +369,9 @@ struct SmallGroupsArgs { const uint32_t* cnt; int bits; uint32_t nslots; int32_t
 int launch_small_groups(dthip_ctx* ctx, const SmallGroupsArgs& a);
 int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const BucketGeom& g, const uint32_t* P,
                             const uint32_t* gpre, uint16_t* kout, const PayCols& pay, bool clustered, uint16_t* dir = nullptr,
-                            uint32_t* bad = nullptr);
+                            uint32_t* bad = nullptr, uint32_t* ovf_rows = nullptr, uint32_t* ovf_n = nullptr, uint32_t ovf_cap = 0);
+// out[pos + i] = in[i] + delta for i < count: one piece of a spliced offsets array
+int launch_offsets_piece(dthip_ctx* ctx, const int32_t* in, int64_t count, int32_t delta, int32_t* out);
 // tile-local layout (no histogram pass): directory transpose + bucket totals + work list, and the aggregation over it
 int launch_dir_prepare(dthip_ctx* ctx, const uint16_t* dir, uint32_t ntiles, uint32_t F, uint16_t* dirT, uint32_t dstride,
                        uint32_t* tot, uint32_t M, WorkItem* items, uint32_t* nitems);

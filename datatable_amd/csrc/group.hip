@@ -359,6 +359,19 @@ int launch_offsets_drop_rows(dthip_ctx* ctx, const int32_t* in, int64_t ngroups,
   return DTHIP_OK;
 }
 
+__global__ void __launch_bounds__(256) offsets_piece_kernel(const int32_t* __restrict__ in, uint32_t count, int32_t delta, int32_t* __restrict__ out) {
+  const uint32_t stride = gridDim.x * 256;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += stride) out[i] = in[i] + delta;
+}
+
+int launch_offsets_piece(dthip_ctx* ctx, const int32_t* in, int64_t count, int32_t delta, int32_t* out) {
+  if (count <= 0) return DTHIP_OK;
+  long long blocks = (count + 2047) / 2048;
+  if (blocks > ctx->num_cus * 8) blocks = ctx->num_cus * 8;
+  DTHIP_LAUNCH(ctx, "offsets_piece_kernel", offsets_piece_kernel, (unsigned)blocks, 256, 0, in, (uint32_t)count, delta, out);
+  return DTHIP_OK;
+}
+
 __global__ void __launch_bounds__(256) iota_kernel(int32_t* out, uint32_t n) {
   const uint32_t stride = gridDim.x * 256;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = (int32_t)i;

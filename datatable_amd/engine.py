@@ -378,10 +378,11 @@ class Context(_ShardMixin):
     def last_call_stats(self):
         """what the last query call did besides its result (dthip_last_call_stats): sweeps repeated after a wrong key-range
         guess / a wrong NA-free guess, routes given up after they had started, and the path that produced the result"""
-        out = (C.c_int64 * 4)()
-        L.check(self._lib.dthip_last_call_stats(self._h, out, 4))
+        out = (C.c_int64 * 5)()
+        L.check(self._lib.dthip_last_call_stats(self._h, out, 5))
         path = {0: None, 1: "sort", 2: "bucketed", 3: "hash", 4: "fused_filter"}.get(int(out[3]), int(out[3]))
-        return {"retries_key_range": int(out[0]), "retries_na_guess": int(out[1]), "routes_abandoned": int(out[2]), "path": path}
+        return {"retries_key_range": int(out[0]), "retries_na_guess": int(out[1]), "routes_abandoned": int(out[2]), "path": path,
+                "outlier_rows_listed": int(out[4])}
 
     def profile(self, on=True):
         L.check(self._lib.dthip_profile_enable(self._h, 1 if on else 0))

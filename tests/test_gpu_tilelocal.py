@@ -82,3 +82,63 @@ def test_default_choice_at_6e6_rows(ctx):
     _vs_oracle(ctx, [k], [v], aggs=("sum",), check_ri=False)
     k[rng.random(n) < 0.2] = 5
     _vs_oracle(ctx, [k], [v], aggs=("sum",), check_ri=False)
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+@pytest.mark.parametrize("na_last,desc", [(False, False), (True, False), (False, True), (True, True)])
+def test_outlier_keys_are_listed_not_retried(tl, dtype, na_last, desc):
+    """round 6: rows whose key lies outside the GUESSED range go to a list instead of making the query start over; their
+    groups are spliced in front of / behind the range's groups (agg.hip splice_outlier_groups).  Outliers on both sides,
+    duplicates among them, NA keys present (first / last), ascending / descending, every reducer + count(): against the
+    oracle, and dthip_last_call_stats must show NO repeated sweep"""
+    from conftest import assert_same
+    from test_gpu_parity import check_agg, _unsampled_rows
+    from oracle import oracle as o
+    rng = np.random.default_rng(91 + int(na_last) * 2 + int(desc))
+    n = 3_000_000
+    k = rng.integers(1000, 3_000_000, n).astype(dtype)
+    k[0], k[-1] = 1000, 2_999_999                                  # (first / last rows are always sampled)
+    k[rng.random(n) < 0.001] = np.iinfo(dtype).min                 # NA keys
+    k[0], k[-1] = 1000, 2_999_999
+    rows = _unsampled_rows(n, np.dtype(dtype).itemsize, 9)
+    k[rows[:3]] = 5_000_000                                        # above: one group of three rows
+    k[rows[3]] = 5_000_001
+    k[rows[4:7]] = [-70_000, -70_000, 12]                          # below: two groups
+    k[rows[7]] = np.iinfo(dtype).max                               # the far ends of the type
+    k[rows[8]] = np.iinfo(dtype).min + 1
+    v = rng.standard_normal(n); v[rng.random(n) < 0.02] = np.nan
+    w = rng.integers(-1000, 1000, n).astype(np.int32)
+    alist = [(opn, vi) for vi in range(2) for opn in ("sum", "mean", "min", "max", "count")] + [("count0", None)]
+    ri, off = o.group([k], desc=[desc], na_last=na_last)
+    tl.set_option("spec_min_rows", 1)
+    try:
+        r = tl.groupby_agg([k], [v, w], alist, desc=[desc], na_last=na_last)
+        st = tl.last_call_stats()
+    finally:
+        tl.set_option("spec_min_rows", 1 << 23)
+    assert st["path"] == "bucketed" and st["retries_key_range"] == 0 and st["outlier_rows_listed"] == 8, st      # (key 12 lies inside the 1/64 margin of the guess)
+    assert_same(r.offsets(), off, "offsets")
+    assert_same(r.key(0), k[ri[off[:-1]]], "group keys")
+    for a, (opn, vi) in enumerate(alist[:-1]):
+        check_agg(r.agg(a), o.reduce(opn, (v, w)[vi], ri, off), opn, (v, w)[vi], ri, off, "%s(v%d)" % (opn, vi))
+    assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count()")
+    r.free()
+
+
+def test_more_outliers_than_the_list_holds_still_retry(tl):
+    """a guess that is simply wrong (a tenth of the rows outside it) overflows the 65536-entry list: the query runs again with
+    the exact range, as before"""
+    from test_gpu_parity import _unsampled_rows
+    rng = np.random.default_rng(93)
+    n = 3_000_000
+    k = rng.integers(1000, 2_000_000, n).astype(np.int64)
+    rows = _unsampled_rows(n, 8, 300_000)
+    k[rows] = rng.integers(2_500_000, 3_000_000, len(rows))
+    v = rng.standard_normal(n)
+    tl.set_option("spec_min_rows", 1)
+    try:
+        _vs_oracle(tl, [k], [v], aggs=("sum", "count"), check_ri=False)
+        r = tl.groupby_agg([k], [v], [("sum", 0)]); st = tl.last_call_stats(); r.free()
+    finally:
+        tl.set_option("spec_min_rows", 1 << 23)
+    assert st["retries_key_range"] == 1, st
