@@ -870,6 +870,41 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
     KeyPlan plan; Grouping g;
     std::vector<const void*> sorted_val(nvalues, nullptr);
     const int32_t* gather_ri = nullptr;
+    // round 6: rows that ARE in key order already (a time-ordered log grouped by day, the output of an earlier sort) need no
+    // grouping pass at all.  One ascending int32 / int64 key, NA first: "non-descending as signed integers" is the grouped
+    // order (NA = INT*_MIN leads).  16384 sampled pairs decide whether the full check is worth its pass; that pass
+    // (count_heads_kernel over the raw column: group heads + a flag for any descent) IS the grouping when the flag stays
+    // clear; the reducers then read the value columns in place (C3 with sorted keys: 13.4 -> see DESIGN 6).  DTHIP_PRESORTED=0: off
+    bool presorted = false;
+    static const bool presorted_ok = !(getenv("DTHIP_PRESORTED") && atoi(getenv("DTHIP_PRESORTED")) == 0);
+    if (presorted_ok && fused && nkeys == 1 && (kd[0].stype == DTHIP_INT64 || kd[0].stype == DTHIP_INT32) &&
+        !(kd[0].flags & DTHIP_FLAG_DESCENDING) && na_pos == DTHIP_NA_FIRST && nrows >= ((int64_t)1 << 22) && ctx->agg_path == 0 && !ctx->in_merge) {
+      uint32_t* d_fl = nullptr;
+      if ((rc = sc.get<uint32_t>(4, &d_fl)) != DTHIP_OK) break;
+      bool maybe = false;
+      if ((rc = launch_sorted_sample(ctx, kd[0].data, kd[0].stype, nrows, d_fl, &maybe)) != DTHIP_OK) break;
+      if (maybe) {
+        const uint32_t nt = (uint32_t)((nrows + SEG_TILE - 1) / SEG_TILE);
+        uint32_t* tile_counts = nullptr; unsigned long long* bitmap = nullptr;
+        if ((rc = sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, &tile_counts)) != DTHIP_OK) break;
+        if ((rc = sc.get<unsigned long long>((size_t)((nrows + 63) / 64) + 1, &bitmap)) != DTHIP_OK) break;
+        int64_t ngs = 0; bool sorted = false;
+        if ((rc = launch_count_heads_presorted(ctx, kd[0].data, kd[0].stype, nrows, tile_counts, bitmap, d_fl, &ngs, &sorted)) != DTHIP_OK) break;
+        if (sorted) {
+          void* off = nullptr;
+          if ((rc = result_alloc(ctx, res, sizeof(int32_t) * (size_t)(ngs + 1), &off)) != DTHIP_OK) break;
+          if ((rc = launch_write_offsets(ctx, bitmap, nrows, tile_counts, ngs, static_cast<int32_t*>(off))) != DTHIP_OK) break;
+          g.n = nrows; g.ngroups = ngs; g.offsets = static_cast<int32_t*>(off); g.bitmap = bitmap; g.tile_first = tile_counts;
+          for (int c : used) sorted_val[c] = vd[c].data;
+          presorted = true;
+          ctx->call_stats[3] = 6;
+        } else {
+          ctx->call_stats[2]++;          // the sample looked sorted, the column is not: one pass over the keys spent for nothing
+        }
+      }
+    }
+    if (presorted) {
+    } else
     if (fused) {
       // first attempt: key ranges guessed from a sample (verified by the bucketed path); if that
       // path does not apply, or the guess was wrong, plan again with the exact ranges
@@ -940,7 +975,8 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
       drop_partial_result(ctx, res);                       // nothing of a half-built attempt survives
       if (plan.nstages != 1) fused = false;
     }
-    if (fused) {
+    if (presorted) {
+    } else if (fused) {
       // values ride through the sort; the RowIndex is never materialised
       PaySpec ps;
       ps.n = (int)used.size();
@@ -964,7 +1000,9 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
       void* kp = nullptr;
       if ((rc = result_alloc(ctx, res, (size_t)ng * stype_size(kd[k].stype), &kp)) != DTHIP_OK) break;
       res->key[k] = kp;
-      if (fused) {
+      if (presorted) {
+        rc = launch_gather(ctx, kd[k].data, kd[k].stype, g.offsets, ng, kp);       // the key at the first row of every group
+      } else if (fused) {
         rc = launch_untransform_keys(ctx, g.sorted_keys, g.key64, g.offsets, ng, plan.col[k], plan.nsig[k], kp);
       } else {
         int32_t* firstrow = nullptr;

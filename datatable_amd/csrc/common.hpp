@@ -307,6 +307,9 @@ int launch_scan_tiles(dthip_ctx* ctx, uint32_t* counts, uint32_t m, uint32_t* to
 int launch_count_heads(dthip_ctx* ctx, const void* keys, int key64, const uint8_t* heads, int64_t n,
                        uint32_t* tile_counts, unsigned long long* bitmap, uint32_t* d_total,
                        int64_t* ngroups_host);
+int launch_count_heads_presorted(dthip_ctx* ctx, const void* keys, int stype, int64_t n, uint32_t* tile_counts,
+                                 unsigned long long* bitmap, uint32_t* d_flags, int64_t* ngroups_host, bool* sorted_host);
+int launch_sorted_sample(dthip_ctx* ctx, const void* keys, int stype, int64_t n, uint32_t* d_flag, bool* maybe_sorted);
 int launch_heads_from_bitmap(dthip_ctx* ctx, const unsigned long long* bitmap, int64_t n, uint32_t* tile_counts, uint32_t* d_total,
                              int64_t* ngroups_host);
 int launch_write_offsets(dthip_ctx* ctx, const unsigned long long* bitmap, int64_t n,

@@ -25,11 +25,15 @@ typedef uint32_t gu32x4 __attribute__((ext_vector_type(4)));
 // number of heads of every 2048-position tile.  Keys are read with 16-byte loads.
 //   KeyT = uint32_t / unsigned long long: head(i) = i==0 || K[i] != K[i-1]
 //   KeyT = uint8_t: K is a byte-per-position flag array (multi-stage sorts)
+//   unsorted (nullable; KeyT = int32_t / long long, the RAW key column of a frame whose rows may already be in key order):
+//   *unsorted <- 1 when some K[i] < K[i-1] -- NA is the smallest value of a signed integer stype, so "ascending as signed
+//   integers" IS the grouped order of an ascending key with NA first, and the heads found here are the group heads
 template <typename KeyT>
 __global__ void __launch_bounds__(GB_BLOCK) count_heads_kernel(const KeyT* __restrict__ K, uint32_t n,
                                                                uint32_t* __restrict__ tile_counts,
-                                                               uint8_t* __restrict__ bitmap) {
+                                                               uint8_t* __restrict__ bitmap, uint32_t* __restrict__ unsorted = nullptr) {
   __shared__ uint32_t wc[GB_BLOCK / 64];
+  bool down = false;
   const uint32_t p0 = blockIdx.x * GB_TILE + threadIdx.x * GB_ITEMS;
   uint32_t hb = 0;
   if (p0 < n) {
@@ -57,13 +61,19 @@ __global__ void __launch_bounds__(GB_BLOCK) count_heads_kernel(const KeyT* __res
 #pragma unroll
       for (int j = 0; j < GB_ITEMS; j++) hb |= (uint32_t)((p0 + j < n) && k[j] != 0) << j;
     } else {
-      const bool h0 = (p0 == 0) || (K[p0 - 1] != k[0]);
+      const KeyT kp = p0 ? K[p0 - 1] : k[0];
+      const bool h0 = (p0 == 0) || (kp != k[0]);
       hb = h0 ? 1u : 0u;
+      down = k[0] < kp;
 #pragma unroll
-      for (int j = 1; j < GB_ITEMS; j++) hb |= (uint32_t)((p0 + j < n) && k[j] != k[j - 1]) << j;
+      for (int j = 1; j < GB_ITEMS; j++) {
+        hb |= (uint32_t)((p0 + j < n) && k[j] != k[j - 1]) << j;
+        down |= (p0 + j < n) && k[j] < k[j - 1];
+      }
     }
     bitmap[p0 >> 3] = (uint8_t)hb;
   }
+  if (unsorted && __ballot(down) && lane_id() == 0) atomicOr(unsorted, 1u);
   const uint32_t c = wave_reduce_sum_u32((uint32_t)__popc(hb));
   if (lane_id() == 0) wc[wave_id()] = c;
   __syncthreads();
@@ -167,6 +177,58 @@ int launch_count_heads(dthip_ctx* ctx, const void* keys, int key64, const uint8_
     DTHIP_TRY(read_back(ctx, &t, d_total, sizeof(t)));
     *ngroups_host = t;
   }
+  return DTHIP_OK;
+}
+
+// the same over the RAW int32 / int64 key column of rows that may already be in key order: *d_flags (zeroed here) <- 1 if some
+// key is smaller than its predecessor; read back, and with it the number of groups when the column is in order
+int launch_count_heads_presorted(dthip_ctx* ctx, const void* keys, int stype, int64_t n, uint32_t* tile_counts,
+                                 unsigned long long* bitmap, uint32_t* d_flags, int64_t* ngroups_host, bool* sorted_host) {
+  const uint32_t nt = ntiles_of(n);
+  uint8_t* bm = reinterpret_cast<uint8_t*>(bitmap);
+  DTHIP_CHECK_HIP(hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));
+  if (stype == DTHIP_INT64)
+    DTHIP_LAUNCH(ctx, "count_heads_kernel", count_heads_kernel<long long>, nt, GB_BLOCK, 0, static_cast<const long long*>(keys), (uint32_t)n, tile_counts, bm, d_flags);
+  else if (stype == DTHIP_INT32)
+    DTHIP_LAUNCH(ctx, "count_heads_kernel", count_heads_kernel<int32_t>, nt, GB_BLOCK, 0, static_cast<const int32_t*>(keys), (uint32_t)n, tile_counts, bm, d_flags);
+  else { set_error("presorted heads: stype %d", stype); return DTHIP_ENOTIMPL; }
+  uint32_t w[2] = {0, 0};
+  DTHIP_TRY(read_back(ctx, &w[1], d_flags, sizeof(uint32_t)));
+  if (w[1] == 0) {                                    // (a column that is not in order needs no scan)
+    DTHIP_TRY(launch_scan_tiles(ctx, tile_counts, nt, tile_counts + nt));
+    DTHIP_TRY(read_back(ctx, &w[0], tile_counts + nt, sizeof(uint32_t)));
+  }
+  *ngroups_host = w[0];
+  *sorted_host = w[1] == 0;
+  return DTHIP_OK;
+}
+
+// 8192 sampled neighbour pairs and 8192 pairs one stratum apart: *flag |= 1 when any of them descends (the cheap test
+// before the full pass above is spent on a column)
+template <typename T>
+__global__ void __launch_bounds__(256) sorted_sample_kernel(const T* __restrict__ K, uint32_t n, uint32_t nsamp, uint32_t* flag) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  bool down = false;
+  if (t < nsamp) {
+    const uint32_t i = (uint32_t)(((unsigned long long)t * n) / nsamp), step = n / nsamp;
+    const T a = K[i];
+    if (i + 1 < n) down |= K[i + 1] < a;
+    if (step && i + step < n) down |= K[i + step] < a;
+  }
+  if (__ballot(down) && lane_id() == 0) atomicOr(flag, 1u);
+}
+
+int launch_sorted_sample(dthip_ctx* ctx, const void* keys, int stype, int64_t n, uint32_t* d_flag, bool* maybe_sorted) {
+  const uint32_t nsamp = (uint32_t)std::min<int64_t>(n, 8192);
+  DTHIP_CHECK_HIP(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), ctx->stream));
+  if (stype == DTHIP_INT64)
+    DTHIP_LAUNCH(ctx, "sorted_sample_kernel", sorted_sample_kernel<long long>, (nsamp + 255) / 256, 256, 0, static_cast<const long long*>(keys), (uint32_t)n, nsamp, d_flag);
+  else if (stype == DTHIP_INT32)
+    DTHIP_LAUNCH(ctx, "sorted_sample_kernel", sorted_sample_kernel<int32_t>, (nsamp + 255) / 256, 256, 0, static_cast<const int32_t*>(keys), (uint32_t)n, nsamp, d_flag);
+  else { *maybe_sorted = false; return DTHIP_OK; }
+  uint32_t w = 0;
+  DTHIP_TRY(read_back(ctx, &w, d_flag, sizeof(w)));
+  *maybe_sorted = w == 0;
   return DTHIP_OK;
 }
 

@@ -380,7 +380,7 @@ class Context(_ShardMixin):
         guess / a wrong NA-free guess, routes given up after they had started, and the path that produced the result"""
         out = (C.c_int64 * 5)()
         L.check(self._lib.dthip_last_call_stats(self._h, out, 5))
-        path = {0: None, 1: "sort", 2: "bucketed", 3: "hash", 4: "fused_filter"}.get(int(out[3]), int(out[3]))
+        path = {0: None, 1: "sort", 2: "bucketed", 3: "hash", 4: "fused_filter", 6: "presorted"}.get(int(out[3]), int(out[3]))
         return {"retries_key_range": int(out[0]), "retries_na_guess": int(out[1]), "routes_abandoned": int(out[2]), "path": path,
                 "outlier_rows_listed": int(out[4])}
 

@@ -244,6 +244,7 @@ int  dthip_timer_stop(dthip_ctx* ctx, float* elapsed_ms);   /* synchronises */
  *   out[1] aggregations repeated because a value column guessed NA-free held an NA,
  *   out[2] routes given up after they had started (fused filter route -> two calls; hash tables full -> sort path),
  *   out[3] the path that produced the result: 1 sort path, 2 bucketed aggregation, 3 hash combiner, 4 fused filter route,
+ *          6 rows found in key order already (dthip_groupby_agg: heads of the raw key column, no grouping pass),
  *   out[4] rows whose key lay outside a guessed range and were LISTED, grouped apart and spliced in (at most 65536 of them:
  *          no second sweep; more than that counts as a wrong guess, out[0]).
  * n = number of values wanted (<= 5).  The reference has no counterpart (its min / max scan is exact, stats.cc:601-640). */

@@ -1023,3 +1023,42 @@ def test_small_path_mapped_words_survive_read_back():
                 r.free()
         finally:
             c.close()
+
+
+@pytest.mark.parametrize("dtype", [np.int64, np.int32])
+def test_rows_already_in_key_order_need_no_grouping_pass(ctx, dtype):
+    """round 6: one ascending integer key, NA first, >= 2^22 rows that ARE in key order (a sampled test, then one pass that
+    finds the group heads and verifies the order): the reducers read the value columns in place.  Sorted keys with NAs and
+    long / short groups; a column with ONE descent at a row the sample does not look at (the pass is spent, the ordinary path
+    answers); a descending request and NA-last (never taken): all against the oracle."""
+    rng = np.random.default_rng(123)
+    n = 5_000_000
+    k = np.sort(rng.integers(-50_000, 900_000, n)).astype(dtype)
+    k[:1234] = np.iinfo(dtype).min                                   # NA keys lead an ascending, NA-first order
+    v = rng.standard_normal(n); v[rng.random(n) < 0.03] = np.nan
+    w = rng.integers(-1000, 1000, n).astype(np.int32)
+    f4 = rng.standard_normal(n).astype(np.float32)
+    alist = [(opn, vi) for vi in range(3) for opn in ("sum", "mean", "min", "max", "count")] + [("count0", None)]
+    vals = (v, w, f4)
+
+    def run(keys, na_last=False, desc=False):
+        ri, off = o.group([keys], desc=[desc], na_last=na_last)
+        r = ctx.groupby_agg([keys], list(vals), alist, desc=[desc], na_last=na_last)
+        st = ctx.last_call_stats()
+        assert_same(r.offsets(), off, "offsets")
+        assert_same(r.key(0), keys[ri[off[:-1]]], "group keys")
+        for a, (opn, vi) in enumerate(alist[:-1]):
+            check_agg(r.agg(a), o.reduce(opn, vals[vi], ri, off), opn, vals[vi], ri, off, "%s(v%d)" % (opn, vi))
+        assert_same(r.agg(len(alist) - 1), np.diff(off).astype(np.int64), "count()")
+        r.free()
+        return st
+
+    st = run(k)
+    assert st["path"] == "presorted" and st["retries_key_range"] == 0, st
+    k2 = k.copy()
+    k2[3_333_333], k2[3_333_334] = k2[3_333_334] + 7, k2[3_333_333]   # one descent between two sampled strata
+    st = run(k2)
+    assert st["path"] != "presorted", st
+    assert run(k, na_last=True)["path"] != "presorted"
+    assert run(k, desc=True)["path"] != "presorted"
+    assert run(np.ascontiguousarray(k[::-1]))["path"] != "presorted"
