@@ -105,6 +105,18 @@ def main():
                 return ng
             run(check=True)
             alg = n * 16
+        elif c == 10:
+            # C3 as the LITERAL seam: dthip_groupby (RowIndex + offsets) then dthip_reduce(SUM) gathering through the RowIndex
+            n = int(1e9 * args.scale)
+            k = torch.randint(0, 10_000_000, (n,), dtype=torch.int64, device=dev, generator=g)
+            v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)
+            sums = torch.empty(min(n, 10_000_000) + 16, dtype=torch.float64, device=dev)
+            def run():
+                r = ctx.groupby([devcol(k)], nrows=n, want_rowindex=True)
+                ng = r.ngroups
+                ctx.reduce_dev("sum", devcol(v), r.rowindex_ptr, r.offsets_ptr, ng, n, sums.data_ptr())
+                r.free(); return ng
+            alg = n * 20
         elif c == 6:
             # hard-keys variant of C3: full-range int64 keys drawn from a pool of 1e7 values
             n = int(1e9 * args.scale)

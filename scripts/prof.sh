@@ -9,7 +9,7 @@
 # by the caller (scripts/prof_keep.sh <tag>).
 export TMPDIR=/tmp
 TAG=${1:?round tag}; shift
-CFGS=${*:-C2 C4 C5 C3_hard}
+CFGS=${*:-C2 C4 C5 C3_hard C3_sgrp}
 REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
 BENCH="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-check --configs= --host-rows 0 --no-shim-resident --no-dist-1rank"
@@ -27,6 +27,7 @@ for name in $CFGS; do
     C4) id=4; alg=16240109656; rows=1000000000;;
     C5) id=5; alg=30400000000; rows=1000000000;;
     C3_hard) id=6; alg=16160000000; rows=1000000000;;
+    C3_sgrp) id=10; alg=20120000000; rows=1000000000;;
     *) echo "unknown config $name"; continue;;
   esac
   ( cd /tmp; timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $OUT/$name -o cfg -- python $REPO/scripts/configs_bench.py --configs $id --reps 3 > $OUT/$name.log 2>&1 )
@@ -37,4 +38,7 @@ for name in $CFGS; do
   done
   python scripts/pmc_config_json.py $name $OUT/${name}_FETCH_SIZE.txt $OUT/${name}_WRITE_SIZE.txt 1 $rows $alg $OUT/pmc_traffic.json >> $OUT/pmc_traffic.txt 2>&1
 done
+# C2: LDS instruction / bank-conflict counters of the aggregation (SQ_INSTS_LDS, SQ_LDS_BANK_CONFLICT)
+( cd /tmp; timeout -k 5 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --kernel-trace -d $OUT/C2_lds -o cfg -- python $REPO/scripts/configs_bench.py --configs 2 --once > $OUT/C2_lds.log 2>&1 )
+db=$(find $OUT/C2_lds -name "*.db" | head -1); [ -n "$db" ] && python scripts/rocpd_summary.py $db > $OUT/C2_lds.txt 2>&1 && rm -rf $OUT/C2_lds
 head -12 $OUT/stats.txt; cat $OUT/pmc_traffic.txt
