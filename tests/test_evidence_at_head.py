@@ -32,9 +32,9 @@ def test_committed_counter_records_belong_to_this_build():
 
 
 def test_committed_bench_lines_name_their_build():
-    """every round-5 bench line kept under profiles/ says which library produced it, and it is this one"""
+    """every round-6 bench line kept under profiles/ says which library produced it, and it is this one"""
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-        if name.startswith("r05_bench") and name.endswith(".json"):
+        if name.startswith("r06_bench") and name.endswith(".json"):
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             assert d.get("library_build_id") == source_hash(), name
             assert d["parity"]["configs"] and all(d["parity"]["configs"].values()), name
