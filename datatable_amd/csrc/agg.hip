@@ -571,7 +571,7 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
     if (vd[c].flags & DTHIP_FLAG_NONA) return DTHIP_NOT_APPLICABLE;
     if (stype_size(vd[c].stype) != 4 && stype_size(vd[c].stype) != 8) return DTHIP_NOT_APPLICABLE;
   }
-  if (ctx->hash_mode != 2 && n < (1 << 22)) return DTHIP_NOT_APPLICABLE;
+  if (ctx->hash_mode < 2 && n < (1 << 22)) return DTHIP_NOT_APPLICABLE;
   const bool need_cnt = bucket_need_counts(ctx, aggs, naggs);
   const uint32_t F = 1u << (HASH_PK_BITS - HASH_R);
   double est = 0;
@@ -582,12 +582,13 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   struct HPass { int col; int slot; int flags; uint32_t C; };
   auto table_entries = [](int flags) {
     const size_t entry = hash_agg_entry_bytes(flags);
-    uint32_t C = (uint32_t)((158 * 1024) / entry) - 1;                // the whole LDS of a CU for one table ...
-    for (;; C--) {                                                     // ... with a prime number of entries (double hashing)
-      bool prime = C % 2 != 0;
-      for (uint32_t q = 3; prime && q * q <= C; q += 2) prime = C % q != 0;
+    uint32_t P = ((uint32_t)((158 * 1024 - hash_agg_queue_bytes()) / entry) - 1) / 2;      // the whole LDS of a CU for one table (+ the waves' queues) ...
+    for (;; P--) {                                                     // ... of P pairs of entries, P prime (double hashing over the pairs)
+      bool prime = P % 2 != 0;
+      for (uint32_t q = 3; prime && q * q <= P; q += 2) prime = P % q != 0;
       if (prime) break;
     }
+    const uint32_t C = 2 * P;
     return C;
   };
   auto fits = [&](int flags) { return est * 1.05 <= 0.75 * (double)F * (double)table_entries(flags); };
@@ -683,7 +684,17 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   const uint32_t max_items = g.F + (uint32_t)((uint64_t)n / M) + 1;
   WorkItem* items = nullptr;
   DTHIP_TRY(sc.get<WorkItem>(max_items, &items));
-  const size_t part_rows = (size_t)n;
+  // round 6: TILE-LOCAL partition for one raw int64 key -- 16384-row tiles written sequentially (each bucket one ~8-row
+  // segment per tile + a 2-byte directory entry), no histogram pass; hash_agg_seg_kernel walks the segments
+  // (DTHIP_HASH_TL=0: histogram + exact scatter positions as in rounds 2-5, A/B)
+  static const bool tl_ok = !(getenv("DTHIP_HASH_TL") && atoi(getenv("DTHIP_HASH_TL")) == 0);
+  bool tile_local = tl_ok && ctx->hash_mode != 3 && fused_pk && km == 1 && g.block == 1024 && (n >= (1 << 22) || ctx->hash_mode == 2);
+  if (tile_local) {
+    int maxw = 8;
+    for (int c : used) maxw = std::max(maxw, stype_size(vd[c].stype));
+    tile_local = bucket_tl16_geometry(ctx, n, maxw, &g);
+  }
+  const size_t part_rows = tile_local ? (size_t)g.ntiles * g.tile : (size_t)n;
   uint16_t* kslot = nullptr;         // not written: the packed key itself travels as payload 0
   unsigned long long* xs_part = nullptr;
   DTHIP_TRY(sc.get<unsigned long long>(part_rows + 8, &xs_part));
@@ -696,7 +707,17 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
     DTHIP_TRY(sc.get<unsigned char>(part_rows * w + 64, &v_part[i]));
     pc.in[pc.n] = vd[used[i]].data; pc.out[pc.n] = v_part[i]; pc.width[pc.n] = w; pc.n++;
   }
-  {
+  const uint16_t* dirT = nullptr; uint32_t dstride = 0;
+  if (tile_local) {
+    uint16_t* dir = nullptr; uint16_t* dT = nullptr; uint32_t* tot = nullptr;
+    dstride = (g.ntiles + 63u) & ~63u;
+    DTHIP_TRY(sc.get<uint16_t>((size_t)g.ntiles * (g.F + 1) + 8, &dir));
+    DTHIP_TRY(sc.get<uint16_t>((size_t)dstride * (g.F + 2) + 8, &dT));
+    DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 1, &tot));
+    DTHIP_TRY(launch_bucket_partition(ctx, pkx, n, g, nullptr, nullptr, kslot, pc, false, dir, d_bad, nullptr, nullptr, 0));
+    DTHIP_TRY(launch_dir_prepare(ctx, dir, g.ntiles, g.F, dT, dstride, tot, M, items, nitems));
+    dirT = dT;
+  } else {
     uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.ntiles * g.F, &P));
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.G * g.F, &gtot));
@@ -729,7 +750,8 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
     if (flags & ACC_MIN) DTHIP_TRY(sci.get<unsigned long long>(out_cap, &ha.o_tab.mn));
     if (flags & ACC_MAX) DTHIP_TRY(sci.get<unsigned long long>(out_cap, &ha.o_tab.mx));
     if (flags & ACC_FSUM) DTHIP_TRY(sci.get<double>(out_cap, &ha.o_tab.fsum));
-    DTHIP_TRY(launch_hash_agg(ctx, ha));
+    if (dirT) DTHIP_TRY(launch_hash_agg_seg(ctx, ha, dirT, dstride, g.tile));
+    else DTHIP_TRY(launch_hash_agg(ctx, ha));
     uint32_t hn[2] = {0, 0};
     DTHIP_TRY(read_back(ctx, hn, d_outn, sizeof(hn)));       // {number of partial groups, overflow bits}
     if (hn[1]) { ctx->call_stats[2]++; return DTHIP_NOT_APPLICABLE; }      // a table filled up: the sort path takes over

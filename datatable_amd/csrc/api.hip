@@ -497,7 +497,7 @@ int dthip_set_option(dthip_ctx* ctx, const char* name, int64_t value) {
   if (!strcmp(name, "join_table")) { ctx->join_table = value != 0; return DTHIP_OK; }
   if (!strcmp(name, "median_pairs")) { ctx->pairs_always = value != 0; return DTHIP_OK; }
   if (!strcmp(name, "hash_mode")) {
-    if (value < 0 || value > 2) { set_error("hash_mode must be 0 (estimate), 1 (never) or 2 (whenever it fits)"); return DTHIP_EINVAL; }
+    if (value < 0 || value > 3) { set_error("hash_mode must be 0 (estimate), 1 (never), 2 (whenever it fits) or 3 (the same, exact-position partition)"); return DTHIP_EINVAL; }
     ctx->hash_mode = (int)value;
     return DTHIP_OK;
   }

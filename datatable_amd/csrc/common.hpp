@@ -75,7 +75,7 @@ struct dthip_ctx {
   int agg_path = 0;          // 0 auto, 1 sort path, 2 bucket path whenever eligible
   int bucket_variant = 0;    // partition tile geometry (experiments)
   int64_t spec_min_rows = 1 << 23;   // key ranges are guessed from a sample only at or above this many rows
-  int hash_mode = 0;         // hash combiner for sparse keys: 0 decide from a distinct-count estimate, 1 never, 2 whenever it fits
+  int hash_mode = 0;         // hash combiner for sparse keys: 0 decide from a distinct-count estimate, 1 never, 2 whenever it fits, 3 = 2 with the exact-position partition
   int pairs_always = 0;      // median / nunique of float columns through the distinct (group, value) pairs too (tests)
   int join_table = 1;        // dthip_join_index: direct key->row table for a dense single integer key (0: always search)
   bool in_merge = false;     // internal: the merge of partial groups must not take the hash path again
@@ -418,7 +418,10 @@ struct HashAggArgs {
   unsigned long long* o_key; AggTable o_tab; uint32_t* out_n; uint32_t out_cap; uint32_t* overflow;
 };
 size_t hash_agg_entry_bytes(int flags);
+size_t hash_agg_queue_bytes();      // LDS the waves' pending-row queues take in front of the table
 int launch_hash_agg(dthip_ctx* ctx, const HashAggArgs& a);
+// the same over a tile-local partition: items = (bucket, tile range), segments through the transposed directory
+int launch_hash_agg_seg(dthip_ctx* ctx, const HashAggArgs& a, const uint16_t* dirT, uint32_t dstride, uint32_t tile_rows);
 struct PartialColsArgs {
   AggTable tab; uint32_t n; int vstype;
   unsigned long long* o_sum; double* o_fsum; void* o_min; void* o_max; int64_t* o_vcnt; int64_t* o_cnt;

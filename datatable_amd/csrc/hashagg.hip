@@ -60,17 +60,22 @@ int launch_hash_pk_raw(dthip_ctx* ctx, const void* key, int64_t n, int32_t* pk) 
 // splitmix round + two 64-bit Lemire reductions -- five 64 x 64-bit multiplies = ~20 quarter-rate v_mul_lo / v_mul_hi per row,
 // about a third of hash_agg_kernel's time (it is bound by its VALU work: profiles/r06_hash_tl_ab.txt).  Here: the two
 // halves by two odd constants (others than hash_pk24's, which chose the bucket), one xorshift-multiply, two multiply-highs.
-__device__ __forceinline__ void hash_tab_probe0(u64 x, uint32_t C, uint32_t& p, uint32_t& step) {
-#ifdef DTHIP_HASH_MIX64            // (A/B flavour: `make var NAME=mix64 VFILE=bucket FLAGS=-DDTHIP_HASH_MIX64`)
+__device__ __forceinline__ void hash_tab_probe0(u64 x, uint32_t P, uint32_t& p, uint32_t& step) {
+#ifdef DTHIP_HASH_MIX64            // (A/B flavour: `make var NAME=mix64 VFILE=hashagg FLAGS=-DDTHIP_HASH_MIX64`)
   const u64 h2 = mix64(x ^ 0x9E3779B97F4A7C15ULL);
-  p = (uint32_t)(((h2 & 0xFFFFFFFFULL) * (u64)C) >> 32);
-  step = 1u + (uint32_t)(((h2 >> 32) * (u64)(C - 1)) >> 32);
+  p = (uint32_t)(((h2 & 0xFFFFFFFFULL) * (u64)P) >> 32);
+  step = 1u + (uint32_t)(((h2 >> 32) * (u64)(P - 1)) >> 32);
 #else
   uint32_t h = (uint32_t)x * 0xC2B2AE3Du + (uint32_t)(x >> 32) * 0x27D4EB2Fu;
   h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
-  p = __umulhi(h, C);
-  step = 1u + __umulhi(h * 0x297A2D39u + 0x165667B1u, C - 1u);
+  p = __umulhi(h, P);
+  step = 1u + __umulhi(h * 0x297A2D39u + 0x165667B1u, P - 1u);
 #endif
+}
+__device__ __forceinline__ uint32_t hash_tab_pair0(u64 x, uint32_t P) {      // the first pair alone (the fast path needs no step)
+  uint32_t p, step;
+  hash_tab_probe0(x, P, p, step);
+  return p;
 }
 
 constexpr u64 HASH_EMPTY = ~0ULL;
@@ -131,8 +136,89 @@ struct HashAggDev {
   uint32_t* overflow;      // set when a table fills up or the output capacity is exceeded
 };
 
+// ---------------------------------------------------------------------------------------
+// One row into a workgroup's hash table, wave by wave (round 6).  The table is C = 2 P entries read as P PAIRS (one 16-byte DS
+// read shows both keys of a pair; double hashing over the pairs, P prime; a key lives in the first entry of its probe sequence
+// -- pair by pair, entry 0 before entry 1 -- that was empty when it arrived).  Rows outnumber keys ~100 : 1, so nearly every row finds its
+// key already in the table, and most of those at the FIRST entry of their probe sequence.  Rounds 2-5 let every lane walk a
+// private queue of eight rows at its own pace inside one fat divergent loop (the whole body ran ~18 times per eight rows for
+// the wave's slowest lane: the kernel was bound by that VALU work, 5.8 ms per 1e9 rows against 3 for its 16 GB).  Now:
+//   step()   straight-line: hash, ONE plain DS read, key found -> accumulate.  Everything else (another key there, or an
+//            empty entry = first row of a key) is a PENDING row: compacted (ballot + mbcnt) into the wave's own queue in LDS
+//   drain()  when 64 rows are pending (or at the end): lane = pending row, the full probe loop with compare-and-swap claims;
+//            the loop runs as long as the slowest of 64 SLOW rows needs, not of all rows
+// DS instructions of a wave execute in order, so the queue needs no barrier beyond the compiler's (wave_barrier).
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t HQ_ROWS = 64;
+constexpr size_t HQ_BYTES = (size_t)(TA_BLOCK / 64) * HQ_ROWS * 16;      // every wave: 64 x {key, value bits}
+
+template <typename VT> __device__ __forceinline__ u64 val_bits(VT v) { u64 b = 0; __builtin_memcpy(&b, &v, sizeof(VT)); return b; }
+template <typename VT> __device__ __forceinline__ VT bits_val(u64 b) { VT v; __builtin_memcpy(&v, &b, sizeof(VT)); return v; }
+
+template <typename VT>
+struct HashIns {
+  u64* hk; LdsTab t; uint32_t C; int flags; uint32_t* s_misc;
+  u64* qx; u64* qv;          // this wave's queue
+  uint32_t qn;               // pending rows in it (wave-uniform: kept in a scalar register)
+  bool full;
+
+  __device__ __forceinline__ void drain() {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t P = C >> 1;
+    __builtin_amdgcn_wave_barrier();
+    bool pend = lane < qn;
+    u64 x = 0; VT v = VT(0);
+    if (pend) {
+      x = __hip_atomic_load(&qx[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      v = bits_val<VT>(__hip_atomic_load(&qv[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
+    }
+    if (pend && x == HASH_EMPTY) { s_misc[16] = 1; acc_row<VT, false>(t, flags, C, v); pend = false; }   // the one key that equals the empty mark
+    uint32_t p = 0, step = 1, probes = 0;
+    hash_tab_probe0(x, P, p, step);
+    while (__ballot(pend)) {
+      if (pend) {
+        const bu32x4 w = *reinterpret_cast<const bu32x4*>(&hk[2u * p]);
+        const u64 k0 = (u64)w.x | ((u64)w.y << 32), k1 = (u64)w.z | ((u64)w.w << 32);
+        if (k0 == x || k1 == x) { acc_row<VT, false>(t, flags, 2u * p + (k0 == x ? 0u : 1u), v); pend = false; }
+        else if (k0 == HASH_EMPTY || k1 == HASH_EMPTY) {
+          // claim the FIRST empty entry of the pair; when another key got there first, look at the same pair again
+          const uint32_t s = 2u * p + (k0 == HASH_EMPTY ? 0u : 1u);
+          const u64 cur = atomicCAS(&hk[s], HASH_EMPTY, x);                  // returns what was there: EMPTY = claimed
+          if (cur == HASH_EMPTY || cur == x) { acc_row<VT, false>(t, flags, s, v); pend = false; }
+        } else {
+          p += step; if (p >= P) p -= P;
+          if (++probes >= P) { full = true; pend = false; }
+        }
+      }
+    }
+    qn = 0;
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // every lane of the wave calls this together (uniform control flow); `active` lanes bring a row
+  __device__ __forceinline__ void step(u64 x, VT v, bool active) {
+    const uint32_t p = hash_tab_pair0(x, C >> 1);
+    const bu32x4 w = *reinterpret_cast<const bu32x4*>(&hk[2u * p]);
+    const u64 k0 = (u64)w.x | ((u64)w.y << 32), k1 = (u64)w.z | ((u64)w.w << 32);
+    const bool hit = active && (k0 == x || k1 == x) && x != HASH_EMPTY;
+    if (hit) acc_row<VT, false>(t, flags, 2u * p + (k0 == x ? 0u : 1u), v);
+    const bool pend = active && !hit;
+    const unsigned long long m = __ballot(pend);
+    if (m) {
+      const uint32_t c = (uint32_t)__popcll(m);
+      if (qn + c > HQ_ROWS) drain();
+      if (pend) {
+        const uint32_t pos = qn + mbcnt64(m);
+        __hip_atomic_store(&qx[pos], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_store(&qv[pos], val_bits<VT>(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      qn = (uint32_t)__builtin_amdgcn_readfirstlane((int)(qn + c));
+    }
+  }
+};
+
 // CFLAGS >= 0: the accumulator set is a compile-time constant (the common sum / sum+count shapes: the
-// eight unrolled inserts then carry no per-row flag tests); -1: taken from the arguments
+// unrolled inserts then carry no per-row flag tests); -1: taken from the arguments
 template <typename VT, int CFLAGS>
 __global__ void __launch_bounds__(TA_BLOCK) hash_agg_kernel(HashAggDev a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -141,118 +227,61 @@ __global__ void __launch_bounds__(TA_BLOCK) hash_agg_kernel(HashAggDev a) {
   const int tid = threadIdx.x;
   const int flags = CFLAGS >= 0 ? CFLAGS : a.flags;
   const uint32_t C = a.C, S = C + 1;                 // entry C is reserved for the key that equals HASH_EMPTY
-  u64* hk = reinterpret_cast<u64*>(smem);            // [S] keys
-  const LdsTab t = carve_tab(smem + (size_t)S * 8, S, flags);
+  u64* hk = reinterpret_cast<u64*>(smem + HQ_BYTES);            // [S] keys (behind the waves' queues)
+  const LdsTab t = carve_tab(smem + HQ_BYTES + (size_t)S * 8, S, flags);
   __shared__ uint32_t s_misc[20];
   hash_tab_init(hk, t, flags, S, s_misc, tid);
   __syncthreads();
   const VT* __restrict__ val = static_cast<const VT*>(a.val);
   const bool hasval = (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) != 0;
-  bool full = false;
-  auto insert = [&](u64 x, VT v) {
-    uint32_t p;
-    if (x == HASH_EMPTY) {
-      p = C;
-      s_misc[16] = 1;
-    } else {
-      // second hash (independent of the bits that chose the bucket): start by Lemire reduction to [0, C),
-      // DOUBLE hashing step in [1, C) -- C is prime, so every step visits all entries.  Linear probing
-      // clusters: at load 0.6 the slowest of a wave's 64 lanes needed ~20 probes, and a wave waits for it.
-      uint32_t step;
-      hash_tab_probe0(x, C, p, step);
-      uint32_t probes = 0;
-      // most rows find their key already in the table (rows >> keys): look with a plain DS read first,
-      // compare-and-swap only into an empty entry
-      while (true) {
-        u64 cur = __hip_atomic_load(&hk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (cur == HASH_EMPTY) cur = atomicCAS(&hk[p], HASH_EMPTY, x);      // returns what was there: EMPTY = claimed
-        if (cur == HASH_EMPTY || cur == x) break;
-        p += step; if (p >= C) p -= C;
-        if (++probes >= C) { full = true; return; }
-      }
-    }
-    acc_row<VT, false>(t, flags, p, v);
-  };
+  HashIns<VT> hi;
+  hi.hk = hk; hi.t = t; hi.C = C; hi.flags = flags; hi.s_misc = s_misc; hi.qn = 0; hi.full = false;
+  hi.qx = reinterpret_cast<u64*>(smem) + (size_t)(tid >> 6) * (2 * HQ_ROWS); hi.qv = hi.qx + HQ_ROWS;
   {
-    // 8 consecutive rows per thread and iteration: all their 16-byte loads are in flight before the first
-    // probe (a probe chain is a dependent sequence of DS operations; one row at a time is latency bound)
+    // 8 consecutive rows per thread and iteration: all their 16-byte loads are in flight before the first probe
     uint32_t a0 = (it.begin + 7u) & ~7u; if (a0 > it.end) a0 = it.end;
     uint32_t a1 = it.end & ~7u; if (a1 < a0) a1 = a0;
-    const uint32_t nh = a0 - it.begin, ntl = it.end - a1;
-    if ((uint32_t)tid < nh) { const uint32_t row = it.begin + tid; insert(a.xs[row], hasval ? val[row] : VT(0)); }
-    else if ((uint32_t)tid >= 64u && (uint32_t)tid - 64u < ntl) { const uint32_t row = a1 + ((uint32_t)tid - 64u); insert(a.xs[row], hasval ? val[row] : VT(0)); }
-    const uint32_t ngr = (a1 - a0) >> 3;
-    for (uint32_t g = tid; g < ngr; g += TA_BLOCK) {
-      const uint32_t row = a0 + g * 8u;
+    const uint32_t nh = a0 - it.begin, ntl = it.end - a1;       // < 8 rows each: the ragged head and tail of the part
+    {
+      const bool act = (uint32_t)tid < nh || ((uint32_t)tid >= 64u && (uint32_t)tid - 64u < ntl);
+      const uint32_t row = (uint32_t)tid < nh ? it.begin + tid : a1 + ((uint32_t)tid - 64u);
+      u64 x = 0; VT v = VT(0);
+      if (act) { x = a.xs[row]; if (hasval) v = val[row]; }
+      if (tid < 128) hi.step(x, v, act);               // (waves 0 and 1, whole)
+    }
+    // a wave takes 512 consecutive rows at a time as four coalesced 1 KB loads of keys (two rows per lane and load) and
+    // four of values, all in flight before the first probe; sums do not care about the order of the rows.  (Rounds 2-5
+    // gave every lane 8 CONSECUTIVE rows: each of its load instructions then touched 64 different 64-byte lines.)
+    typedef VT VT2 __attribute__((ext_vector_type(2)));
+    const uint32_t lane2 = ((uint32_t)tid & 63u) * 2u;
+    for (uint32_t base = a0 + (uint32_t)(tid >> 6) * 512u; base < a1; base += (TA_BLOCK / 64) * 512u) {
       bu32x4 kw[4];
-      const bu32x4* kp = reinterpret_cast<const bu32x4*>(a.xs + row);
+      VT2 vv[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) kw[j] = kp[j];
-      VT v[8];
-      if (hasval) {
-        constexpr int NV = (int)sizeof(VT) / 2;
-        bu32x4 w[NV];
-        const bu32x4* vp = reinterpret_cast<const bu32x4*>(val + row);
-#pragma unroll
-        for (int j = 0; j < NV; j++) w[j] = vp[j];
-        const VT* wv = reinterpret_cast<const VT*>(w);
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = wv[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = VT(0);
-      }
-      // Every lane walks through ITS eight rows at its own pace: one probe step per loop iteration on the
-      // lane's current row, and a lane that resolved its row accumulates and moves on to its next one.
-      // Row-by-row in lock-step, each row costs the wave the probe count of its slowest lane (~9 at load
-      // 0.6); this way a wave runs about max-over-lanes of the SUM of a lane's probes (~18 for 8 rows, not 72).
-      u64 qx[8]; VT qv[8];
-      {
-        const u64* kx8 = reinterpret_cast<const u64*>(kw);
-#pragma unroll
-        for (int j = 0; j < 8; j++) { qx[j] = kx8[j]; qv[j] = v[j]; }
-      }
-      int left = 8;
-      uint32_t p = 0, step = 0, probes = 0;
-      bool fresh = true;
-      while (__any(left > 0)) {
-        if (left > 0) {
-          const u64 x = qx[0];
-          bool resolved = false;
-          if (fresh) {
-            fresh = false; probes = 0;
-            if (x == HASH_EMPTY) { p = C; s_misc[16] = 1; resolved = true; }
-            else {
-              hash_tab_probe0(x, C, p, step);
-            }
-          }
-          if (!resolved) {
-            u64 cur = __hip_atomic_load(&hk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (cur == HASH_EMPTY) cur = atomicCAS(&hk[p], HASH_EMPTY, x);
-            if (cur == HASH_EMPTY || cur == x) resolved = true;
-            else {
-              p += step; if (p >= C) p -= C;
-              if (++probes >= C) { full = true; left = 0; }
-            }
-          }
-          if (resolved) {
-            // (acc_row's wave-uniform fast path is off here: lanes are on different rows)
-            acc_row<VT, false>(t, flags, p, qv[0]);
-#pragma unroll
-            for (int j = 0; j < 7; j++) { qx[j] = qx[j + 1]; qv[j] = qv[j + 1]; }
-            left--;
-            fresh = true;
-          }
+      for (int j = 0; j < 4; j++) {
+        const uint32_t row = base + (uint32_t)j * 128u + lane2;
+        kw[j].x = 0; kw[j].y = 0; kw[j].z = 0; kw[j].w = 0; vv[j].x = VT(0); vv[j].y = VT(0);
+        if (row < a1) {
+          kw[j] = *reinterpret_cast<const bu32x4*>(a.xs + row);
+          if (hasval) vv[j] = *reinterpret_cast<const VT2*>(val + row);
         }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool act = base + (uint32_t)j * 128u + lane2 < a1;
+        hi.step((u64)kw[j].x | ((u64)kw[j].y << 32), vv[j].x, act);
+        hi.step((u64)kw[j].z | ((u64)kw[j].w << 32), vv[j].y, act);
       }
     }
   }
-  if (__ballot(full) && (tid & 63) == 0) atomicOr(a.overflow, 1u);
+  if (hi.qn) hi.drain();
+  if (__ballot(hi.full) && (tid & 63) == 0) atomicOr(a.overflow, 1u);
   __syncthreads();
   hash_tab_flush(hk, t, flags, C, s_misc, a.o_key, a.o_tab, a.out_n, a.out_cap, a.overflow, tid);
 }
 
 size_t hash_agg_entry_bytes(int flags) { return 8 + table_agg_slot_bytes(flags); }
+size_t hash_agg_queue_bytes() { return HQ_BYTES; }
 
 template <typename VT, int CFLAGS>
 static int hash_agg_t(dthip_ctx* ctx, const HashAggDev& d, uint32_t grid, size_t lds) {
@@ -267,8 +296,9 @@ int launch_hash_agg(dthip_ctx* ctx, const HashAggArgs& a) {
   HashAggDev d;
   d.items = a.items; d.nitems = a.nitems; d.xs = a.xs; d.val = a.val; d.C = a.C; d.flags = a.flags;
   d.o_key = a.o_key; d.o_tab = a.o_tab; d.out_n = a.out_n; d.out_cap = a.out_cap; d.overflow = a.overflow;
-  const size_t lds = (size_t)(a.C + 1) * hash_agg_entry_bytes(a.flags) + 32;
+  const size_t lds = hash_agg_queue_bytes() + (size_t)(a.C + 1) * hash_agg_entry_bytes(a.flags) + 32;
   if (lds > 160 * 1024 - 512) { set_error("hash_agg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
+  if ((a.C & 1u) || a.C < 6) { set_error("hash_agg: the table is read as pairs of entries (C = %u)", a.C); return DTHIP_EINVAL; }
   const int st = a.val ? a.vstype : DTHIP_INT32;
   if (st == DTHIP_FLOAT64 && a.flags == ACC_SUM) return hash_agg_t<double, ACC_SUM>(ctx, d, a.max_items, lds);
   if (st == DTHIP_FLOAT64 && a.flags == (ACC_SUM | ACC_CNT)) return hash_agg_t<double, ACC_SUM | ACC_CNT>(ctx, d, a.max_items, lds);
@@ -281,11 +311,126 @@ int launch_hash_agg(dthip_ctx* ctx, const HashAggArgs& a) {
   }
 }
 
-// (round 6, measured and dropped: the same tables fed from a TILE-LOCAL partition -- 16384-row tiles, 8-row segments per bucket
-// found through the transposed directory, 8 lanes per segment, every lane walking up to eight rows of eight segments.  The
-// partition took 5.9 ms instead of 8.6 + 1.6 for histogram + exact positions, but this kernel 13.5 instead of 5.8: it is
-// bound by the VALU work of its walk loop, and segments of 8 +- 3 rows fill the lanes' queues unevenly -- three rounds per
-// 64 tiles for what eight full slots do in one.  22.1 ms against 18.5: profiles/r06_hash_tl_ab.txt, r06_hash_tabhash_ab.txt)
+// ---------------------------------------------------------------------------------------
+// The same tables fed from a TILE-LOCAL partition (round 6): 16384-row tiles written sequentially, bucket b's rows are one
+// segment of ~8 rows per tile, found through the transposed directory dirT[b][tile] (bucket.hip dir_transpose_kernel).  No
+// histogram pass and no scattered 48-byte runs: the partition takes 5.9 ms instead of 8.5 + 1.6 (1e9 rows).
+// A wave takes 56 tiles at a time (lane = tile: coalesced directory reads), lays their segments end to end as ONE sequence of
+// T ~ 448 rows (prefix sum of the lengths across the lanes) and deals it out 64 rows per step: a lane finds the segment of
+// its row by binary search in the prefix sums (six ds_bpermute).  8 steps cover T <= 512 (mean + 3 sigma); all their loads are
+// in flight before the first probe.  (A first version of this kernel -- 8 lanes per segment, every lane walking a private
+// queue of rows -- took 14.2 ms: half the lanes idle and the walk loop's VALU work; profiles/r06_hash_tl_ab.txt.)
+// ---------------------------------------------------------------------------------------
+struct HashAggSegDev {
+  const WorkItem* items; const uint32_t* nitems;
+  const u64* xs; const void* val;
+  const uint16_t* dirT; uint32_t dstride; uint32_t tile_rows;
+  uint32_t C; int flags;
+  u64* o_key; AggTable o_tab; uint32_t* out_n; uint32_t out_cap;
+  uint32_t* overflow;
+};
+
+constexpr uint32_t HSEG_TILES = 56;
+
+template <typename VT, int CFLAGS>
+__global__ void __launch_bounds__(TA_BLOCK) hash_agg_seg_kernel(HashAggSegDev a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // items are dealt to XCDs in contiguous bucket ranges (as in table_agg_seg_kernel): the sectors two neighbouring buckets'
+  // segments share are fetched from HBM once
+  const uint32_t nit = *a.nitems;
+  const uint32_t bi = blockIdx.x, xq = nit / 8, xr = nit % 8, xc = bi % 8, q0 = bi / 8;
+  if (q0 >= xq + (xc < xr ? 1u : 0u)) return;
+  const WorkItem it = a.items[xc * xq + (xc < xr ? xc : xr) + q0];
+  const int tid = threadIdx.x;
+  const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
+  const int flags = CFLAGS >= 0 ? CFLAGS : a.flags;
+  const uint32_t C = a.C, S = C + 1;
+  u64* hk = reinterpret_cast<u64*>(smem + HQ_BYTES);
+  const LdsTab t = carve_tab(smem + HQ_BYTES + (size_t)S * 8, S, flags);
+  __shared__ uint32_t s_misc[20];
+  hash_tab_init(hk, t, flags, S, s_misc, tid);
+  __syncthreads();
+  const VT* __restrict__ val = static_cast<const VT*>(a.val);
+  const u64* __restrict__ xs = a.xs;
+  const bool hasval = (flags & (ACC_SUM | ACC_MIN | ACC_MAX | ACC_VCNT | ACC_FSUM)) != 0;
+  HashIns<VT> hi;
+  hi.hk = hk; hi.t = t; hi.C = C; hi.flags = flags; hi.s_misc = s_misc; hi.qn = 0; hi.full = false;
+  hi.qx = reinterpret_cast<u64*>(smem) + (size_t)wave * (2 * HQ_ROWS); hi.qv = hi.qx + HQ_ROWS;
+  const uint16_t* __restrict__ ds = a.dirT + (size_t)it.bucket * a.dstride;
+  const uint16_t* __restrict__ de = ds + a.dstride;
+  const uint32_t t1 = it.end, tr = a.tile_rows;
+  constexpr uint32_t WSTEP = (TA_BLOCK / 64) * HSEG_TILES;
+  // directory entries of the wave's first chunk; the next chunk's are loaded while the current one is processed
+  uint32_t c = it.begin + wave * HSEG_TILES;
+  uint32_t st_n = 0, ln_n = 0;
+  if (lane < HSEG_TILES && c + lane < t1) { st_n = ds[c + lane]; ln_n = (uint32_t)de[c + lane] - st_n; }
+  for (; c < t1; c += WSTEP) {
+    const uint32_t st = st_n, ln = ln_n;
+    {
+      const uint32_t tn = c + WSTEP + lane;
+      st_n = 0; ln_n = 0;
+      if (lane < HSEG_TILES && tn < t1) { st_n = ds[tn]; ln_n = (uint32_t)de[tn] - st_n; }
+    }
+    uint32_t inc = ln;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)inc, o, 64); if (lane >= (uint32_t)o) inc += u; }
+    const uint32_t excl = inc - ln;
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    for (uint32_t k0 = 0; k0 < T; k0 += 512u) {
+      u64 kx[8]; VT vv[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t r = k0 + 64u * (uint32_t)j + lane;
+        uint32_t lo = 0;
+#pragma unroll
+        for (int bit = 32; bit > 0; bit >>= 1) {
+          const uint32_t e = (uint32_t)__shfl((int)excl, (int)(lo + (uint32_t)bit), 64);
+          if (e <= r) lo += (uint32_t)bit;
+        }
+        const uint32_t off = r - (uint32_t)__shfl((int)excl, (int)lo, 64);
+        const uint32_t row = (c + lo) * tr + (uint32_t)__shfl((int)st, (int)lo, 64) + off;
+        kx[j] = 0; vv[j] = VT(0);
+        if (r < T) { kx[j] = xs[row]; if (hasval) vv[j] = val[row]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) hi.step(kx[j], vv[j], k0 + 64u * (uint32_t)j + lane < T);
+    }
+  }
+  if (hi.qn) hi.drain();
+  if (__ballot(hi.full) && lane == 0) atomicOr(a.overflow, 1u);
+  __syncthreads();
+  hash_tab_flush(hk, t, flags, C, s_misc, a.o_key, a.o_tab, a.out_n, a.out_cap, a.overflow, tid);
+}
+
+template <typename VT, int CFLAGS>
+static int hash_agg_seg_t(dthip_ctx* ctx, const HashAggSegDev& d, uint32_t grid, size_t lds) {
+  auto kfn = hash_agg_seg_kernel<VT, CFLAGS>;
+  DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 256));
+  DTHIP_LAUNCH(ctx, "hash_agg_seg_kernel", kfn, grid, TA_BLOCK, lds, d);
+  return DTHIP_OK;
+}
+
+int launch_hash_agg_seg(dthip_ctx* ctx, const HashAggArgs& a, const uint16_t* dirT, uint32_t dstride, uint32_t tile_rows) {
+  if (a.max_items == 0) return DTHIP_OK;
+  HashAggSegDev d;
+  d.items = a.items; d.nitems = a.nitems; d.xs = a.xs; d.val = a.val; d.C = a.C; d.flags = a.flags;
+  d.dirT = dirT; d.dstride = dstride; d.tile_rows = tile_rows;
+  d.o_key = a.o_key; d.o_tab = a.o_tab; d.out_n = a.out_n; d.out_cap = a.out_cap; d.overflow = a.overflow;
+  const size_t lds = hash_agg_queue_bytes() + (size_t)(a.C + 1) * hash_agg_entry_bytes(a.flags) + 32;
+  if (lds > 160 * 1024 - 512) { set_error("hash_agg_seg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
+  if ((a.C & 1u) || a.C < 6) { set_error("hash_agg_seg: the table is read as pairs of entries (C = %u)", a.C); return DTHIP_EINVAL; }
+  const uint32_t grid = (a.max_items + 7u) & ~7u;
+  const int st = a.val ? a.vstype : DTHIP_INT32;
+  if (st == DTHIP_FLOAT64 && a.flags == ACC_SUM) return hash_agg_seg_t<double, ACC_SUM>(ctx, d, grid, lds);
+  if (st == DTHIP_FLOAT64 && a.flags == (ACC_SUM | ACC_CNT)) return hash_agg_seg_t<double, ACC_SUM | ACC_CNT>(ctx, d, grid, lds);
+  switch (st) {
+    case DTHIP_INT32: return hash_agg_seg_t<int32_t, -1>(ctx, d, grid, lds);
+    case DTHIP_INT64: return hash_agg_seg_t<long long, -1>(ctx, d, grid, lds);
+    case DTHIP_FLOAT32: return hash_agg_seg_t<float, -1>(ctx, d, grid, lds);
+    case DTHIP_FLOAT64: return hash_agg_seg_t<double, -1>(ctx, d, grid, lds);
+    default: set_error("hash_agg_seg: unsupported value stype %d", a.vstype); return DTHIP_ENOTIMPL;
+  }
+}
 
 // raw accumulators of the partial groups -> typed columns the merge can reduce:
 //   psum  float64 (float values) / int64 (integer values)      pfsum float64 (integer values, for mean)

@@ -207,7 +207,9 @@ int  dthip_trim(dthip_ctx* ctx);
  *                    key -> row table instead of binary-searching J; 0 = always search
  *   "hash_mode"      0 (default): sparse key ranges (too wide for the bucketed aggregation) are combined
  *                    through LDS hash tables when a sampled distinct-count estimate says they fit, and the
- *                    partial groups are merged by the sort path; 1 = never; 2 = whenever the query shape allows
+ *                    partial groups are merged by the sort path; 1 = never; 2 = whenever the query shape allows;
+ *                    3 = like 2, but the rows are partitioned by histogram + exact scatter positions (rounds 2-5) even
+ *                    where the tile-local partition of round 6 (one aligned int64 key) applies -- tests and A/B runs
  *   "cluster_mode"   0 (default): a sample of neighbouring rows decides whether the bucketed aggregation
  *                    runs its variants for sorted / clustered / constant keys (a wave that addresses one
  *                    bucket or slot is counted / reduced in registers first); 1 = never, 2 = always

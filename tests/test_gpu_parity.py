@@ -118,7 +118,7 @@ def _vs_oracle(ctx, keys, vals, aggs=OPS, key_stypes=None, check_ri=True):
         r.free()
     # sparse key ranges: the hash combiner (LDS hash tables -> partial groups -> merge), forced on
     # (takes effect where the bucketed path does not apply; several value columns: one pass of hash tables per column)
-    for hm in (2,):
+    for hm in (2, 3):
         ctx.set_option("hash_mode", hm)
         try:
             r = ctx.groupby_agg(keys, vals, alist, key_stypes=key_stypes)
@@ -304,17 +304,20 @@ def test_hash_combiner_sparse_keys(ctx):
     fv = rng.standard_normal(n).astype(np.float32)
     i32 = rng.integers(-1000, 1000, n).astype(np.int32)
     i32[rng.random(n) < 0.1] = -2**31
-    ctx.set_option("hash_mode", 2)
-    try:
-        for keys in ([k_int], [k_f], [k_skew], [k_a, k_b]):
-            for val in (v, iv, fv, i32):
-                _vs_oracle(ctx, keys, [val], check_ri=False)
-            _vs_oracle(ctx, keys, [], aggs=(), check_ri=False)
-        # several value columns ride through ONE partition
-        _vs_oracle(ctx, [k_int], [v, iv, i32], check_ri=False)
-        _vs_oracle(ctx, [k_skew], [v, fv], check_ri=False)
-    finally:
-        ctx.set_option("hash_mode", 0)
+    # hash_mode 2: one aligned int64 key goes through the TILE-LOCAL partition (round 6: segments + directory, hash_agg_seg_kernel),
+    # everything else -- and everything under hash_mode 3 -- through histogram + exact scatter positions (hash_agg_kernel)
+    for hm in (2, 3):
+        ctx.set_option("hash_mode", hm)
+        try:
+            for keys in ([k_int], [k_f], [k_skew], [k_a, k_b]):
+                for val in (v, iv, fv, i32):
+                    _vs_oracle(ctx, keys, [val], check_ri=False)
+                _vs_oracle(ctx, keys, [], aggs=(), check_ri=False)
+            # several value columns ride through ONE partition
+            _vs_oracle(ctx, [k_int], [v, iv, i32], check_ri=False)
+            _vs_oracle(ctx, [k_skew], [v, fv], check_ri=False)
+        finally:
+            ctx.set_option("hash_mode", 0)
 
 
 def test_clustered_key_variants(ctx):
@@ -817,7 +820,7 @@ def test_partial_sums_that_look_like_na_on_the_hash_path(ctx):
     for col, vals in ((0, v), (1, w)):
         for opn in ("sum", "mean", "count"):
             exp = o.reduce(opn, vals, ri, off)
-            for hm in (0, 2):
+            for hm in (0, 2, 3):
                 ctx.set_option("hash_mode", hm)
                 try:
                     r = ctx.groupby_agg([k], [v, w], [(opn, col)])
