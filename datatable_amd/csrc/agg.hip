@@ -695,14 +695,17 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
     tile_local = bucket_tl16_geometry(ctx, n, maxw, &g);
   }
   const size_t part_rows = tile_local ? (size_t)g.ntiles * g.tile : (size_t)n;
+  // one 8-byte value column: key and value travel as ONE 16-byte record (hash_partition_rec_kernel; DTHIP_HASH_REC=0: columns, A/B)
+  static const bool rec_env = !(getenv("DTHIP_HASH_REC") && atoi(getenv("DTHIP_HASH_REC")) == 0);
+  const bool rec_mode = tile_local && rec_env && used.size() == 1 && stype_size(vd[used[0]].stype) == 8;
   uint16_t* kslot = nullptr;         // not written: the packed key itself travels as payload 0
   unsigned long long* xs_part = nullptr;
-  DTHIP_TRY(sc.get<unsigned long long>(part_rows + 8, &xs_part));
+  DTHIP_TRY(sc.get<unsigned long long>((rec_mode ? 2 * part_rows : part_rows) + 8, &xs_part));
   PayCols pc;
   memset(&pc, 0, sizeof(pc));
   pc.in[0] = raw_key ? kd[0].data : static_cast<const void*>(xs); pc.out[0] = xs_part; pc.width[0] = 8; pc.n = 1;
   std::vector<unsigned char*> v_part(std::max<size_t>(used.size(), 1), nullptr);
-  for (size_t i = 0; i < used.size(); i++) {
+  for (size_t i = 0; i < used.size() && !rec_mode; i++) {
     const int w = stype_size(vd[used[i]].stype);
     DTHIP_TRY(sc.get<unsigned char>(part_rows * w + 64, &v_part[i]));
     pc.in[pc.n] = vd[used[i]].data; pc.out[pc.n] = v_part[i]; pc.width[pc.n] = w; pc.n++;
@@ -714,7 +717,8 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
     DTHIP_TRY(sc.get<uint16_t>((size_t)g.ntiles * (g.F + 1) + 8, &dir));
     DTHIP_TRY(sc.get<uint16_t>((size_t)dstride * (g.F + 2) + 8, &dT));
     DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 1, &tot));
-    DTHIP_TRY(launch_bucket_partition(ctx, pkx, n, g, nullptr, nullptr, kslot, pc, false, dir, d_bad, nullptr, nullptr, 0));
+    if (rec_mode) DTHIP_TRY(launch_hash_partition_rec(ctx, kd[0].data, vd[used[0]].data, n, g.r, g.F, g.ntiles, xs_part, dir));
+    else DTHIP_TRY(launch_bucket_partition(ctx, pkx, n, g, nullptr, nullptr, kslot, pc, false, dir, d_bad, nullptr, nullptr, 0));
     DTHIP_TRY(launch_dir_prepare(ctx, dir, g.ntiles, g.F, dT, dstride, tot, M, items, nitems));
     dirT = dT;
   } else {
@@ -750,7 +754,7 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
     if (flags & ACC_MIN) DTHIP_TRY(sci.get<unsigned long long>(out_cap, &ha.o_tab.mn));
     if (flags & ACC_MAX) DTHIP_TRY(sci.get<unsigned long long>(out_cap, &ha.o_tab.mx));
     if (flags & ACC_FSUM) DTHIP_TRY(sci.get<double>(out_cap, &ha.o_tab.fsum));
-    if (dirT) DTHIP_TRY(launch_hash_agg_seg(ctx, ha, dirT, dstride, g.tile));
+    if (dirT) DTHIP_TRY(launch_hash_agg_seg(ctx, ha, dirT, dstride, g.tile, rec_mode));
     else DTHIP_TRY(launch_hash_agg(ctx, ha));
     uint32_t hn[2] = {0, 0};
     DTHIP_TRY(read_back(ctx, hn, d_outn, sizeof(hn)));       // {number of partial groups, overflow bits}

@@ -190,12 +190,6 @@ int dev_trim(dthip_ctx* ctx) {
 
 int read_back(dthip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
   if (bytes > ctx->pinned_bytes) {
-#ifdef DTHIP_REPRO_UAF
-    // `make uaf` only: the round-4 defect put back -- the mapped words of the small-table path freed
-    // with the read-back buffer, their pointers left behind -- to show that it is what made ranks die of "Memory access
-    // fault" on some boxes (profiles/r05_fault_hunt.txt).  Never in the product library.
-    if (ctx->host_words) (void)hipHostFree(ctx->host_words);
-#endif
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     ctx->pinned = nullptr;
     ctx->pinned_bytes = 0;

@@ -269,7 +269,6 @@ struct RadixPass {
   // last pass only: write the original values of ONE int32 / int64 key column here instead of the packed keys
   void* ukout; int uk_stype; int uk_desc; int uk_bits;
   unsigned long long uk_edge, uk_na_repl, uk_inc;
-  uint32_t* headbits;            // final MSD level only: 1 bit per row, set where a run of equal keys starts (zeroed by the caller)
   // gather mode (tlsort.hip; g_dirT != null): the level ABOVE wrote its rows tile-locally (rows of digit b of tile t at
   // [t * g_T1 + dirT[b][t], t * g_T1 + dirT[b + 1][t]) of kin / pay.in), so tile t of THIS level -- tdesc[4 t ..] = {first
   // row of the bucket-ordered sequence, rows, histogram group, bucket} -- collects its rows from those segments
@@ -290,8 +289,6 @@ uint32_t radix_tile_items(int key64, int maxpaywidth);
 int launch_radix_tile_hist(dthip_ctx* ctx, const void* keys, int key64, uint32_t n, int shift, int bits,
                            uint32_t ntiles, uint32_t tpg, uint32_t G, uint32_t* P, uint32_t* gtot,
                            const uint32_t* tdesc = nullptr, const uint32_t* gdesc = nullptr);
-int launch_msd_windows(dthip_ctx* ctx, const uint32_t* fstart, uint32_t nbk, uint32_t n, const uint32_t* maxsize, uint32_t tile,
-                       uint32_t nwmax, uint32_t* wbounds, uint32_t* wfirst, uint32_t* info);
 int launch_msd_windows_greedy(dthip_ctx* ctx, const uint32_t* fstart, uint32_t nparents, uint32_t pb, uint32_t tile, uint32_t maxspan,
                               uint32_t nwmax, uint32_t* wbounds, uint32_t* wfirst, uint32_t* info);
 int launch_msd_scan(dthip_ctx* ctx, uint32_t* gtot, const uint32_t* gfirst, const uint32_t* pstart, int bits, uint32_t nb,
@@ -310,8 +307,6 @@ int launch_count_heads(dthip_ctx* ctx, const void* keys, int key64, const uint8_
 int launch_count_heads_presorted(dthip_ctx* ctx, const void* keys, int stype, int64_t n, uint32_t* tile_counts,
                                  unsigned long long* bitmap, uint32_t* d_flags, int64_t* ngroups_host, bool* sorted_host);
 int launch_sorted_sample(dthip_ctx* ctx, const void* keys, int stype, int64_t n, uint32_t* d_flag, bool* maybe_sorted);
-int launch_heads_from_bitmap(dthip_ctx* ctx, const unsigned long long* bitmap, int64_t n, uint32_t* tile_counts, uint32_t* d_total,
-                             int64_t* ngroups_host);
 int launch_write_offsets(dthip_ctx* ctx, const unsigned long long* bitmap, int64_t n,
                          const uint32_t* tile_base, int64_t ngroups, int32_t* offsets);
 int launch_mark_heads(dthip_ctx* ctx, const void* keys, int key64, int64_t n, uint8_t* heads);
@@ -421,7 +416,10 @@ size_t hash_agg_entry_bytes(int flags);
 size_t hash_agg_queue_bytes();      // LDS the waves' pending-row queues take in front of the table
 int launch_hash_agg(dthip_ctx* ctx, const HashAggArgs& a);
 // the same over a tile-local partition: items = (bucket, tile range), segments through the transposed directory
-int launch_hash_agg_seg(dthip_ctx* ctx, const HashAggArgs& a, const uint16_t* dirT, uint32_t dstride, uint32_t tile_rows);
+int launch_hash_agg_seg(dthip_ctx* ctx, const HashAggArgs& a, const uint16_t* dirT, uint32_t dstride, uint32_t tile_rows, bool rec);
+// tile-local hash partition of one int64 key + one 8-byte value column into 16-byte records (16384-row tiles) + directory
+int launch_hash_partition_rec(dthip_ctx* ctx, const void* key, const void* val, int64_t n, int r, uint32_t F, uint32_t ntiles,
+                              void* rec, uint16_t* dir);
 struct PartialColsArgs {
   AggTable tab; uint32_t n; int vstype;
   unsigned long long* o_sum; double* o_fsum; void* o_min; void* o_max; int64_t* o_vcnt; int64_t* o_cnt;

@@ -232,37 +232,6 @@ int launch_sorted_sample(dthip_ctx* ctx, const void* keys, int stype, int64_t n,
   return DTHIP_OK;
 }
 
-// heads per 2048-position tile from a head bitmap that somebody else filled (the final MSD level writes it: its buckets /
-// windows sit in LDS in sorted order, so the neighbour compare costs no pass over the keys)
-__global__ void __launch_bounds__(GB_BLOCK) bitmap_tile_counts_kernel(const uint8_t* __restrict__ bitmap, uint32_t n,
-                                                                      uint32_t* __restrict__ tile_counts) {
-  __shared__ uint32_t wc[GB_BLOCK / 64];
-  const uint32_t p0 = blockIdx.x * GB_TILE + threadIdx.x * GB_ITEMS;
-  const uint32_t hb = (p0 < n) ? bitmap[p0 >> 3] : 0u;
-  const uint32_t c = wave_reduce_sum_u32((uint32_t)__popc(hb));
-  if (lane_id() == 0) wc[wave_id()] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (int w = 0; w < GB_BLOCK / 64; w++) t += wc[w];
-    tile_counts[blockIdx.x] = t;
-  }
-}
-
-int launch_heads_from_bitmap(dthip_ctx* ctx, const unsigned long long* bitmap, int64_t n, uint32_t* tile_counts, uint32_t* d_total,
-                             int64_t* ngroups_host) {
-  static_assert(GB_ITEMS == 8, "one bitmap byte per thread");
-  const uint32_t nt = ntiles_of(n);
-  DTHIP_LAUNCH(ctx, "bitmap_tile_counts_kernel", bitmap_tile_counts_kernel, nt, GB_BLOCK, 0, reinterpret_cast<const uint8_t*>(bitmap), (uint32_t)n, tile_counts);
-  DTHIP_TRY(launch_scan_tiles(ctx, tile_counts, nt, d_total));
-  if (ngroups_host) {
-    uint32_t t = 0;
-    DTHIP_TRY(read_back(ctx, &t, d_total, sizeof(t)));
-    *ngroups_host = t;
-  }
-  return DTHIP_OK;
-}
-
 int launch_write_offsets(dthip_ctx* ctx, const unsigned long long* bitmap, int64_t n,
                          const uint32_t* tile_base, int64_t ngroups, int32_t* offsets) {
   const uint32_t nt = ntiles_of(n);

@@ -312,6 +312,123 @@ int launch_hash_agg(dthip_ctx* ctx, const HashAggArgs& a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Tile-local hash partition into 16-BYTE RECORDS {key, value} (round 6): ONE aligned int64 key column, one 8-byte value
+// column.  1024 threads x 16 rows; every row is ranked inside its bucket (hash_pk24 >> r) by one DS atomic, the tile's
+// rows go back over the tile's own records in bucket order (two rounds of 8192 records through 128 KB of LDS, dwordx4 both
+// ways), dir[tile][b] = first record of bucket b inside the tile (b <= F).  Against the column layout (bucket_partition_kernel
+// with the key as payload 0): the key column is read once, and bucket b's ~8 rows of a tile are 128 contiguous bytes for
+// hash_agg_seg_kernel instead of 64 + 64 at two places (2.75 instead of 3.75 sectors of 64 bytes per segment).
+// ---------------------------------------------------------------------------------------
+struct HashPartRecArgs {
+  const u64* key; const u64* val; uint32_t n; int r; uint32_t F;
+  bu32x4* rec; uint16_t* dir;
+};
+
+__global__ void __launch_bounds__(1024) hash_partition_rec_kernel(HashPartRecArgs a) {
+  constexpr uint32_t BLOCK = 1024, ITEMS = 16, TILE = BLOCK * ITEMS, HALF = TILE / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t F = a.F, Fp = (F + 4u) & ~3u;
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);          // [Fp] bucket counts, then tile-local exclusive starts
+  uint32_t* misc = cnt + Fp;                                  // [32]
+  bu32x4* stage = reinterpret_cast<bu32x4*>(misc + 32);       // [HALF] records
+  const uint32_t tid = threadIdx.x;
+  const uint32_t nt = gridDim.x, bi = blockIdx.x;
+  const uint32_t xq = nt / 8, xr = nt % 8, xc = bi % 8, q0 = bi / 8;
+  const uint32_t tile = xc * xq + (xc < xr ? xc : xr) + q0;
+  const uint32_t tile_base = tile * TILE;
+  const uint32_t nvalid = (a.n - tile_base < TILE) ? (a.n - tile_base) : TILE;
+  const bool full = nvalid == TILE;
+  for (uint32_t b = tid; b < F + 1u; b += BLOCK) cnt[b] = 0;
+  // item j of a thread = row ((j / 2) * BLOCK + tid) * 2 + j % 2 of the tile: 16-byte loads of two consecutive rows
+  bu32x4 kw[ITEMS / 2], vw[ITEMS / 2];
+  const bu32x4* ksrc = reinterpret_cast<const bu32x4*>(a.key + tile_base);
+  const bu32x4* vsrc = reinterpret_cast<const bu32x4*>(a.val + tile_base);
+  if (full) {
+#pragma unroll
+    for (int q = 0; q < (int)ITEMS / 2; q++) kw[q] = ksrc[(uint32_t)q * BLOCK + tid];
+#pragma unroll
+    for (int q = 0; q < (int)ITEMS / 2; q++) vw[q] = vsrc[(uint32_t)q * BLOCK + tid];
+  } else {
+#pragma unroll
+    for (int q = 0; q < (int)ITEMS / 2; q++) {
+      const uint32_t r0 = ((uint32_t)q * BLOCK + tid) * 2u;
+      kw[q].x = 0; kw[q].y = 0; kw[q].z = 0; kw[q].w = 0; vw[q] = kw[q];
+      if (r0 < nvalid) { const u64 k = a.key[tile_base + r0], v = a.val[tile_base + r0]; kw[q].x = (uint32_t)k; kw[q].y = (uint32_t)(k >> 32); vw[q].x = (uint32_t)v; vw[q].y = (uint32_t)(v >> 32); }
+      if (r0 + 1u < nvalid) { const u64 k = a.key[tile_base + r0 + 1u], v = a.val[tile_base + r0 + 1u]; kw[q].z = (uint32_t)k; kw[q].w = (uint32_t)(k >> 32); vw[q].z = (uint32_t)v; vw[q].w = (uint32_t)(v >> 32); }
+    }
+  }
+  __syncthreads();
+  // (bucket << 16) | arrival rank inside the bucket; rows past the end of a ragged last tile go to the extra bin F behind
+  // the rows that count and are never written
+  uint32_t pk[ITEMS];
+#pragma unroll
+  for (int j = 0; j < (int)ITEMS; j++) {
+    const bu32x4 w = kw[j >> 1];
+    const u64 k = (j & 1) ? ((u64)w.z | ((u64)w.w << 32)) : ((u64)w.x | ((u64)w.y << 32));
+    uint32_t b = hash_pk24(k) >> a.r;
+    if (!full && (((uint32_t)(j >> 1) * BLOCK + tid) * 2u + (uint32_t)(j & 1)) >= nvalid) b = F;
+    pk[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
+  }
+  __syncthreads();
+  {
+    const uint32_t K = (F + BLOCK - 1) / BLOCK;            // consecutive bins per thread (F <= 2048: K <= 2)
+    uint32_t c[2], sm = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const uint32_t b = tid * K + (uint32_t)k;
+      c[k] = ((uint32_t)k < K && b < F) ? cnt[b] : 0u;
+      sm += c[k];
+    }
+    uint32_t e = block_excl_scan_u32<BLOCK>(sm, misc, nullptr);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const uint32_t b = tid * K + (uint32_t)k;
+      if ((uint32_t)k < K && b < F) { cnt[b] = e; a.dir[(size_t)tile * (F + 1) + b] = (uint16_t)e; e += c[k]; }
+    }
+    if (tid == 0) { const uint32_t ngood = TILE - cnt[F]; a.dir[(size_t)tile * (F + 1) + F] = (uint16_t)ngood; cnt[F] = ngood; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < (int)ITEMS; j++) pk[j] = cnt[pk[j] >> 16] + (pk[j] & 0xFFFFu);      // place of the row among the tile's records
+  bu32x4* out = a.rec + (size_t)tile_base;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    if (h) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < (int)ITEMS; j++) {
+      const uint32_t pl = pk[j] - (uint32_t)h * HALF;
+      if (pl < HALF) {
+        const bu32x4 wk = kw[j >> 1], wv = vw[j >> 1];
+        bu32x4 rcd;
+        if (j & 1) { rcd.x = wk.z; rcd.y = wk.w; rcd.z = wv.z; rcd.w = wv.w; }
+        else { rcd.x = wk.x; rcd.y = wk.y; rcd.z = wv.x; rcd.w = wv.y; }
+        stage[pl] = rcd;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (int)(HALF / BLOCK); i++) {
+      const uint32_t sl = (uint32_t)h * HALF + (uint32_t)i * BLOCK + tid;
+      if (sl < nvalid) out[sl] = stage[sl - (uint32_t)h * HALF];
+    }
+  }
+}
+
+int launch_hash_partition_rec(dthip_ctx* ctx, const void* key, const void* val, int64_t n, int r, uint32_t F, uint32_t ntiles,
+                              void* rec, uint16_t* dir) {
+  if (n == 0) return DTHIP_OK;
+  if (F > 2048 || F < 1) { set_error("hash partition: F=%u", F); return DTHIP_EINVAL; }
+  HashPartRecArgs a;
+  a.key = static_cast<const u64*>(key); a.val = static_cast<const u64*>(val); a.n = (uint32_t)n; a.r = r; a.F = F;
+  a.rec = static_cast<bu32x4*>(rec); a.dir = dir;
+  const size_t lds = (size_t)(((F + 4u) & ~3u) + 32) * 4 + (size_t)8192 * 16;
+  auto kfn = hash_partition_rec_kernel;
+  DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 256));
+  DTHIP_LAUNCH(ctx, "hash_partition_rec_kernel", kfn, ntiles, 1024, lds, a);
+  return DTHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // The same tables fed from a TILE-LOCAL partition (round 6): 16384-row tiles written sequentially, bucket b's rows are one
 // segment of ~8 rows per tile, found through the transposed directory dirT[b][tile] (bucket.hip dir_transpose_kernel).  No
 // histogram pass and no scattered 48-byte runs: the partition takes 5.9 ms instead of 8.5 + 1.6 (1e9 rows).
@@ -323,24 +440,36 @@ int launch_hash_agg(dthip_ctx* ctx, const HashAggArgs& a) {
 // ---------------------------------------------------------------------------------------
 struct HashAggSegDev {
   const WorkItem* items; const uint32_t* nitems;
-  const u64* xs; const void* val;
+  const u64* xs; const void* val;          // REC: xs = the 16-byte records {key, value bits}, val unused
   const uint16_t* dirT; uint32_t dstride; uint32_t tile_rows;
   uint32_t C; int flags;
+  uint32_t map;        // work item of workgroup i: 0 = XCD i % 8 takes a contiguous range of items, 1 = item i, m > 1 = item (i * m) % nitems
   u64* o_key; AggTable o_tab; uint32_t* out_n; uint32_t out_cap;
   uint32_t* overflow;
 };
 
 constexpr uint32_t HSEG_TILES = 56;
 
-template <typename VT, int CFLAGS>
+template <typename VT, int CFLAGS, bool REC>
 __global__ void __launch_bounds__(TA_BLOCK) hash_agg_seg_kernel(HashAggSegDev a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // items are dealt to XCDs in contiguous bucket ranges (as in table_agg_seg_kernel): the sectors two neighbouring buckets'
   // segments share are fetched from HBM once
   const uint32_t nit = *a.nitems;
-  const uint32_t bi = blockIdx.x, xq = nit / 8, xr = nit % 8, xc = bi % 8, q0 = bi / 8;
-  if (q0 >= xq + (xc < xr ? 1u : 0u)) return;
-  const WorkItem it = a.items[xc * xq + (xc < xr ? xc : xr) + q0];
+  const uint32_t bi = blockIdx.x;
+  uint32_t ii;
+  if (a.map == 0) {
+    const uint32_t xq = nit / 8, xr = nit % 8, xc = bi % 8, q0 = bi / 8;
+    if (q0 >= xq + (xc < xr ? 1u : 0u)) return;
+    ii = xc * xq + (xc < xr ? xc : xr) + q0;
+  } else if (a.map == 1) {
+    if (bi >= nit) return;
+    ii = bi;
+  } else {
+    if (bi >= nit) return;
+    ii = (uint32_t)(((unsigned long long)bi * (unsigned long long)a.map) % nit);       // a.map coprime to nit (host)
+  }
+  const WorkItem it = a.items[ii];
   const int tid = threadIdx.x;
   const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
   const int flags = CFLAGS >= 0 ? CFLAGS : a.flags;
@@ -377,23 +506,40 @@ __global__ void __launch_bounds__(TA_BLOCK) hash_agg_seg_kernel(HashAggSegDev a)
     const uint32_t excl = inc - ln;
     const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     for (uint32_t k0 = 0; k0 < T; k0 += 512u) {
-      u64 kx[8]; VT vv[8];
+      u64 kx[REC ? 1 : 8]; VT vv[REC ? 1 : 8];
+      bu32x4 rw[REC ? 8 : 1];
+      // the eight binary searches run side by side: one round = eight independent ds_bpermute, one wait
+      uint32_t lo[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) lo[j] = 0;
+#pragma unroll
+      for (int bit = 32; bit > 0; bit >>= 1) {
+        uint32_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) e[j] = (uint32_t)__shfl((int)excl, (int)(lo[j] + (uint32_t)bit), 64);
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (e[j] <= k0 + 64u * (uint32_t)j + lane) lo[j] += (uint32_t)bit;
+      }
+      uint32_t fe[8], fs[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { fe[j] = (uint32_t)__shfl((int)excl, (int)lo[j], 64); fs[j] = (uint32_t)__shfl((int)st, (int)lo[j], 64); }
 #pragma unroll
       for (int j = 0; j < 8; j++) {
         const uint32_t r = k0 + 64u * (uint32_t)j + lane;
-        uint32_t lo = 0;
-#pragma unroll
-        for (int bit = 32; bit > 0; bit >>= 1) {
-          const uint32_t e = (uint32_t)__shfl((int)excl, (int)(lo + (uint32_t)bit), 64);
-          if (e <= r) lo += (uint32_t)bit;
-        }
-        const uint32_t off = r - (uint32_t)__shfl((int)excl, (int)lo, 64);
-        const uint32_t row = (c + lo) * tr + (uint32_t)__shfl((int)st, (int)lo, 64) + off;
-        kx[j] = 0; vv[j] = VT(0);
-        if (r < T) { kx[j] = xs[row]; if (hasval) vv[j] = val[row]; }
+        const uint32_t row = (c + lo[j]) * tr + fs[j] + (r - fe[j]);
+        // lanes past the end of the sequence load the first row of the chunk's first tile (always there) and ignore it: no
+        // branch around the loads.  (With `if (r < T) load` the compiler merged the eight conditionally written registers
+        // as one array and followed every load by s_waitcnt vmcnt(0): eight dependent round trips per 448 rows.)
+        const uint32_t rs = r < T ? row : c * tr;
+        if (REC) rw[j] = reinterpret_cast<const bu32x4*>(xs)[rs];      // one 16-byte record per row (hash_partition_rec_kernel)
+        else { kx[j] = xs[rs]; vv[j] = hasval ? val[rs] : VT(0); }
       }
 #pragma unroll
-      for (int j = 0; j < 8; j++) hi.step(kx[j], vv[j], k0 + 64u * (uint32_t)j + lane < T);
+      for (int j = 0; j < 8; j++) {
+        const bool act = k0 + 64u * (uint32_t)j + lane < T;
+        if (REC) hi.step((u64)rw[j].x | ((u64)rw[j].y << 32), bits_val<VT>((u64)rw[j].z | ((u64)rw[j].w << 32)), act);
+        else hi.step(kx[j], vv[j], act);
+      }
     }
   }
   if (hi.qn) hi.drain();
@@ -402,25 +548,34 @@ __global__ void __launch_bounds__(TA_BLOCK) hash_agg_seg_kernel(HashAggSegDev a)
   hash_tab_flush(hk, t, flags, C, s_misc, a.o_key, a.o_tab, a.out_n, a.out_cap, a.overflow, tid);
 }
 
-template <typename VT, int CFLAGS>
+template <typename VT, int CFLAGS, bool REC = false>
 static int hash_agg_seg_t(dthip_ctx* ctx, const HashAggSegDev& d, uint32_t grid, size_t lds) {
-  auto kfn = hash_agg_seg_kernel<VT, CFLAGS>;
+  auto kfn = hash_agg_seg_kernel<VT, CFLAGS, REC>;
   DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 256));
   DTHIP_LAUNCH(ctx, "hash_agg_seg_kernel", kfn, grid, TA_BLOCK, lds, d);
   return DTHIP_OK;
 }
 
-int launch_hash_agg_seg(dthip_ctx* ctx, const HashAggArgs& a, const uint16_t* dirT, uint32_t dstride, uint32_t tile_rows) {
+int launch_hash_agg_seg(dthip_ctx* ctx, const HashAggArgs& a, const uint16_t* dirT, uint32_t dstride, uint32_t tile_rows, bool rec) {
   if (a.max_items == 0) return DTHIP_OK;
   HashAggSegDev d;
   d.items = a.items; d.nitems = a.nitems; d.xs = a.xs; d.val = a.val; d.C = a.C; d.flags = a.flags;
   d.dirT = dirT; d.dstride = dstride; d.tile_rows = tile_rows;
+  static const int map_env = getenv("DTHIP_HSEG_MAP") ? atoi(getenv("DTHIP_HSEG_MAP")) : 0;
+  d.map = (uint32_t)map_env;
   d.o_key = a.o_key; d.o_tab = a.o_tab; d.out_n = a.out_n; d.out_cap = a.out_cap; d.overflow = a.overflow;
   const size_t lds = hash_agg_queue_bytes() + (size_t)(a.C + 1) * hash_agg_entry_bytes(a.flags) + 32;
   if (lds > 160 * 1024 - 512) { set_error("hash_agg_seg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
   if ((a.C & 1u) || a.C < 6) { set_error("hash_agg_seg: the table is read as pairs of entries (C = %u)", a.C); return DTHIP_EINVAL; }
   const uint32_t grid = (a.max_items + 7u) & ~7u;
-  const int st = a.val ? a.vstype : DTHIP_INT32;
+  const int st = (a.val || rec) ? a.vstype : DTHIP_INT32;
+  if (rec) {        // records: one 8-byte value column
+    if (st == DTHIP_FLOAT64 && a.flags == ACC_SUM) return hash_agg_seg_t<double, ACC_SUM, true>(ctx, d, grid, lds);
+    if (st == DTHIP_FLOAT64 && a.flags == (ACC_SUM | ACC_CNT)) return hash_agg_seg_t<double, ACC_SUM | ACC_CNT, true>(ctx, d, grid, lds);
+    if (st == DTHIP_FLOAT64) return hash_agg_seg_t<double, -1, true>(ctx, d, grid, lds);
+    if (st == DTHIP_INT64) return hash_agg_seg_t<long long, -1, true>(ctx, d, grid, lds);
+    set_error("hash_agg_seg: records carry an 8-byte value column"); return DTHIP_EINVAL;
+  }
   if (st == DTHIP_FLOAT64 && a.flags == ACC_SUM) return hash_agg_seg_t<double, ACC_SUM>(ctx, d, grid, lds);
   if (st == DTHIP_FLOAT64 && a.flags == (ACC_SUM | ACC_CNT)) return hash_agg_seg_t<double, ACC_SUM | ACC_CNT>(ctx, d, grid, lds);
   switch (st) {

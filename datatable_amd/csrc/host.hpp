@@ -34,12 +34,9 @@ struct PaySpec {
   bool iota = false;            // column 0 is the row number
   // single int32 / int64 key whose column is wanted in sorted order: the last pass writes its ORIGINAL values here
   void* ukey_out = nullptr;
-  // zeroed bitmap of n bits: the final MSD level marks the first row of every run of equal keys (SortOut::heads_done)
-  unsigned long long* head_bitmap = nullptr;
 };
 
 struct SortOut {
-  bool heads_done = false;      // PaySpec::head_bitmap was filled
   bool ukey_done = false;       // PaySpec::ukey_out was filled (then `keys` is NOT: the last pass wrote the original values instead)
   void* keys = nullptr;         // sorted packed keys (scratch-owned)
   int key64 = 0;
@@ -85,9 +82,8 @@ int plan_windows(dthip_ctx* ctx, Scratch& sc, const uint32_t* fstart, uint32_t n
                  uint32_t tile, int maxw, int rb, WindowPlan* wp);
 int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stage, int64_t n,
                const int32_t* order, const PaySpec& pay, SortOut* out);
-int alloc_head_bitmap(dthip_ctx* ctx, Scratch& sc, int64_t n, unsigned long long** bitmap);
 int heads_to_offsets(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const void* keys, int key64,
-                     const uint8_t* heads, int64_t n, Grouping* g, unsigned long long* ready = nullptr);
+                     const uint8_t* heads, int64_t n, Grouping* g);
 int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthip_col* keys_dev, int nkeys,
                int64_t n, int na_pos, KeyPlan* plan, Grouping* g);
 

@@ -136,31 +136,28 @@ MsdPlan msd_plan(const dthip_ctx* ctx, int64_t n, int bits, int key64, uint32_t 
 }
 
 // ---- windows of the final MSD level (whole buckets, together at most one tile of rows), planned on the device ----------
-// Round 5: packed greedily per parent bucket (radix.hip msd_window_greedy_kernel; DTHIP_MSD_GREEDY=0: round 4's equal-step
-// windows, kept for A/B).  ok = the windowed final level can run; maxsize = the largest final bucket either way.
+// Packed greedily per parent bucket (radix.hip msd_window_greedy_kernel; round 4's equal-step windows filled 66 % of a tile
+// instead of 88 % and went in round 6).  ok = the windowed final level can run; maxsize = the largest final bucket either way.
 int plan_windows(dthip_ctx* ctx, Scratch& sc, const uint32_t* fstart, uint32_t nb1, uint32_t bins2, int64_t n, const uint32_t* d_max,
                         uint32_t tile, int maxw, int rb, WindowPlan* wp) {
-  static const bool greedy = !(getenv("DTHIP_MSD_GREEDY") && atoi(getenv("DTHIP_MSD_GREEDY")) == 0);
-  const uint32_t nbk = nb1 * bins2;
   // the (bucket, digit) counts of a window and their prefix live in the tile's exchange buffer: 2 x buckets x bins words
   uint32_t maxspan = 16;
   while (maxspan > 1 && (size_t)2 * maxspan * ((size_t)1 << rb) * 4 > (size_t)tile * maxw) maxspan >>= 1;
-  const uint32_t nwmax = greedy ? (uint32_t)(2 * (n / tile)) + nb1 + 8 : (uint32_t)(n / (tile / 2)) + 2;
+  const uint32_t nwmax = (uint32_t)(2 * (n / tile)) + nb1 + 8;
   uint32_t* wplan = nullptr;
   DTHIP_TRY(sc.get<uint32_t>((size_t)3 * (nwmax + 2) + 4, &wplan));
   uint32_t* wbounds = wplan; uint32_t* wfirst = wplan + 2 * (nwmax + 2); uint32_t* winfo = wfirst + nwmax + 2;
   DTHIP_CHECK_HIP(hipMemsetAsync(winfo, 0, 4 * sizeof(uint32_t), ctx->stream));
-  if (greedy) DTHIP_TRY(launch_msd_windows_greedy(ctx, fstart, nb1, bins2, tile, maxspan, nwmax, wbounds, wfirst, winfo));
-  else DTHIP_TRY(launch_msd_windows(ctx, fstart, nbk, (uint32_t)n, d_max, tile, nwmax, wbounds, wfirst, winfo));
-  uint32_t wi[4] = {0, 0, 0, 0};                     // equal-step: {windows, rows per step, largest span, -}; greedy: {~0 = infeasible, -, span, windows}
+  DTHIP_TRY(launch_msd_windows_greedy(ctx, fstart, nb1, bins2, tile, maxspan, nwmax, wbounds, wfirst, winfo));
+  uint32_t wi[4] = {0, 0, 0, 0};                     // {~0 = infeasible, -, largest span, windows}
   DTHIP_TRY(read_back(ctx, wi, winfo, sizeof(wi)));
   DTHIP_TRY(read_back(ctx, &wp->maxsize, d_max, sizeof(uint32_t)));
-  wp->bounds = wbounds; wp->wfirst = wfirst; wp->pairs = greedy ? 1 : 0; wp->span = wi[2];
-  wp->nwin = greedy ? wi[3] : wi[0];
-  wp->step = greedy ? 0 : wi[1];
+  wp->bounds = wbounds; wp->wfirst = wfirst; wp->pairs = 1; wp->span = wi[2];
+  wp->nwin = wi[3];
+  wp->step = 0;
   wp->bits2 = 1;
   while ((1u << wp->bits2) < wi[2]) wp->bits2++;
-  wp->ok = wp->nwin > 0 && wp->nwin <= nwmax && wi[2] >= 1 && wi[2] <= maxspan && !(greedy && wi[0] == 0xFFFFFFFFu) &&
+  wp->ok = wp->nwin > 0 && wp->nwin <= nwmax && wi[2] >= 1 && wi[2] <= maxspan && wi[0] != 0xFFFFFFFFu &&
            (size_t)2 * ((size_t)1 << wp->bits2) * ((size_t)1 << rb) * 4 <= (size_t)tile * maxw;
   static const int win_env = getenv("DTHIP_MSD_WINDOWS") ? atoi(getenv("DTHIP_MSD_WINDOWS")) : 1;   // 0: one workgroup per bucket (A/B)
   if (win_env == 0) wp->ok = false;
@@ -283,7 +280,7 @@ int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stage, int6
       pbuf[1][c] = b1;
     }
   }
-  out->ukey_done = false; out->heads_done = false;
+  out->ukey_done = false;
   if (use_msd) {
     // ---- level 1: stable scatter by the top s1 bits (regular tiles) ------------------------------------------------
     const int p1 = 2, p2 = 1;
@@ -348,10 +345,6 @@ int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stage, int6
         // of several whole buckets fill the tile (3.8 ms at ~6000 rows) at the price of a second ranking round in LDS
         rp.ntiles = wp.nwin; rp.bounds = wp.bounds; rp.wfirst = wp.wfirst; rp.block = 0;
         rp.bits2 = wp.bits2; rp.wpairs = wp.pairs;
-#ifdef DTHIP_RP_EXPERIMENT
-        if (getenv("DTHIP_MSD_R1ONLY")) rp.bits2 = 99;        // timing experiment: wrong results
-        if (getenv("DTHIP_MSD_WIN_NOR2")) rp.wfirst = nullptr; // timing experiment: the one-round kernel over the real windows
-#endif
       }
       for (int c = 0; c < pay.n; c++) { rp.pay.in[c] = pbuf[1][c]; rp.pay.out[c] = pbuf[0][c]; }
       if (pay.ukey_out) {
@@ -360,21 +353,7 @@ int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stage, int6
         rp.uk_edge = kc.edge; rp.uk_na_repl = kc.na_repl; rp.uk_inc = kc.inc;
         out->ukey_done = true;
       }
-      if (pay.head_bitmap) { rp.headbits = reinterpret_cast<uint32_t*>(pay.head_bitmap); out->heads_done = true; }
       rp.label = "msd_final_kernel";
-#ifdef DTHIP_RP_EXPERIMENT
-      if (const char* fw = getenv("DTHIP_MSD_FAKE_WINDOW")) {
-        // TIMING EXPERIMENT ONLY (wrong results): the final level over fixed windows of W rows instead of buckets
-        const uint32_t W = (uint32_t)atoi(fw);
-        std::vector<uint32_t> wb;
-        for (uint64_t r = 0; r < (uint64_t)n; r += W) wb.push_back((uint32_t)r);
-        wb.push_back((uint32_t)n);
-        uint32_t* d_wb = nullptr;
-        DTHIP_TRY(sc.get<uint32_t>(wb.size(), &d_wb));
-        DTHIP_CHECK_HIP(hipMemcpyAsync(d_wb, wb.data(), wb.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        rp.bounds = d_wb; rp.ntiles = (uint32_t)wb.size() - 1; rp.block = 0;
-      }
-#endif
       DTHIP_TRY(launch_radix_pass(ctx, rp));
       out->keys = kB;
       for (int c = 0; c < pay.n; c++) out->pay[c] = pbuf[0][c];
@@ -421,40 +400,17 @@ int sort_stage(dthip_ctx* ctx, Scratch& sc, const KeyPlan& plan, int stage, int6
   return DTHIP_OK;
 }
 
-// the final MSD level can mark the group heads (its keys sit in LDS in sorted order): built, bit-exact on the forced
-// suites, and measured a LOSS -- the level 4.75 -> 6.04 ms for a count_heads pass of 0.73 ms saved -- so it stays off
-// AND out of the product build: with the head phase compiled in, the ordinary scatter variant of radix_pass_kernel spilled
-// 60 instead of 24 VGPRs and C5's two scatter levels went from 4.3 + 4.9 to 5.7 + 6.0 ms although the phase never ran.
-// `make -C datatable_amd/csrc heads` builds the flavour (-DDTHIP_RP_HEADS); there DTHIP_FUSE_HEADS=1 switches it on.
-static bool fuse_heads_enabled() {
-#ifdef DTHIP_RP_HEADS
-  static const bool on = getenv("DTHIP_FUSE_HEADS") && atoi(getenv("DTHIP_FUSE_HEADS")) == 1;
-  return on;
-#else
-  return false;
-#endif
-}
+// (rounds 4-5 carried a build flavour in which the final MSD level also marked the group heads: bit-exact, measured a LOSS --
+// the level 4.75 -> 6.04 ms for a count_heads pass of 0.73 ms saved -- and removed in round 6)
 
-int alloc_head_bitmap(dthip_ctx* ctx, Scratch& sc, int64_t n, unsigned long long** bitmap) {
-  *bitmap = nullptr;
-  if (!fuse_heads_enabled()) return DTHIP_OK;
-  const size_t words = (size_t)((n + 63) / 64) + 1;
-  DTHIP_TRY(sc.get<unsigned long long>(words, bitmap));
-  DTHIP_CHECK_HIP(hipMemsetAsync(*bitmap, 0, words * 8, ctx->stream));
-  return DTHIP_OK;
-}
-
-// ready: a head bitmap the sort itself filled (final MSD level) -- no pass over the keys
 int heads_to_offsets(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const void* keys, int key64,
-                            const uint8_t* heads, int64_t n, Grouping* g, unsigned long long* ready) {
+                            const uint8_t* heads, int64_t n, Grouping* g) {
   const uint32_t nt = (uint32_t)((n + SEG_TILE - 1) / SEG_TILE);
   uint32_t* tile_counts = nullptr;
   DTHIP_TRY(sc.get<uint32_t>((size_t)nt + 4 + nt / 8192, &tile_counts));
-  unsigned long long* bitmap = ready;
-  if (!bitmap) DTHIP_TRY(sc.get<unsigned long long>((size_t)((n + 63) / 64) + 1, &bitmap));
+  unsigned long long* bitmap = nullptr;
+  DTHIP_TRY(sc.get<unsigned long long>((size_t)((n + 63) / 64) + 1, &bitmap));
   int64_t ng = 0;
-  if (ready) DTHIP_TRY(launch_heads_from_bitmap(ctx, bitmap, n, tile_counts, tile_counts + nt, &ng));
-  else
   DTHIP_TRY(launch_count_heads(ctx, keys, key64, heads, n, tile_counts, bitmap, tile_counts + nt, &ng));
   void* off = nullptr;
   DTHIP_TRY(result_alloc(ctx, res, sizeof(int32_t) * (size_t)(ng + 1), &off));
@@ -471,7 +427,6 @@ int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthip_col* 
   // int64 column); the key-transform pass of every stage verifies the guess, a wrong one costs one more round
   const int32_t* order = nullptr;
   SortOut so;
-  unsigned long long* gc_bitmap = nullptr;
   for (int attempt = 0; attempt < 2; attempt++) {
     DTHIP_TRY(plan_keys(ctx, sc, keys_dev, nkeys, n, na_pos, plan, attempt == 0, true));
     order = nullptr;
@@ -480,10 +435,6 @@ int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthip_col* 
       PaySpec ps;
       ps.n = 1; ps.width[0] = 4;
       if (order) { ps.in[0] = order; ps.iota = false; } else { ps.in[0] = nullptr; ps.iota = true; }
-      if (plan->nstages == 1) {
-        if (!gc_bitmap) DTHIP_TRY(alloc_head_bitmap(ctx, sc, n, &gc_bitmap));      // (null unless DTHIP_FUSE_HEADS=1)
-        ps.head_bitmap = gc_bitmap;
-      }
       rc = sort_stage(ctx, sc, *plan, s, n, order, ps, &so);
       if (rc != DTHIP_OK) break;
       order = static_cast<const int32_t*>(so.pay[0]);
@@ -496,7 +447,7 @@ int group_core(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const dthip_col* 
   g->rowindex = const_cast<int32_t*>(order);
   g->sorted_keys = so.keys; g->key64 = so.key64;
   if (plan->nstages == 1) {
-    DTHIP_TRY(heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, n, g, so.heads_done ? gc_bitmap : nullptr));
+    DTHIP_TRY(heads_to_offsets(ctx, sc, res, so.keys, so.key64, nullptr, n, g));
   } else {
     uint8_t* heads = nullptr;
     DTHIP_TRY(sc.get<uint8_t>((size_t)n, &heads));

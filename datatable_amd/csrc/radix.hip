@@ -209,8 +209,6 @@ struct PassArgsT {
   // are written instead of the packed transformed keys (saves the untransform pass: 4 B read + 8 B written per row)
   void* ukout; int uk_stype; int uk_desc; int uk_bits;
   unsigned long long uk_edge, uk_na_repl, uk_inc;
-  uint32_t* headbits;       // final MSD level: head bitmap of the sorted order (the tile's keys sit in LDS in sorted order anyway)
-  uint32_t hw_off;          // byte offset of the head-bitmap words inside the workgroup's LDS
   // gather mode (GATH): see RadixPass::g_dirT
   const uint16_t* dirT; uint32_t dstride; const uint32_t* cc; uint32_t ntb, ntiles1, T1; const uint32_t* pstart;
   uint16_t* dir2;           // GATH == 3 / 4: tile-local output + directory instead of P / gpre (RadixPass::tl_dir2)
@@ -307,58 +305,8 @@ __global__ void __launch_bounds__(HIST_STRIDE) msd_scan_kernel(uint32_t* __restr
   if (b + 1 == nb && d == 0) fstart[(size_t)nb * bins] = n;
 }
 
-// Windows of the final MSD level: window w = the buckets whose first row lies in [w * W, (w + 1) * W), W = tile - (largest
-// bucket), hence at most one tile of rows, whole buckets only, and no bucket in two windows.  wbounds[w] = first row,
-// wfirst[w] = first bucket; info = {number of windows, W, largest number of buckets in a window}.
-__global__ void __launch_bounds__(256) msd_window_kernel(const uint32_t* __restrict__ fstart, uint32_t nbk, uint32_t n, const uint32_t* __restrict__ maxsize,
-                                                         uint32_t tile, uint32_t nwmax, uint32_t* __restrict__ wbounds, uint32_t* __restrict__ wfirst,
-                                                         uint32_t* __restrict__ info) {
-  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t mx = *maxsize;
-  if (mx > tile / 2) { if (w == 0) { info[0] = 0; info[1] = 0; info[2] = 0; } return; }
-  const uint32_t W = tile - mx;
-  const uint32_t NW = (n + W - 1) / W;
-  if (w == 0) { info[0] = NW; info[1] = W; }
-  if (w > NW || w > nwmax) return;
-  auto first_bucket = [&](uint32_t ww) -> uint32_t {
-    const unsigned long long target = (unsigned long long)ww * W;
-    if (target >= n) return nbk;
-    uint32_t lo = 0, hi = nbk;                         // first b with fstart[b] >= target
-    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (fstart[mid] < target) lo = mid + 1; else hi = mid; }
-    return lo;
-  };
-  const uint32_t b0 = first_bucket(w);
-  const uint32_t row0 = fstart[b0];
-  wbounds[w] = row0;
-  // EMPTY buckets share their first row with the next bucket that holds rows: the window's bucket numbers run from the
-  // LAST bucket starting at row0 (the one that holds its first row) to the last bucket starting before the window's end --
-  // empty buckets in front of and behind the window's rows (the unused top of the key range: 63780 of them behind C5's
-  // last row) must not count
-  auto last_at = [&](uint32_t row) -> uint32_t {       // last b <= nbk with fstart[b] <= row
-    uint32_t lo = 0, hi = nbk + 1;
-    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (fstart[mid] <= row) lo = mid + 1; else hi = mid; }
-    return lo - 1;
-  };
-  auto first_at = [&](uint32_t row) -> uint32_t {      // first b <= nbk with fstart[b] >= row
-    uint32_t lo = 0, hi = nbk;
-    while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (fstart[mid] < row) lo = mid + 1; else hi = mid; }
-    return lo;
-  };
-  uint32_t c0 = b0;
-  if (w < NW) {
-    const uint32_t b1 = first_bucket(w + 1);
-    const uint32_t row1 = fstart[b1];
-    if (row1 > row0) {
-      c0 = last_at(row0);                               // holds the window's first row
-      const uint32_t cend = first_at(row1);             // first bucket starting at the window's end: cend - 1 holds its last row
-      atomicMax(&info[2], cend - c0);
-    }
-  }
-  wfirst[w] = c0;
-}
-
 // Round 5: windows packed GREEDILY -- whole buckets are added while they fit the tile (and the window spans <= maxspan bucket
-// numbers): ~88 % of a tile instead of the 66 % the equal-step rule above leaves when the largest bucket is 1.5x the average
+// numbers): ~88 % of a tile instead of the 66 % of round 4's equal-step rule leaves when the largest bucket is 1.5x the average
 // (config 5: 69k windows instead of 92k).  A greedy scan is sequential, so it runs per PARENT bucket (pb = buckets per parent;
 // a window never spans two parents): one wave per parent, lane 0 walks the parent's pb bucket starts in LDS, the windows of a
 // parent take a block of slots from an atomic counter.  Windows are (start, end) PAIRS: wbounds[2 w], wbounds[2 w + 1] -- their
@@ -401,12 +349,6 @@ __global__ void __launch_bounds__(64) msd_window_greedy_kernel(const uint32_t* _
     wbounds[2 * (base + i) + 1] = fs[e];
     wfirst[base + i] = p * pb + c0;
   }
-}
-
-int launch_msd_windows(dthip_ctx* ctx, const uint32_t* fstart, uint32_t nbk, uint32_t n, const uint32_t* maxsize, uint32_t tile,
-                       uint32_t nwmax, uint32_t* wbounds, uint32_t* wfirst, uint32_t* info) {
-  DTHIP_LAUNCH(ctx, "msd_window_kernel", msd_window_kernel, (nwmax + 1 + 255) / 256, 256, 0, fstart, nbk, n, maxsize, tile, nwmax, wbounds, wfirst, info);
-  return DTHIP_OK;
 }
 
 // info[4] zeroed by the caller; afterwards info[3] = number of windows (info[0] = ~0: a bucket outgrows a tile), info[2] = span
@@ -579,12 +521,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     __syncthreads();                                        // (full tiles: every wave has read its transposed keys)
     rank_round<BLOCK, ITEMS, RB>([&](int i) { return (uint32_t)key[i] & dmask; }, vmask, bins, wh, bin_excl, misc, exch, SLICE, pos);
     __syncthreads();
-#ifdef DTHIP_RP_EXPERIMENT
-    if (a.bits2 == 99) {       // TIMING EXPERIMENT (wrong results): round 1 only
-      for (int b = tid; b < bins; b += BLOCK) bin_delta[b] = tile_base;
-      __syncthreads();
-    } else {
-#endif
     // The window's rows arrive ordered by bucket (the scatter levels put them there), so the round above -- stable by
     // the low digit d -- leaves every d-group ordered by bucket.  The wanted order is (bucket, d): a row's place is
     //   first row of its (bucket, d) group  +  its rank inside the group
@@ -627,9 +563,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     __syncthreads();
     for (int b = tid; b < bins; b += BLOCK) bin_delta[b] = tile_base;
     __syncthreads();
-#ifdef DTHIP_RP_EXPERIMENT
-    }
-#endif
   } else {
   // ---- stable rank of every key among equal digits of its wave --------------
   // (the cross-lane traffic below goes through wavefront-scope relaxed atomics, not `volatile`: volatile accesses lose
@@ -663,21 +596,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
         }
       }
     }
-#ifdef DTHIP_RP_EXPERIMENT
-  } else if (RK == 2) {
-    // TIMING EXPERIMENT ONLY (unstable, so the sort is wrong): arrival ranks from one DS atomic per key -- what an
-    // unordered partition would pay for its ranks
-    constexpr uint32_t SLICE = 64u * ITEMS * (uint32_t)sizeof(KeyT);
-    uint32_t* c32 = reinterpret_cast<uint32_t*>(exch + (size_t)wave * SLICE);
-    for (int b = lane; b < bins; b += 64) c32[b] = 0u;
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-      const bool valid = RP_VALID(i);
-      const uint32_t d = (uint32_t)(key[i] >> a.shift) & dmask;
-      pos[i] = valid ? atomicAdd(&c32[d], 1u) : 0u;
-    }
-    for (int b = lane; b < bins; b += 64) mywh[b] = (uint16_t)c32[b];
-#endif
   } else {
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
@@ -753,45 +671,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
     }
   }
   __syncthreads();
-#ifdef DTHIP_RP_HEADS          // a build flavour only (`make heads`): compiled in, the phase costs every variant registers
-  if (a.headbits) {
-    // group heads of the final order: the tile (a bucket, or a window of whole buckets) starts a new key prefix, inside it
-    // a row is a head when its key differs from its predecessor's.  Lane = slot (conflict-free LDS reads), one ballot per
-    // 64 slots, the tile's piece of the bitmap is assembled in LDS (bit = row - first row of the tile's first WORD) and
-    // written out as words: the first and the last may be shared with the neighbouring tiles (atomic OR into the zeroed
-    // bitmap), the others are the tile's own.  (A first version looped over bitmap bytes per thread -- eight strided
-    // LDS reads each, 8-way bank conflicts: +1.2 ms on the level; this one costs ~0.1.)
-    // [TILE / 32 + 2] words: in the per-wave digit counters (dead by now) when they are big enough -- one more KB of LDS
-    // would cost the second workgroup per CU (measured: the level 5.0 -> 6.3 ms) --, else behind the exchange buffer
-    uint32_t* hw = reinterpret_cast<uint32_t*>(smem + a.hw_off);
-    const uint32_t r = tile_base & 31u, nwords = (r + nvalid + 31u) >> 5;
-    for (uint32_t w = tid; w < nwords; w += BLOCK) hw[w] = 0u;
-    __syncthreads();
-    for (uint32_t s0 = (uint32_t)wave * 64u; s0 < nvalid; s0 += BLOCK) {
-      const uint32_t sl = s0 + (uint32_t)lane;
-      const bool h = sl < nvalid && (sl == 0u || ek[sl] != ek[sl - 1u]);
-      const unsigned long long bal = __ballot(h);
-      if (lane < 3) {
-        // the wave's 64 bits start at bit (r + s0) of the tile's piece: they fall into three consecutive words at most
-        const uint32_t bit0 = r + s0, w0 = bit0 >> 5, sh = bit0 & 31u;
-        const uint32_t lo = (uint32_t)bal, hi = (uint32_t)(bal >> 32);
-        uint32_t v;
-        if (lane == 0) v = lo << sh;
-        else if (lane == 1) v = (sh ? (lo >> (32u - sh)) : 0u) | (hi << sh);
-        else v = sh ? (hi >> (32u - sh)) : 0u;
-        if (v) atomicOr(&hw[w0 + (uint32_t)lane], v);
-      }
-    }
-    __syncthreads();
-    uint32_t* gw = a.headbits + (tile_base >> 5);
-    for (uint32_t w = tid; w < nwords; w += BLOCK) {
-      const uint32_t v = hw[w];
-      if (w == 0 || w + 1 == nwords) { if (v) atomicOr(&gw[w], v); }
-      else gw[w] = v;
-    }
-    __syncthreads();
-  }
-#endif
   // thread owns slots (g*BLOCK + tid)*4 .. +3 for g in [0, GROUPS)
   uint32_t gpos[SEQOUT ? 1 : ITEMS];
 #pragma unroll
@@ -923,22 +802,10 @@ static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
   a.wfirst = p.wfirst; a.bits2 = p.bits2; a.wpairs = p.wpairs;
   a.ukout = p.ukout; a.uk_stype = p.uk_stype; a.uk_desc = p.uk_desc; a.uk_bits = p.uk_bits;
   a.uk_edge = p.uk_edge; a.uk_na_repl = p.uk_na_repl; a.uk_inc = p.uk_inc;
-  a.headbits = p.bounds ? p.headbits : nullptr;
-#ifndef DTHIP_RP_HEADS
-  if (a.headbits) { set_error("radix pass: head marking is a build flavour (make heads), not part of this library"); return DTHIP_ENOTIMPL; }
-#endif
-#ifdef DTHIP_RP_EXPERIMENT
-  if (getenv("DTHIP_RP_SEQ") && atoi(getenv("DTHIP_RP_SEQ"))) a.seq = 1;      // timing experiment: wrong results
-#endif
   int maxw = (int)sizeof(KeyT);
   for (int c = 0; c < p.pay.n; c++) maxw = p.pay.width[c] > maxw ? p.pay.width[c] : maxw;
   const int bins = 1 << (R2 && p.bits2 > p.bits && p.bits2 < 32 ? p.bits2 : p.bits);
   size_t lds = (size_t)(BLK / 64) * bins * 2 + (size_t)(2 * bins + 16) * 4 + (size_t)(BLK * RP_ITEMS) * maxw;
-  a.hw_off = 0;
-  if (a.headbits) {
-    const size_t need = (size_t)((BLK * RP_ITEMS) / 32 + 4) * 4;
-    if ((size_t)(BLK / 64) * bins * 2 < need) { a.hw_off = (uint32_t)lds; lds += need; }
-  }
   auto kfn = radix_pass_kernel<KeyT, RB, P0W, P1W, RK, BLK, R2, GATH>;
   DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 1024));
   const uint32_t ntiles = p.ntiles ? p.ntiles : (p.n + RP_TILE - 1) / RP_TILE;
@@ -946,19 +813,14 @@ static int launch_pass_r(dthip_ctx* ctx, const RadixPass& p) {
   return DTHIP_OK;
 }
 
-// DTHIP_RP_RANK = 0: the ballot ranking of rounds 1-3 (kept selectable for A/B runs); default: the LDS lane masks
+// ranking through the LDS lane masks (RK = 1); the ballot ranking of rounds 1-3 (RK = 0) serves the 10-bit final level only
 template <typename KeyT, int RB, int P0W, int P1W = 0>
 static int launch_pass_t(dthip_ctx* ctx, const RadixPass& p) {
-  static const int rank = getenv("DTHIP_RP_RANK") ? atoi(getenv("DTHIP_RP_RANK")) : 1;
   if (p.wfirst) {        // final MSD level over windows: two rounds in LDS (4-byte keys, digits of <= 9 bits)
     if (sizeof(KeyT) != 4 || RB != 9) { set_error("radix pass: the windowed final level takes 4-byte keys"); return DTHIP_EINVAL; }
     return launch_pass_r<uint32_t, 9, P0W, P1W, 1, RP_BLOCK, true>(ctx, p);
   }
   if (p.block == 256 && sizeof(KeyT) == 4) return launch_pass_r<uint32_t, RB, P0W, P1W, 1, 256>(ctx, p);   // final MSD level, small buckets
-  if (rank == 0) return launch_pass_r<KeyT, RB, P0W, P1W, 0>(ctx, p);
-#ifdef DTHIP_RP_EXPERIMENT
-  if (rank == 2) return launch_pass_r<KeyT, RB, P0W, P1W, 2>(ctx, p);
-#endif
   return launch_pass_r<KeyT, RB, P0W, P1W, 1>(ctx, p);
 }
 

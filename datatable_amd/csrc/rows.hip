@@ -123,7 +123,6 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
         if ((rc = result_alloc(ctx, res, (size_t)nrows * stype_size(kd[0].stype), &q)) != DTHIP_OK) break;
         ps.ukey_out = q;
       }
-      if ((rc = alloc_head_bitmap(ctx, sc, nrows, &ps.head_bitmap)) != DTHIP_OK) break;
       rc = sort_stage(ctx, sc, plan, 0, nrows, nullptr, ps, &so);
       if (rc == DTHIP_RETRY_EXACT) {
         ctx->call_stats[0]++;
@@ -136,9 +135,7 @@ int dthip_groupby_rows(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const d
       if (rc != DTHIP_OK) break;
     }
     if (ride) {
-      if (so.heads_done) {
-        if ((rc = heads_to_offsets(ctx, sc, res, nullptr, 0, nullptr, nrows, &g, ps.head_bitmap)) != DTHIP_OK) break;
-      } else if (so.ukey_done) {
+      if (so.ukey_done) {
         // groups = runs of equal ORIGINAL key values (the transform is a bijection, NA <-> NA)
         if ((rc = heads_to_offsets(ctx, sc, res, ps.ukey_out, kd[0].stype == DTHIP_INT64, nullptr, nrows, &g)) != DTHIP_OK) break;
       } else

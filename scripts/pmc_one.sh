@@ -11,3 +11,8 @@ for P in "$P1" "$P2"; do
   db=$(find $OUT/p$i -name "*.db" | head -1); [ -n "$db" ] && python scripts/rocpd_summary.py $db > $OUT/p$i.txt 2>&1 && rm -rf $OUT/p$i
 done
 grep -h "${3:-hash_agg}" $OUT/p1.txt $OUT/p2.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp; timeout -k 5 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/$C -o cfg -- python $REPO/scripts/configs_bench.py --configs $ID --once > $OUT/$C.log 2>&1 )
+  db=$(find $OUT/$C -name "*.db" | head -1); [ -n "$db" ] && python scripts/rocpd_summary.py $db > $OUT/$C.txt 2>&1 && rm -rf $OUT/$C
+  grep -h "${3:-hash_agg}" $OUT/$C.txt | grep "$C"
+done
