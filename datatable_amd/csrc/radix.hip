@@ -713,22 +713,40 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
   }
 
   // ---- payload columns follow the same permutation --------------------------
-  for (int c = 0; c < a.pay.n; c++) {
+  // KIND 1 / 2: the column waits in pay0 / pay1 (prefetched with the keys), 3: it is the row numbers, 0: it is loaded here --
+  // ALL of the thread's loads first (rows past the end of a short tile read the tile's first row and drop it), then the LDS
+  // writes.  (Rounds 1-5 had `if (valid) e[pos] = load` per item: sixteen load -> s_waitcnt vmcnt(0) -> ds_write round trips
+  // per thread, tile and column.)  Columns 0 and 1 are peeled off the loop so that pay0 / pay1 are dead in the other branches.
+#ifndef RP_INPL
+#define RP_INPL 4         // loads of a column that is loaded here in flight per thread
+#endif
+  auto paycol = [&](int c, auto kindc) {
+    constexpr int KIND = decltype(kindc)::value;
+    const bool w4 = KIND == 3 ? true : KIND == 1 ? P0W == 4 : KIND == 2 ? P1W == 4 : a.pay.width[c] == 4;
     __syncthreads();
-    if (a.pay.width[c] == 4) {
+    if (w4) {
       uint32_t* e4 = reinterpret_cast<uint32_t*>(exch);
       const uint32_t* pin = static_cast<const uint32_t*>(a.pay.in[c]);
       uint32_t* pout = static_cast<uint32_t*>(a.pay.out[c]);
+      if (KIND == 0) {
 #pragma unroll
-      for (int i = 0; i < ITEMS; i++) {
-        const uint32_t loc = wbase + 64u * i;
-        if (RP_VALID(i)) {
-          uint32_t v;
-          if (c == 0 && a.iota) v = tile_base + loc;
-          else if (c == 0 && P0W == 4) v = (uint32_t)pay0[i];
-          else if (c == 1 && P1W == 4) v = (uint32_t)pay1[i];
-          else v = RP_LD(&pin[tile_base + loc]);
-          e4[pos[i]] = v;
+        for (int h = 0; h < ITEMS; h += RP_INPL) {
+          uint32_t v4[RP_INPL];
+#pragma unroll
+          for (int i = 0; i < RP_INPL; i++) v4[i] = RP_LD(&pin[tile_base + (RP_VALID(h + i) ? wbase + 64u * (h + i) : 0u)]);
+#pragma unroll
+          for (int i = 0; i < RP_INPL; i++) if (RP_VALID(h + i)) e4[pos[h + i]] = v4[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+          if (RP_VALID(i)) {
+            uint32_t v;
+            if (KIND == 3) v = tile_base + wbase + 64u * i;
+            else if (KIND == 1) v = (uint32_t)pay0[i];
+            else v = (uint32_t)pay1[i];
+            e4[pos[i]] = v;
+          }
         }
       }
       __syncthreads();
@@ -745,15 +763,19 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
       unsigned long long* e8 = reinterpret_cast<unsigned long long*>(exch);
       const unsigned long long* pin = static_cast<const unsigned long long*>(a.pay.in[c]);
       unsigned long long* pout = static_cast<unsigned long long*>(a.pay.out[c]);
+      if (KIND == 0) {
 #pragma unroll
-      for (int i = 0; i < ITEMS; i++) {
-        const uint32_t loc = wbase + 64u * i;
-        if (RP_VALID(i)) {
-          unsigned long long v;
-          if (c == 0 && P0W == 8) v = (unsigned long long)pay0[i];
-          else if (c == 1 && P1W == 8) v = (unsigned long long)pay1[i];
-          else v = RP_LD(&pin[tile_base + loc]);
-          e8[pos[i]] = v;
+        for (int h = 0; h < ITEMS; h += RP_INPL) {
+          unsigned long long v8[RP_INPL];
+#pragma unroll
+          for (int i = 0; i < RP_INPL; i++) v8[i] = RP_LD(&pin[tile_base + (RP_VALID(h + i) ? wbase + 64u * (h + i) : 0u)]);
+#pragma unroll
+          for (int i = 0; i < RP_INPL; i++) if (RP_VALID(h + i)) e8[pos[h + i]] = v8[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+          if (RP_VALID(i)) e8[pos[i]] = KIND == 1 ? (unsigned long long)pay0[i] : (unsigned long long)pay1[i];
         }
       }
       __syncthreads();
@@ -768,7 +790,17 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DTHIP_
         if (nv) store_group4<unsigned long long>(pout, gp, vv, nv);
       }
     }
+  };
+  if (a.pay.n > 0) {
+    if (a.iota) paycol(0, std::integral_constant<int, 3>());
+    else if (P0W) paycol(0, std::integral_constant<int, 1>());
+    else paycol(0, std::integral_constant<int, 0>());
   }
+  if (a.pay.n > 1) {
+    if (P1W) paycol(1, std::integral_constant<int, 2>());
+    else paycol(1, std::integral_constant<int, 0>());
+  }
+  for (int c = 2; c < a.pay.n; c++) paycol(c, std::integral_constant<int, 0>());
 }
 
 #undef RP_VALID
