@@ -636,7 +636,9 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   // per row hash_xform moved), the key column itself is payload 0 of the partition, and the partial groups' keys come
   // out typed already
   static const bool raw_ok = !(getenv("DTHIP_HASH_RAW") && atoi(getenv("DTHIP_HASH_RAW")) == 0);
-  const bool raw_key = raw_ok && nkeys == 1 && kd[0].stype == DTHIP_INT64;
+  // (round 6: a float64 key column too -- its BITS are the image; the NaN patterns, one NA group in the reference, meet in
+  // the merge, which groups the typed keys; -0.0 and 0.0 stay two groups as in the reference)
+  const bool raw_key = raw_ok && nkeys == 1 && (kd[0].stype == DTHIP_INT64 || kd[0].stype == DTHIP_FLOAT64);
   // round 6: with a raw key the histogram and partition kernels HASH THE KEY COLUMN ON THE FLY (a two-multiply 24-bit hash,
   // keyxform.hpp hash_pk24) instead of reading a pseudo-key array that a pass of its own wrote: 12 of the 80 bytes per row
   // and one sweep less (DTHIP_HASH_FUSED=0: the pseudo-key pass of rounds 3-5, A/B)
@@ -684,11 +686,11 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   const uint32_t max_items = g.F + (uint32_t)((uint64_t)n / M) + 1;
   WorkItem* items = nullptr;
   DTHIP_TRY(sc.get<WorkItem>(max_items, &items));
-  // round 6: TILE-LOCAL partition for one raw int64 key -- 16384-row tiles written sequentially (each bucket one ~8-row
+  // round 6: TILE-LOCAL partition (aligned columns: a raw int64 key hashed on the fly, or the int32 pseudo keys) -- 16384-row tiles written sequentially (each bucket one ~8-row
   // segment per tile + a 2-byte directory entry), no histogram pass; hash_agg_seg_kernel walks the segments
   // (DTHIP_HASH_TL=0: histogram + exact scatter positions as in rounds 2-5, A/B)
   static const bool tl_ok = !(getenv("DTHIP_HASH_TL") && atoi(getenv("DTHIP_HASH_TL")) == 0);
-  bool tile_local = tl_ok && ctx->hash_mode != 3 && fused_pk && km == 1 && g.block == 1024 && (n >= (1 << 22) || ctx->hash_mode == 2);
+  bool tile_local = tl_ok && ctx->hash_mode != 3 && km != 0 && g.block == 1024 && (n >= (1 << 22) || ctx->hash_mode == 2);
   if (tile_local) {
     int maxw = 8;
     for (int c : used) maxw = std::max(maxw, stype_size(vd[c].stype));
@@ -697,7 +699,7 @@ static int hash_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, cons
   const size_t part_rows = tile_local ? (size_t)g.ntiles * g.tile : (size_t)n;
   // one 8-byte value column: key and value travel as ONE 16-byte record (hash_partition_rec_kernel; DTHIP_HASH_REC=0: columns, A/B)
   static const bool rec_env = !(getenv("DTHIP_HASH_REC") && atoi(getenv("DTHIP_HASH_REC")) == 0);
-  const bool rec_mode = tile_local && rec_env && used.size() == 1 && stype_size(vd[used[0]].stype) == 8;
+  const bool rec_mode = tile_local && rec_env && fused_pk && used.size() == 1 && stype_size(vd[used[0]].stype) == 8;
   uint16_t* kslot = nullptr;         // not written: the packed key itself travels as payload 0
   unsigned long long* xs_part = nullptr;
   DTHIP_TRY(sc.get<unsigned long long>((rec_mode ? 2 * part_rows : part_rows) + 8, &xs_part));

@@ -296,6 +296,12 @@ def test_hash_combiner_sparse_keys(ctx):
     k_f = rng.choice(rng.standard_normal(5_000), n)
     k_f[rng.random(n) < 0.02] = np.nan
     k_skew = np.where(rng.random(n) < 0.85, pool[7], rng.choice(pool, n)).astype(np.int64)
+    # float64 keys ride as their BITS (round 6): -0.0 / 0.0 are two groups (as in the reference), NaNs of different bit patterns ONE
+    k_f2 = k_f.copy()
+    k_f2[rng.random(n) < 0.01] = -0.0
+    k_f2[rng.random(n) < 0.01] = 0.0
+    k_f2.view(np.uint64)[rng.random(n) < 0.01] = np.uint64(0x7FF8000000000001)
+    k_f2.view(np.uint64)[rng.random(n) < 0.01] = np.uint64(0xFFF8000000000000)
     k_a = rng.integers(0, 2**31 - 1, n).astype(np.int32) // 50_000 * 50_000
     k_b = rng.choice(pool[:300], n).astype(np.int64)
     v = rng.standard_normal(n)
@@ -309,7 +315,7 @@ def test_hash_combiner_sparse_keys(ctx):
     for hm in (2, 3):
         ctx.set_option("hash_mode", hm)
         try:
-            for keys in ([k_int], [k_f], [k_skew], [k_a, k_b]):
+            for keys in ([k_int], [k_f], [k_f2], [k_skew], [k_a, k_b]):
                 for val in (v, iv, fv, i32):
                     _vs_oracle(ctx, keys, [val], check_ri=False)
                 _vs_oracle(ctx, keys, [], aggs=(), check_ri=False)
