@@ -31,6 +31,7 @@ static int acc_flags_for(const dthip_agg* aggs, int naggs, int col, int vstype, 
 static int floor_log2_sz(size_t v) { int b = -1; while (v) { b++; v >>= 1; } return b; }
 
 constexpr size_t BUCKET_LDS_TABLE = 144 * 1024;   // LDS bytes one aggregation table may take
+constexpr size_t BUCKET_LDS_TABLE_HALF = 78 * 1024;   // ... when two workgroups are to share a CU
 constexpr int BUCKET_MAX_R = 14;                  // slot keys are uint16
 constexpr int BUCKET_MAX_D = 11;                  // <= 2048 buckets in one partition pass
 
@@ -50,15 +51,28 @@ static bool bucket_eligible(const dthip_ctx* ctx, const KeyPlan& plan, const std
   const int first_flag = (bucket_need_counts(ctx, aggs, naggs) || guess_nona) ? ACC_CNT : ACC_PRES;
   int r = BUCKET_MAX_R;
   bool first = true;
-  auto fit = [&](int f) { int rc = BUCKET_MAX_R; while (rc > 0 && table_agg_lds_bytes(f, 1u << rc) > BUCKET_LDS_TABLE) rc--; return rc; };
-  for (int c : used) {
-    const int sz = stype_size(vd[c].stype);
-    if (sz != 4 && sz != 8) return false;
-    const int f = acc_flags_for(aggs, naggs, c, vd[c].stype, vd[c].flags, guess_nona) | (first ? first_flag : 0);
-    first = false;
-    r = std::min(r, fit(f));
+  // A table with three or more 8-byte accumulators per slot (sum + min + max: BASELINE C2) is bound by its LDS atomics, not by
+  // HBM: capped at half the LDS, two workgroups share a CU and one's table set-up / flush hides behind the other's rows
+  // (C2 table_agg 0.24 -> 0.22 ms per column, profiles/r06_c2_tab_ab.txt); DTHIP_TAB_KB overrides (A/B)
+  static const size_t tab_cap_env = getenv("DTHIP_TAB_KB") ? (size_t)atoi(getenv("DTHIP_TAB_KB")) * 1024 : 0;
+  auto fit = [&](int f, bool half_ok) {
+    const size_t cap = tab_cap_env ? tab_cap_env : (half_ok && table_agg_slot_bytes(f) >= 24 ? BUCKET_LDS_TABLE_HALF : BUCKET_LDS_TABLE);
+    int rc = BUCKET_MAX_R;
+    while (rc > 0 && table_agg_lds_bytes(f, 1u << rc) > cap) rc--;
+    return rc;
+  };
+  for (int pass = 0; pass < 2; pass++) {          // (the smaller tables must not cost a wide key range its place on this path)
+    r = BUCKET_MAX_R; first = true;
+    for (int c : used) {
+      const int sz = stype_size(vd[c].stype);
+      if (sz != 4 && sz != 8) return false;
+      const int f = acc_flags_for(aggs, naggs, c, vd[c].stype, vd[c].flags, guess_nona) | (first ? first_flag : 0);
+      first = false;
+      r = std::min(r, fit(f, pass == 0));
+    }
+    if (first) r = std::min(r, fit(first_flag, pass == 0));
+    if (B - std::min(r, B) <= BUCKET_MAX_D) break;
   }
-  if (first) r = std::min(r, fit(first_flag));
   if (r > B) r = B;
   if (B - r > BUCKET_MAX_D) return false;
   // the dense accumulator arrays have 2^B slots: only worth it when the key range is dense enough
@@ -279,13 +293,18 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   // Worth it when the segments are short and alike: >= 1024 buckets (<= 12 rows of a tile per bucket) and no hot bucket
   // (sampled).  Measured on 1e9 rows: C3 9.5 -> 9.1 ms, C4 11.0 -> 9.4; but 4 x float64 columns over 32 buckets 2.8 -> 3.9
   // and a heavily skewed key 10.6 -> 14.1, which therefore keep the exact-position layout.
+  // Round 6, third part: also with FEW buckets (<= 128: a tile's segment per bucket is >= 128 rows, streamed by whole waves --
+  // table_agg_seg_kernel's long mode; a hot bucket only makes them longer): the histogram pass goes (C2 2.62 -> see DESIGN 6).
+  // In between (256 / 512 buckets: 32- to 64-row segments suit neither mode) the exact-position layout stays.
+  static const bool tl_few = !(getenv("DTHIP_TL_FEW") && atoi(getenv("DTHIP_TL_FEW")) == 0);
   const bool tile_local = g.d > 0 && !clustered && ctx->bucket_variant != 2 && g.block == 1024 &&
-                          ((n >= (1 << 22) && g.F >= 1024 && even) || ctx->bucket_variant == 3);   // variant 3: forced (tests)
+                          ((n >= (1 << 22) && ((g.F >= 1024 && even) || (g.F <= 128 && tl_few))) || ctx->bucket_variant == 3);   // variant 3: forced (tests)
   if (tile_local) {
     // round 6: 1024 x 16-row tiles (segments of 16 instead of 12 rows: fewer partly used sectors for the aggregation);
     // DTHIP_TL_ITEMS=12 keeps round 5's tiles (A/B)
     static const int tl_items = getenv("DTHIP_TL_ITEMS") ? atoi(getenv("DTHIP_TL_ITEMS")) : 16;
-    if (tl_items == 16) {
+    // (few buckets keep the 12-row tiles: C2 2.67 -> 2.58 ms against the 16-row ones, profiles/r06_c2_tl_few_ab.txt)
+    if (tl_items == 16 && g.F > 128) {
       int maxw = 4;
       for (int c : used) maxw = std::max(maxw, stype_size(vd[c].stype));
       (void)bucket_tl16_geometry(ctx, n, maxw, &g);
@@ -377,6 +396,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
       memset(&sa, 0, sizeof(sa));
       sa.items = items; sa.nitems = nitems; sa.max_items = max_items; sa.kpart = kpart; sa.val = vsrc[c]; sa.vstype = vd[c].stype;
       sa.dirT = dirT; sa.dstride = dstride; sa.tile_rows = g.tile; sa.S = g.S; sa.flags = f; sa.tab = t; sa.bad = d_bad;
+      sa.all_long = g.F <= 128;
       DTHIP_TRY(launch_table_agg_seg(ctx, sa));
       first = false;
       continue;
@@ -392,7 +412,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     TableAggSegArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.items = items; sa.nitems = nitems; sa.max_items = max_items; sa.kpart = kpart; sa.val = nullptr; sa.vstype = DTHIP_INT32;
-    sa.dirT = dirT; sa.dstride = dstride; sa.tile_rows = g.tile; sa.S = g.S; sa.flags = first_flag;
+    sa.dirT = dirT; sa.dstride = dstride; sa.tile_rows = g.tile; sa.S = g.S; sa.flags = first_flag; sa.all_long = g.F <= 128;
     if (need_cnt) sa.tab.cnt = d_cnt; else sa.tab.pres = d_cnt;
     DTHIP_TRY(launch_table_agg_seg(ctx, sa));
   } else if (first) {   // no value column at all: row counts (or key presence) alone

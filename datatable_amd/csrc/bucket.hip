@@ -976,8 +976,10 @@ struct TableAggSegDev {
   uint32_t* bad;
 };
 
-template <typename VT>
-__global__ void __launch_bounds__(TA_BLOCK) table_agg_seg_kernel(TableAggSegDev a) {
+// LONG: every item is walked in the long-segment mode (few buckets); the instance keeps none of the short mode's register
+// arrays and two workgroups share a CU when the table allows it
+template <typename VT, bool LONG>
+__global__ void __launch_bounds__(TA_BLOCK) __attribute__((amdgpu_waves_per_eu(LONG ? 8 : 1))) table_agg_seg_kernel(TableAggSegDev a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t nit = *a.nitems;
   const uint32_t bi = blockIdx.x, xq = nit / 8, xr = nit % 8, xc = bi % 8, q0 = bi / 8;
@@ -997,40 +999,74 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_seg_kernel(TableAggSegDev 
   const uint16_t* __restrict__ de = ds + a.dstride;
   const uint32_t t0 = it.begin, t1 = it.end;
   const uint32_t tr = a.tile_rows;
-  // directory entries of the wave's first 64 tiles; the next chunk's are loaded while the current one is processed
-  uint32_t c = t0 + (uint32_t)wave * 64u;
+  // directory entries of the wave's first 64 tiles; the next chunk's are loaded while the current one is processed.
+  // Long segments (few buckets: hundreds of rows of a tile per bucket; or a hot bucket): the waves take turns FOUR tiles at
+  // a time -- a part of such a bucket spans a few hundred tiles at most, and chunks of 64 left 13 of the 16 waves idle
+  // (BASELINE C2 on this layout: 1.20 -> see DESIGN 3.1 "Round 6, third part")
+  const bool long_mode = LONG || (it.single & 2u) != 0;
+  const uint32_t cw = long_mode ? 4u : 64u;                 // tiles per wave and turn
+  const uint32_t cstep = (TA_BLOCK / 64) * cw;
+  uint32_t c = t0 + (uint32_t)wave * cw;
   uint32_t st_n = 0, ln_n = 0;
-  if (c + (uint32_t)lane < t1) { st_n = ds[c + lane]; ln_n = (uint32_t)de[c + lane] - st_n; }
-  const bool long_mode = (it.single & 2u) != 0;      // this bucket's segments are long (few buckets, or a hot bucket)
-  for (; c < t1; c += (TA_BLOCK / 64) * 64u) {
+  if ((uint32_t)lane < cw && c + (uint32_t)lane < t1) { st_n = ds[c + lane]; ln_n = (uint32_t)de[c + lane] - st_n; }
+  for (; c < t1; c += cstep) {
     const uint32_t st = st_n, ln = ln_n;
     {
-      const uint32_t tn = c + (TA_BLOCK / 64) * 64u + (uint32_t)lane;
+      const uint32_t tn = c + cstep + (uint32_t)lane;
       st_n = 0; ln_n = 0;
-      if (tn < t1) { st_n = ds[tn]; ln_n = (uint32_t)de[tn] - st_n; }
+      if ((uint32_t)lane < cw && tn < t1) { st_n = ds[tn]; ln_n = (uint32_t)de[tn] - st_n; }
     }
     if (long_mode) {
-      // one segment at a time with the whole wave: coalesced 512-byte loads, four of them in flight per lane
-      const uint32_t nseg = (t1 - c < 64u) ? (t1 - c) : 64u;
-      for (uint32_t sg = 0; sg < nseg; sg++) {
-        const uint32_t sst = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)sg), sln = (uint32_t)__builtin_amdgcn_readlane((int)ln, (int)sg);
-        const uint32_t base = (c + sg) * tr + sst;
-        for (uint32_t j0 = 0; j0 < sln; j0 += 256u) {
+      // whole waves stream the segments (coalesced 512-byte loads).  The first 192 rows of the turn's FOUR segments are loaded
+      // before the first DS atomic (twelve loads per lane in flight: a segment of 64 buckets x 12288-row tiles is ~192 rows),
+      // what is left of longer segments follows four loads at a time
+      const uint32_t nseg = (t1 - c < cw) ? (t1 - c) : cw;
+      uint32_t sst[4], sln[4];
+#pragma unroll
+      for (int sg = 0; sg < 4; sg++) {
+        sst[sg] = (uint32_t)__builtin_amdgcn_readlane((int)st, sg);
+        sln[sg] = (uint32_t)sg < nseg ? (uint32_t)__builtin_amdgcn_readlane((int)ln, sg) : 0u;
+      }
+      {
+        uint32_t slot[4][3];
+        VT v[4][3];
+#pragma unroll
+        for (int sg = 0; sg < 4; sg++) {
+          const uint32_t base = (c + (uint32_t)sg) * tr + sst[sg];
+#pragma unroll
+          for (int u = 0; u < 3; u++) {
+            const uint32_t j = (uint32_t)u * 64u + (uint32_t)lane;
+            slot[sg][u] = 0; v[sg][u] = VT(0);
+            if (j < sln[sg]) { slot[sg][u] = kp[base + j]; if (hasval) v[sg][u] = val[base + j]; }
+          }
+        }
+#pragma unroll
+        for (int sg = 0; sg < 4; sg++)
+#pragma unroll
+          for (int u = 0; u < 3; u++)
+            if ((uint32_t)u * 64u + (uint32_t)lane < sln[sg]) acc_row<VT, false>(t, flags, slot[sg][u], v[sg][u]);
+      }
+#pragma unroll
+      for (int sg = 0; sg < 4; sg++) {
+        if (sln[sg] <= 192u) continue;
+        const uint32_t base = (c + (uint32_t)sg) * tr + sst[sg];
+        for (uint32_t j0 = 192u; j0 < sln[sg]; j0 += 256u) {
           uint32_t slot[4];
           VT v[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t j = j0 + (uint32_t)u * 64u + (uint32_t)lane;
             slot[u] = 0; v[u] = VT(0);
-            if (j < sln) { slot[u] = kp[base + j]; if (hasval) v[u] = val[base + j]; }
+            if (j < sln[sg]) { slot[u] = kp[base + j]; if (hasval) v[u] = val[base + j]; }
           }
 #pragma unroll
           for (int u = 0; u < 4; u++)
-            if (j0 + (uint32_t)u * 64u + (uint32_t)lane < sln) acc_row<VT, false>(t, flags, slot[u], v[u]);
+            if (j0 + (uint32_t)u * 64u + (uint32_t)lane < sln[sg]) acc_row<VT, false>(t, flags, slot[u], v[u]);
         }
       }
       continue;
     }
+    if (LONG) continue;
     // 16 lanes per segment, four segments per wave instruction.  The first 32 rows of 32 segments are loaded (two
     // loads per lane and segment) before their DS atomics start, so the usual segment (12 .. 25 rows) never waits on a
     // second, dependent round of loads; longer ones finish in a plain loop.
@@ -1074,8 +1110,14 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_seg_kernel(TableAggSegDev 
 }
 
 template <typename VT>
-static int table_agg_seg_t(dthip_ctx* ctx, const TableAggSegDev& d, uint32_t grid, size_t lds) {
-  auto kfn = table_agg_seg_kernel<VT>;
+static int table_agg_seg_t(dthip_ctx* ctx, const TableAggSegDev& d, uint32_t grid, size_t lds, bool all_long) {
+  if (all_long) {
+    auto kfn = table_agg_seg_kernel<VT, true>;
+    DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 256));
+    DTHIP_LAUNCH(ctx, "table_agg_seg_kernel", kfn, grid, TA_BLOCK, lds, d);
+    return DTHIP_OK;
+  }
+  auto kfn = table_agg_seg_kernel<VT, false>;
   DTHIP_TRY(ensure_dyn_lds(ctx, reinterpret_cast<const void*>(kfn), 160 * 1024 - 256));
   DTHIP_LAUNCH(ctx, "table_agg_seg_kernel", kfn, grid, TA_BLOCK, lds, d);
   return DTHIP_OK;
@@ -1090,10 +1132,10 @@ int launch_table_agg_seg(dthip_ctx* ctx, const TableAggSegArgs& a) {
   if (lds > 160 * 1024 - 256) { set_error("table_agg_seg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
   const uint32_t grid = (a.max_items + 7u) & ~7u;
   switch (a.val ? a.vstype : DTHIP_INT32) {
-    case DTHIP_INT32: return table_agg_seg_t<int32_t>(ctx, d, grid, lds);
-    case DTHIP_INT64: return table_agg_seg_t<long long>(ctx, d, grid, lds);
-    case DTHIP_FLOAT32: return table_agg_seg_t<float>(ctx, d, grid, lds);
-    case DTHIP_FLOAT64: return table_agg_seg_t<double>(ctx, d, grid, lds);
+    case DTHIP_INT32: return table_agg_seg_t<int32_t>(ctx, d, grid, lds, a.all_long);
+    case DTHIP_INT64: return table_agg_seg_t<long long>(ctx, d, grid, lds, a.all_long);
+    case DTHIP_FLOAT32: return table_agg_seg_t<float>(ctx, d, grid, lds, a.all_long);
+    case DTHIP_FLOAT64: return table_agg_seg_t<double>(ctx, d, grid, lds, a.all_long);
     default: set_error("table_agg_seg: unsupported value stype %d", a.vstype); return DTHIP_ENOTIMPL;
   }
 }

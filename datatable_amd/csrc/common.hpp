@@ -379,6 +379,7 @@ struct TableAggSegArgs {
   const uint16_t* dirT; uint32_t dstride; uint32_t tile_rows;
   uint32_t S; int flags; AggTable tab;
   uint32_t* bad;
+  bool all_long;            // few buckets: every segment is long (the instance without the short mode)
 };
 int launch_table_agg_seg(dthip_ctx* ctx, const TableAggSegArgs& a);
 int launch_value_na_sample(dthip_ctx* ctx, const void* data, int stype, int64_t n, uint32_t* flag);
