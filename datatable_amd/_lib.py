@@ -15,10 +15,10 @@ BOOL, INT8, INT16, INT32, INT64, FLOAT32, FLOAT64 = 1, 2, 3, 4, 5, 6, 7
 SUM, MEAN, MIN, MAX, COUNT, COUNT0, FIRST, LAST = 0, 1, 2, 3, 4, 5, 6, 7
 SD, MEDIAN, NUNIQUE, PROD, COUNTNA = 8, 9, 10, 11, 12   # dthip_reduce only
 COV, CORR = 0, 1                                    # enum dthip_op2
-CUMSUM, CUMPROD, CUMMIN, CUMMAX, CUMCOUNT, NGROUP = 0, 1, 2, 3, 4, 5   # enum dthip_cumop
+CUMSUM, CUMPROD, CUMMIN, CUMMAX, CUMCOUNT, NGROUP, FILLNA = 0, 1, 2, 3, 4, 5, 6   # enum dthip_cumop
 UNION, INTERSECT, SETDIFF, SYMDIFF = 0, 1, 2, 3     # enum dthip_setfn
 HOST, DEVICE = 0, 1
-ABI_VERSION = 6                                     # DTHIP_ABI_VERSION of include/dthip.h
+ABI_VERSION = 7                                     # DTHIP_ABI_VERSION of include/dthip.h
 NA_FIRST, NA_LAST, NA_REMOVE = 0, 1, 2
 FLAG_DESCENDING = 1
 GT, GE, LT, LE, EQ, NE, NOTNA, ISNA = 0, 1, 2, 3, 4, 5, 6, 7

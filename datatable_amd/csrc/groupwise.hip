@@ -3,6 +3,7 @@
 //   median, nunique          expr/head_reduce_unary.cc:377-387,424-470
 //   cumsum/cumprod/cummin/cummax (+reverse)   column/cumsumprod.h:52-92, column/cumminmax.h:48-98
 //   cumcount/ngroup          column/cumcountngroup.h:55-72
+//   fillna(reverse)          expr/fexpr_fillna.cc:85-117 (the same scan: the state is the last valid value)
 //
 // The reference runs one sequential loop per group (parallel over groups, so one huge group is
 // serial).  Here every operator that is an associative fold is one *segmented scan* over the
@@ -471,7 +472,7 @@ template <> __device__ __forceinline__ bool load_as<double>(const void* data, in
   return !(v != v);
 }
 
-enum { CUM_SUM = 0, CUM_PROD = 1, CUM_MIN = 2, CUM_MAX = 3 };
+enum { CUM_SUM = 0, CUM_PROD = 1, CUM_MIN = 2, CUM_MAX = 3, CUM_FILL = 6 };     // (= enum dthip_cumop; 4 / 5: cumcount / ngroup)
 
 template <typename A, int OP> struct CumP {
   typedef CumSt<A> St; typedef CumArgs Args; typedef CumOut Out;
@@ -484,7 +485,7 @@ template <typename A, int OP> struct CumP {
     if (OP == CUM_SUM) r.v = add(a.v, b.v);
     else if (OP == CUM_PROD) r.v = mul(a.v, b.v);
     else if (!b.has) r.v = a.v;
-    else if (!a.has) r.v = b.v;
+    else if (!a.has || OP == CUM_FILL) r.v = b.v;                         // fillna: the last valid value (fexpr_fillna.cc:101-113)
     else if (OP == CUM_MIN) r.v = (a.v < b.v) ? a.v : b.v;               // ties keep the later row's value
     else r.v = (a.v > b.v) ? a.v : b.v;                                  // (cumminmax.h:83-87)
     return r;
@@ -585,6 +586,7 @@ int launch_cumulate(dthip_ctx* ctx, const void* data, int stype, const int32_t* 
     DTHIP_CUM_CASE(CUM_PROD)
     DTHIP_CUM_CASE(CUM_MIN)
     DTHIP_CUM_CASE(CUM_MAX)
+    DTHIP_CUM_CASE(CUM_FILL)
     default: set_error("bad cumulative op %d", op); return DTHIP_EINVAL;
   }
 #undef DTHIP_CUM_CASE

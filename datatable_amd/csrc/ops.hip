@@ -275,7 +275,7 @@ int dthip_cumulate(dthip_ctx* ctx, int op, const dthip_col* value, const int32_t
   if (ngroups < 0 || ngroups > nrows) { set_error("ngroups=%lld inconsistent with nrows=%lld", (long long)ngroups, (long long)nrows); return DTHIP_EINVAL; }
   if (nrows == 0) return DTHIP_OK;
   if (!offsets || !out || ngroups == 0) { set_error("null argument"); return DTHIP_EINVAL; }
-  if (op < DTHIP_CUMSUM || op > DTHIP_NGROUP) { set_error("bad cumulative op %d", op); return DTHIP_EINVAL; }
+  if (op < DTHIP_CUMSUM || op > DTHIP_FILLNA) { set_error("bad cumulative op %d", op); return DTHIP_EINVAL; }
   const bool counting = op == DTHIP_CUMCOUNT || op == DTHIP_NGROUP;
   if (!counting && (!value || !value->data)) { set_error("cumulative op needs a value column"); return DTHIP_EINVAL; }
   Scratch sc(ctx);

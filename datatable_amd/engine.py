@@ -22,7 +22,7 @@ OPS = {"sum": L.SUM, "mean": L.MEAN, "min": L.MIN, "max": L.MAX, "count": L.COUN
 OPS2 = {"cov": L.COV, "corr": L.CORR}
 SETOPS = {"union": L.UNION, "intersect": L.INTERSECT, "setdiff": L.SETDIFF, "symdiff": L.SYMDIFF}
 CUMOPS = {"cumsum": L.CUMSUM, "cumprod": L.CUMPROD, "cummin": L.CUMMIN, "cummax": L.CUMMAX,
-          "cumcount": L.CUMCOUNT, "ngroup": L.NGROUP}
+          "cumcount": L.CUMCOUNT, "ngroup": L.NGROUP, "fillna": L.FILLNA}
 CMP = {">": L.GT, ">=": L.GE, "<": L.LT, "<=": L.LE, "==": L.EQ, "!=": L.NE}
 
 
@@ -496,7 +496,7 @@ class Context(_ShardMixin):
         return out
 
     def cumulate(self, op, values, rowindex, offsets, reverse=False, stype=None):
-        """cumsum / cumprod / cummin / cummax inside groups, cumcount / ngroup; output in grouped row order"""
+        """cumsum / cumprod / cummin / cummax / fillna inside groups, cumcount / ngroup; output in grouped row order"""
         opc = CUMOPS[op] if isinstance(op, str) else int(op)
         offsets = np.ascontiguousarray(offsets, np.int32)
         ng = len(offsets) - 1

@@ -30,7 +30,7 @@ from . import _lib as L
 from .engine import CUMOPS as L_CUMOPS, NP2ST, OPS as L_OPS, ST2NP, default_context
 
 __all__ = ["Frame", "f", "by", "sort", "sum", "mean", "min", "max", "count", "first", "last",
-           "sd", "median", "nunique", "cov", "corr", "cumsum", "cumprod", "cummin", "cummax", "cumcount", "ngroup",
+           "sd", "median", "nunique", "cov", "corr", "cumsum", "cumprod", "cummin", "cummax", "cumcount", "ngroup", "fillna",
            "unique", "union", "intersect", "setdiff", "symdiff", "join"]
 
 _NA_INT = {1: np.iinfo(np.int8).min, 2: np.iinfo(np.int16).min, 4: np.iinfo(np.int32).min, 8: np.iinfo(np.int64).min}
@@ -104,8 +104,8 @@ class Reducer2(FExpr):
 
 
 class Cumulative(FExpr):
-    """cumsum / cumprod / cummin / cummax(f.col, reverse=False), cumcount(reverse) / ngroup(reverse)
-    (src/core/expr/fexpr_cumsumprod.cc, fexpr_cumminmax.cc, fexpr_cumcountngroup.cc): one value per row,
+    """cumsum / cumprod / cummin / cummax / fillna(f.col, reverse=False), cumcount(reverse) / ngroup(reverse)
+    (src/core/expr/fexpr_cumsumprod.cc, fexpr_cumminmax.cc, fexpr_cumcountngroup.cc, fexpr_fillna.cc): one value per row,
     rows in grouped order"""
 
     def __init__(self, op, arg, reverse=False):
@@ -224,6 +224,17 @@ cumsum = _cumulative("cumsum")
 cumprod = _cumulative("cumprod")
 cummin = _cumulative("cummin")
 cummax = _cumulative("cummax")
+
+
+def fillna(cols=None, value=None, reverse=False):
+    """fillna(f.col, reverse=False): NAs take the previous (reverse: the next) valid value of their group
+    (FExpr_FillNA, src/core/expr/fexpr_fillna.cc:85-117).  Filling with a `value` is an ifelse over the column, not a
+    group-wise operator: outside the accelerated path"""
+    if value is not None:
+        raise NotImplementedError("fillna(value=...) is outside the accelerated path")
+    if cols is None:
+        raise TypeError("Function `datatable.fillna()` requires exactly 1 positional argument, but none were given")
+    return Cumulative("fillna", _colarg(cols, "fillna()"), reverse)
 
 
 def cumcount(reverse=False):

@@ -52,13 +52,14 @@
 extern "C" {
 #endif
 
-#define DTHIP_ABI_VERSION 6   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10
+#define DTHIP_ABI_VERSION 7   /* 2: + dthip_reduce2, dthip_cumulate, dthip_setop, dthip_join_index, reducer ops 8-10
                                  3: + dthip_comm_*, dthip_sharded_groupby_* (multi-GPU inside the library), DTHIP_FLAG_NONA,
                                     dthip_host_register / dthip_host_unregister
                                  4: + dthip_comm_last_stats; options sort_path, msd_min_rows, msd_bucket_rows, filter_path
                                  5: + dthip_build_id, dthip_from_arrow (Arrow-layout columns: validity bitmap -> sentinels on the device),
                                     dthip_filter_groupby_rows (config 5 in one call); option filter_rows_fused
-                                 6: + dthip_last_call_stats; reducers DTHIP_PROD, DTHIP_COUNTNA (dthip_reduce) */
+                                 6: + dthip_last_call_stats; reducers DTHIP_PROD, DTHIP_COUNTNA (dthip_reduce)
+                                 7: + DTHIP_FILLNA (dthip_cumulate) */
 
 /* error codes */
 #define DTHIP_OK        0
@@ -109,7 +110,11 @@ enum dthip_op2 { DTHIP_COV = 0, DTHIP_CORR = 1 };
 enum dthip_cumop {
   DTHIP_CUMSUM = 0, DTHIP_CUMPROD = 1, DTHIP_CUMMIN = 2, DTHIP_CUMMAX = 3,
   DTHIP_CUMCOUNT = 4,  /* cumcount(): row number inside the group, int64 (no value column) */
-  DTHIP_NGROUP = 5     /* ngroup():   group number, int64 (no value column) */
+  DTHIP_NGROUP = 5,    /* ngroup():   group number, int64 (no value column) */
+  DTHIP_FILLNA = 6     /* fillna(col, reverse): every NA takes the last valid value before it in its group (the next one
+                          when reverse), NA while there is none; output stype = input stype (FExpr_FillNA::fill_rowindex,
+                          src/core/expr/fexpr_fillna.cc:85-117; the reference builds a RowIndex and views the column
+                          through it, the values are the same) */
 };
 
 enum dthip_mem { DTHIP_HOST = 0, DTHIP_DEVICE = 1 };
@@ -336,7 +341,8 @@ int  dthip_reduce2(dthip_ctx* ctx, int op /* enum dthip_op2 */, const dthip_col*
  * group's last row backwards when reverse != 0), and cumcount() / ngroup()
  * (FExpr_CumSumProd::evaluate1, src/core/expr/fexpr_cumsumprod.cc:72-99: integers -> int64,
  * float32 stays float32; NA counts as 0 / 1.  FExpr_CumMinMax::evaluate1,
- * fexpr_cumminmax.cc:87-101: output stype = input stype, NA until the first valid row).
+ * fexpr_cumminmax.cc:87-101: output stype = input stype, NA until the first valid row;
+ * fillna(col, reverse): fexpr_fillna.cc:85-117, ABI v7).
  * out: T_out[nrows], row i of the result is grouped position i (value[rowindex[i]]). */
 int  dthip_cumulate_out_stype(int op /* enum dthip_cumop */, int stype);
 int  dthip_cumulate(dthip_ctx* ctx, int op, const dthip_col* value,

@@ -1,7 +1,7 @@
 """Reference-side binding (seam S-py): what a datatable maintainer adds to route
 the `DT[:, {sum|mean|min|max|count}(f.col) ..., by(cols)]` hot path to libdthip.so -- and, through
 the S-red entry points, the other reducers and group-wise operators that share its Groupby
-(first/last/sd/median/nunique, cov/corr, cumsum/cumprod/cummin/cummax/cumcount/ngroup).
+(first/last/sd/median/nunique, cov/corr, cumsum/cumprod/cummin/cummax/fillna/cumcount/ngroup).
 
 It runs INSIDE the reference's Python process (needs `import datatable`), touches no reference
 source, and forwards every other form of `DT[...]` to the reference unchanged:
@@ -231,7 +231,7 @@ _CREF = r"(?:f\.\w+|f\['[^']+'\]|f\[\d+\])"
 # old-style expression nodes print as  Expr:stdev(FExpr<f.v>; )
 _REDUCER_OLD = re.compile(r"^Expr:(stdev|median|nunique|first|last)\((FExpr<%s>); \)$" % _CREF)
 _REDUCER2 = re.compile(r"^Expr:(cov|corr)\((FExpr<%s>), (FExpr<%s>); \)$" % (_CREF, _CREF))
-_CUMULATIVE = re.compile(r"^FExpr<(cumsum|cumprod|cummin|cummax)\((%s), reverse=(True|False)\)>$" % _CREF)
+_CUMULATIVE = re.compile(r"^FExpr<(cumsum|cumprod|cummin|cummax|fillna)\((%s), reverse=(True|False)\)>$" % _CREF)
 _CUMCOUNT = re.compile(r"^FExpr<(cumcount|ngroup)\(reverse=(True|False)\)>$")
 _OLD2OP = {"stdev": "sd"}
 _FUSED = ("sum", "mean", "min", "max", "count", "count0")

@@ -20,6 +20,7 @@
  *   cov/corr  expr/head_reduce_binary.cc:113-135,167-198  pairwise-valid Welford in T
  *   cumsum/cumprod   column/cumsumprod.h:52-92    NA -> 0 / 1, running op, optional reverse
  *   cummin/cummax    column/cumminmax.h:48-98     NA until the first valid, then running
+ *   fillna(reverse)  expr/fexpr_fillna.cc:85-117  last valid value seen in the group (next one when reverse)
  *   cumcount/ngroup  column/cumcountngroup.h:55-72
  *   output stypes    expr/fexpr_cumsumprod.cc:72-99, fexpr_cumminmax.cc:87-101,
  *                    head_reduce_unary.cc:221-229,484-491, head_reduce_binary.cc:47-51
@@ -33,7 +34,7 @@ typedef struct { const void* data; int32_t stype; int32_t flags; } dto_col;
 enum { ST_BOOL = 1, ST_INT8 = 2, ST_INT16 = 3, ST_INT32 = 4, ST_INT64 = 5, ST_FLOAT32 = 6, ST_FLOAT64 = 7 };
 enum { OP_SD = 8, OP_MEDIAN = 9, OP_NUNIQUE = 10 };
 enum { OP2_COV = 0, OP2_CORR = 1 };
-enum { CUM_SUM = 0, CUM_PROD = 1, CUM_MIN = 2, CUM_MAX = 3, CUM_COUNT = 4, CUM_NGROUP = 5 };
+enum { CUM_SUM = 0, CUM_PROD = 1, CUM_MIN = 2, CUM_MAX = 3, CUM_COUNT = 4, CUM_NGROUP = 5, CUM_FILLNA = 6 };
 
 static int is_float(int st) { return st == ST_FLOAT32 || st == ST_FLOAT64; }
 
@@ -236,6 +237,26 @@ int dto_cumulate(int op, const dto_col* col, const int32_t* ri, const int32_t* o
           uint64_t x = ok ? (uint64_t)v : (op == CUM_SUM ? 0u : 1u);
           acc = (p == first) ? x : (op == CUM_SUM ? acc + x : acc * x);
           ((int64_t*)out)[p] = (int64_t)acc;
+        }
+      }
+    } else if (op == CUM_FILLNA) {                                /* fexpr_fillna.cc:85-117 (fill_rowindex) */
+      /* the reference builds a RowIndex: every row points at the last valid row seen so far in its group (walking
+       * backwards when reverse), a leading run of NAs at the group's first row walked -- i.e. at an NA; the result column
+       * is the view through it.  Here: the value carried along */
+      if (is_float(st)) {
+        double acc = 0; int have = 0;
+        for (int64_t p = first; p != stop; p += step) {
+          double v; int ok = get_f64(col, ri ? ri[p] : p, &v);
+          if (ok) { acc = v; have = 1; }
+          if (st == ST_FLOAT32) ((float*)out)[p] = have ? (float)acc : NAN;
+          else ((double*)out)[p] = have ? acc : NAN;
+        }
+      } else {
+        int64_t acc = 0; int have = 0;
+        for (int64_t p = first; p != stop; p += step) {
+          int64_t v; int ok = get_int(col, ri ? ri[p] : p, &v);
+          if (ok) { acc = v; have = 1; }
+          put_int(out, st, p, acc, have);
         }
       }
     } else {                                                      /* cumminmax.h:48-98 */

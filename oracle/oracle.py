@@ -147,11 +147,11 @@ def gather(values, ri, stype=None):
 # ---- group-wise operators sharing the Groupby (dt_oracle_groupwise.c) --------------------------
 SD, MEDIAN, NUNIQUE = 8, 9, 10
 COV, CORR = 0, 1
-CUMSUM, CUMPROD, CUMMIN, CUMMAX, CUMCOUNT, NGROUP = 0, 1, 2, 3, 4, 5
+CUMSUM, CUMPROD, CUMMIN, CUMMAX, CUMCOUNT, NGROUP, FILLNA = 0, 1, 2, 3, 4, 5, 6
 OPSX = {"sd": SD, "median": MEDIAN, "nunique": NUNIQUE}
 OPS2 = {"cov": COV, "corr": CORR}
 CUMOPS = {"cumsum": CUMSUM, "cumprod": CUMPROD, "cummin": CUMMIN, "cummax": CUMMAX, "cumcount": CUMCOUNT,
-          "ngroup": NGROUP}
+          "ngroup": NGROUP, "fillna": FILLNA}
 
 
 def _ri_off(ri, offsets):
@@ -191,7 +191,7 @@ def reduce2(op, va, vb, ri, offsets, stypes=(None, None)):
 
 
 def cumulate(op, values, ri, offsets, reverse=False, stype=None):
-    """cumsum / cumprod / cummin / cummax / cumcount / ngroup inside groups; output in grouped order."""
+    """cumsum / cumprod / cummin / cummax / fillna / cumcount / ngroup inside groups; output in grouped order."""
     opc = CUMOPS[op] if isinstance(op, str) else op
     ri, rip, offsets = _ri_off(ri, offsets)
     ng = len(offsets) - 1

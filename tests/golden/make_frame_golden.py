@@ -16,7 +16,7 @@ SRC = os.environ.get("DT_REFERENCE_SRC", "/tmp/dt_oracle/src")
 sys.path.insert(0, SRC)
 import datatable as dt  # noqa: E402
 from datatable import f, by, sort, sum, mean, min, max, count, first, last  # noqa: E402,A004
-from datatable import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup  # noqa: E402
+from datatable import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup, fillna  # noqa: E402
 
 dt.options.progress.enabled = False
 inf = math.inf
@@ -116,6 +116,13 @@ QUERIES = [
     ("big", "DT[:, [cov(f.v, f.n), corr(f.v, f.n)], by(f.k)]"),
     ("big", "DT[:, [cumsum(f.n), cummax(f.v), cummin(f.n, reverse=True), cumcount()], by(f.k)]"),
     ("big", "DT[:, [cumsum(f.v), cumsum(f.n), ngroup()]]"),
+    # fillna(col, reverse) (fexpr_fillna.cc:85-117): the same segmented scan
+    ("appendixB", "DT[:, [fillna(f.v), fillna(f.v, reverse=True), fillna(f.i)], by(f.k)]"),
+    ("appendixB", "DT[:, fillna(f[:], reverse=True)]"),
+    ("types", "DT[:, fillna(f[:]), by(f.g)]"),
+    ("types", "DT[:, fillna(f[:], reverse=True), by(f.g)]"),
+    ("big", "DT[:, [fillna(f.n), fillna(f.n, reverse=True), cumsum(f.n)], by(f.k)]"),
+    ("big", "DT[f.v > 0, :][:, fillna(f.n), by(f.k)]"),
 ]
 
 ST = {1: dt.bool8, 2: dt.int8, 3: dt.int16, 4: dt.int32, 5: dt.int64, 6: dt.float32, 7: dt.float64}

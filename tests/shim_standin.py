@@ -254,7 +254,7 @@ class StandinLib:
         self.calls.append(("cumulate", mem))
         offs = _view(off, ng + 1, L.INT32)
         name = {L.CUMSUM: "cumsum", L.CUMPROD: "cumprod", L.CUMMIN: "cummin", L.CUMMAX: "cummax", L.CUMCOUNT: "cumcount",
-                L.NGROUP: "ngroup"}[op]
+                L.NGROUP: "ngroup", L.FILLNA: "fillna"}[op]
         if col is None:
             _store(dst, o.cumulate(name, None, None, offs, reverse=bool(reverse))); return 0
         c = col._obj

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.SIGNATURES) == set(declared_symbols())
     import re
     hdr = open(os.path.join(ROOT, "include", "dthip.h")).read()
-    assert lib.dthip_abi_version() == int(re.search(r"#define DTHIP_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION == 6
+    assert lib.dthip_abi_version() == int(re.search(r"#define DTHIP_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION == 7
     bid = lib.dthip_build_id().decode()
     assert len(bid) == 12 and all(ch in "0123456789abcdef" for ch in bid)
 

@@ -28,7 +28,7 @@ def _dec(x):
 def test_frame_query_matches_reference(qi):
     from datatable_amd import frame as dt
     from datatable_amd.frame import f, by, sort, sum, mean, min, max, count, first, last   # noqa: F401,A004
-    from datatable_amd.frame import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup  # noqa: F401
+    from datatable_amd.frame import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup, fillna  # noqa: F401
     q = GOLD["queries"][qi]
     spec = GOLD["frames"][q["frame"]]
     DT = dt.Frame({nm: [_dec(x) for x in c["values"]] for nm, c in spec.items()},
@@ -73,7 +73,7 @@ def test_fuzz_query_matches_reference(qi):
     names, stypes and values as the unmodified reference returned them"""
     from datatable_amd import frame as dt
     from datatable_amd.frame import f, by, sort, sum, mean, min, max, count, first, last   # noqa: F401,A004
-    from datatable_amd.frame import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup  # noqa: F401
+    from datatable_amd.frame import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup, fillna  # noqa: F401
     _run_fuzz_query(FUZZ["queries"][qi], resident=False)
 
 
@@ -86,7 +86,7 @@ def test_fuzz_query_on_resident_frame(qi):
 def _run_fuzz_query(q, resident):
     from datatable_amd import frame as dt
     from datatable_amd.frame import f, by, sort, sum, mean, min, max, count, first, last   # noqa: F401,A004
-    from datatable_amd.frame import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup  # noqa: F401
+    from datatable_amd.frame import sd, median, nunique, cov, corr, cumsum, cumprod, cummin, cummax, cumcount, ngroup, fillna  # noqa: F401
     spec = FUZZ["frames"][q["frame"]]
     DT = dt.Frame({nm: [_dec2(x) for x in c["values"]] for nm, c in spec.items()},
                   stypes={nm: c["stype"] for nm, c in spec.items()})

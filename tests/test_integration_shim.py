@@ -52,6 +52,10 @@ def test_match_groupwise_operators():
     j = [datatable.cumsum(f.v), datatable.cummax(f.w, reverse=True), datatable.cumcount(), datatable.ngroup(reverse=True)]
     assert shim.match(DT, (slice(None), j, shim.by(f.k))) == \
         ([0], [("cumsum", 1, False), ("cummax", 2, True), ("cumcount", None, False), ("ngroup", None, True)])
+    # fillna(col, reverse) rides the same scan (fexpr_fillna.cc:85-117); fillna(col, value=...) is an ifelse: the reference's
+    j = [datatable.fillna(f.v), datatable.fillna(f.w, reverse=True)]
+    assert shim.match(DT, (slice(None), j, shim.by(f.k))) == ([0], [("fillna", 1, False), ("fillna", 2, True)])
+    assert shim.match(DT, (slice(None), datatable.fillna(f.v, value=0.0), shim.by(f.k))) is None
     # a reducer next to a row-level operator, or a string argument: the reference evaluates it
     assert shim.match(DT, (slice(None), [datatable.sd(f.v), datatable.cumsum(f.v)], shim.by(f.k))) is None
     assert shim.match(DT, (slice(None), datatable.nunique(f.s), shim.by(f.k))) is None

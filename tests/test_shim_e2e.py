@@ -152,7 +152,8 @@ def test_sred_route_cumulative(env, n, reverse):
     j = [datatable.cumsum(f.f8, reverse=reverse), datatable.cumsum(f.i4, reverse=reverse),
          datatable.cummin(f.f4, reverse=reverse), datatable.cummax(f.i8, reverse=reverse),
          datatable.cummax(f.b, reverse=reverse), datatable.cumprod(f.i1, reverse=reverse),
-         datatable.cumcount(reverse=reverse), datatable.ngroup(reverse=reverse)]
+         datatable.cumcount(reverse=reverse), datatable.ngroup(reverse=reverse),
+         datatable.fillna(f.f8, reverse=reverse), datatable.fillna(f.i2, reverse=reverse), datatable.fillna(f.b, reverse=reverse)]
     got, exp = both(dt, shim, DT, j, [f.k, f.k2])
     assert_frames_equal(dt, got, exp)
 

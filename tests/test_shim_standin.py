@@ -161,7 +161,8 @@ def test_sred_routes(env, mode):
             j = [datatable.cumsum(f.f8, reverse=reverse), datatable.cumsum(f.i4, reverse=reverse),
                  datatable.cummin(f.f4, reverse=reverse), datatable.cummax(f.i8, reverse=reverse),
                  datatable.cummax(f.b, reverse=reverse), datatable.cumprod(f.i1, reverse=reverse),
-                 datatable.cumcount(reverse=reverse), datatable.ngroup(reverse=reverse)]
+                 datatable.cumcount(reverse=reverse), datatable.ngroup(reverse=reverse),
+         datatable.fillna(f.f8, reverse=reverse), datatable.fillna(f.i2, reverse=reverse), datatable.fillna(f.b, reverse=reverse)]
             got = _as_frame(shim, DT[:, j, shim.by(f.k, f.k2)])
             assert_frames_equal(dt, got, dt.Frame.__getitem__(DT, (slice(None), j, dt.by(f.k, f.k2))))
     kinds = {c[0] for c in ctx._lib.calls}
