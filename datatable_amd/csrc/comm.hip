@@ -566,6 +566,7 @@ static int run_sharded_agg(dthip_comm* comm, std::vector<Job>& jobs, const std::
   }
   auto alloc_recv = [&](size_t q, int64_t rows) -> int {
     Job& j = jobs[q]; const AggArgs& a = args[q];
+    for (auto& c : j.cols) if (c.recv) j.sc->release(c.recv);        // (a share above the bound: the bound-sized buffers go first)
     j.cols.clear();
     for (int k = 0; k < nkeys; k++) {
       XCol c; c.stype = a.keys[k].stype; c.elem = stype_size(c.stype); c.send = j.local->key[k];
@@ -739,6 +740,7 @@ static int run_sharded_rows(dthip_comm* comm, std::vector<Job>& jobs, const std:
     recv_bound = rows_recv_bound(total, world);
   }
   auto alloc_recv = [&](Job& j, int64_t rows) -> int {
+    for (auto& c : j.cols) if (c.recv) { j.sc->release(c.recv); c.recv = nullptr; }     // (the bound-sized buffers, when a share exceeds them)
     for (auto& c : j.cols) { unsigned char* r = nullptr; DTHIP_TRY(j.sc->get<unsigned char>((size_t)rows * c.elem + 16, &r)); c.recv = r; }
     return DTHIP_OK;
   };

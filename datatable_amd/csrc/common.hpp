@@ -162,6 +162,10 @@ struct Scratch {
     *out = static_cast<T*>(p);
     return DTHIP_OK;
   }
+  // give one buffer back early (stream-ordered, like the destructor)
+  void release(void* p) {
+    for (auto& b : bufs) if (b == p) { b = bufs.back(); bufs.pop_back(); dev_release(ctx, p); return; }
+  }
   // hand a buffer over to a longer-lived owner
   void disown(void* p) {
     for (auto& b : bufs) if (b == p) { b = bufs.back(); bufs.pop_back(); return; }

@@ -62,8 +62,8 @@ constexpr int SPLIT_SAMPLES = 1024;
 
 // samples[r * SPLIT_SAMPLES + i] = image at position floor(i * n[r] / SPLIT_SAMPLES) of rank r's ascending sequence
 // (ignored when n[r] == 0).  Every sample stands for n[r] / SPLIT_SAMPLES elements; the boundary of rank k is the
-// smallest sample image below which at least k / world of the total weight lies.  All ranks hold the same samples and
-// get the same boundaries.  Rank k's share exceeds its fair share by at most sum_r n[r] / SPLIT_SAMPLES elements plus
+// sample image at which the fair share of rank k - 1 (of what ranks 0..k-2 left) is reached.  All ranks hold the same samples
+// and get the same boundaries.  Rank k's share exceeds its fair share by at most sum_r n[r] / SPLIT_SAMPLES elements plus
 // the elements that share the boundary image (one key is never cut).
 // (q samples per rank: SPLIT_SAMPLES exact local quantiles on the aggregate path, ROW_SAMPLES random-sample quantiles on the
 // rows path)
@@ -79,13 +79,51 @@ inline void sample_bounds_q(const unsigned long long* samples, const long long* 
   }
   if (pts.empty()) return;
   std::sort(pts.begin(), pts.end(), [](const std::pair<unsigned long long, double>& a, const std::pair<unsigned long long, double>& b) { return a.first < b.first; });
+  // Runs of EQUAL images stay together (one key is never cut).  Round 6: a run heavier than a fair share -- the NA
+  // group of a frame with many NAs, a hot key -- used to collapse the boundaries around it onto its image: the ranks before it
+  // received nothing and its owner the run plus a fair share on top.  Now a heavy run gets a rank of its own (together with
+  // the light keys just before it when that keeps the largest share smaller), and the light ranks split the LIGHT weight that
+  // is left evenly among the light ranks that are left, wherever the heavy runs sit in the key order.
+  struct Run { unsigned long long img; double w; bool heavy; };
+  std::vector<Run> runs;
+  for (size_t a = 0; a < pts.size();) {
+    size_t e = a; double w = 0;
+    while (e < pts.size() && pts[e].first == pts[a].first) { w += pts[e].second; e++; }
+    runs.push_back(Run{pts[a].first, w, world > 1 && w > total / world});
+    a = e;
+  }
+  std::vector<double> hw_after(runs.size() + 1, 0.0);        // weight / number of the heavy runs at and after position i
+  std::vector<int> hn_after(runs.size() + 1, 0);
+  for (size_t a = runs.size(); a-- > 0;) {
+    hw_after[a] = hw_after[a + 1] + (runs[a].heavy ? runs[a].w : 0.0);
+    hn_after[a] = hn_after[a + 1] + (runs[a].heavy ? 1 : 0);
+  }
   double cum = 0;
   size_t i = 0;
   for (int k = 1; k < world; k++) {
-    const double target = total * k / world;
-    while (i < pts.size() && cum + pts[i].second <= target) { cum += pts[i].second; i++; }
-    // samples [0, i) weigh <= target: the boundary is the next sample's image (everything below it goes to ranks < k)
-    (*bounds)[k - 1] = i < pts.size() ? pts[i].first : ~0ULL;
+    const double assigned = cum;
+    const int light_ranks = std::max(1, (world - k + 1) - hn_after[i]);
+    const double share = (total - cum - hw_after[i]) / light_ranks;       // a light rank's fair share of the light weight left
+    const double target = cum + share;
+    while (i < runs.size()) {
+      const Run& r = runs[i];
+      if (r.heavy) {
+        // its own rank -- together with the light keys this rank already holds when that makes the largest share smaller
+        // than closing this rank here would (the light ranks after it then are one more)
+        const double before = cum - assigned, l_after = total - cum - hw_after[i];
+        const int nl_nm = (world - k) - 1 - hn_after[i + 1], nl_m = nl_nm + 1;
+        const double big = 4.0 * total + 1.0;
+        const double max_nm = std::max(r.w, nl_nm >= 1 ? l_after / nl_nm : (l_after > 0 ? big : 0.0));
+        const double max_m = std::max(before + r.w, nl_m >= 1 ? l_after / nl_m : (l_after > 0 ? big : 0.0));
+        if (before <= 0 || max_m <= max_nm) { cum += r.w; i++; }
+        break;
+      }
+      if (cum + r.w <= target) { cum += r.w; i++; continue; }
+      if (cum <= assigned || (cum + r.w - target) < (target - cum)) { cum += r.w; i++; }
+      break;
+    }
+    // runs [0, i) go to ranks < k: the boundary is the next run's image (everything below it goes to ranks < k)
+    (*bounds)[k - 1] = i < runs.size() ? runs[i].img : ~0ULL;
   }
   for (int k = 1; k < world - 1; k++) if ((*bounds)[k] < (*bounds)[k - 1]) (*bounds)[k] = (*bounds)[k - 1];
 }

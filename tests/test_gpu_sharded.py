@@ -337,6 +337,34 @@ def test_shards_rows_vs_oracle(comms, world, kind):
         r.free()
 
 
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("na_last", [False, True])
+def test_shards_rows_heavy_na_group(comms, world, na_last):
+    """round 6: an NA group heavier than a fair share (30 % of the rows) -- bit-exact against the oracle, the
+    NA group on ONE shard (a share above the receive bound: exact buffers + the status round), nobody starved and the other
+    shards splitting the rest evenly (split_plan.hpp sample_bounds_q)"""
+    from oracle import oracle as o
+    rng = np.random.default_rng(40 + world)
+    n = 240_000
+    k = rng.integers(0, 50_000, n).astype(np.int64)
+    k[rng.random(n) < 0.30] = np.iinfo(np.int64).min
+    v = rng.standard_normal(n)
+    ri, off = o.group([k], na_last=na_last)
+    ksh, cuts = shard([k], world, uneven=True)
+    csh, _ = shard([k, v], world, uneven=True)
+    res = comms[world].groupby_rows(ksh, csh, cuts[:-1], na_last=na_last)
+    assert_same(concat(res, lambda r: r.col(2)).astype(np.int32), ri, "global row ids == the oracle's RowIndex")
+    assert_same(concat(res, lambda r: r.col(1)), v[ri], "value column in grouped order")
+    rows = [r.nrows for r in res]
+    nna = int((k == np.iinfo(np.int64).min).sum())
+    fair = (n - nna) / (world - 1)
+    owner = 0 if not na_last else world - 1
+    assert nna <= rows[owner] <= nna + 0.5 * fair, rows
+    assert min(rows) > 0 and max(rows[r_] for r_ in range(world) if r_ != owner) <= 1.5 * fair, rows
+    for r in res:
+        r.free()
+
+
 def test_sharded_errors_reach_every_rank(comms):
     """a query the distributed path refuses (first() needs the row order of a whole group) or bad arguments come back
     as ONE error for the call, nothing is left half-done, and the communicator keeps working"""

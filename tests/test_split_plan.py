@@ -218,7 +218,8 @@ def test_row_sample_positions_and_heavy_keys(lib):
     b = row_sample_plan(lib, slices)
     got = np.bincount(dest(b, np.concatenate(slices)), minlength=4)
     lib.sp_rows_recv_bound.restype = C.c_longlong
-    assert got.max() >= 0.7 * n and got.max() > lib.sp_rows_recv_bound(C.c_longlong(n), 4)
+    assert got.max() >= int((k == 5_000_000).sum()) and got.max() > lib.sp_rows_recv_bound(C.c_longlong(n), 4)
+    assert got.min() > 0            # (round 6) ... and no rank is left without rows
     # empty ranks and a rank with fewer rows than samples
     b = row_sample_plan(lib, [np.zeros(0, np.uint64), image_i64(rng.integers(0, 1000, 50)), image_i64(rng.integers(0, 1000, 100_000))])
     assert np.all(b[1:] >= b[:-1])
@@ -247,3 +248,44 @@ def test_status_agreement(lib):
     assert ff([0, -3, -1], [5, 5, 5]) == (-3, 1, True)            # first failing rank and ITS code, seen by every rank
     assert ff([0, 0, 0, 0], [5, 5, 6, 5]) == (0, -1, False)       # ranks called with different queries
     assert ff([-2], [1]) == (-2, 0, True)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("where", ["na_first", "middle", "two_heavy"])
+def test_row_sample_splitters_with_heavy_keys(lib, world, where):
+    """round 6: a key (the NA group of an NA-first frame, image 0) heavier than a fair share neither starves the
+    ranks before it nor comes on top of a fair share: its owner holds the run (+ the few light keys before it at most), the
+    other ranks split the REST -- the largest share is the heavy key's, no rank stays empty"""
+    rng = np.random.default_rng(world * 31 + len(where))
+    n = 400_000
+    k = rng.integers(1, 10**7, n)
+    img = image_i64(k)
+    if where == "na_first":
+        heavy_img, share = np.uint64(0), 0.30
+        img[rng.random(n) < share] = heavy_img
+    elif where == "middle":
+        heavy_img = image_i64(np.array([5_000_000]))[0]
+        img[rng.random(n) < 0.35] = heavy_img
+    else:
+        img[rng.random(n) < 0.25] = np.uint64(0)
+        heavy_img = image_i64(np.array([7_000_000]))[0]
+        img[(rng.random(n) < 0.25) & (img != 0)] = heavy_img
+    slices = [img[r * n // world:(r + 1) * n // world] for r in range(world)]
+    b = row_sample_plan(lib, slices)
+    assert np.all(b[1:] >= b[:-1])
+    d = dest(b, img)
+    got = np.bincount(d, minlength=world)
+    assert got.sum() == n
+    vals, cnts = np.unique(img, return_counts=True)
+    heavies = vals[cnts > n / world]
+    owners = {int(d[img == h][0]) for h in heavies}
+    assert all(len(set(d[img == h].tolist())) == 1 for h in heavies)               # never cut
+    rest = n - int(cnts[cnts > n / world].sum())
+    fair = rest / (world - len(heavies))
+    # the largest share is a heavy key's own (+ a sample step), or a light rank's: light keys keep their ORDER around the
+    # heavy ones, so a light rank may hold up to the whole stretch between two heavy keys -- never a heavy key on top of it
+    assert got.max() <= max(int(cnts.max()) + 4 * n / 4096, 1.6 * fair + 4 * n / 4096), (where, got, fair)
+    assert got.min() > 0, (where, got)
+    for h, c in zip(heavies, cnts[cnts > n / world]):
+        o = int(d[img == h][0])
+        assert got[o] <= c + 0.5 * fair + 4 * n / 4096, (where, o, got, c)
