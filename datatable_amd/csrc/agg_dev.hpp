@@ -85,17 +85,20 @@ __device__ __forceinline__ double wave_reduce_f64(double v) {
   return v;
 }
 
-// the whole (fully active) wave addresses ONE slot -- sorted / constant / heavily skewed keys: reduce in
-// registers, one lane updates the table (64 same-address DS atomics would serialise)
+// Many lanes of a (fully active) wave address ONE slot -- sorted / constant keys (all 64), a hot key inside its bucket (most
+// of them): the lanes of `in` are reduced in registers and one lane updates the table (64 same-address DS atomics would
+// serialise); the other lanes contribute the identity and go the ordinary way afterwards.  All 64 lanes call.
 template <typename VT>
-__device__ __forceinline__ void acc_wave_uniform(const LdsTab& t, int flags, uint32_t slot, VT v) {
+__device__ __forceinline__ void acc_wave_masked(const LdsTab& t, int flags, uint32_t slot, VT v, bool in) {
   const bool lead = (threadIdx.x & 63) == 0;
-  if (lead && (flags & ACC_CNT)) atomicAdd(&t.cnt[slot], 64u);
+  const uint32_t nin = (uint32_t)__popcll(__ballot(in));
+  if (lead && (flags & ACC_CNT)) atomicAdd(&t.cnt[slot], nin);
   if (lead && (flags & ACC_PRES)) atomicOr(&t.pres[slot >> 5], 1u << (slot & 31));
   if (!(flags & (ACC_VALUE_MASK))) return;
-  const bool ok = (flags & ACC_NONA) || !ValTraits<VT>::isna(v);
+  const bool valid = (flags & ACC_NONA) || !ValTraits<VT>::isna(v);
+  const bool ok = in && valid;
   const uint32_t nok = (uint32_t)__popcll(__ballot(ok));
-  if ((flags & ACC_CHKNA) && nok != 64u && lead) *t.naflag = 1u;
+  if ((flags & ACC_CHKNA) && nok != nin && lead) *t.naflag = 1u;
   if (nok == 0) return;
   if (lead && (flags & ACC_VCNT)) atomicAdd(&t.vcnt[slot], nok);
   if (ValTraits<VT>::is_float) {
@@ -112,11 +115,18 @@ __device__ __forceinline__ void acc_wave_uniform(const LdsTab& t, int flags, uin
   }
 }
 
+// UNI (clustered keys: the launch's instance) or `hot` (this work item's bucket holds a hot key -- wave-uniform, decided per
+// item): when at least 16 lanes of the fully active wave share the first lane's slot they are combined in registers
+// (acc_wave_masked); a -0.0 sum identity aside, the table ends up as if every lane had issued its own atomics
 template <typename VT, bool UNI>
-__device__ __forceinline__ void acc_row(const LdsTab& t, int flags, uint32_t slot, VT v) {
-  if (UNI && __ballot(1) == ~0ULL && __ballot(slot == (uint32_t)__builtin_amdgcn_readfirstlane(slot)) == ~0ULL) {
-    acc_wave_uniform<VT>(t, flags, (uint32_t)__builtin_amdgcn_readfirstlane(slot), v);
-    return;
+__device__ __forceinline__ void acc_row(const LdsTab& t, int flags, uint32_t slot, VT v, bool hot = false) {
+  if ((UNI || hot) && __ballot(1) == ~0ULL) {
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane(slot);
+    const bool in = slot == s0;
+    if (__popcll(__ballot(in)) >= 16) {
+      acc_wave_masked<VT>(t, flags, s0, v, in);
+      if (in) return;
+    }
   }
   if (flags & ACC_CNT) atomicAdd(&t.cnt[slot], 1u);
   if (flags & ACC_PRES) atomicOr(&t.pres[slot >> 5], 1u << (slot & 31));

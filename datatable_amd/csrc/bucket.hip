@@ -404,7 +404,9 @@ __global__ void __launch_bounds__(1024) bucket_plan_kernel(const uint32_t* tot, 
         it.bucket = b;
         it.begin = e + i * M;
         it.end = (i + 1 == np[k]) ? e + sz[k] : e + (i + 1) * M;
-        it.single = np[k] == 1 ? 1u : 0u;
+        // bit 0: the bucket has a single part (plain stores of the table); bit 2: it holds more than 3x its fair share of the
+        // rows -- a hot key: table_agg_kernel combines the lanes that share a slot in registers (agg_dev.hpp acc_row)
+        it.single = (np[k] == 1 ? 1u : 0u) | ((unsigned long long)sz[k] * F > 3ull * stot ? 4u : 0u);
         items[pe + i] = it;
       }
       e += sz[k]; pe += np[k];
@@ -854,12 +856,13 @@ struct TableAggDev {
   uint32_t S; int flags; int isfloat;
   AggTable tab;
   uint32_t* bad;
+  int hot_ok;                 // DTHIP_HOT_COMBINE=0: hot buckets like the others (A/B)
 };
 
 // SRC: 0 = slot keys (uint16) + value column of the partitioned rows, 1 = raw rows (keys transformed
 // on the fly; one table holds the whole key range)
 template <typename VT, int SRC, bool UNI>
-__global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
+__global__ void __launch_bounds__(TA_BLOCK) __attribute__((amdgpu_waves_per_eu(SRC == 0 ? 8 : 1))) table_agg_kernel(TableAggDev a) {
   constexpr bool RAW = SRC == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (blockIdx.x >= *a.nitems) return;
@@ -882,6 +885,7 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
     if (__ballot(bad) && (tid & 63) == 0) atomicOr(a.bad, 1u);
   } else {
     const uint16_t* __restrict__ kp = a.kpart;
+    const bool hot = (it.single & 4u) != 0 && a.hot_ok;
     uint32_t a0 = (it.begin + 7u) & ~7u; if (a0 > it.end) a0 = it.end;
     uint32_t a1 = it.end & ~7u; if (a1 < a0) a1 = a0;
     // ragged head [begin, a0) and tail [a1, end): fewer than 8 rows each
@@ -917,11 +921,11 @@ __global__ void __launch_bounds__(TA_BLOCK) table_agg_kernel(TableAggDev a) {
         for (int j = 0; j < 8; j++) v[j] = VT(0);
       }
 #pragma unroll
-      for (int j = 0; j < 8; j++) acc_row<VT, UNI>(t, flags, slot[j], v[j]);
+      for (int j = 0; j < 8; j++) acc_row<VT, UNI>(t, flags, slot[j], v[j], hot);
     }
   }
   __syncthreads();
-  flush_table(t, a.tab, it.bucket, S, flags, it.single != 0, a.isfloat, tid);
+  flush_table(t, a.tab, it.bucket, S, flags, (it.single & 1u) != 0, a.isfloat, tid);
   if ((flags & ACC_CHKNA) && tid == 0 && *t.naflag) atomicOr(a.bad, 2u);
 }
 
@@ -938,6 +942,8 @@ int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a) {
   TableAggDev d;
   d.items = a.items; d.nitems = a.nitems; d.kpart = a.kpart; d.kx = a.kx; d.val = a.val;
   d.S = a.S; d.flags = a.flags; d.isfloat = stype_is_float(a.vstype) ? 1 : 0; d.tab = a.tab; d.bad = a.bad;
+  static const int hot_ok = !(getenv("DTHIP_HOT_COMBINE") && atoi(getenv("DTHIP_HOT_COMBINE")) == 0);
+  d.hot_ok = hot_ok;
   const size_t lds = table_agg_lds_bytes(a.flags, a.S);
   if (lds > 160 * 1024 - 256) { set_error("table_agg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
   if ((a.flags & ACC_PRES) && (a.S & 31) && a.src != 1) { set_error("table_agg: presence bitmaps need S %% 32 == 0"); return DTHIP_EINVAL; }

@@ -80,14 +80,17 @@ def main():
                 r = ctx.groupby_agg([devcol(a), devcol(b)], [devcol(v)], [("count0", None), ("sum", 0)], nrows=n)
                 ng = r.ngroups; r.free(); return ng
             alg = n * 16
-        elif c in (7, 8, 9):
+        elif c in (7, 8, 9, 11):
             # robustness variants of C3: 7 = heavy skew (key = 1e7 * u^6: a few keys hold most rows),
-            # 8 = keys already sorted, 9 = one single key
+            # 8 = keys already sorted, 9 = one single key, 11 = bench.py's C3_hotkey (7 % of the rows in ONE key)
             n = int(1e9 * args.scale)
             if c == 7:
                 k = (torch.rand(n, dtype=torch.float64, device=dev, generator=g) ** 6 * 1e7).to(torch.int64)
             elif c == 8:
                 k = (torch.arange(n, dtype=torch.int64, device=dev) // 100)
+            elif c == 11:
+                k = torch.randint(0, 10_000_000, (n,), dtype=torch.int64, device=dev, generator=g)
+                k = torch.where(torch.rand(n, device=dev, generator=g) < 0.07, torch.tensor(12_345, dtype=torch.int64, device=dev), k)
             else:
                 k = torch.full((n,), 12345, dtype=torch.int64, device=dev)
             v = torch.randn(n, dtype=torch.float64, device=dev, generator=g)

@@ -347,6 +347,27 @@ def test_clustered_key_variants(ctx):
                 ctx.set_option("cluster_mode", 0)
 
 
+def test_hot_key_lanes_combined_in_registers(ctx):
+    """round 6: a bucket holding more than 3x its fair share of the rows (a hot key) has the lanes of a wave that share the
+    first lane's slot combined in registers before ONE DS atomic (agg_dev.hpp acc_wave_masked) -- the hot key, its bucket
+    neighbours, NA values (valid counts, the NA-free guess and its retry), int and float accumulators, every reducer: same
+    results as the oracle"""
+    rng = np.random.default_rng(61)
+    n = 1_500_000
+    base = rng.integers(0, 3_000_000, n).astype(np.int64)              # 22 key bits: several hundred buckets
+    for share in (0.07, 0.6):
+        k = np.where(rng.random(n) < share, 1_234_567, base).astype(np.int64)
+        v = rng.standard_normal(n)
+        iv = rng.integers(-1000, 1000, n).astype(np.int64)
+        fv = rng.standard_normal(n).astype(np.float32)
+        _vs_oracle(ctx, [k], [v, iv, fv], check_ri=False)               # NA-free columns: guessed, verified
+        v2 = v.copy(); v2[rng.random(n) < 0.05] = np.nan
+        iv2 = iv.copy(); iv2[rng.random(n) < 0.05] = np.iinfo(np.int64).min
+        _vs_oracle(ctx, [k], [v2, iv2], check_ri=False)                 # NAs: valid counts
+        v3 = v.copy(); v3[(k == 1_234_567).nonzero()[0][-1]] = np.nan    # ONE NaN, in the hot key: the guess fails late
+        _vs_oracle(ctx, [k], [v3], check_ri=False)
+
+
 def test_range_bucket_and_ungroup(ctx):
     """the two small helpers of the multi-GPU row exchange / GtoALL broadcast"""
     rng = np.random.default_rng(49)
