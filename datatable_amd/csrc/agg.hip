@@ -241,10 +241,11 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   std::vector<const void*> vsrc(vd.size(), nullptr);
   for (int c : used) vsrc[c] = vd[c].data;
   uint32_t* bbase = nullptr; WorkItem* items = nullptr; uint32_t* nitems = nullptr;
-  DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 5, &bbase));
+  DTHIP_TRY(sc.get<uint32_t>((size_t)g.F + 6, &bbase));
   nitems = bbase + g.F + 1;
   uint32_t* d_bad = bbase + g.F + 2;
   uint32_t* d_clustered = bbase + g.F + 3;        // [2]
+  uint32_t* nitems2 = bbase + g.F + 5;            // tile-local layout: the second work list (seg_plan_kernel)
   // SMALL path (one table of <= SMALL_SLOTS slots: BASELINE C1, 1e6 rows / 100 groups, is bound by its ~17 launches, not by
   // bytes): the plan kernel also initialises every table, and one single-workgroup kernel turns the slot counts into the
   // group list, the offsets and the group count
@@ -277,7 +278,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     m = (m + 7) & ~7ULL;
     M = (uint32_t)std::min<uint64_t>(m, 0x7FFFFFF8ULL);
   }
-  const uint32_t max_items = g.F + (uint32_t)((uint64_t)n / M) + 1;
+  const uint32_t max_items = g.F + (uint32_t)((uint64_t)n / M) + 1 + 16;       // (+ the padding between seg_plan_kernel's two lists)
   DTHIP_TRY(sc.get<WorkItem>(max_items, &items));
   // sorted / clustered / constant keys? (decides which kernel variants run; one tiny read-back)
   bool clustered = ctx->cluster_mode == 2;
@@ -334,7 +335,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
       DTHIP_CHECK_HIP(hipMemsetAsync(ovf_n, 0, sizeof(uint32_t), ctx->stream));
     }
     DTHIP_TRY(launch_bucket_partition(ctx, kx, n, g, nullptr, nullptr, kpart, pc, false, dir, d_bad, ovf_rows, ovf_n, OUTLIER_CAP));
-    DTHIP_TRY(launch_dir_prepare(ctx, dir, g.ntiles, g.F, dT, dstride, tot, M, items, nitems));
+    DTHIP_TRY(launch_dir_prepare(ctx, dir, g.ntiles, g.F, dT, dstride, tot, M, items, nitems, nitems2));
     dirT = dT;
   } else if (g.d > 0) {
     uint32_t* P = nullptr; uint32_t* gtot = nullptr; uint32_t* tot = nullptr;
@@ -394,7 +395,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     if (src == 2) {
       TableAggSegArgs sa;
       memset(&sa, 0, sizeof(sa));
-      sa.items = items; sa.nitems = nitems; sa.max_items = max_items; sa.kpart = kpart; sa.val = vsrc[c]; sa.vstype = vd[c].stype;
+      sa.items = items; sa.nitems = nitems; sa.nitems2 = nitems2; sa.max_items = max_items; sa.kpart = kpart; sa.val = vsrc[c]; sa.vstype = vd[c].stype;
       sa.dirT = dirT; sa.dstride = dstride; sa.tile_rows = g.tile; sa.S = g.S; sa.flags = f; sa.tab = t; sa.bad = d_bad;
       sa.all_long = g.F <= 128;
       DTHIP_TRY(launch_table_agg_seg(ctx, sa));
@@ -411,7 +412,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   if (first && src == 2) {
     TableAggSegArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.items = items; sa.nitems = nitems; sa.max_items = max_items; sa.kpart = kpart; sa.val = nullptr; sa.vstype = DTHIP_INT32;
+    sa.items = items; sa.nitems = nitems; sa.nitems2 = nitems2; sa.max_items = max_items; sa.kpart = kpart; sa.val = nullptr; sa.vstype = DTHIP_INT32;
     sa.dirT = dirT; sa.dstride = dstride; sa.tile_rows = g.tile; sa.S = g.S; sa.flags = first_flag; sa.all_long = g.F <= 128;
     if (need_cnt) sa.tab.cnt = d_cnt; else sa.tab.pres = d_cnt;
     DTHIP_TRY(launch_table_agg_seg(ctx, sa));

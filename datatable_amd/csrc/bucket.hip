@@ -26,6 +26,8 @@
 // Integer results (counts, int sums, min/max, group keys/sizes) are exact and order
 // independent; float sums are accumulated in a data-dependent order (<= 1e-6 relative,
 // the tolerance BASELINE.json states).  Not usable when a RowIndex is requested.
+#include <algorithm>
+#include <functional>
 #include "agg_dev.hpp"
 #include "keyxform.hpp"
 
@@ -226,6 +228,17 @@ int launch_bucket_cluster_sample(dthip_ctx* ctx, const KeyXform& kx, int64_t n, 
   uint32_t mx = 0, used = 0;
   for (uint32_t b = 0; b < F; b++) { mx = h[b] > mx ? h[b] : mx; used += h[b] ? 1u : 0u; }
   *even = (unsigned long long)mx * used * 2ull <= 5ull * nsamp + 64ull * used;
+  if (!*even && F >= 1024) {
+    // round 6: a FEW hot buckets (one hot key, the NA group, a handful of them) among otherwise even ones are fine too -- their
+    // segments are long, table_agg_seg_kernel streams them with whole waves and their parts are dealt over all XCDs (seg_plan's
+    // list A).  The same test without the four largest buckets; DTHIP_TL_HOT=0: as before (A/B)
+    static const bool hot_ok = !(getenv("DTHIP_TL_HOT") && atoi(getenv("DTHIP_TL_HOT")) == 0);
+    std::vector<uint32_t> c(h.begin(), h.begin() + F);
+    std::partial_sort(c.begin(), c.begin() + 5, c.end(), std::greater<uint32_t>());
+    unsigned long long rest = nsamp; uint32_t used2 = used;
+    for (int i = 0; i < 4; i++) { rest -= c[i]; used2 -= c[i] ? 1u : 0u; }
+    if (hot_ok && used2 >= 512 && (unsigned long long)c[4] * used2 * 2ull <= 5ull * rest + 64ull * used2) *even = true;
+  }
   return DTHIP_OK;
 }
 
@@ -974,7 +987,7 @@ int launch_table_agg(dthip_ctx* ctx, const TableAggArgs& a) {
 // straddle two neighbouring buckets' segments are then fetched from HBM once and hit in that XCD's L2 the second time.
 // ---------------------------------------------------------------------------------------
 struct TableAggSegDev {
-  const WorkItem* items; const uint32_t* nitems;
+  const WorkItem* items; const uint32_t* nitems; const uint32_t* nitems2;
   const uint16_t* kpart; const void* val;
   const uint16_t* dirT; uint32_t dstride; uint32_t tile_rows;
   uint32_t S; int flags; int isfloat;
@@ -987,10 +1000,21 @@ struct TableAggSegDev {
 template <typename VT, bool LONG>
 __global__ void __launch_bounds__(TA_BLOCK) __attribute__((amdgpu_waves_per_eu(LONG ? 8 : 1))) table_agg_seg_kernel(TableAggSegDev a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t nit = *a.nitems;
-  const uint32_t bi = blockIdx.x, xq = nit / 8, xr = nit % 8, xc = bi % 8, q0 = bi / 8;
-  if (q0 >= xq + (xc < xr ? 1u : 0u)) return;
-  const WorkItem it = a.items[xc * xq + (xc < xr ? xc : xr) + q0];
+  // list A (parts of multi-part buckets: first, round robin over the XCDs), then list B (one item per bucket: XCD c takes a
+  // contiguous range of buckets) -- seg_plan_kernel
+  const uint32_t na = a.nitems2 ? *a.nitems : 0u, na_pad = (na + 7u) & ~7u;
+  uint32_t bi = blockIdx.x, item_at;
+  if (bi < na_pad) {
+    if (bi >= na) return;
+    item_at = bi;
+  } else {
+    bi -= na_pad;
+    const uint32_t nit = a.nitems2 ? *a.nitems2 : *a.nitems;
+    const uint32_t xq = nit / 8, xr = nit % 8, xc = bi % 8, q0 = bi / 8;
+    if (q0 >= xq + (xc < xr ? 1u : 0u)) return;
+    item_at = na_pad + xc * xq + (xc < xr ? xc : xr) + q0;
+  }
+  const WorkItem it = a.items[item_at];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = lane >> 4, sub = lane & 15;
   const int flags = a.flags;
@@ -1027,6 +1051,7 @@ __global__ void __launch_bounds__(TA_BLOCK) __attribute__((amdgpu_waves_per_eu(L
       // before the first DS atomic (twelve loads per lane in flight: a segment of 64 buckets x 12288-row tiles is ~192 rows),
       // what is left of longer segments follows four loads at a time
       const uint32_t nseg = (t1 - c < cw) ? (t1 - c) : cw;
+      const bool hot = !LONG;          // a long bucket among short ones holds a hot key: lanes that share a slot are combined (acc_row)
       uint32_t sst[4], sln[4];
 #pragma unroll
       for (int sg = 0; sg < 4; sg++) {
@@ -1050,7 +1075,7 @@ __global__ void __launch_bounds__(TA_BLOCK) __attribute__((amdgpu_waves_per_eu(L
         for (int sg = 0; sg < 4; sg++)
 #pragma unroll
           for (int u = 0; u < 3; u++)
-            if ((uint32_t)u * 64u + (uint32_t)lane < sln[sg]) acc_row<VT, false>(t, flags, slot[sg][u], v[sg][u]);
+            if ((uint32_t)u * 64u + (uint32_t)lane < sln[sg]) acc_row<VT, false>(t, flags, slot[sg][u], v[sg][u], hot);
       }
 #pragma unroll
       for (int sg = 0; sg < 4; sg++) {
@@ -1067,7 +1092,7 @@ __global__ void __launch_bounds__(TA_BLOCK) __attribute__((amdgpu_waves_per_eu(L
           }
 #pragma unroll
           for (int u = 0; u < 4; u++)
-            if (j0 + (uint32_t)u * 64u + (uint32_t)lane < sln[sg]) acc_row<VT, false>(t, flags, slot[u], v[u]);
+            if (j0 + (uint32_t)u * 64u + (uint32_t)lane < sln[sg]) acc_row<VT, false>(t, flags, slot[u], v[u], hot);
         }
       }
       continue;
@@ -1132,7 +1157,7 @@ static int table_agg_seg_t(dthip_ctx* ctx, const TableAggSegDev& d, uint32_t gri
 int launch_table_agg_seg(dthip_ctx* ctx, const TableAggSegArgs& a) {
   if (a.max_items == 0) return DTHIP_OK;
   TableAggSegDev d;
-  d.items = a.items; d.nitems = a.nitems; d.kpart = a.kpart; d.val = a.val; d.dirT = a.dirT; d.dstride = a.dstride;
+  d.items = a.items; d.nitems = a.nitems; d.nitems2 = a.nitems2; d.kpart = a.kpart; d.val = a.val; d.dirT = a.dirT; d.dstride = a.dstride;
   d.tile_rows = a.tile_rows; d.S = a.S; d.flags = a.flags; d.isfloat = stype_is_float(a.vstype) ? 1 : 0; d.tab = a.tab; d.bad = a.bad;
   const size_t lds = table_agg_lds_bytes(a.flags, a.S);
   if (lds > 160 * 1024 - 256) { set_error("table_agg_seg: table of %zu bytes exceeds LDS", lds); return DTHIP_EINVAL; }
@@ -1177,24 +1202,33 @@ __global__ void __launch_bounds__(256) dir_totals_kernel(const uint16_t* __restr
   if (threadIdx.x == 0) tot[b] = part[0] + part[1] + part[2] + part[3];
 }
 
-// work list over the tile-local layout: bucket b in ceil(tot[b] / M) parts of equal TILE ranges
+// work list over the tile-local layout: bucket b in ceil(tot[b] / M) parts of equal TILE ranges.
+// nitems2 != nullptr (the bucketed aggregation; round 6): TWO lists.  A = the parts of buckets that need several (a hot key's
+// bucket; every bucket when there are few): items[0 .. nA), dispatched first and dealt to the XCDs round robin -- as one
+// contiguous run of the list below they all landed on ONE XCD, which then had 1.5x the rows of the others (C3 with 7 % of the
+// rows in one key: table_agg_seg 2.8 -> 3.9 ms).  B = the buckets that are one item each: items[pad8(nA) .. + nB), dealt to the
+// XCDs in contiguous bucket ranges (neighbouring segments share sectors in that XCD's L2).  *nitems = nA, *nitems2 = nB.
 __global__ void __launch_bounds__(1024) seg_plan_kernel(const uint32_t* tot, uint32_t F, uint32_t ntiles, uint32_t M,
-                                                        WorkItem* items, uint32_t* nitems) {
+                                                        WorkItem* items, uint32_t* nitems, uint32_t* nitems2) {
   __shared__ uint32_t scratch[16];
   const int tid = threadIdx.x;
-  uint32_t np[2], ps = 0;
+  uint32_t np[2], ps = 0, pb = 0;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const uint32_t b = (uint32_t)tid * 2 + k;
     np[k] = b < F ? (tot[b] + M - 1) / M : 0u;
     if (np[k] > ntiles) np[k] = ntiles;
-    ps += np[k];
+    if (nitems2 && np[k] == 1) pb += 1; else ps += np[k];
   }
-  uint32_t ptot;
+  uint32_t ptot, btot = 0;
   uint32_t pe = block_excl_scan_u32<1024>(ps, scratch, &ptot);
+  uint32_t be = 0;
+  if (nitems2) { __syncthreads(); be = block_excl_scan_u32<1024>(pb, scratch, &btot); }
+  const uint32_t bbase_ = (ptot + 7u) & ~7u;
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const uint32_t b = (uint32_t)tid * 2 + k;
+    const bool lone = nitems2 && np[k] == 1;
     for (uint32_t i = 0; i < np[k]; i++) {
       WorkItem it;
       it.bucket = b;
@@ -1203,20 +1237,20 @@ __global__ void __launch_bounds__(1024) seg_plan_kernel(const uint32_t* tot, uin
       // bit 0: the bucket has a single part (plain stores of the table); bit 1: its segments average more than 48
       // rows per tile (few buckets, or a hot bucket): whole-wave streaming instead of 16 lanes per segment
       it.single = (np[k] == 1 ? 1u : 0u) | ((unsigned long long)tot[b] > 48ull * ntiles ? 2u : 0u);
-      items[pe + i] = it;
+      items[lone ? bbase_ + be : pe + i] = it;
     }
-    pe += np[k];
+    if (lone) be += 1; else pe += np[k];
   }
-  if (tid == 0) *nitems = ptot;
+  if (tid == 0) { *nitems = ptot; if (nitems2) *nitems2 = btot; }
 }
 
 int launch_dir_prepare(dthip_ctx* ctx, const uint16_t* dir, uint32_t ntiles, uint32_t F, uint16_t* dirT, uint32_t dstride,
-                       uint32_t* tot, uint32_t M, WorkItem* items, uint32_t* nitems) {
+                       uint32_t* tot, uint32_t M, WorkItem* items, uint32_t* nitems, uint32_t* nitems2) {
   if (F > 2048) { set_error("seg plan: F=%u > 2048", F); return DTHIP_EINVAL; }
   dim3 grid((dstride + 63) / 64, (F + 1 + 63) / 64);
   DTHIP_LAUNCH(ctx, "dir_transpose_kernel", dir_transpose_kernel, grid, 256, 0, dir, ntiles, F + 1, dirT, dstride);
   DTHIP_LAUNCH(ctx, "dir_totals_kernel", dir_totals_kernel, F, 256, 0, dirT, ntiles, dstride, tot);
-  DTHIP_LAUNCH(ctx, "seg_plan_kernel", seg_plan_kernel, 1, 1024, 0, tot, F, ntiles, M, items, nitems);
+  DTHIP_LAUNCH(ctx, "seg_plan_kernel", seg_plan_kernel, 1, 1024, 0, tot, F, ntiles, M, items, nitems, nitems2);
   return DTHIP_OK;
 }
 

@@ -376,9 +376,9 @@ int launch_bucket_partition(dthip_ctx* ctx, const KeyXform& kx, int64_t n, const
 int launch_offsets_piece(dthip_ctx* ctx, const int32_t* in, int64_t count, int32_t delta, int32_t* out);
 // tile-local layout (no histogram pass): directory transpose + bucket totals + work list, and the aggregation over it
 int launch_dir_prepare(dthip_ctx* ctx, const uint16_t* dir, uint32_t ntiles, uint32_t F, uint16_t* dirT, uint32_t dstride,
-                       uint32_t* tot, uint32_t M, WorkItem* items, uint32_t* nitems);
+                       uint32_t* tot, uint32_t M, WorkItem* items, uint32_t* nitems, uint32_t* nitems2 = nullptr);
 struct TableAggSegArgs {
-  const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
+  const WorkItem* items; const uint32_t* nitems; const uint32_t* nitems2; uint32_t max_items;      // nitems2: seg_plan_kernel's two lists
   const uint16_t* kpart; const void* val; int vstype;
   const uint16_t* dirT; uint32_t dstride; uint32_t tile_rows;
   uint32_t S; int flags; AggTable tab;

@@ -73,15 +73,23 @@ def test_guessed_key_range_verified_by_the_partition_pass(tl):
 
 
 def test_default_choice_at_6e6_rows(ctx):
-    """from 2^22 rows on the layout is picked by the sampled bucket histogram: even keys take it, a hot key does not;
-    both must agree with the oracle"""
+    """from 2^22 rows on the layout is picked by the sampled bucket histogram: even keys take it; round 6: so do even keys
+    with a FEW hot buckets among them (one hot key, a hot key + the NA group: their parts form seg_plan_kernel's list A,
+    dealt over all XCDs); a smoothly skewed key keeps the exact-position layout; all must agree with the oracle"""
     rng = np.random.default_rng(8)
     n = 6_000_000
     k = rng.integers(0, 10_000_000, n).astype(np.int64)
     v = rng.standard_normal(n)
+    w = rng.integers(-50, 50, n).astype(np.int32)
     _vs_oracle(ctx, [k], [v], aggs=("sum",), check_ri=False)
     k[rng.random(n) < 0.2] = 5
     _vs_oracle(ctx, [k], [v], aggs=("sum",), check_ri=False)
+    assert ctx.last_call_stats()["path"] == "bucketed"
+    k[rng.random(n) < 0.1] = np.iinfo(np.int64).min                  # + a heavy NA group
+    v[rng.random(n) < 0.01] = np.nan
+    _vs_oracle(ctx, [k], [v, w], aggs=("sum", "mean", "min", "max", "count"), check_ri=False)
+    ks = (rng.random(n) ** 6 * 1e7).astype(np.int64)                  # smooth skew: hundreds of uneven buckets
+    _vs_oracle(ctx, [ks], [v, w], aggs=("sum", "count"), check_ri=False)
 
 
 @pytest.mark.parametrize("dtype", [np.int64, np.int32])
