@@ -392,7 +392,7 @@ def adversarial_legs(ctx, dev, n, groups, steps, verify, threads, budget, c3_ms)
     oldv = float(v[rowv].item()); v[rowv] = float("nan")
     if hv is not None:
         hv[rowv] = np.nan
-    timed("C3_na_planted", k, v, aggs2, "the same with ONE NaN planted at row %d (value column guessed NA-free -> aggregated again with valid counts)" % rowv,
+    timed("C3_na_planted", k, v, aggs2, "the same with ONE NaN planted at row %d (value column guessed NA-free -> the NA row is skipped and counted apart: no second aggregation since round 6)" % rowv,
           host=([hk], [hv]) if hk is not None else None)
     out["C3_na_planted"]["x_clean"] = out["C3_na_planted"]["ms"] / out["C3_mean_clean"]["ms"]
     v[rowv] = oldv

@@ -203,11 +203,10 @@ static int splice_outlier_groups(dthip_ctx* ctx, Scratch& sc, dthip_result* res,
 
 static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, const KeyPlan& plan,
                               const std::vector<dthip_col>& kd, const std::vector<dthip_col>& vd,
-                              const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int r, bool guess_nona = false,
-                              int r_counting = -1) {
-  // r_counting: the slot bits the same query gets WITHOUT the NA-free guess.  When they equal r, a wrong guess repeats only
-  // the aggregation over the rows already partitioned (the partition's output does not depend on the guess) instead of
-  // the whole query (DTHIP_RETRY_NA): C3 with mean(), one planted NaN: 2.0x -> see DESIGN 6 "adversarial inputs"
+                              const std::vector<int>& used, const dthip_agg* aggs, int naggs, int64_t n, int r, bool guess_nona = false) {
+  // guess_nona: value columns whose sample showed no NA keep no valid counter in LDS; an NA row that turns up after all is
+  // skipped and counted apart by a global atomic (AggTable::nacnt) -- round 6: no second aggregation (rounds 4-5 aggregated
+  // again, counting: C3 with mean() and one planted NaN 1.4 - 2.0x), DESIGN 6 "adversarial inputs"
   const int nkeys = plan.nkeys;
   const int B = plan.stage_bits[0];
   KeyXform kx;
@@ -369,7 +368,6 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   int32_t* idx = nullptr;
   int64_t ng = 0;
   DTHIP_TRY(sc.get<int32_t>(std::min<size_t>(nslots, (size_t)n) + 1, &idx));
-  for (int round = 0;; round++) {
   const size_t cnt_words = need_cnt ? nslots : (nslots + 31) / 32;
   DTHIP_TRY(sc.get<uint32_t>(cnt_words, &d_cnt));
   DTHIP_TRY(fill(d_cnt, cnt_words * 4, 0));
@@ -386,6 +384,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     if (f & ACC_MAX) { DTHIP_TRY(sc.get<unsigned long long>(nslots, &t.mx)); DTHIP_TRY(fill(t.mx, nslots * 8, 0)); }
     if (f & ACC_FSUM) { DTHIP_TRY(sc.get<double>(nslots, &t.fsum)); DTHIP_TRY(fill(t.fsum, nslots * 8, 0)); }
     if (f & ACC_VCNT) { DTHIP_TRY(sc.get<uint32_t>(nslots, &t.vcnt)); DTHIP_TRY(fill(t.vcnt, nslots * 4, 0)); }
+    if (f & ACC_CHKNA) { DTHIP_TRY(sc.get<uint32_t>(nslots, &t.nacnt)); DTHIP_TRY(fill(t.nacnt, nslots * 4, 0)); }
   }
   if (small) DTHIP_TRY(launch_bucket_plan(ctx, nullptr, 1, (uint32_t)n, M, bbase, items, nitems, &fills));
   first = true;
@@ -451,33 +450,19 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
       DTHIP_TRY(read_back(ctx, w, d_clustered, sizeof(w)));
     }
     if (plan.speculative && (w[1] & 1u)) return DTHIP_RETRY_EXACT;
-    if (w[1] & 2u) return DTHIP_RETRY_NA;
     ng = w[0];
     res->offsets = static_cast<int32_t*>(off);
   } else {
     DTHIP_TRY(launch_compact(ctx, pa, (int64_t)nslots, idx, &ng));
-    if (plan.speculative || guess_nona) {
+    if (plan.speculative) {
       uint32_t bad = 0;
       DTHIP_TRY(read_back(ctx, &bad, d_bad, sizeof(bad)));
-      if (plan.speculative && (bad & 1u)) return DTHIP_RETRY_EXACT;
-      if (ovf_rows && round == 0) {
+      if (bad & 1u) return DTHIP_RETRY_EXACT;
+      if (ovf_rows) {
         DTHIP_TRY(read_back(ctx, &n_outliers, ovf_n, sizeof(n_outliers)));
         if (n_outliers > OUTLIER_CAP) return DTHIP_RETRY_EXACT;      // not a few outliers: the guess was simply wrong
       }
-      if (bad & 2u) {
-        if (round == 0 && guess_nona && r_counting == r) {
-          // the NA-free guess was wrong, the partitioned rows are still right: aggregate them once more, counting
-          ctx->call_stats[1]++;
-          guess_nona = false;
-          need_cnt = want_offsets; first_flag = need_cnt ? ACC_CNT : ACC_PRES;
-          DTHIP_CHECK_HIP(hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
-          continue;
-        }
-        return DTHIP_RETRY_NA;
-      }
     }
-  }
-  break;
   }
   res->nrows = n; res->ngroups = ng;
   if (want_offsets && !small) {
@@ -504,7 +489,7 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
     TableFinArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.idx = idx; fa.ng = (uint32_t)ng; fa.tab = tabs[c]; fa.vstype = vd[c].stype;
-    if (tflags[c] & ACC_CHKNA) fa.tab.vcnt = d_cnt;        // verified NA-free: the valid count of a group is its size
+    if (tflags[c] & ACC_CHKNA) fa.tab.vcnt = d_cnt;        // guessed NA-free: the valid count of a group is its size minus tab.nacnt
     std::vector<std::pair<int, int>> dups;
     int first_of_op[6] = {-1, -1, -1, -1, -1, -1};
     for (int a = 0; a < naggs; a++) {
@@ -1001,13 +986,7 @@ int dthip_groupby_agg(dthip_ctx* ctx, const dthip_col* keys, int nkeys, const dt
           continue;
         }
         if (bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &slot_bits, guess_nona)) {
-          int sb_counting = -1;
-          if (guess_nona && !bucket_eligible(ctx, plan, vd, used, aggs, naggs, nrows, &sb_counting, false)) sb_counting = -1;
-          rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits, guess_nona, sb_counting);
-          if (rc == DTHIP_RETRY_NA) {                    // same plan once more, with valid counts
-            ctx->call_stats[1]++;
-            guess_nona = false; rc = DTHIP_OK; drop_partial_result(ctx, res); attempt--; continue;
-          }
+          rc = bucket_groupby_agg(ctx, sc, res, plan, kd, vd, used, aggs, naggs, nrows, slot_bits, guess_nona);
           if (rc == DTHIP_RETRY_EXACT && attempt == 0) { ctx->call_stats[0]++; rc = DTHIP_OK; drop_partial_result(ctx, res); continue; }
           if (rc == DTHIP_RETRY_EXACT) { set_error("bucketed aggregation: exact key range violated"); rc = DTHIP_EDEVICE; }
           done = true;

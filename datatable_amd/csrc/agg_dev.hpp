@@ -43,7 +43,7 @@ __device__ __forceinline__ u64 sortable_i64(long long v) { return (u64)v ^ 0x800
 
 struct LdsTab {
   u64* sum; u64* mn; u64* mx; double* fsum; uint32_t* cnt; uint32_t* vcnt; uint32_t* pres;
-  uint32_t* naflag;      // ACC_CHKNA: set when a value turned out to be NA (the column was GUESSED to hold none)
+  uint32_t* g_na;        // ACC_CHKNA: this bucket's slice of AggTable::nacnt (GLOBAL memory): NA rows of a column guessed NA-free
 };
 
 // accumulators (or checks) that look at the VALUE of a row; without any of them the value column is not even read
@@ -59,7 +59,7 @@ __device__ __forceinline__ LdsTab carve_tab(unsigned char* smem, uint32_t S, int
   t.cnt = reinterpret_cast<uint32_t*>(p); if (flags & ACC_CNT) p += (size_t)S * 4;
   t.vcnt = reinterpret_cast<uint32_t*>(p); if (flags & ACC_VCNT) p += (size_t)S * 4;
   t.pres = reinterpret_cast<uint32_t*>(p); if (flags & ACC_PRES) p += (size_t)((S + 31) / 32) * 4;
-  t.naflag = reinterpret_cast<uint32_t*>(p);           // (inside the 16 spare bytes of table_agg_lds_bytes)
+  t.g_na = nullptr;
   return t;
 }
 
@@ -98,7 +98,7 @@ __device__ __forceinline__ void acc_wave_masked(const LdsTab& t, int flags, uint
   const bool valid = (flags & ACC_NONA) || !ValTraits<VT>::isna(v);
   const bool ok = in && valid;
   const uint32_t nok = (uint32_t)__popcll(__ballot(ok));
-  if ((flags & ACC_CHKNA) && nok != nin && lead) *t.naflag = 1u;
+  if ((flags & ACC_CHKNA) && in && !valid) atomicAdd(&t.g_na[slot], 1u);      // (rare: the column was guessed NA-free)
   if (nok == 0) return;
   if (lead && (flags & ACC_VCNT)) atomicAdd(&t.vcnt[slot], nok);
   if (ValTraits<VT>::is_float) {
@@ -152,7 +152,9 @@ __device__ __forceinline__ void acc_row(const LdsTab& t, int flags, uint32_t slo
         }
       }
     } else if (flags & ACC_CHKNA) {
-      *t.naflag = 1u;           // the guess "this column holds no NA" was wrong: the caller aggregates again with valid counts
+      // the guess "this column holds no NA" was wrong for this row: it is skipped like any NA and counted apart -- no valid
+      // counter per slot in LDS, and (round 6) no second aggregation either: valid rows = rows - these
+      atomicAdd(&t.g_na[slot], 1u);
     }
   }
 }

@@ -859,7 +859,6 @@ __device__ __forceinline__ void init_table(const LdsTab& t, uint32_t S, int flag
     if (flags & ACC_VCNT) t.vcnt[s] = 0;
   }
   if (flags & ACC_PRES) for (uint32_t s = tid; s < (S + 31) / 32; s += TA_BLOCK) t.pres[s] = 0;
-  if ((flags & ACC_CHKNA) && tid == 0) *t.naflag = 0u;
 }
 
 struct TableAggDev {
@@ -883,7 +882,8 @@ __global__ void __launch_bounds__(TA_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   const int tid = threadIdx.x;
   const int flags = a.flags;
   const uint32_t S = a.S;
-  const LdsTab t = carve_tab(smem, S, flags);
+  LdsTab t = carve_tab(smem, S, flags);
+  t.g_na = a.tab.nacnt ? a.tab.nacnt + (size_t)it.bucket * S : nullptr;
   init_table(t, S, flags, tid);
   __syncthreads();
   const VT* __restrict__ val = static_cast<const VT*>(a.val);
@@ -939,7 +939,6 @@ __global__ void __launch_bounds__(TA_BLOCK) __attribute__((amdgpu_waves_per_eu(S
   }
   __syncthreads();
   flush_table(t, a.tab, it.bucket, S, flags, (it.single & 1u) != 0, a.isfloat, tid);
-  if ((flags & ACC_CHKNA) && tid == 0 && *t.naflag) atomicOr(a.bad, 2u);
 }
 
 template <typename VT, int SRC, bool UNI>
@@ -1019,7 +1018,8 @@ __global__ void __launch_bounds__(TA_BLOCK) __attribute__((amdgpu_waves_per_eu(L
   const int grp = lane >> 4, sub = lane & 15;
   const int flags = a.flags;
   const uint32_t S = a.S;
-  const LdsTab t = carve_tab(smem, S, flags);
+  LdsTab t = carve_tab(smem, S, flags);
+  t.g_na = a.tab.nacnt ? a.tab.nacnt + (size_t)it.bucket * S : nullptr;
   init_table(t, S, flags, tid);
   __syncthreads();
   const VT* __restrict__ val = static_cast<const VT*>(a.val);
@@ -1137,7 +1137,6 @@ __global__ void __launch_bounds__(TA_BLOCK) __attribute__((amdgpu_waves_per_eu(L
   }
   __syncthreads();
   flush_table(t, a.tab, it.bucket, S, flags, (it.single & 1u) != 0, a.isfloat, tid);
-  if ((flags & ACC_CHKNA) && tid == 0 && *t.naflag) atomicOr(a.bad, 2u);
 }
 
 template <typename VT>
@@ -1262,7 +1261,7 @@ __global__ void __launch_bounds__(256) table_finalize_kernel(TableFinArgs a) {
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
   if (g >= a.ng) return;
   const uint32_t s = (uint32_t)a.idx[g];
-  const uint32_t vc = a.tab.vcnt ? a.tab.vcnt[s] : 0u;
+  const uint32_t vc = a.tab.vcnt ? a.tab.vcnt[s] - (a.tab.nacnt ? a.tab.nacnt[s] : 0u) : 0u;
   const int st = a.vstype;
   const bool isf = st == DTHIP_FLOAT32 || st == DTHIP_FLOAT64;
   if (a.o_sum) {

@@ -338,7 +338,8 @@ struct BucketGeom {
 struct WorkItem { uint32_t bucket, begin, end, single; };
 enum { ACC_CNT = 1, ACC_SUM = 2, ACC_MIN = 4, ACC_MAX = 8, ACC_VCNT = 16, ACC_FSUM = 32, ACC_PRES = 64,
        ACC_NONA = 128 /* DTHIP_FLAG_NONA: every bit pattern of the value column is a value */,
-       ACC_CHKNA = 256 /* the column was GUESSED to hold no NA (no valid count kept): an NA row sets bit 1 of *bad */ };
+       ACC_CHKNA = 256 /* the column was GUESSED to hold no NA (no valid count kept in LDS): an NA row is skipped and counted in
+                          AggTable::nacnt by a global atomic -- the valid count of a group is its size minus that */ };
 // dense accumulator arrays of F*S slots (slot index == transformed key)
 struct AggTable {
   uint32_t* cnt = nullptr;              // rows per slot
@@ -348,6 +349,7 @@ struct AggTable {
   uint32_t* vcnt = nullptr;             // non-NA rows per slot
   double* fsum = nullptr;               // float64 sum of integer values (mean)
   uint32_t* pres = nullptr;             // 1 bit per slot: some row has this key (when row counts are not wanted)
+  uint32_t* nacnt = nullptr;            // ACC_CHKNA: NA rows per slot of a column GUESSED NA-free (global atomics, rare): valid = cnt - nacnt
 };
 void bucket_geometry(dthip_ctx* ctx, int64_t n, int B, int r, int km, BucketGeom* g);
 bool bucket_tl16_geometry(dthip_ctx* ctx, int64_t n, int maxw, BucketGeom* g);

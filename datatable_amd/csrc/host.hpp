@@ -15,7 +15,6 @@ namespace dthip {
 
 constexpr uint32_t SPEC_SAMPLES = 1u << 17;
 constexpr int DTHIP_RETRY_EXACT = 1;              // internal: a guessed key range was wrong, redo with the exact one
-constexpr int DTHIP_RETRY_NA = 3;                 // internal: a value column guessed NA-free holds an NA, aggregate again with valid counts
 
 struct KeyPlan {
   int nkeys = 0;

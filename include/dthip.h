@@ -248,7 +248,8 @@ int  dthip_timer_stop(dthip_ctx* ctx, float* elapsed_ms);   /* synchronises */
  * its result -- the default path GUESSES key ranges and NA-freeness from samples and verifies every row, so a wrong guess
  * costs a second sweep that nothing else reports:
  *   out[0] sweeps repeated because a guessed integer key range was violated by some row (an outlier key),
- *   out[1] aggregations repeated because a value column guessed NA-free held an NA,
+ *   out[1] aggregations repeated because a value column guessed NA-free held an NA (rounds 4-5; always 0 since round 6: such
+ *          rows are skipped and counted apart, the valid count of a group is its size minus them -- no second aggregation),
  *   out[2] routes given up after they had started (fused filter route -> two calls; hash tables full -> sort path),
  *   out[3] the path that produced the result: 1 sort path, 2 bucketed aggregation, 3 hash combiner, 4 fused filter route,
  *          6 rows found in key order already (dthip_groupby_agg: heads of the raw key column, no grouping pass),
