@@ -364,6 +364,10 @@ int launch_bucket_gscan(dthip_ctx* ctx, const BucketGeom& g, uint32_t* gtot, uin
 // tot (nullable: one bucket of n_raw rows) -> bbase[F+1], work items of <= M rows, *nitems
 // fills: (small path) buffers the plan kernel also initialises -- saves one launch per memset on latency-bound calls
 struct FillList { int n; uint32_t* p[12]; uint32_t words[12]; uint32_t val[12]; };
+// the general sequence: every table of a query initialised by ONE launch (BASELINE C2 issued 22 runtime memsets per query:
+// 0.1 ms of its 2.5; round 6).  16-byte stores; buffers come from the allocator (256-byte aligned), sizes are whole words
+struct BigFill { int n; uint32_t* p[24]; unsigned long long words[24]; uint32_t val[24]; };
+int launch_fill_list(dthip_ctx* ctx, const BigFill& f);
 int launch_bucket_plan(dthip_ctx* ctx, const uint32_t* tot, uint32_t F, uint32_t n_raw, uint32_t M,
                        uint32_t* bbase, WorkItem* items, uint32_t* nitems, const FillList* fills = nullptr);
 // small slot tables (<= SMALL_SLOTS): non-empty slots -> idx, their row counts -> offsets (exclusive scan, total appended),
@@ -388,7 +392,7 @@ struct TableAggSegArgs {
   bool all_long;            // few buckets: every segment is long (the instance without the short mode)
 };
 int launch_table_agg_seg(dthip_ctx* ctx, const TableAggSegArgs& a);
-int launch_value_na_sample(dthip_ctx* ctx, const void* data, int stype, int64_t n, uint32_t* flag);
+int launch_value_na_sample(dthip_ctx* ctx, const void* const* data, const int* stype, int ncols, int64_t n, uint32_t* flag);
 struct TableAggArgs {
   const WorkItem* items; const uint32_t* nitems; uint32_t max_items;
   int src;                    // 0: kpart + val of the partitioned rows, 1: raw rows (kx + val)
