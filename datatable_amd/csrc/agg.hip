@@ -309,10 +309,12 @@ static int bucket_groupby_agg(dthip_ctx* ctx, Scratch& sc, dthip_result* res, co
   // and a heavily skewed key 10.6 -> 14.1, which therefore keep the exact-position layout.
   // Round 6, third part: also with FEW buckets (<= 128: a tile's segment per bucket is >= 128 rows, streamed by whole waves --
   // table_agg_seg_kernel's long mode; a hot bucket only makes them longer): the histogram pass goes (C2 2.62 -> see DESIGN 6).
-  // In between (256 / 512 buckets: 32- to 64-row segments suit neither mode) the exact-position layout stays.
+  // In between (256 / 512 buckets: 32- to 64-row segments suit neither mode) the exact-position layout stays, and so it does
+  // for few buckets with a hot one: there table_agg_kernel combines the lanes that share a slot in registers, which the
+  // all-long instance cannot do profitably (C2 shape, 30 % of the rows in one key: 3.23 against 3.75 ms, profiles/r06_long_combine_ab.txt).
   static const bool tl_few = !(getenv("DTHIP_TL_FEW") && atoi(getenv("DTHIP_TL_FEW")) == 0);
   const bool tile_local = g.d > 0 && !clustered && ctx->bucket_variant != 2 && g.block == 1024 &&
-                          ((n >= (1 << 22) && ((g.F >= 1024 && even) || (g.F <= 128 && tl_few))) || ctx->bucket_variant == 3);   // variant 3: forced (tests)
+                          ((n >= (1 << 22) && ((g.F >= 1024 && even) || (g.F <= 128 && tl_few && even))) || ctx->bucket_variant == 3);   // variant 3: forced (tests)
   if (tile_local) {
     // round 6: 1024 x 16-row tiles (segments of 16 instead of 12 rows: fewer partly used sectors for the aggregation);
     // DTHIP_TL_ITEMS=12 keeps round 5's tiles (A/B)
